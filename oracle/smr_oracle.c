@@ -1,0 +1,968 @@
+/*
+ * smr_oracle.c — CPU restatement of smelter-render's per-frame rasteriser passes.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library.  The product path (libsmr_hip.so) never
+ * links, loads or falls back to it.
+ *
+ * Parity status: the reference (Rust on wgpu 30 / naga 30) cannot be built in this
+ * environment (no cargo/rustc, no Vulkan ICD).  This file restates each WGSL pass
+ * and its Rust driver one-for-one (multi-pass structure, u8 / f16 quantisation
+ * points and all), and is pinned by the reference's in-tree known-answer tests
+ * (integration-tests/src/render_tests/yuv_tests.rs, pixel_input_format_tests.rs,
+ * smelter-render/src/transformations/layout/resampler.rs tests) — see
+ * tests/test_oracle_golden.py.  Image-level parity for layout/resample/border/shadow
+ * scenes is "parity unpinned" (the PNG snapshots live in an un-vendored submodule).
+ *
+ * Arithmetic conventions:
+ *   - f32 everywhere the WGSL uses f32; built with -ffp-contract=off so every
+ *     multiply/add is individually rounded as the WGSL source is written.
+ *   - unorm8 store  = floor(clamp(x,0,1)*255 + 0.5)
+ *   - sRGB decode   = IEC 61966-2-1 (smelter-render/src/wgpu/utils.rs:74-81), LUT of 256
+ *   - sRGB encode   = exact inverse as a monotone step function: u8 = #{i : T[i] <= x},
+ *                     T[i] = decode((i-0.5)/255) evaluated in f64, rounded to f32
+ *   - f16 store     = round-to-nearest-even (Rgba16Float render target)
+ *   - bilinear      = ideal-precision weights, clamp-to-edge
+ *                     (smelter-render/src/wgpu/common_pipeline.rs:55-66)
+ *
+ * All images are tightly packed (row stride = width * bytes-per-pixel), matching
+ * smelter-render/src/wgpu/texture/base.rs:61-77.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+
+/* ------------------------------------------------------------------------- */
+/* scalar helpers                                                            */
+/* ------------------------------------------------------------------------- */
+
+static float g_srgb_dec[256];   /* decode LUT                                     */
+static float g_srgb_thr[257];   /* thr[i], i=1..255: smallest linear value -> i   */
+static int g_init_done = 0;
+
+static double srgb_to_linear_f64(double c) {
+    /* smelter-render/src/wgpu/utils.rs:74-81 */
+    if (c < 0.04045) return c / 12.92;
+    return pow((c + 0.055) / 1.055, 2.4);
+}
+
+ORC_API void orc_init(void) {
+    if (g_init_done) return;
+    for (int i = 0; i < 256; i++) g_srgb_dec[i] = (float)srgb_to_linear_f64((double)i / 255.0);
+    g_srgb_thr[0] = -INFINITY;
+    for (int i = 1; i < 256; i++) g_srgb_thr[i] = (float)srgb_to_linear_f64(((double)i - 0.5) / 255.0);
+    g_srgb_thr[256] = INFINITY;
+    g_init_done = 1;
+}
+
+ORC_API const float *orc_srgb_decode_table(void) { orc_init(); return g_srgb_dec; }
+ORC_API const float *orc_srgb_threshold_table(void) { orc_init(); return g_srgb_thr; }
+
+static inline float clampf(float x, float lo, float hi) {
+    /* WGSL clamp(e, low, high) = min(max(e, low), high); NaN -> low */
+    if (!(x > lo)) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+
+static inline u8 unorm8(float x) {
+    x = clampf(x, 0.0f, 1.0f);
+    return (u8)(int)(x * 255.0f + 0.5f);
+}
+
+static inline u8 srgb_encode8(float x) {
+    /* u8 = #{ i in 1..255 : thr[i] <= x } (binary search) */
+    if (!(x > 0.0f)) return 0;
+    int lo = 0, hi = 255; /* invariant: thr[lo] <= x, answer in [lo, hi] */
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (g_srgb_thr[mid] <= x) lo = mid; else hi = mid - 1;
+    }
+    return (u8)lo;
+}
+
+ORC_API u8 orc_srgb_encode8(float x) { orc_init(); return srgb_encode8(x); }
+
+/* f32 <-> f16 (IEEE binary16), round-to-nearest-even */
+static inline u16 f32_to_f16(float f) {
+    union { float f; uint32_t u; } v = { f };
+    uint32_t x = v.u;
+    uint32_t sign = (x >> 16) & 0x8000u;
+    uint32_t absx = x & 0x7fffffffu;
+    if (absx >= 0x7f800000u) { /* inf / nan */
+        return (u16)(sign | 0x7c00u | ((absx > 0x7f800000u) ? 0x200u : 0));
+    }
+    if (absx >= 0x477ff000u) { /* >= 65520 -> inf */
+        return (u16)(sign | 0x7c00u);
+    }
+    if (absx < 0x38800000u) { /* subnormal half or zero (< 2^-14) */
+        if (absx < 0x33000000u) return (u16)sign; /* < 2^-25 -> 0 */
+        uint32_t e = absx >> 23;
+        uint32_t m = (absx & 0x7fffffu) | 0x800000u;
+        uint32_t shift = 126 - e; /* 14..24 */
+        uint32_t half = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u);
+        uint32_t halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (half & 1u))) half++;
+        return (u16)(sign | half);
+    }
+    uint32_t e = (absx >> 23) - 112;
+    uint32_t m = absx & 0x7fffffu;
+    uint32_t half = (e << 10) | (m >> 13);
+    uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;
+    return (u16)(sign | half);
+}
+
+static inline float f16_to_f32(u16 h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu;
+    uint32_t m = h & 0x3ffu;
+    union { float f; uint32_t u; } v;
+    if (e == 0) {
+        if (m == 0) { v.u = sign; return v.f; }
+        /* subnormal */
+        float r = (float)m * (1.0f / 16777216.0f); /* m * 2^-24 */
+        return sign ? -r : r;
+    }
+    if (e == 31) { v.u = sign | 0x7f800000u | (m << 13); return v.f; }
+    v.u = sign | ((e + 112) << 23) | (m << 13);
+    return v.f;
+}
+
+ORC_API u16 orc_f32_to_f16(float f) { return f32_to_f16(f); }
+ORC_API float orc_f16_to_f32(u16 h) { return f16_to_f32(h); }
+
+static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* Bilinear textureSample of one u8 channel plane with clamp-to-edge.
+ * (u, v) normalised coords; plane has `comps` interleaved channels. Returns unorm float. */
+static inline float sample_plane_bilinear(const u8 *p, int w, int h, int comps, int c, float u, float v) {
+    float sx = u * (float)w - 0.5f;
+    float sy = v * (float)h - 0.5f;
+    float fx0 = floorf(sx), fy0 = floorf(sy);
+    float fx = sx - fx0, fy = sy - fy0;
+    int x0 = clampi((int)fx0, 0, w - 1), x1 = clampi((int)fx0 + 1, 0, w - 1);
+    int y0 = clampi((int)fy0, 0, h - 1), y1 = clampi((int)fy0 + 1, 0, h - 1);
+    float a = (float)p[((size_t)y0 * w + x0) * comps + c] / 255.0f;
+    float b = (float)p[((size_t)y0 * w + x1) * comps + c] / 255.0f;
+    float cc = (float)p[((size_t)y1 * w + x0) * comps + c] / 255.0f;
+    float d = (float)p[((size_t)y1 * w + x1) * comps + c] / 255.0f;
+    float top = a * (1.0f - fx) + b * fx;
+    float bot = cc * (1.0f - fx) + d * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+/* ------------------------------------------------------------------------- */
+/* a3: input format converters -> RGBA8 node texture bytes                    */
+/* ------------------------------------------------------------------------- */
+
+static inline void yuv_to_rgb_store(float y, float u, float v, int full_range, u8 *out) {
+    /* smelter-render/src/wgpu/format/planar_yuv_to_rgba.wgsl:45-57 */
+    if (!full_range) {
+        y = clampf((y - (16.0f / 255.0f)) / 0.85882352941f, 0.0f, 1.0f);
+        u = clampf((u - (16.0f / 255.0f)) / 0.87843137254f, 0.0f, 1.0f);
+        v = clampf((v - (16.0f / 255.0f)) / 0.87843137254f, 0.0f, 1.0f);
+    }
+    float r = y + 1.5748f * (v - 0.5f);
+    float g = y - 0.1873f * (u - 0.5f) - 0.4681f * (v - 0.5f);
+    float b = y + 1.8556f * (u - 0.5f);
+    out[0] = unorm8(r);
+    out[1] = unorm8(g);
+    out[2] = unorm8(b);
+    out[3] = 255;
+}
+
+/* variant: 0=YUV420 1=YUV422 2=YUV444 3=YUVJ420
+ * (smelter-render/src/wgpu/texture/planar_yuv.rs:65-84, format/planar_yuv_to_rgba.rs:118-126) */
+static void chroma_dims(int w, int h, int variant, int *cw, int *ch) {
+    switch (variant) {
+    case 1: *cw = w / 2; *ch = h; break;
+    case 2: *cw = w; *ch = h; break;
+    default: *cw = w / 2; *ch = h / 2; break;
+    }
+}
+
+ORC_API void orc_planar_yuv_to_rgba(const u8 *yp, const u8 *up, const u8 *vp, int w, int h, int variant, u8 *rgba) {
+    orc_init();
+    int cw, ch;
+    chroma_dims(w, h, variant, &cw, &ch);
+    int full = (variant == 3);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float tu = ((float)x + 0.5f) / (float)w;
+            float tv = ((float)y + 0.5f) / (float)h;
+            float yy = (float)yp[(size_t)y * w + x] / 255.0f; /* exact texel centre */
+            float uu = sample_plane_bilinear(up, cw, ch, 1, 0, tu, tv);
+            float vv = sample_plane_bilinear(vp, cw, ch, 1, 0, tu, tv);
+            yuv_to_rgb_store(yy, uu, vv, full, rgba + ((size_t)y * w + x) * 4);
+        }
+    }
+}
+
+/* smelter-render/src/wgpu/format/nv12_to_rgba.wgsl:26-48 */
+ORC_API void orc_nv12_to_rgba(const u8 *yp, const u8 *uvp, int w, int h, u8 *rgba) {
+    orc_init();
+    int cw = w / 2, ch = h / 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float tu = ((float)x + 0.5f) / (float)w;
+            float tv = ((float)y + 0.5f) / (float)h;
+            float yy = (float)yp[(size_t)y * w + x] / 255.0f;
+            float uu = sample_plane_bilinear(uvp, cw, ch, 2, 0, tu, tv);
+            float vv = sample_plane_bilinear(uvp, cw, ch, 2, 1, tu, tv);
+            yuv_to_rgb_store(yy, uu, vv, 0, rgba + ((size_t)y * w + x) * 4);
+        }
+    }
+}
+
+/* smelter-render/src/wgpu/format/interleaved_uyvy_to_rgba.wgsl:24-62 and
+ * interleaved_yuyv_to_rgba.wgsl:24-62.  The packed texture is (w/2) x h RGBA8;
+ * the shader snaps the x coordinate to the texel centre, so the fetch is exact.
+ * order: 0 = UYVY (u,y0,v,y1), 1 = YUYV (y0,u,y1,v) */
+ORC_API void orc_interleaved422_to_rgba(const u8 *data, int w, int h, int order, u8 *rgba) {
+    orc_init();
+    int tw = w / 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            /* x_pos = u32((tex.x * dim.x - half_pixel_width + eps) * 2.0) */
+            float dimx = (float)tw;
+            float half_pixel_width = 0.5f / dimx;
+            float tcx = ((float)x + 0.5f) / (float)w;
+            float xf = (tcx * dimx - half_pixel_width + 0.0001f) * 2.0f;
+            unsigned x_pos = (unsigned)xf;
+            int tx = clampi((int)(x_pos / 2), 0, tw - 1);
+            const u8 *t = data + ((size_t)y * tw + tx) * 4;
+            float c0 = t[0] / 255.0f, c1 = t[1] / 255.0f, c2 = t[2] / 255.0f, c3 = t[3] / 255.0f;
+            float yy, uu, vv;
+            if (order == 0) { uu = c0; vv = c2; yy = (x_pos % 2 != 0) ? c3 : c1; }
+            else            { uu = c1; vv = c3; yy = (x_pos % 2 != 0) ? c2 : c0; }
+            yuv_to_rgb_store(yy, uu, vv, 0, rgba + ((size_t)y * w + x) * 4);
+        }
+    }
+}
+
+/* smelter-render/src/wgpu/format/bgra_to_rgba.wgsl:24-28 (sample.bgra) and
+ * argb_to_rgba.wgsl:24-28 (sample.argb): pure channel permutations of the bytes as
+ * uploaded; pinned by integration-tests/src/render_tests/pixel_input_format_tests.rs.
+ * kind 0: out = [x2,x1,x0,x3]; kind 1: out = [x3,x0,x1,x2]. */
+ORC_API void orc_swizzle_to_rgba(const u8 *data, int w, int h, int kind, u8 *rgba) {
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++) {
+        const u8 *s = data + i * 4;
+        u8 *d = rgba + i * 4;
+        if (kind == 0) { d[0] = s[2]; d[1] = s[1]; d[2] = s[0]; d[3] = s[3]; }
+        else           { d[0] = s[3]; d[1] = s[0]; d[2] = s[1]; d[3] = s[2]; }
+    }
+}
+
+/* smelter-render/src/wgpu/utils/add_premultiplied_alpha.wgsl:24-35.
+ * srgb != 0: source sampled through an sRGB view and written to an sRGB target
+ * (srgb_rgba_add_premult_alpha, wgpu/utils.rs:38-42); else plain unorm. */
+ORC_API void orc_add_premultiplied_alpha(const u8 *src, int w, int h, int srgb, u8 *dst) {
+    orc_init();
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++) {
+        const u8 *s = src + i * 4;
+        u8 *d = dst + i * 4;
+        float a = (float)s[3] / 255.0f;
+        float am = a > 0.00001f ? a : 0.00001f;
+        for (int c = 0; c < 3; c++) {
+            float v = srgb ? g_srgb_dec[s[c]] : (float)s[c] / 255.0f;
+            v = clampf(v * am, 0.0f, 1.0f);
+            d[c] = srgb ? srgb_encode8(v) : unorm8(v);
+        }
+        d[3] = unorm8(a);
+    }
+}
+
+/* smelter-render/src/wgpu/utils/remove_premultiplied_alpha.wgsl:24-35 (linear unorm only) */
+ORC_API void orc_remove_premultiplied_alpha(const u8 *src, int w, int h, u8 *dst) {
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++) {
+        const u8 *s = src + i * 4;
+        u8 *d = dst + i * 4;
+        float a = (float)s[3] / 255.0f;
+        float am = a > 0.00001f ? a : 0.00001f;
+        for (int c = 0; c < 3; c++) d[c] = unorm8(((float)s[c] / 255.0f) / am);
+        d[3] = unorm8(a);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a11: RGBA8 node texture bytes -> planar YUV / NV12                          */
+/* ------------------------------------------------------------------------- */
+
+/* Sample raw (unorm, "linear view") RGBA8 bilinearly, clamp-to-edge. */
+static inline void sample_rgba_unorm(const u8 *p, int w, int h, float u, float v, float out[4]) {
+    for (int c = 0; c < 4; c++) out[c] = sample_plane_bilinear(p, w, h, 4, c, u, v);
+}
+
+static inline float yuv_component(const float c[4], int plane) {
+    /* smelter-render/src/wgpu/format/rgba_to_yuv.wgsl:26-54 */
+    float comp;
+    if (plane == 0) {
+        float y = c[0] * 0.2126f + c[1] * 0.7152f + c[2] * 0.0722f;
+        comp = (y * 0.85882352941f) + (16.0f / 255.0f);
+    } else if (plane == 1) {
+        float u = c[0] * -0.1146f + c[1] * -0.3854f + c[2] * 0.5f;
+        comp = ((u + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
+    } else {
+        float v = c[0] * 0.5f + c[1] * -0.4542f + c[2] * -0.0458f;
+        comp = ((v + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
+    }
+    return clampf(comp, 0.0f, 1.0f);
+}
+
+/* variant: 0=420 1=422 2=444 (output never J; smelter-render/src/state/output_texture.rs:26-38) */
+ORC_API void orc_rgba_to_planar_yuv(const u8 *rgba, int w, int h, int variant, u8 *yp, u8 *up, u8 *vp) {
+    int cw, ch;
+    chroma_dims(w, h, variant, &cw, &ch);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float c[4];
+            sample_rgba_unorm(rgba, w, h, ((float)x + 0.5f) / (float)w, ((float)y + 0.5f) / (float)h, c);
+            yp[(size_t)y * w + x] = unorm8(yuv_component(c, 0));
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < ch; y++) {
+        for (int x = 0; x < cw; x++) {
+            float c[4];
+            sample_rgba_unorm(rgba, w, h, ((float)x + 0.5f) / (float)cw, ((float)y + 0.5f) / (float)ch, c);
+            up[(size_t)y * cw + x] = unorm8(yuv_component(c, 1));
+            vp[(size_t)y * cw + x] = unorm8(yuv_component(c, 2));
+        }
+    }
+}
+
+/* smelter-render/src/wgpu/format/rgba_to_nv12.wgsl:24-52 */
+ORC_API void orc_rgba_to_nv12(const u8 *rgba, int w, int h, u8 *yp, u8 *uvp) {
+    int cw = w / 2, ch = h / 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float c[4];
+            sample_rgba_unorm(rgba, w, h, ((float)x + 0.5f) / (float)w, ((float)y + 0.5f) / (float)h, c);
+            yp[(size_t)y * w + x] = unorm8(yuv_component(c, 0));
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < ch; y++) {
+        for (int x = 0; x < cw; x++) {
+            float c[4];
+            sample_rgba_unorm(rgba, w, h, ((float)x + 0.5f) / (float)cw, ((float)y + 0.5f) / (float)ch, c);
+            uvp[((size_t)y * cw + x) * 2 + 0] = unorm8(yuv_component(c, 1));
+            uvp[((size_t)y * cw + x) * 2 + 1] = unorm8(yuv_component(c, 2));
+        }
+    }
+}
+
+/* RGBColor::to_yuv, smelter-render/src/scene/types.rs:28-41 + r8 fill
+ * (state/render_loop.rs:127-139): black fallback frame. */
+ORC_API void orc_rgb_to_yuv_bytes(int r8, int g8, int b8, u8 out[3]) {
+    float r = (float)r8 / 255.0f, g = (float)g8 / 255.0f, b = (float)b8 / 255.0f;
+    float y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+    float u = r * -0.1146f + g * -0.3854f + b * 0.5f;
+    float v = r * 0.5f + g * -0.4542f + b * -0.0458f;
+    out[0] = unorm8(clampf((y * 0.85882354f) + (16.0f / 255.0f), 0.0f, 1.0f));
+    out[1] = unorm8(clampf(((u + 0.5f) * 0.8784314f) + (16.0f / 255.0f), 0.0f, 1.0f));
+    out[2] = unorm8(clampf(((v + 0.5f) * 0.8784314f) + (16.0f / 255.0f), 0.0f, 1.0f));
+}
+
+/* Test-harness decoder: integration-tests/src/render_tests/harness/utils.rs:31-65 */
+ORC_API void orc_harness_yuv420_to_rgba(const u8 *yp, const u8 *up, const u8 *vp, int w, int h, u8 *rgba) {
+    int cw_ = w - (w % 2), ch_ = h - (h % 2);
+    size_t o = 0;
+    for (int i = 0; i < ch_; i++) {
+        for (int j = 0; j < cw_; j++) {
+            float y = (float)yp[(size_t)i * w + j];
+            float u = (float)up[(size_t)(i / 2) * (w / 2) + (j / 2)];
+            float v = (float)vp[(size_t)(i / 2) * (w / 2) + (j / 2)];
+            y = clampf((y - 16.0f) / 0.85882354f, 0.0f, 255.0f);
+            u = clampf((u - 16.0f) / 0.8784314f, 0.0f, 255.0f);
+            v = clampf((v - 16.0f) / 0.8784314f, 0.0f, 255.0f);
+            float r = clampf(y + 1.5748f * (v - 128.0f), 0.0f, 255.0f);
+            float g = clampf(y - 0.1873f * (u - 128.0f) - 0.4681f * (v - 128.0f), 0.0f, 255.0f);
+            float b = clampf(y + 1.8556f * (u - 128.0f), 0.0f, 255.0f);
+            rgba[o++] = (u8)r; rgba[o++] = (u8)g; rgba[o++] = (u8)b; rgba[o++] = 255;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a7/a8: Lanczos3 resampler                                                   */
+/* ------------------------------------------------------------------------- */
+
+/* Pixel formats for resample sources / targets */
+enum { ORC_PX_RGBA8_SRGB = 0, ORC_PX_RGBA8_UNORM = 1, ORC_PX_RGBA16F = 2 };
+
+static inline void load_texel(const void *src, int fmt, int w, int x, int y, float out[4]) {
+    if (fmt == ORC_PX_RGBA16F) {
+        const u16 *p = (const u16 *)src + ((size_t)y * w + x) * 4;
+        for (int c = 0; c < 4; c++) out[c] = f16_to_f32(p[c]);
+    } else {
+        const u8 *p = (const u8 *)src + ((size_t)y * w + x) * 4;
+        if (fmt == ORC_PX_RGBA8_SRGB) {
+            out[0] = g_srgb_dec[p[0]]; out[1] = g_srgb_dec[p[1]]; out[2] = g_srgb_dec[p[2]];
+        } else {
+            out[0] = (float)p[0] / 255.0f; out[1] = (float)p[1] / 255.0f; out[2] = (float)p[2] / 255.0f;
+        }
+        out[3] = (float)p[3] / 255.0f;
+    }
+}
+
+static inline void store_texel(void *dst, int fmt, int w, int x, int y, const float v[4]) {
+    if (fmt == ORC_PX_RGBA16F) {
+        u16 *p = (u16 *)dst + ((size_t)y * w + x) * 4;
+        for (int c = 0; c < 4; c++) p[c] = f32_to_f16(v[c]);
+    } else {
+        u8 *p = (u8 *)dst + ((size_t)y * w + x) * 4;
+        if (fmt == ORC_PX_RGBA8_SRGB) {
+            p[0] = srgb_encode8(v[0]); p[1] = srgb_encode8(v[1]); p[2] = srgb_encode8(v[2]);
+        } else {
+            p[0] = unorm8(v[0]); p[1] = unorm8(v[1]); p[2] = unorm8(v[2]);
+        }
+        p[3] = unorm8(v[3]);
+    }
+}
+
+/* smelter-render/src/transformations/layout/downsample.wgsl:27-40.
+ * The render target is cleared to transparent and the fragment is blended
+ * PREMULTIPLIED_ALPHA over it (common_pipeline.rs:125): out = src + 0*(1-a) = src. */
+ORC_API void orc_downsample(const void *src, int src_fmt, int sw, int sh, int fx, int fy, void *dst, int dw, int dh) {
+    orc_init();
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++) {
+        for (int x = 0; x < dw; x++) {
+            float sum[4] = { 0, 0, 0, 0 };
+            for (int dy = 0; dy < fy; dy++) {
+                for (int dx = 0; dx < fx; dx++) {
+                    int sx = clampi(x * fx + dx, 0, sw - 1);
+                    int sy = clampi(y * fy + dy, 0, sh - 1);
+                    float t[4];
+                    load_texel(src, src_fmt, sw, sx, sy, t);
+                    for (int c = 0; c < 4; c++) sum[c] = sum[c] + t[c];
+                }
+            }
+            float n = (float)(unsigned)(fx * fy);
+            float o[4] = { sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n };
+            store_texel(dst, ORC_PX_RGBA16F, dw, x, y, o);
+        }
+    }
+}
+
+/* smelter-render/src/transformations/layout/resample.wgsl:31-87, one pass.
+ * axis 0 = horizontal, 1 = vertical. Target is dw x dh. */
+ORC_API void orc_resample_pass(const void *src, int src_fmt, int sw, int sh, int axis, float scale, float offset,
+                               int perp_offset, void *dst, int dst_fmt, int dw, int dh) {
+    orc_init();
+    const float PI = 3.14159265359f;
+#pragma omp parallel for schedule(static)
+    for (int py = 0; py < dh; py++) {
+        for (int px = 0; px < dw; px++) {
+            int out_coord = axis == 1 ? py : px;
+            int max_src = (axis == 1 ? sh : sw) - 1;
+            int perp = clampi((axis == 1 ? px : py) + perp_offset, 0, (axis == 1 ? sw : sh) - 1);
+
+            float kernel_scale = scale > 1.0f ? scale : 1.0f;
+            float inv_k = 1.0f / kernel_scale;
+            float support = 3.0f * kernel_scale;
+            float center = offset + ((float)out_coord + 0.5f) * scale - 0.5f;
+            float first = ceilf(center - support);
+            int taps = (int)ceilf(2.0f * support) + 1;
+
+            float x0 = (first - center) * inv_k;
+            float s1 = sinf(PI * x0), c1 = cosf(PI * x0);
+            float s3 = sinf(PI * x0 / 3.0f), c3 = cosf(PI * x0 / 3.0f);
+            float sd1 = sinf(PI * inv_k), cd1 = cosf(PI * inv_k);
+            float sd3 = sinf(PI * inv_k / 3.0f), cd3 = cosf(PI * inv_k / 3.0f);
+
+            float sum[4] = { 0, 0, 0, 0 };
+            float weight_sum = 0.0f;
+            for (int t = 0; t < taps; t++) {
+                float x = x0 + (float)t * inv_k;
+                float weight = 0.0f;
+                if (fabsf(x) < 1e-5f) weight = 1.0f;
+                else if (fabsf(x) < 3.0f) weight = 3.0f * s1 * s3 / (PI * PI * x * x);
+                int s = clampi((int)first + t, 0, max_src);
+                float tx[4];
+                if (axis == 1) load_texel(src, src_fmt, sw, perp, s, tx);
+                else load_texel(src, src_fmt, sw, s, perp, tx);
+                for (int c = 0; c < 4; c++) sum[c] = sum[c] + tx[c] * weight;
+                weight_sum = weight_sum + weight;
+
+                float ns1 = s1 * cd1 + c1 * sd1;
+                c1 = c1 * cd1 - s1 * sd1;
+                s1 = ns1;
+                float ns3 = s3 * cd3 + c3 * sd3;
+                c3 = c3 * cd3 - s3 * sd3;
+                s3 = ns3;
+            }
+            float o[4] = { sum[0] / weight_sum, sum[1] / weight_sum, sum[2] / weight_sum, sum[3] / weight_sum };
+            store_texel(dst, dst_fmt, dw, px, py, o);
+        }
+    }
+}
+
+/* Pass planning: smelter-render/src/transformations/layout/resampler.rs:36-145 */
+typedef struct {
+    int axis;          /* 0 horizontal, 1 vertical */
+    float crop_offset;
+    float crop_len;
+    int dst_len;
+} orc_axis_mapping;
+
+typedef struct {
+    int kind;               /* 0 = direct (no resample), 1 = single pass, 2 = separable */
+    int levels[2];          /* box pre-decimation levels [h, v] */
+    int reduced_w, reduced_h; /* size after box reduce (== src when levels are 0) */
+    /* passes, in execution order */
+    int axis[2];
+    float scale[2];
+    float offset[2];
+    int perp_offset[2];
+    int mid_w, mid_h;       /* separable: size of the f16 intermediate */
+} orc_resample_plan;
+
+static float map_scale(const orc_axis_mapping *m) { return m->crop_len / (float)m->dst_len; }
+
+static int predecimate_levels(const orc_axis_mapping *m) {
+    /* ((scale / 4).log2().ceil().max(0.0) as u32).min(16); Rust `as u32` saturates, NaN -> 0 */
+    float v = ceilf(log2f(map_scale(m) / 4.0f));
+    /* f32::max(NaN, 0.0) = 0.0 */
+    if (isnan(v)) v = 0.0f;
+    if (v < 0.0f) v = 0.0f;
+    unsigned u = v >= 4294967296.0f ? 0xffffffffu : (unsigned)v;
+    return u > 16 ? 16 : (int)u;
+}
+
+static int is_same_px(float a, float b) { return fabsf(a - b) < 0.001f; }
+
+static float rust_round(float x) { return roundf(x); /* half away from zero, same as Rust f32::round */ }
+
+static int as_direct(const orc_axis_mapping *m, int *perp) {
+    int direct = is_same_px(m->crop_len, (float)m->dst_len) && is_same_px(m->crop_offset, rust_round(m->crop_offset));
+    if (direct) *perp = (int)rust_round(m->crop_offset);
+    return direct;
+}
+
+/* returns kind; fills passes */
+static int plan_passes(const orc_axis_mapping maps[2], orc_resample_plan *p) {
+    int ph = 0, pv = 0;
+    int dh_ = as_direct(&maps[0], &ph);
+    int dv_ = as_direct(&maps[1], &pv);
+    if (dh_ && dv_) return 0;
+    if (!dh_ && dv_) {
+        p->axis[0] = 0; p->scale[0] = map_scale(&maps[0]); p->offset[0] = maps[0].crop_offset; p->perp_offset[0] = pv;
+        return 1;
+    }
+    if (dh_ && !dv_) {
+        p->axis[0] = 1; p->scale[0] = map_scale(&maps[1]); p->offset[0] = maps[1].crop_offset; p->perp_offset[0] = ph;
+        return 1;
+    }
+    int first = map_scale(&maps[1]) > map_scale(&maps[0]) ? 1 : 0;
+    int second = 1 - first;
+    p->axis[0] = first; p->scale[0] = map_scale(&maps[first]); p->offset[0] = maps[first].crop_offset; p->perp_offset[0] = 0;
+    p->axis[1] = second; p->scale[1] = map_scale(&maps[second]); p->offset[1] = maps[second].crop_offset; p->perp_offset[1] = 0;
+    return 2;
+}
+
+/* ResampledChild::is_needed + ::render planning (resampler.rs:286-378).
+ * crop = {top, left, width, height} (layout.rs:39-45 field order). */
+ORC_API int orc_resample_plan_make(int src_w, int src_h, const float crop[4], int dst_w, int dst_h, orc_resample_plan *p) {
+    memset(p, 0, sizeof(*p));
+    orc_axis_mapping maps[2] = {
+        { 0, crop[1], crop[2], dst_w },
+        { 1, crop[0], crop[3], dst_h },
+    };
+    p->reduced_w = src_w; p->reduced_h = src_h;
+    orc_resample_plan tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    if (plan_passes(maps, &tmp) == 0) { p->kind = 0; return 0; }
+    for (int a = 0; a < 2; a++) p->levels[a] = predecimate_levels(&maps[a]);
+    int fx = 1 << p->levels[0], fy = 1 << p->levels[1];
+    if (fx != 1 || fy != 1) {
+        p->reduced_w = (src_w + fx - 1) / fx;
+        p->reduced_h = (src_h + fy - 1) / fy;
+    }
+    orc_axis_mapping residual[2];
+    for (int a = 0; a < 2; a++) {
+        float factor = (float)(1u << p->levels[a]);
+        residual[a] = maps[a];
+        residual[a].crop_offset = maps[a].crop_offset / factor;
+        residual[a].crop_len = maps[a].crop_len / factor;
+    }
+    p->kind = plan_passes(residual, p);
+    /* .expect("box reduction leaves a residual scale...") — kind 0 here would panic in the reference */
+    if (p->kind == 0) return -1;
+    if (p->kind == 2) {
+        if (p->axis[0] == 0) { p->mid_w = residual[0].dst_len; p->mid_h = p->reduced_h; }
+        else { p->mid_w = p->reduced_w; p->mid_h = residual[1].dst_len; }
+    }
+    return p->kind;
+}
+
+/* Full ResampledChild::render (resampler.rs:305-378).  src_fmt is the node texture
+ * interpretation (SRGB in GpuOptimized); dst is encoded the same way.
+ * Returns plan kind (0 = direct: dst untouched), <0 on error. */
+ORC_API int orc_resample(const u8 *src, int src_fmt, int sw, int sh, const float crop[4], u8 *dst, int dw, int dh) {
+    orc_init();
+    orc_resample_plan p;
+    int kind = orc_resample_plan_make(sw, sh, crop, dw, dh, &p);
+    if (kind <= 0) return kind;
+    const void *cur = src;
+    int cur_fmt = src_fmt, cw = sw, ch = sh;
+    void *reduced = NULL, *mid = NULL;
+    int fx = 1 << p.levels[0], fy = 1 << p.levels[1];
+    if (fx != 1 || fy != 1) {
+        reduced = malloc((size_t)p.reduced_w * p.reduced_h * 8);
+        orc_downsample(src, src_fmt, sw, sh, fx, fy, reduced, p.reduced_w, p.reduced_h);
+        cur = reduced; cur_fmt = ORC_PX_RGBA16F; cw = p.reduced_w; ch = p.reduced_h;
+    }
+    int last = 0;
+    if (kind == 2) {
+        mid = malloc((size_t)p.mid_w * p.mid_h * 8);
+        orc_resample_pass(cur, cur_fmt, cw, ch, p.axis[0], p.scale[0], p.offset[0], p.perp_offset[0], mid, ORC_PX_RGBA16F,
+                          p.mid_w, p.mid_h);
+        cur = mid; cur_fmt = ORC_PX_RGBA16F; cw = p.mid_w; ch = p.mid_h;
+        last = 1;
+    }
+    orc_resample_pass(cur, cur_fmt, cw, ch, p.axis[last], p.scale[last], p.offset[last], p.perp_offset[last], dst, src_fmt, dw,
+                      dh);
+    free(reduced);
+    free(mid);
+    return kind;
+}
+
+/* smelter-render/src/wgpu/format/rgba_rescale.wgsl:24-27 via
+ * state/frame_pre_processor.rs:117-132: bilinear, filtering in the node's sampling
+ * space (sRGB-decoded in GpuOptimized), target encoded the same way. */
+ORC_API void orc_rescale_bilinear(const u8 *src, int fmt, int sw, int sh, u8 *dst, int dw, int dh) {
+    orc_init();
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < dh; y++) {
+        for (int x = 0; x < dw; x++) {
+            float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
+            float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
+            float fx0 = floorf(sx), fy0 = floorf(sy);
+            float fx = sx - fx0, fy = sy - fy0;
+            int x0 = clampi((int)fx0, 0, sw - 1), x1 = clampi((int)fx0 + 1, 0, sw - 1);
+            int y0 = clampi((int)fy0, 0, sh - 1), y1 = clampi((int)fy0 + 1, 0, sh - 1);
+            float a[4], b[4], c[4], d[4], o[4];
+            load_texel(src, fmt, sw, x0, y0, a);
+            load_texel(src, fmt, sw, x1, y0, b);
+            load_texel(src, fmt, sw, x0, y1, c);
+            load_texel(src, fmt, sw, x1, y1, d);
+            for (int k = 0; k < 4; k++) {
+                float top = a[k] * (1.0f - fx) + b[k] * fx;
+                float bot = c[k] * (1.0f - fx) + d[k] * fx;
+                o[k] = top * (1.0f - fy) + bot * fy;
+            }
+            store_texel(dst, fmt, dw, x, y, o);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a9/a10: layout compositor                                                   */
+/* ------------------------------------------------------------------------- */
+
+#define ORC_MAX_MASKS 20
+
+typedef struct {
+    float radius[4]; /* tl, tr, br, bl (params.rs:337-344) */
+    float top, left, width, height;
+} orc_mask;
+
+typedef struct {
+    float top, left, width, height;
+    float rotation_degrees;
+    float border_radius[4];   /* tl, tr, br, bl */
+    uint32_t type;            /* 0 texture, 1 colour, 2 box shadow (params.rs:223-303) */
+    uint32_t source_index;    /* texture: index into sources[] ; 0xffffffff = empty 1x1 transparent */
+    float color[4];           /* premultiplied, already mode-converted (wgpu/utils.rs:51-72) */
+    float border_color[4];
+    float border_width;
+    float crop[4];            /* top, left, width, height */
+    float blur_radius;
+    uint32_t masks_len;
+    orc_mask masks[ORC_MAX_MASKS];
+} orc_layout;
+
+typedef struct {
+    const u8 *data; /* RGBA8 tight */
+    int w, h;
+} orc_source;
+
+static inline float smoothstepf(float e0, float e1, float x) {
+    if (e0 == e1) return x >= e1 ? 1.0f : 0.0f; /* degenerate edge (blur 0): step */
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+/* apply_layouts.wgsl:246-256 */
+static inline float rounded_rect_sdf(float dx, float dy, float sw, float sh, const float radius[4]) {
+    float hx = sw / 2.0f, hy = sh / 2.0f;
+    /* r = select(radius.yz, radius.xw, dist.x < 0) ; r.x = select(r.x, r.y, dist.y < 0) */
+    float rx, ry;
+    if (dx < 0.0f) { rx = radius[0]; ry = radius[3]; } else { rx = radius[1]; ry = radius[2]; }
+    float r = (dy < 0.0f) ? ry : rx;
+    float qx = fabsf(dx) - hx + r, qy = fabsf(dy) - hy + r;
+    float mx = qx > 0.0f ? qx : 0.0f, my = qy > 0.0f ? qy : 0.0f;
+    float m = qx > qy ? qx : qy;
+    float inner = m < 0.0f ? m : 0.0f;
+    return inner + sqrtf(mx * mx + my * my) - r;
+}
+
+/* Sample an RGBA8 source with bilinear + clamp; srgb: decode texels before filtering. */
+static inline void sample_source(const orc_source *s, int srgb, float u, float v, float out[4]) {
+    if (!s || !s->data) { out[0] = out[1] = out[2] = out[3] = 0.0f; return; }
+    int w = s->w, h = s->h;
+    float sx = u * (float)w - 0.5f, sy = v * (float)h - 0.5f;
+    float fx0 = floorf(sx), fy0 = floorf(sy);
+    float fx = sx - fx0, fy = sy - fy0;
+    int x0 = clampi((int)fx0, 0, w - 1), x1 = clampi((int)fx0 + 1, 0, w - 1);
+    int y0 = clampi((int)fy0, 0, h - 1), y1 = clampi((int)fy0 + 1, 0, h - 1);
+    float a[4], b[4], c[4], d[4];
+    int fmt = srgb ? ORC_PX_RGBA8_SRGB : ORC_PX_RGBA8_UNORM;
+    load_texel(s->data, fmt, w, x0, y0, a);
+    load_texel(s->data, fmt, w, x1, y0, b);
+    load_texel(s->data, fmt, w, x0, y1, c);
+    load_texel(s->data, fmt, w, x1, y1, d);
+    for (int k = 0; k < 4; k++) {
+        float top = a[k] * (1.0f - fx) + b[k] * fx;
+        float bot = c[k] * (1.0f - fx) + d[k] * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
+}
+
+/* Fragment shader of apply_layouts.wgsl:258-377 for one pixel of one layout.
+ * (fx, fy) = framebuffer position of the pixel centre; (lx, ly) = center_position
+ * (rect-local, y-up); (tu, tv) = tex coords. */
+static void layout_fragment(const orc_layout *L, const orc_source *src, int srgb, float fx, float fy, float lx, float ly,
+                            float tu, float tv, float out[4]) {
+    float mask_alpha = 1.0f;
+    unsigned nm = L->masks_len > ORC_MAX_MASKS ? ORC_MAX_MASKS : L->masks_len;
+    for (unsigned i = 0; i < nm; i++) {
+        const orc_mask *m = &L->masks[i];
+        float dx = m->left + (m->width / 2.0f) - fx;
+        float dy = m->top + (m->height / 2.0f) - fy;
+        float dist = rounded_rect_sdf(dx, dy, m->width, m->height, m->radius);
+        mask_alpha = mask_alpha * smoothstepf(-0.5f, 0.5f, -dist);
+    }
+    float edge_distance = -rounded_rect_sdf(lx, ly, L->width, L->height, L->border_radius);
+    float bw = L->border_width;
+    if (L->type == 0) {
+        float sample[4];
+        sample_source(src, srgb, tu, tv, sample);
+        if (bw < 1.0f) {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            for (int c = 0; c < 4; c++) out[c] = sample[c] * ca * mask_alpha;
+        } else if (mask_alpha < 0.01f) {
+            out[0] = out[1] = out[2] = out[3] = 0.0f;
+        } else if (edge_distance > bw / 2.0f) {
+            float ba = smoothstepf(bw - 0.5f, bw + 0.5f, edge_distance);
+            for (int c = 0; c < 4; c++) out[c] = (L->border_color[c] * (1.0f - ba) + sample[c] * ba) * mask_alpha;
+        } else {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            for (int c = 0; c < 4; c++) out[c] = L->border_color[c] * ca * mask_alpha;
+        }
+    } else if (L->type == 1) {
+        if (bw < 1.0f) {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            for (int c = 0; c < 4; c++) out[c] = L->color[c] * ca * mask_alpha;
+        } else if (edge_distance > bw / 2.0f) {
+            float ba = smoothstepf(bw, bw + 1.0f, edge_distance);
+            for (int c = 0; c < 4; c++) out[c] = (L->border_color[c] * (1.0f - ba) + L->color[c] * ba) * mask_alpha;
+        } else {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            for (int c = 0; c < 4; c++) out[c] = L->border_color[c] * ca * mask_alpha;
+        }
+    } else if (L->type == 2) {
+        float blur = L->blur_radius;
+        float ba = smoothstepf(-blur / 2.0f, blur / 2.0f, edge_distance) * mask_alpha;
+        for (int c = 0; c < 4; c++) out[c] = L->color[c] * ba;
+    } else {
+        out[0] = out[1] = out[2] = out[3] = 0.0f;
+    }
+}
+
+/* LayoutShader::render (layout/shader.rs:93-167): clear to transparent, then one
+ * quad per layout, back to front, PREMULTIPLIED_ALPHA blending, target re-quantised
+ * to RGBA8 after every draw (sRGB-encoded when srgb != 0: GpuOptimized).
+ *
+ * Rasterisation: a fragment exists where the pixel centre lies inside the
+ * transformed quad (apply_layouts.wgsl:127-157 vertex transform: scale -> rotate
+ * (CCW, y-up pixel space) -> translate). Half-open coverage: local x in
+ * [-w/2, w/2), framebuffer-y-down in [top, bottom) for the unrotated case. */
+ORC_API void orc_apply_layouts(u8 *target, int W, int H, const orc_layout *layouts, int n, const orc_source *sources,
+                               int n_sources, int srgb) {
+    orc_init();
+    memset(target, 0, (size_t)W * H * 4);
+    const float DEG = 0.017453292519943295f;
+    for (int li = 0; li < n; li++) {
+        const orc_layout *L = &layouts[li];
+        const orc_source *src = NULL;
+        orc_source empty = { NULL, 1, 1 };
+        if (L->type == 0) src = (L->source_index < (uint32_t)n_sources) ? &sources[L->source_index] : &empty;
+        /* quad geometry (box shadow quad is grown by blur on each side, wgsl:216-229) */
+        float qleft = L->left, qtop = L->top, qw = L->width, qh = L->height;
+        if (L->type == 2) {
+            qleft = L->left - L->blur_radius; qtop = L->top - L->blur_radius;
+            qw = L->width + 2.0f * L->blur_radius; qh = L->height + 2.0f * L->blur_radius;
+        }
+        if (!(qw > 0.0f) || !(qh > 0.0f)) continue;
+        float cx = qleft + qw / 2.0f, cy = qtop + qh / 2.0f;
+        float ang = L->rotation_degrees * DEG;
+        float cs = cosf(ang), sn = sinf(ang);
+        /* bounding box of rotated quad */
+        float ex = fabsf(cs) * qw / 2.0f + fabsf(sn) * qh / 2.0f;
+        float ey = fabsf(sn) * qw / 2.0f + fabsf(cs) * qh / 2.0f;
+        int x_lo = clampi((int)floorf(cx - ex - 1.0f), 0, W), x_hi = clampi((int)ceilf(cx + ex + 1.0f), 0, W);
+        int y_lo = clampi((int)floorf(cy - ey - 1.0f), 0, H), y_hi = clampi((int)ceilf(cy + ey + 1.0f), 0, H);
+        int tex_w = 1, tex_h = 1;
+        if (src && src->data) { tex_w = src->w; tex_h = src->h; }
+#pragma omp parallel for schedule(static)
+        for (int py = y_lo; py < y_hi; py++) {
+            for (int px = x_lo; px < x_hi; px++) {
+                float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+                /* y-up offsets from quad centre, then inverse rotation */
+                float dx = fx - cx, dy = -(fy - cy);
+                float lx = cs * dx + sn * dy;
+                float ly = -sn * dx + cs * dy;
+                /* coverage: half-open so abutting quads never double-cover */
+                if (!(lx >= -qw / 2.0f && lx < qw / 2.0f)) continue;
+                if (!(-ly >= -qh / 2.0f && -ly < qh / 2.0f)) continue;
+                /* varyings */
+                float u01 = lx / qw + 0.5f, v01 = 0.5f - ly / qh;
+                float tu = u01, tv = v01;
+                if (L->type == 0) {
+                    tu = (L->crop[1] + u01 * L->crop[2]) / (float)tex_w;
+                    tv = (L->crop[0] + v01 * L->crop[3]) / (float)tex_h;
+                }
+                float frag[4];
+                layout_fragment(L, src, srgb, fx, fy, lx, ly, tu, tv, frag);
+                u8 *t = target + ((size_t)py * W + px) * 4;
+                float da = (float)t[3] / 255.0f;
+                float inv = 1.0f - frag[3];
+                if (srgb) {
+                    for (int c = 0; c < 3; c++) t[c] = srgb_encode8(frag[c] + g_srgb_dec[t[c]] * inv);
+                } else {
+                    for (int c = 0; c < 3; c++) t[c] = unorm8(frag[c] + ((float)t[c] / 255.0f) * inv);
+                }
+                t[3] = unorm8(frag[3] + da * inv);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a12: glyph blit (arithmetic only; glyph shapes are third-party, unpinned)    */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int32_t dst_x, dst_y;     /* top-left in target */
+    int32_t w, h;             /* glyph bitmap size */
+    int32_t atlas_x, atlas_y; /* top-left in the A8 coverage atlas */
+    float color[4];           /* straight (non-premultiplied) RGBA in 0..1, gamma-encoded sRGB */
+} orc_glyph;
+
+/* Clear to `bg` (premultiplied, mode-converted, text_renderer.rs:62,371-374) then
+ * OVER-blend colour * coverage per glyph, target RGBA8 in the node encoding. */
+ORC_API void orc_blit_glyphs(u8 *target, int W, int H, const float bg[4], const orc_glyph *glyphs, int n, const u8 *atlas,
+                             int aw, int ah, int srgb) {
+    orc_init();
+    (void)ah;
+    for (size_t i = 0; i < (size_t)W * H; i++) {
+        u8 *t = target + i * 4;
+        for (int c = 0; c < 3; c++) t[c] = srgb ? srgb_encode8(bg[c]) : unorm8(bg[c]);
+        t[3] = unorm8(bg[3]);
+    }
+    for (int gi = 0; gi < n; gi++) {
+        const orc_glyph *g = &glyphs[gi];
+        float col[3];
+        for (int c = 0; c < 3; c++) {
+            float v = clampf(g->color[c], 0.0f, 1.0f);
+            col[c] = srgb ? (float)srgb_to_linear_f64((double)v) : v;
+        }
+        for (int y = 0; y < g->h; y++) {
+            int ty = g->dst_y + y;
+            if (ty < 0 || ty >= H) continue;
+            for (int x = 0; x < g->w; x++) {
+                int tx = g->dst_x + x;
+                if (tx < 0 || tx >= W) continue;
+                float cov = (float)atlas[(size_t)(g->atlas_y + y) * aw + (g->atlas_x + x)] / 255.0f;
+                float a = g->color[3] * cov;
+                u8 *t = target + ((size_t)ty * W + tx) * 4;
+                float inv = 1.0f - a;
+                for (int c = 0; c < 3; c++) {
+                    float d = srgb ? g_srgb_dec[t[c]] : (float)t[c] / 255.0f;
+                    float o = col[c] * a + d * inv;
+                    t[c] = srgb ? srgb_encode8(o) : unorm8(o);
+                }
+                t[3] = unorm8(a + ((float)t[3] / 255.0f) * inv);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* a13 stand-in: built-in separable gaussian blur "shader"                      */
+/* ------------------------------------------------------------------------- */
+
+/* One ShaderNode pass (shader/pipeline.rs:81-141): the fragment samples the source
+ * through the sampling view at texel centres, output is blended over a cleared
+ * target. radius = ceil(3*sigma) taps each side, weights exp(-x^2/(2 sigma^2))
+ * normalised, clamp-to-edge. Horizontal then vertical, RGBA8 between the passes. */
+static void blur_axis(const u8 *src, int fmt, int w, int h, float sigma, int axis, u8 *dst) {
+    int r = (int)ceilf(3.0f * sigma);
+    if (r < 0) r = 0;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float sum[4] = { 0, 0, 0, 0 }, ws = 0.0f;
+            for (int k = -r; k <= r; k++) {
+                float wt = sigma > 0.0f ? expf(-((float)k * (float)k) / (2.0f * sigma * sigma)) : (k == 0 ? 1.0f : 0.0f);
+                int sx = axis == 0 ? clampi(x + k, 0, w - 1) : x;
+                int sy = axis == 1 ? clampi(y + k, 0, h - 1) : y;
+                float t[4];
+                load_texel(src, fmt, w, sx, sy, t);
+                for (int c = 0; c < 4; c++) sum[c] = sum[c] + t[c] * wt;
+                ws = ws + wt;
+            }
+            float o[4] = { sum[0] / ws, sum[1] / ws, sum[2] / ws, sum[3] / ws };
+            store_texel(dst, fmt, w, x, y, o);
+        }
+    }
+}
+
+ORC_API void orc_gaussian_blur(const u8 *src, int fmt, int w, int h, float sigma, u8 *tmp, u8 *dst) {
+    orc_init();
+    blur_axis(src, fmt, w, h, sigma, 0, tmp);
+    blur_axis(tmp, fmt, w, h, sigma, 1, dst);
+}
+
+ORC_API int orc_sizeof_layout(void) { return (int)sizeof(orc_layout); }
+ORC_API int orc_sizeof_plan(void) { return (int)sizeof(orc_resample_plan); }
+ORC_API int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
