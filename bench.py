@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py — composited frames/s of the scene rasteriser hot path on MI355X.
+
+Workload (BASELINE.json metric "8x1080p -> 1 4K scene", configs[2]): 8 planar YUV420 1080p inputs,
+Tiles{8 x View{Rescaler{InputStream} border_radius 24, Text label}} -> one 3840x2160 YUV420 frame.
+One step = one composited output frame, inputs already resident in HBM, output left in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  N > 1: launched by torchrun (one rank per GPU); inputs are sharded across ranks, each rank
+  resamples its inputs to tiles, tiles are gathered on rank 0 over RCCL, rank 0 composes
+  (strong scaling of one scene: total work fixed).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md §measurement for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+IN_W, IN_H, OUT_W, OUT_H, N_IN = 1920, 1080, 3840, 2160, 8
+RING = 12  # distinct input frame sets cycled through, 12 x 24.9 MB > the 256 MB Infinity Cache
+
+
+def yuv420_bytes(w, h):
+    return w * h * 3 // 2
+
+
+ALGO_BYTES_PER_FRAME = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H)  # 37 324 800
+
+
+def build_scene():
+    """The scene as *data*: POD layout list + per-source resolutions (the scene maths is host-side
+    and outside the timed region; see tests/scenes.py)."""
+    from tests import scenes
+    from oracle import scene as S
+    kids, res = [], []
+    for i in range(N_IN):
+        label = S.View(children=[S.NodeChild(scenes.LABEL_W, scenes.LABEL_H)], background_color=(0, 0, 0, 128), border_radius=8.0,
+                       absolute=S.AbsolutePosition(width=scenes.LABEL_W + 16.0, height=scenes.LABEL_H + 8.0, left=24.0, bottom=24.0),
+                       padding=S.Padding(4.0, 8.0, 4.0, 8.0))
+        kids.append(S.View(children=[S.Rescaler(child=S.InputStream(i), border_radius=24.0), label], background_color=(16, 16, 24, 255)))
+        res += [(IN_W, IN_H), (scenes.LABEL_W, scenes.LABEL_H)]
+    root = S.Tiles(children=kids, background_color=(32, 32, 48, 255))
+    return S.scene_layouts(root, OUT_W, OUT_H, res), res
+
+
+def make_inputs(ctx, hip, frame_sets, input_ids):
+    """frame_sets x len(input_ids) device frames of synthetic 1080p YUV420 (TestInput pattern + seeded noise + shift)."""
+    from tests import scenes
+    ring = []
+    for s in range(frame_sets):
+        row = {}
+        for i in input_ids:
+            y, u, v = scenes.test_input(i, IN_W, IN_H, noise_seed=1234 + i + 100 * s, shift=s * 7)
+            row[i] = ctx.frame(hip.FRAME_PLANAR_YUV420, IN_W, IN_H, [y, u, v])
+        ring.append(row)
+    return ring
+
+
+def make_label(ctx):
+    from tests import scenes
+    from oracle.oracle import color_to_shader
+    atlas, glyphs = scenes.label_glyphs("CAM 3 LIVE", 3)
+    t = ctx.surface(scenes.LABEL_W, scenes.LABEL_H)
+    ctx.blit_glyphs(t, color_to_shader((0, 0, 0, 0), True), glyphs, atlas)
+    return t
+
+
+def cpu_baseline(layouts, res):
+    """The CPU restatement of the reference renderer (oracle, kind 'port') on the same workload:
+    ONE composited frame (8 x 1080p YUV420 -> 4K YUV420), all passes, OpenMP on all host cores."""
+    from tests import refpipe, scenes
+    from oracle import oracle as orc
+    orc.build()
+    planes = [scenes.test_input(i, IN_W, IN_H, noise_seed=1234 + i) for i in range(N_IN)]
+    atlas, glyphs = scenes.label_glyphs("CAM 3 LIVE", 3)
+    label = orc.blit_glyphs(scenes.LABEL_W, scenes.LABEL_H, orc.color_to_shader((0, 0, 0, 0), True), glyphs, atlas)
+    cores = orc.num_threads(omp=True)
+    t0 = time.perf_counter()
+    nodes, k = [], 0
+    for r in res:
+        if r == (IN_W, IN_H):
+            y, u, v = planes[k]
+            k += 1
+            nodes.append(orc.planar_yuv_to_rgba(y, u, v, IN_W, IN_H, omp=True))
+        else:
+            nodes.append(label)
+    refpipe.render_yuv420(layouts, nodes, OUT_W, OUT_H, omp=True)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "1 composited frame of the same workload (8x1080p YUV420 -> 4K YUV420, all passes), "
+                      f"oracle/smr_oracle.c -O2 + OpenMP on {cores} threads, {dt:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency-frames", type=int, default=500)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from smelter_amd import build as hip_build
+    if not os.path.exists(hip_build.LIB):
+        raise SystemExit("libsmr_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    from smelter_amd import dist as smr_dist
+    from smelter_amd import hip
+
+    # the renderer enqueues on torch's current stream so RCCL traffic and kernels stay ordered
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = hip.Context(local_rank, stream=stream if world > 1 else None)
+    layouts, res = build_scene()
+    packed = hip.pack_layouts(layouts)
+    label = make_label(ctx)
+
+    plan = smr_dist.ShardPlan(n_inputs=N_IN, world=world)
+    my_inputs = plan.inputs_of(rank)
+    ring = make_inputs(ctx, hip, RING, my_inputs)
+    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(4)] if rank == 0 else []
+    input_source_slot = [i for i, r in enumerate(res) if r == (IN_W, IN_H)]  # source index of input k
+
+    if world == 1:
+        def sources_for(step):
+            row = ring[step % RING]
+            srcs, k = [], 0
+            for r in res:
+                if r == (IN_W, IN_H):
+                    srcs.append(row[k]); k += 1
+                else:
+                    srcs.append(label)
+            return srcs
+        src_cache = [sources_for(s) for s in range(RING)]
+
+        def step_fn(step):
+            ctx.render_layouts(layouts, src_cache[step % RING], OUT_W, OUT_H, out=outs[step % len(outs)], packed=packed)
+    else:
+        sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
+
+        def step_fn(step):
+            sharded.step(ring[step % RING], outs[step % len(outs)] if rank == 0 else None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        step_fn(s)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        step_fn(s)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        fps = args.steps / elapsed
+        result = {
+            "metric": "composited frames/sec, 8x1080p->1 4K scene", "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 5),
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "u8 (f32 arithmetic, f16 resampler intermediate)", "data": "synthetic",
+            "config": {"workload": "configs[2]: 8x1080p YUV420 inputs tiled -> 3840x2160 YUV420, Tiles + Rescaler(border_radius 24) "
+                                   "+ text label per tile, GpuOptimized (linear-light Lanczos3 + blend)",
+                       "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
+                       "layouts": len(layouts), "input_ring": RING,
+                       "parallelism": "single GPU" if world == 1 else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
+            "frame": {"algorithmic_bytes": ALGO_BYTES_PER_FRAME, "achieved_GBps": round(ALGO_BYTES_PER_FRAME * fps / 1e9, 2),
+                      "frac_of_hbm_peak": round(ALGO_BYTES_PER_FRAME * fps / 1e9 / HBM_PEAK_GBPS, 5)},
+        }
+
+    # ---- per-kernel timing with HIP events on the ctx stream (outside the timed region: per-launch events
+    #      serialise the pipeline), then the dominant kernel's roofline entry
+    if world == 1:
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for s in range(min(args.steps, 200)):
+            step_fn(s)
+        ctx.sync()
+        prof = ctx.profile_read()
+        ctx.profile_enable(False)
+        stages = {k: {"avg_us": round(1000.0 * ms / n, 3), "launches": n} for k, (ms, n) in prof.items() if n}
+        tile_bytes = 0
+        for L in layouts:
+            if L.type == 0 and res[L.source_index] == (IN_W, IN_H):
+                tile_bytes += max(int(np.floor(L.width + 0.5)), 1) * max(int(np.floor(L.height + 0.5)), 1) * 4
+        kernel_bytes = {
+            "fused_ingest_resample": N_IN * yuv420_bytes(IN_W, IN_H) + tile_bytes,  # reads the raw planes once, writes the tiles once
+            "fused_compose_output": tile_bytes + yuv420_bytes(OUT_W, OUT_H),        # reads the tiles once, writes Y,U,V once
+        }
+        dom = max(stages, key=lambda k: stages[k]["avg_us"]) if stages else None
+        if dom is not None:
+            b = kernel_bytes.get(dom, ALGO_BYTES_PER_FRAME)
+            ach = b / (stages[dom]["avg_us"] * 1e-6) / 1e9
+            result["roofline"] = {"bound": "hbm", "kernel": {"fused_ingest_resample": "k_ingest_resample", "fused_compose_output": "k_compose_output"}.get(dom, dom),
+                                  "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                                  "bytes_per_launch": b, "avg_launch_us": stages[dom]["avg_us"], "traffic": None}
+        result["kernels"] = stages
+        # latency: one frame in flight, inputs resident -> output planes resident in HBM
+        lat = []
+        for s in range(args.latency_frames):
+            t1 = time.perf_counter()
+            step_fn(s)
+            ctx.sync()
+            lat.append(time.perf_counter() - t1)
+        lat = np.array(lat) * 1e3
+        result["latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
+                                "frames": args.latency_frames, "definition": "host enqueue -> output planes resident in HBM, 1 frame in flight"}
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(layouts, res)
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,245 @@
+/*
+ * smr.h — C ABI of libsmr_hip: the MI355X (gfx950) scene rasteriser that replaces the
+ * wgpu back half of smelter-render (everything below scene/flatten).
+ *
+ * What binds to it: smelter-render's InputTexture / ResampledChild / LayoutShader /
+ * OutputTexture / FramePreProcessor (see INTEGRATION.md for the Rust `extern "C"`
+ * block a maintainer adds).  Each entry point names the reference interface it
+ * replaces (paths relative to the smelter repository root).
+ *
+ * Conventions
+ *   - every function returns 0 (SMR_OK) or a negative smr_status; the message is
+ *     available from smr_last_error(ctx) (ctx-owned, valid until the next call).
+ *     Error classes mirror smelter-render/src/wgpu.rs:78-97 WgpuError::{Validation,
+ *     OutOfMemory, Internal}.
+ *   - no global state, no callbacks.  A ctx may be used from any thread but calls must
+ *     be externally serialised (smelter-render already holds one Mutex around the
+ *     renderer: smelter-render/src/state.rs:55).
+ *   - all work is enqueued on the ctx stream; only *_download, smr_sync and
+ *     smr_timer_stop block the host.
+ *   - surfaces live in HBM as pitched 2-D arrays (pitch is a multiple of 256 B);
+ *     host buffers handed to upload/download are tightly packed unless a pitch is
+ *     given (reference: wgpu/texture/base.rs:61-77, output_texture.rs:105-108).
+ *   - RGBA8 node surfaces hold premultiplied alpha.  In SMR_MODE_GPU_OPTIMIZED their
+ *     bytes are sRGB-encoded and every filter / blend happens in linear light
+ *     (Rgba8UnormSrgb + two views: wgpu/texture/rgba_multiview.rs:17-49,
+ *     state/node_texture.rs:104-142); in SMR_MODE_CPU_OPTIMIZED they are plain unorm.
+ */
+#ifndef SMR_H
+#define SMR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMR_API __attribute__((visibility("default")))
+
+typedef struct smr_ctx smr_ctx;
+typedef struct smr_surface smr_surface;
+
+typedef enum smr_status {
+    SMR_OK = 0,
+    SMR_ERR_INVALID = -1,  /* WgpuError::Validation  */
+    SMR_ERR_OOM = -2,      /* WgpuError::OutOfMemory */
+    SMR_ERR_INTERNAL = -3, /* WgpuError::Internal    */
+} smr_status;
+
+/* smelter-render/src/types.rs:8-18 RenderingMode (WebGl is wasm-only: out of scope) */
+typedef enum smr_mode { SMR_MODE_GPU_OPTIMIZED = 0, SMR_MODE_CPU_OPTIMIZED = 1 } smr_mode;
+
+typedef enum smr_pixel_format {
+    SMR_PX_RGBA8 = 0,   /* node texture (wgpu Rgba8UnormSrgb / Rgba8Unorm)          */
+    SMR_PX_RGBA16F = 1, /* resampler intermediate (layout/resampler.rs:25-28)       */
+    SMR_PX_R8 = 2,      /* Y / U / V plane (wgpu/texture/planar_yuv.rs:111-129)     */
+    SMR_PX_RG8 = 3,     /* NV12 chroma plane (wgpu/texture/nv12.rs)                 */
+} smr_pixel_format;
+
+/* smelter-render/src/types.rs:27-40 FrameData */
+typedef enum smr_frame_format {
+    SMR_FRAME_PLANAR_YUV420 = 0,
+    SMR_FRAME_PLANAR_YUV422 = 1,
+    SMR_FRAME_PLANAR_YUV444 = 2,
+    SMR_FRAME_PLANAR_YUVJ420 = 3,
+    SMR_FRAME_UYVY422 = 4,
+    SMR_FRAME_YUYV422 = 5,
+    SMR_FRAME_NV12 = 6,
+    SMR_FRAME_BGRA = 7,
+    SMR_FRAME_ARGB = 8,
+    SMR_FRAME_RGBA = 9, /* Rgba8UnormWgpuTexture: straight alpha, premultiplied on ingest */
+} smr_frame_format;
+
+/* One video frame resident in HBM: up to three pitched plane surfaces.
+ * planes[] per format: planar YUV {Y,U,V}; NV12 {Y (R8), UV (RG8)}; packed formats {data}.
+ * UYVY/YUYV planes are RGBA8 surfaces of width/2 texels (wgpu/texture/interleaved_yuv422.rs). */
+typedef struct smr_frame {
+    uint32_t format; /* smr_frame_format */
+    uint32_t width;
+    uint32_t height;
+    smr_surface *planes[3];
+} smr_frame;
+
+typedef struct smr_surface_info {
+    uint32_t width, height, format;
+    uint32_t owned; /* 0 when wrapped around caller memory */
+    size_t pitch;   /* bytes per row */
+    void *dptr;     /* device pointer */
+} smr_surface_info;
+
+#define SMR_MAX_MASKS 20            /* layout/params.rs:15 */
+#define SMR_DEFAULT_MAX_LAYOUTS 100 /* layout.rs:23 */
+#define SMR_NO_SOURCE 0xffffffffu
+
+/* layout/layout.rs:47-55 Mask + params.rs:292-300 byte order */
+typedef struct smr_mask {
+    float radius[4]; /* top_left, top_right, bottom_right, bottom_left */
+    float top, left, width, height;
+} smr_mask;
+
+/* POD mirror of RenderLayout (layout.rs:58-96) in the conventions of
+ * ParamsBindGroups::update (layout/params.rs:169-334): colours are premultiplied
+ * and already mode-converted by the host (wgpu/utils.rs:51-81). */
+typedef struct smr_layout {
+    float top, left, width, height;
+    float rotation_degrees;
+    float border_radius[4]; /* tl, tr, br, bl */
+    uint32_t type;          /* 0 texture (ChildNode), 1 colour, 2 box shadow */
+    uint32_t source_index;  /* texture: index into sources[]; SMR_NO_SOURCE = empty 1x1 */
+    float color[4];
+    float border_color[4];
+    float border_width;
+    float crop[4]; /* top, left, width, height (layout.rs:39-45) */
+    float blur_radius;
+    uint32_t masks_len;
+    smr_mask masks[SMR_MAX_MASKS];
+} smr_layout;
+
+/* Resampler pass plan (layout/resampler.rs:36-145, 305-378) */
+typedef struct smr_resample_plan {
+    int32_t kind;      /* 0 direct (layout shader samples the source 1:1), 1 single pass, 2 separable */
+    int32_t levels[2]; /* box pre-decimation levels [horizontal, vertical] */
+    int32_t reduced_w, reduced_h;
+    int32_t axis[2]; /* per pass, in execution order: 0 horizontal, 1 vertical */
+    float scale[2];
+    float offset[2];
+    int32_t perp_offset[2];
+    int32_t mid_w, mid_h; /* separable: f16 intermediate size */
+} smr_resample_plan;
+
+/* One glyph quad of a text node (transformations/text_renderer.rs:92-132). */
+typedef struct smr_glyph {
+    int32_t dst_x, dst_y;
+    int32_t w, h;
+    int32_t atlas_x, atlas_y;
+    float color[4]; /* straight RGBA 0..1, gamma-encoded */
+} smr_glyph;
+
+/* Source of a texture layout for the fused render entry point. */
+typedef enum smr_source_kind { SMR_SOURCE_NONE = 0, SMR_SOURCE_SURFACE = 1, SMR_SOURCE_FRAME = 2 } smr_source_kind;
+typedef struct smr_source {
+    uint32_t kind;
+    const smr_surface *surface; /* RGBA8 node surface (text, image, shader output, ...) */
+    const smr_frame *frame;     /* raw input frame: colour conversion is fused into the resampler */
+} smr_source;
+
+/* ---- context ---------------------------------------------------------------------
+ * replaces WgpuCtx::new (smelter-render/src/wgpu/ctx.rs:34-107) + RendererOptions
+ * {rendering_mode, max_layouts_count} (state.rs:43-52).
+ * hip_stream: an existing hipStream_t to enqueue on, or NULL to let the ctx create one. */
+SMR_API int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hip_stream, smr_ctx **out);
+SMR_API void smr_ctx_destroy(smr_ctx *ctx);
+SMR_API const char *smr_last_error(const smr_ctx *ctx);
+SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — render_loop.rs:177-183 */
+SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
+SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */
+/* Per-kernel-class timing with HIP events on the ctx stream (off by default).
+ * stage ids: 0 ingest/convert, 1 resample, 2 layouts/compose, 3 output convert, 4 fused ingest+resample,
+ * 5 fused compose+output. Accumulates ms and launch counts until reset. */
+SMR_API int smr_profile_enable(smr_ctx *ctx, int enable);
+SMR_API int smr_profile_read(smr_ctx *ctx, int stage, float *total_ms, uint32_t *launches);
+SMR_API int smr_profile_reset(smr_ctx *ctx);
+
+/* ---- surfaces (NodeTexture / wgpu::Texture; state/node_texture.rs:11-163) -------- */
+SMR_API int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, smr_surface **out);
+SMR_API int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
+                             smr_surface **out);
+SMR_API void smr_surface_destroy(smr_ctx *ctx, smr_surface *s);
+SMR_API int smr_surface_info_get(const smr_surface *s, smr_surface_info *out);
+/* queue.write_texture (wgpu/texture/base.rs:61-77); host_pitch 0 = tight rows */
+SMR_API int smr_surface_upload(smr_ctx *ctx, smr_surface *s, const void *host, size_t host_pitch);
+/* copy_texture_to_buffer + map + strip padding (texture/base.rs:97-118, output_texture.rs:85-113) */
+SMR_API int smr_surface_download(smr_ctx *ctx, const smr_surface *s, void *host, size_t host_pitch);
+SMR_API int smr_surface_clear(smr_ctx *ctx, smr_surface *s);
+
+/* ---- frames (InputTexture upload side: state/input_texture.rs:69-201) ------------ */
+SMR_API int smr_frame_create(smr_ctx *ctx, uint32_t format, uint32_t w, uint32_t h, smr_frame *out);
+SMR_API void smr_frame_destroy(smr_ctx *ctx, smr_frame *f);
+SMR_API int smr_frame_upload(smr_ctx *ctx, const smr_frame *f, const void *const host_planes[3]);
+SMR_API int smr_frame_download(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]);
+
+/* ---- a3: InputTexture::convert_to_node_texture (input_texture.rs:203-219) ---------
+ * wgpu/format/{planar_yuv,nv12,interleaved_uyvy,interleaved_yuyv,bgra,argb}_to_rgba.{rs,wgsl};
+ * RGBA frames go through add_premultiplied_alpha (input_texture/rgba_texture.rs:38-63). */
+SMR_API int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node);
+SMR_API int smr_add_premultiplied_alpha(smr_ctx *ctx, const smr_surface *src, smr_surface *dst);
+SMR_API int smr_remove_premultiplied_alpha(smr_ctx *ctx, const smr_surface *src, smr_surface *dst);
+
+/* ---- a11: read_outputs (render_loop.rs:59-230) -------------------------------------
+ * RgbaToYuvConverter::convert (format/rgba_to_yuv.rs:67-117) for planar 420/422/444,
+ * RgbaToNv12Converter::convert (format/rgba_to_nv12.rs:54-82) for NV12. */
+SMR_API int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *out);
+/* PlanarYuvTextures::fill_with_color(BLACK) (wgpu/texture/planar_yuv.rs:190-202) */
+SMR_API int smr_frame_fill_black(smr_ctx *ctx, const smr_frame *out);
+
+/* ---- a7/a8: resampler (layout/resampler.rs) ---------------------------------------- */
+/* ResampledChild::is_needed + pass planning; pure host function. crop = {top,left,width,height}. */
+SMR_API int smr_resample_plan_make(uint32_t src_w, uint32_t src_h, const float crop[4], uint32_t dst_w, uint32_t dst_h,
+                                   smr_resample_plan *out);
+/* ResampledChild::render: box pre-reduce + 1 or 2 Lanczos3 passes. Returns the plan kind
+ * (0 = direct: dst untouched) or a negative status. */
+SMR_API int smr_resample(smr_ctx *ctx, const smr_surface *src, const float crop[4], smr_surface *dst);
+/* single passes (resample.wgsl / downsample.wgsl), exposed for tests and the Rust seam */
+SMR_API int smr_resample_pass(smr_ctx *ctx, const smr_surface *src, int axis, float scale, float offset, int perp_offset,
+                              smr_surface *dst);
+SMR_API int smr_downsample(smr_ctx *ctx, const smr_surface *src, uint32_t fx, uint32_t fy, smr_surface *dst);
+/* format/rgba_rescale.wgsl via FramePreProcessor::rescale_node_texture (frame_pre_processor.rs:117-132) */
+SMR_API int smr_rescale_bilinear(smr_ctx *ctx, const smr_surface *src, smr_surface *dst);
+
+/* ---- a9/a10: LayoutShader::render (layout/shader.rs:93-167 + apply_layouts.wgsl) ---
+ * Clears target to transparent, draws layouts back to front with premultiplied OVER.
+ * sources[i] may be NULL (sampled as the 1x1 transparent texture, layout.rs:204-212). */
+SMR_API int smr_apply_layouts(smr_ctx *ctx, smr_surface *target, const smr_layout *layouts, uint32_t n,
+                              const smr_surface *const *sources, uint32_t n_sources);
+
+/* ---- fused hot path: LayoutNode::render + read_outputs in (at most) two kernel waves --
+ * Equivalent to: for every texture layout resample_scaled_children (layout.rs:238-278) from the
+ * raw frame / surface, LayoutShader::render, then rgba_to_yuv / rgba_to_nv12 into `out`
+ * (or a copy into `out_rgba` when out == NULL).  Bit-identical to the unfused sequence. */
+SMR_API int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint32_t n, const smr_source *sources,
+                               uint32_t n_sources, uint32_t out_w, uint32_t out_h, const smr_frame *out,
+                               smr_surface *out_rgba);
+
+/* Per-input half of the above, for sharding inputs across GPUs: InputTexture::convert_to_node_texture
+ * (input_texture.rs:203-219) + ResampledChild::render (resampler.rs:305-378) in one step, frame -> dst-sized
+ * RGBA8 tile.  Returns the plan kind (0 = direct: dst untouched) or a negative status. */
+SMR_API int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const float crop[4], smr_surface *dst);
+
+/* ---- a12: text node blit (transformations/text_renderer.rs:72-167) ----------------- */
+SMR_API int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const smr_glyph *glyphs, uint32_t n,
+                            const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
+
+/* ---- a13 stand-in: built-in "shader" kernels (user WGSL is out of scope) ------------ */
+typedef enum smr_builtin_shader_id { SMR_SHADER_GAUSSIAN_BLUR = 0 } smr_builtin_shader_id;
+typedef struct smr_gaussian_blur_params { float sigma; } smr_gaussian_blur_params;
+SMR_API int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t params_size,
+                               const smr_surface *const *src, uint32_t n_src, smr_surface *dst, float time_s);
+
+SMR_API uint32_t smr_abi_version(void);
+SMR_API uint32_t smr_sizeof_layout(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMR_H */

@@ -22,7 +22,7 @@
  *   - sRGB encode   = exact inverse as a monotone step function: u8 = #{i : T[i] <= x},
  *                     T[i] = decode((i-0.5)/255) evaluated in f64, rounded to f32
  *   - f16 store     = round-to-nearest-even (Rgba16Float render target)
- *   - bilinear      = ideal-precision weights, clamp-to-edge
+ *   - bilinear      = f32 lerp, weights with 8 fractional bits, clamp-to-edge
  *                     (smelter-render/src/wgpu/common_pipeline.rs:55-66)
  *
  * All images are tightly packed (row stride = width * bytes-per-pixel), matching
@@ -145,13 +145,19 @@ ORC_API float orc_f16_to_f32(u16 h) { return f16_to_f32(h); }
 
 static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+/* Bilinear filter weights carry 8 fractional bits, as on every sampler the reference runs on
+ * (Vulkan subTexelPrecisionBits = 8 on lavapipe and on the T4 of the published benchmarks):
+ * texel-aligned fetches are exact copies, which is what pins pixel_input_format_tests.rs to
+ * "exact". */
+static inline float subtexel(float f) { return floorf(f * 256.0f + 0.5f) / 256.0f; }
+
 /* Bilinear textureSample of one u8 channel plane with clamp-to-edge.
  * (u, v) normalised coords; plane has `comps` interleaved channels. Returns unorm float. */
 static inline float sample_plane_bilinear(const u8 *p, int w, int h, int comps, int c, float u, float v) {
     float sx = u * (float)w - 0.5f;
     float sy = v * (float)h - 0.5f;
     float fx0 = floorf(sx), fy0 = floorf(sy);
-    float fx = sx - fx0, fy = sy - fy0;
+    float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
     int x0 = clampi((int)fx0, 0, w - 1), x1 = clampi((int)fx0 + 1, 0, w - 1);
     int y0 = clampi((int)fy0, 0, h - 1), y1 = clampi((int)fy0 + 1, 0, h - 1);
     float a = (float)p[((size_t)y0 * w + x0) * comps + c] / 255.0f;
@@ -660,7 +666,7 @@ ORC_API void orc_rescale_bilinear(const u8 *src, int fmt, int sw, int sh, u8 *ds
             float u = ((float)x + 0.5f) / (float)dw, v = ((float)y + 0.5f) / (float)dh;
             float sx = u * (float)sw - 0.5f, sy = v * (float)sh - 0.5f;
             float fx0 = floorf(sx), fy0 = floorf(sy);
-            float fx = sx - fx0, fy = sy - fy0;
+            float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
             int x0 = clampi((int)fx0, 0, sw - 1), x1 = clampi((int)fx0 + 1, 0, sw - 1);
             int y0 = clampi((int)fy0, 0, sh - 1), y1 = clampi((int)fy0 + 1, 0, sh - 1);
             float a[4], b[4], c[4], d[4], o[4];
@@ -735,7 +741,7 @@ static inline void sample_source(const orc_source *s, int srgb, float u, float v
     int w = s->w, h = s->h;
     float sx = u * (float)w - 0.5f, sy = v * (float)h - 0.5f;
     float fx0 = floorf(sx), fy0 = floorf(sy);
-    float fx = sx - fx0, fy = sy - fy0;
+    float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
     int x0 = clampi((int)fx0, 0, w - 1), x1 = clampi((int)fx0 + 1, 0, w - 1);
     int y0 = clampi((int)fy0, 0, h - 1), y1 = clampi((int)fy0 + 1, 0, h - 1);
     float a[4], b[4], c[4], d[4];

@@ -1,0 +1,304 @@
+// smr_convert.hip — colour-format converters either side of the node texture.
+//
+// Replaces (one kernel per WGSL pass; each fragment = one thread-iteration):
+//   wgpu/format/planar_yuv_to_rgba.{rs,wgsl}, nv12_to_rgba, interleaved_{uyvy,yuyv}_to_rgba,
+//   bgra_to_rgba, argb_to_rgba, wgpu/utils/{add,remove}_premultiplied_alpha,
+//   wgpu/format/rgba_to_yuv.{rs,wgsl} (3 passes fused into one launch), rgba_to_nv12,
+//   wgpu/utils/r8_fill_with_color (black fallback).
+//
+// HBM-bound byte work: every thread handles 4 horizontally adjacent pixels so loads are
+// 4 B (luma) and stores 16 B per lane; rows are pitched to 256 B so every row starts
+// on a fresh cache line.
+#include "smr_convert_dev.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// kind: 0 planar (3 R8 planes), 1 NV12 (R8 + RG8)
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba(SurfView yp, SurfView up, SurfView vp, SurfView dst, int full) {
+    const int groups = (dst.w + 3) >> 2;
+    const int gx = blockIdx.x * BLOCK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (gx >= groups) return;
+    const int x0 = gx * 4;
+    const float tv = ((float)y + 0.5f) / (float)dst.h;
+    u32 px[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x0 + i;
+        if (x >= dst.w) { px[i] = 0; continue; }
+        float tu = ((float)x + 0.5f) / (float)dst.w;
+        float yy = (float)yp.ptr[(size_t)y * yp.pitch + x] / 255.0f;
+        float uu, vv;
+        if (KIND == 0) {
+            uu = sample_plane_bilinear(up, 1, 0, tu, tv);
+            vv = sample_plane_bilinear(vp, 1, 0, tu, tv);
+        } else {
+            uu = sample_plane_bilinear(up, 2, 0, tu, tv);
+            vv = sample_plane_bilinear(up, 2, 1, tu, tv);
+        }
+        px[i] = yuv_to_rgb_px(yy, uu, vv, full != 0);
+    }
+    u8 *row = dst.ptr + (size_t)y * dst.pitch;
+    if (x0 + 3 < dst.w) {
+        *(uint4 *)(row + (size_t)x0 * 4) = make_uint4(px[0], px[1], px[2], px[3]);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < dst.w; i++) *(u32 *)(row + (size_t)(x0 + i) * 4) = px[i];
+    }
+}
+
+// interleaved_{uyvy,yuyv}_to_rgba.wgsl:24-62. src is the (w/2) x h RGBA8 packed texture.
+__global__ __launch_bounds__(BLOCK) void k_interleaved422_to_rgba(SurfView src, SurfView dst, int order) {
+    const int x = blockIdx.x * BLOCK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dst.w) return;
+    const int tw = src.w;
+    float dimx = (float)tw;
+    float half_pixel_width = 0.5f / dimx;
+    float tcx = ((float)x + 0.5f) / (float)dst.w;
+    float xf = (tcx * dimx - half_pixel_width + 0.0001f) * 2.0f;
+    unsigned x_pos = (unsigned)xf;
+    int tx = clampi((int)(x_pos / 2), 0, tw - 1);
+    u32 t = *(const u32 *)(src.ptr + (size_t)y * src.pitch + (size_t)tx * 4);
+    float c0 = (float)(t & 0xff) / 255.0f, c1 = (float)((t >> 8) & 0xff) / 255.0f;
+    float c2 = (float)((t >> 16) & 0xff) / 255.0f, c3 = (float)(t >> 24) / 255.0f;
+    float yy, uu, vv;
+    if (order == 0) { uu = c0; vv = c2; yy = (x_pos % 2 != 0) ? c3 : c1; }
+    else            { uu = c1; vv = c3; yy = (x_pos % 2 != 0) ? c2 : c0; }
+    *(u32 *)(dst.ptr + (size_t)y * dst.pitch + (size_t)x * 4) = yuv_to_rgb_px(yy, uu, vv, false);
+}
+
+// bgra_to_rgba.wgsl:24-28 (sample.bgra) / argb_to_rgba.wgsl:24-28 (sample.argb): byte permutes.
+__global__ __launch_bounds__(BLOCK) void k_swizzle(SurfView src, SurfView dst, int kind) {
+    const int groups = (dst.w + 3) >> 2;
+    const int gx = blockIdx.x * BLOCK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (gx >= groups) return;
+    const int x0 = gx * 4;
+    const u8 *srow = src.ptr + (size_t)y * src.pitch;
+    u8 *drow = dst.ptr + (size_t)y * dst.pitch;
+    u32 in[4], o[4];
+    if (x0 + 3 < dst.w) {
+        uint4 v = *(const uint4 *)(srow + (size_t)x0 * 4);
+        in[0] = v.x; in[1] = v.y; in[2] = v.z; in[3] = v.w;
+    } else {
+        for (int i = 0; i < 4; i++) in[i] = (x0 + i < dst.w) ? *(const u32 *)(srow + (size_t)(x0 + i) * 4) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u32 p = in[i];
+        if (kind == 0) o[i] = (p & 0xff00ff00u) | ((p & 0xff) << 16) | ((p >> 16) & 0xff);  // [x2,x1,x0,x3]
+        else o[i] = (p >> 24) | (p << 8);                                                    // [x3,x0,x1,x2]
+    }
+    if (x0 + 3 < dst.w) {
+        *(uint4 *)(drow + (size_t)x0 * 4) = make_uint4(o[0], o[1], o[2], o[3]);
+    } else {
+        for (int i = 0; i < 4 && x0 + i < dst.w; i++) *(u32 *)(drow + (size_t)(x0 + i) * 4) = o[i];
+    }
+}
+
+// add_premultiplied_alpha.wgsl:24-35 / remove_premultiplied_alpha.wgsl:24-35
+// mode 0: add (pxi decides sRGB vs unorm), mode 1: remove (unorm only)
+__global__ __launch_bounds__(BLOCK) void k_premult(SurfView src, SurfView dst, int pxi, int mode, const float *__restrict__ tables) {
+    const int x = blockIdx.x * BLOCK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dst.w) return;
+    const float *dec = tables, *thr = tables + 256;
+    u32 p = *(const u32 *)(src.ptr + (size_t)y * src.pitch + (size_t)x * 4);
+    u32 c[3] = {p & 0xff, (p >> 8) & 0xff, (p >> 16) & 0xff};
+    float a = (float)(p >> 24) / 255.0f;
+    float am = a > 0.00001f ? a : 0.00001f;
+    u32 o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (mode == 0) {
+            float v = (pxi == PXI_RGBA8_SRGB) ? dec[c[k]] : (float)c[k] / 255.0f;
+            v = clampf(v * am, 0.0f, 1.0f);
+            o[k] = (pxi == PXI_RGBA8_SRGB) ? srgb_encode8(v, thr) : unorm8(v);
+        } else {
+            o[k] = unorm8(((float)c[k] / 255.0f) / am);
+        }
+    }
+    *(u32 *)(dst.ptr + (size_t)y * dst.pitch + (size_t)x * 4) = o[0] | (o[1] << 8) | (o[2] << 16) | (unorm8(a) << 24);
+}
+
+// Y plane: exact texel fetch (target size == source size), 4 px per thread.
+__global__ __launch_bounds__(BLOCK) void k_rgba_to_y(SurfView src, SurfView yp) {
+    const int groups = (yp.w + 3) >> 2;
+    const int gx = blockIdx.x * BLOCK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (gx >= groups) return;
+    const int x0 = gx * 4;
+    const u8 *srow = src.ptr + (size_t)y * src.pitch;
+    u32 out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int x = x0 + i;
+        if (x >= yp.w) break;
+        u32 p = *(const u32 *)(srow + (size_t)x * 4);
+        float4 c = make_float4((float)(p & 0xff) / 255.0f, (float)((p >> 8) & 0xff) / 255.0f,
+                               (float)((p >> 16) & 0xff) / 255.0f, (float)(p >> 24) / 255.0f);
+        out |= unorm8(yuv_component(c, 0)) << (8 * i);
+    }
+    u8 *drow = yp.ptr + (size_t)y * yp.pitch;
+    if (x0 + 3 < yp.w) *(u32 *)(drow + x0) = out;
+    else for (int i = 0; i < 4 && x0 + i < yp.w; i++) drow[x0 + i] = (u8)(out >> (8 * i));
+}
+
+// chroma: one bilinear tap at the chroma texel centre (=> 2x2 mean for 4:2:0).
+// NV = 0: separate U, V planes (R8); NV = 1: interleaved UV plane (RG8)
+template <int NV>
+__global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView up, SurfView vp, int cw, int ch) {
+    const int x = blockIdx.x * BLOCK + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cw || y >= ch) return;
+    float4 c = sample_rgba_bilinear(src, PXI_RGBA8_UNORM, ((float)x + 0.5f) / (float)cw, ((float)y + 0.5f) / (float)ch, nullptr);
+    u32 u = unorm8(yuv_component(c, 1)), v = unorm8(yuv_component(c, 2));
+    if (NV == 0) {
+        up.ptr[(size_t)y * up.pitch + x] = (u8)u;
+        vp.ptr[(size_t)y * vp.pitch + x] = (u8)v;
+    } else {
+        *(u16 *)(up.ptr + (size_t)y * up.pitch + (size_t)x * 2) = (u16)(u | (v << 8));
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_bytes(SurfView p, int row_bytes, u32 value4) {
+    const int x = (blockIdx.x * BLOCK + threadIdx.x) * 4;
+    const int y = blockIdx.y;
+    if (x >= row_bytes) return;
+    u8 *row = p.ptr + (size_t)y * p.pitch;
+    if (x + 3 < row_bytes) *(u32 *)(row + x) = value4;
+    else for (int i = 0; x + i < row_bytes; i++) row[x + i] = (u8)(value4 >> (8 * i));
+}
+
+inline dim3 grid_px(int w_items, int h) { return dim3((unsigned)((w_items + BLOCK - 1) / BLOCK), (unsigned)h, 1); }
+
+u32 host_unorm8(float x) {
+    if (!(x > 0.0f)) x = 0.0f;
+    if (x > 1.0f) x = 1.0f;
+    return (u32)(int)(x * 255.0f + 0.5f);
+}
+
+}  // namespace
+
+extern "C" {
+
+int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
+    if (!ctx || !in || !node) return SMR_ERR_INVALID;
+    if (node->fmt != SMR_PX_RGBA8 || node->w != in->width || node->h != in->height)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
+    if (!in->planes[0]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: frame has no planes");
+    StageScope scope(ctx, SMR_STAGE_INGEST);
+    SurfView dst = view_of(node);
+    const int w = (int)in->width, h = (int)in->height;
+    switch (in->format) {
+    case SMR_FRAME_PLANAR_YUV420:
+    case SMR_FRAME_PLANAR_YUV422:
+    case SMR_FRAME_PLANAR_YUV444:
+    case SMR_FRAME_PLANAR_YUVJ420: {
+        if (!in->planes[1] || !in->planes[2]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: missing chroma plane");
+        SurfView yp = view_of(in->planes[0]), up = view_of(in->planes[1]), vp = view_of(in->planes[2]);
+        // planes keep a 1x1 placeholder when the logical chroma size is 0; sample with the logical size
+        hipLaunchKernelGGL(k_yuv_to_rgba<0>, grid_px((w + 3) / 4, h), dim3(BLOCK), 0, ctx->stream, yp, up, vp, dst,
+                           in->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0);
+        break;
+    }
+    case SMR_FRAME_NV12: {
+        if (!in->planes[1]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: missing UV plane");
+        SurfView yp = view_of(in->planes[0]), up = view_of(in->planes[1]);
+        hipLaunchKernelGGL(k_yuv_to_rgba<1>, grid_px((w + 3) / 4, h), dim3(BLOCK), 0, ctx->stream, yp, up, up, dst, 0);
+        break;
+    }
+    case SMR_FRAME_UYVY422:
+    case SMR_FRAME_YUYV422:
+        hipLaunchKernelGGL(k_interleaved422_to_rgba, grid_px(w, h), dim3(BLOCK), 0, ctx->stream, view_of(in->planes[0]), dst,
+                           in->format == SMR_FRAME_UYVY422 ? 0 : 1);
+        break;
+    case SMR_FRAME_BGRA:
+    case SMR_FRAME_ARGB:
+        hipLaunchKernelGGL(k_swizzle, grid_px((w + 3) / 4, h), dim3(BLOCK), 0, ctx->stream, view_of(in->planes[0]), dst,
+                           in->format == SMR_FRAME_BGRA ? 0 : 1);
+        break;
+    case SMR_FRAME_RGBA:
+        // input_texture/rgba_texture.rs:38-63: straight-alpha texture -> premultiplied node texture
+        hipLaunchKernelGGL(k_premult, grid_px(w, h), dim3(BLOCK), 0, ctx->stream, view_of(in->planes[0]), dst,
+                           ctx->srgb() ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM, 0, ctx->d_tables);
+        break;
+    default:
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: unknown frame format %u", in->format);
+    }
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}
+
+static int premult_common(smr_ctx *ctx, const smr_surface *src, smr_surface *dst, int mode) {
+    if (!ctx || !src || !dst) return SMR_ERR_INVALID;
+    if (src->fmt != SMR_PX_RGBA8 || dst->fmt != SMR_PX_RGBA8 || src->w != dst->w || src->h != dst->h)
+        return smr_fail(ctx, SMR_ERR_INVALID, "premultiply: surfaces must be RGBA8 of equal size");
+    StageScope scope(ctx, SMR_STAGE_INGEST);
+    hipLaunchKernelGGL(k_premult, grid_px((int)dst->w, (int)dst->h), dim3(BLOCK), 0, ctx->stream, view_of(src), view_of(dst),
+                       (ctx->srgb() && mode == 0) ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM, mode, ctx->d_tables);
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_add_premultiplied_alpha(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) { return premult_common(ctx, src, dst, 0); }
+int smr_remove_premultiplied_alpha(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) { return premult_common(ctx, src, dst, 1); }
+
+int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *out) {
+    if (!ctx || !node || !out) return SMR_ERR_INVALID;
+    if (node->fmt != SMR_PX_RGBA8 || node->w != out->width || node->h != out->height)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: node must be RGBA8 %ux%u", out->width, out->height);
+    StageScope scope(ctx, SMR_STAGE_OUTPUT);
+    const int w = (int)out->width, h = (int)out->height;
+    SurfView src = view_of(node);
+    int cw, ch;
+    switch (out->format) {
+    case SMR_FRAME_PLANAR_YUV420: cw = w / 2; ch = h / 2; break;
+    case SMR_FRAME_PLANAR_YUV422: cw = w / 2; ch = h; break;
+    case SMR_FRAME_PLANAR_YUV444: cw = w; ch = h; break;
+    case SMR_FRAME_NV12: cw = w / 2; ch = h / 2; break;
+    default:
+        // output_texture.rs:26-38 only offers 420/422/444 planar, RGBA and NV12 outputs
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: unsupported output frame format %u", out->format);
+    }
+    if (!out->planes[0] || !out->planes[1]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: missing planes");
+    hipLaunchKernelGGL(k_rgba_to_y, grid_px((w + 3) / 4, h), dim3(BLOCK), 0, ctx->stream, src, view_of(out->planes[0]));
+    if (cw > 0 && ch > 0) {
+        if (out->format == SMR_FRAME_NV12) {
+            SurfView uv = view_of(out->planes[1]);
+            hipLaunchKernelGGL(k_rgba_to_chroma<1>, grid_px(cw, ch), dim3(BLOCK), 0, ctx->stream, src, uv, uv, cw, ch);
+        } else {
+            if (!out->planes[2]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: missing V plane");
+            hipLaunchKernelGGL(k_rgba_to_chroma<0>, grid_px(cw, ch), dim3(BLOCK), 0, ctx->stream, src, view_of(out->planes[1]),
+                               view_of(out->planes[2]), cw, ch);
+        }
+    }
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}
+
+int smr_frame_fill_black(smr_ctx *ctx, const smr_frame *out) {
+    if (!ctx || !out || !out->planes[0]) return SMR_ERR_INVALID;
+    // RGBColor::BLACK.to_yuv(), smelter-render/src/scene/types.rs:28-41
+    const float y = (0.0f * 0.85882354f) + (16.0f / 255.0f);
+    const float c = ((0.0f + 0.5f) * 0.8784314f) + (16.0f / 255.0f);
+    const u32 yb = host_unorm8(y), cb = host_unorm8(c);
+    StageScope scope(ctx, SMR_STAGE_OUTPUT);
+    for (int i = 0; i < 3; i++) {
+        const smr_surface *s = out->planes[i];
+        if (!s) continue;
+        u32 b = (i == 0 && (out->format <= SMR_FRAME_PLANAR_YUVJ420 || out->format == SMR_FRAME_NV12)) ? yb : cb;
+        if (out->format > SMR_FRAME_PLANAR_YUVJ420 && out->format != SMR_FRAME_NV12)
+            return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_fill_black: only planar YUV / NV12 frames");
+        int row_bytes = (int)(s->w * bytes_per_px(s->fmt));
+        hipLaunchKernelGGL(k_fill_bytes, grid_px((row_bytes + 3) / 4, (int)s->h), dim3(BLOCK), 0, ctx->stream, view_of(s),
+                           row_bytes, b * 0x01010101u);
+    }
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// smr_convert_dev.h — colour maths shared by the converter kernels and the fused kernels.
+#pragma once
+
+#include "smr_internal.h"
+
+#ifdef __HIPCC__
+
+// planar_yuv_to_rgba.wgsl:45-57: limited->full range (unless J), BT.709 matrix, clamp, unorm8 store.
+__device__ __forceinline__ u32 yuv_to_rgb_px(float y, float u, float v, bool full) {
+    if (!full) {
+        y = clampf((y - (16.0f / 255.0f)) / 0.85882352941f, 0.0f, 1.0f);
+        u = clampf((u - (16.0f / 255.0f)) / 0.87843137254f, 0.0f, 1.0f);
+        v = clampf((v - (16.0f / 255.0f)) / 0.87843137254f, 0.0f, 1.0f);
+    }
+    float r = y + 1.5748f * (v - 0.5f);
+    float g = y - 0.1873f * (u - 0.5f) - 0.4681f * (v - 0.5f);
+    float b = y + 1.8556f * (u - 0.5f);
+    return unorm8(r) | (unorm8(g) << 8) | (unorm8(b) << 16) | 0xff000000u;
+}
+
+// rgba_to_yuv.wgsl:26-54 — one plane component from a (gamma-encoded, raw-byte) RGBA value.
+__device__ __forceinline__ float yuv_component(float4 c, int plane) {
+    float comp;
+    if (plane == 0) {
+        float y = c.x * 0.2126f + c.y * 0.7152f + c.z * 0.0722f;
+        comp = (y * 0.85882352941f) + (16.0f / 255.0f);
+    } else if (plane == 1) {
+        float u = c.x * -0.1146f + c.y * -0.3854f + c.z * 0.5f;
+        comp = ((u + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
+    } else {
+        float v = c.x * 0.5f + c.y * -0.4542f + c.z * -0.0458f;
+        comp = ((v + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
+    }
+    return clampf(comp, 0.0f, 1.0f);
+}
+
+__device__ __forceinline__ float4 unpack_unorm(u32 p) {
+    return make_float4((float)(p & 0xff) / 255.0f, (float)((p >> 8) & 0xff) / 255.0f, (float)((p >> 16) & 0xff) / 255.0f,
+                       (float)(p >> 24) / 255.0f);
+}
+
+#endif

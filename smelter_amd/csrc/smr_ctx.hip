@@ -1,0 +1,400 @@
+// smr_ctx.hip — context, pitched surfaces, frames, transfers, timers.
+//
+// Replaces: WgpuCtx (smelter-render/src/wgpu/ctx.rs:34-107), wgpu texture wrappers
+// (wgpu/texture/*.rs), queue.write_texture (texture/base.rs:61-77) and the padded-row
+// read-back (texture/base.rs:97-118, state/output_texture.rs:85-113).
+#include "smr_internal.h"
+
+#include <cmath>
+
+int smr_fail(smr_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+int smr_check_hip(smr_ctx *ctx, hipError_t e, const char *what) {
+    if (e == hipSuccess) return SMR_OK;
+    int code = (e == hipErrorOutOfMemory) ? SMR_ERR_OOM
+               : (e == hipErrorInvalidValue ? SMR_ERR_INVALID : SMR_ERR_INTERNAL);
+    (void)hipGetLastError();
+    return smr_fail(ctx, code, "%s: %s", what, hipGetErrorString(e));
+}
+
+void *smr_scratch(smr_ctx *ctx, int slot, size_t bytes) {
+    if ((size_t)slot >= ctx->scratch.size()) ctx->scratch.resize(slot + 1);
+    auto &s = ctx->scratch[slot];
+    if (s.bytes >= bytes && s.ptr) return s.ptr;
+    if (s.ptr) {
+        // the old buffer may still be in use by enqueued kernels
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.bytes = 0;
+    }
+    size_t want = (bytes + 4095) & ~(size_t)4095;
+    hipError_t e = hipMalloc(&s.ptr, want);
+    if (e != hipSuccess) {
+        smr_check_hip(ctx, e, "hipMalloc(scratch)");
+        s.ptr = nullptr;
+        return nullptr;
+    }
+    s.bytes = want;
+    return s.ptr;
+}
+
+smr_surface *smr_cached_surface(smr_ctx *ctx, size_t slot, u32 w, u32 h, u32 fmt) {
+    if (slot >= ctx->surf_cache.size()) ctx->surf_cache.resize(slot + 1, nullptr);
+    smr_surface *&s = ctx->surf_cache[slot];
+    if (s && s->w == w && s->h == h && s->fmt == fmt) return s;
+    if (s) {
+        smr_surface_destroy(ctx, s);
+        s = nullptr;
+    }
+    if (smr_surface_create(ctx, w, h, fmt, &s) != SMR_OK) return nullptr;
+    return s;
+}
+
+static hipEvent_t take_event(smr_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+StageScope::StageScope(smr_ctx *c, int s) : ctx(c), stage(s) {
+    if (!ctx->profiling) return;
+    a = take_event(ctx);
+    b = take_event(ctx);
+    if (a) (void)hipEventRecord(a, ctx->stream);
+}
+
+StageScope::~StageScope() {
+    if (!ctx->profiling || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({a, b, stage});
+}
+
+static void drain_profile(smr_ctx *ctx) {
+    for (auto &p : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->stage_ms[p.stage] += ms;
+            ctx->stage_launches[p.stage] += 1;
+        }
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->pending.clear();
+}
+
+static double srgb_to_linear_f64(double c) {
+    // smelter-render/src/wgpu/utils.rs:74-81
+    if (c < 0.04045) return c / 12.92;
+    return pow((c + 0.055) / 1.055, 2.4);
+}
+
+extern "C" {
+
+uint32_t smr_abi_version(void) { return 1; }
+uint32_t smr_sizeof_layout(void) { return (uint32_t)sizeof(smr_layout); }
+
+int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hip_stream, smr_ctx **out) {
+    if (!out) return SMR_ERR_INVALID;
+    *out = nullptr;
+    if (mode > SMR_MODE_CPU_OPTIMIZED) return SMR_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || hip_device < 0 || hip_device >= n) return SMR_ERR_INVALID;
+    if (hipSetDevice(hip_device) != hipSuccess) return SMR_ERR_INTERNAL;
+    smr_ctx *ctx = new smr_ctx();
+    ctx->device = hip_device;
+    ctx->mode = mode;
+    ctx->max_layouts = max_layouts ? max_layouts : SMR_DEFAULT_MAX_LAYOUTS;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return SMR_ERR_INTERNAL;
+        }
+        ctx->own_stream = true;
+    }
+    float tables[256 + 257];
+    for (int i = 0; i < 256; i++) tables[i] = (float)srgb_to_linear_f64((double)i / 255.0);
+    tables[256] = -INFINITY;
+    for (int i = 1; i < 256; i++) tables[256 + i] = (float)srgb_to_linear_f64(((double)i - 0.5) / 255.0);
+    tables[256 + 256] = INFINITY;
+    if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
+        hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        smr_ctx_destroy(ctx);
+        return SMR_ERR_INTERNAL;
+    }
+    *out = ctx;
+    return SMR_OK;
+}
+
+void smr_ctx_destroy(smr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    drain_profile(ctx);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &s : ctx->scratch)
+        if (s.ptr) (void)hipFree(s.ptr);
+    for (auto *s : ctx->surf_cache)
+        if (s) smr_surface_destroy(ctx, s);
+    for (auto &t : ctx->weight_tables)
+        if (t.dev) (void)hipFree(t.dev);
+    for (auto &l : ctx->layout_ring) {
+        if (l.host) (void)hipHostFree(l.host);
+        if (l.dev) (void)hipFree(l.dev);
+        if (l.done) (void)hipEventDestroy(l.done);
+    }
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *smr_last_error(const smr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int smr_sync(smr_ctx *ctx) {
+    if (!ctx) return SMR_ERR_INVALID;
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SMR_OK;
+}
+
+int smr_timer_start(smr_ctx *ctx) {
+    if (!ctx) return SMR_ERR_INVALID;
+    SMR_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return SMR_OK;
+}
+
+int smr_timer_stop(smr_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return SMR_ERR_INVALID;
+    SMR_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    SMR_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+    SMR_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return SMR_OK;
+}
+
+int smr_profile_enable(smr_ctx *ctx, int enable) {
+    if (!ctx) return SMR_ERR_INVALID;
+    if (!enable) {
+        SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        drain_profile(ctx);
+    }
+    ctx->profiling = enable != 0;
+    return SMR_OK;
+}
+
+int smr_profile_read(smr_ctx *ctx, int stage, float *total_ms, uint32_t *launches) {
+    if (!ctx || stage < 0 || stage >= SMR_NUM_STAGES) return SMR_ERR_INVALID;
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_profile(ctx);
+    if (total_ms) *total_ms = ctx->stage_ms[stage];
+    if (launches) *launches = ctx->stage_launches[stage];
+    return SMR_OK;
+}
+
+int smr_profile_reset(smr_ctx *ctx) {
+    if (!ctx) return SMR_ERR_INVALID;
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    drain_profile(ctx);
+    for (int i = 0; i < SMR_NUM_STAGES; i++) {
+        ctx->stage_ms[i] = 0.f;
+        ctx->stage_launches[i] = 0;
+    }
+    return SMR_OK;
+}
+
+// ---------------------------------------------------------------------------- surfaces
+int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, smr_surface **out) {
+    if (!ctx || !out) return SMR_ERR_INVALID;
+    *out = nullptr;
+    u32 bpp = bytes_per_px(format);
+    if (!bpp) return smr_fail(ctx, SMR_ERR_INVALID, "smr_surface_create: unknown pixel format %u", format);
+    // MAX_NODE_RESOLUTION, smelter-render/src/types.rs:146-149
+    if (w == 0 || h == 0 || w > 7682 * 2 || h > 4320 * 2)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_surface_create: bad size %ux%u", w, h);
+    SMR_HIP(ctx, hipSetDevice(ctx->device));
+    smr_surface *s = new smr_surface();
+    s->w = w;
+    s->h = h;
+    s->fmt = format;
+    s->pitch = ((size_t)w * bpp + 255) & ~(size_t)255;
+    s->owned = true;
+    hipError_t e = hipMalloc(&s->ptr, s->pitch * h);
+    if (e != hipSuccess) {
+        delete s;
+        return smr_check_hip(ctx, e, "hipMalloc(surface)");
+    }
+    *out = s;
+    return SMR_OK;
+}
+
+int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
+                     smr_surface **out) {
+    if (!ctx || !out || !dptr) return SMR_ERR_INVALID;
+    u32 bpp = bytes_per_px(format);
+    if (!bpp || w == 0 || h == 0 || pitch < (size_t)w * bpp || (pitch % 4) != 0 || ((uintptr_t)dptr % 16) != 0)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_surface_wrap: bad geometry (pitch %zu, %ux%u fmt %u)", pitch, w, h,
+                        format);
+    smr_surface *s = new smr_surface();
+    s->ptr = dptr;
+    s->pitch = pitch;
+    s->w = w;
+    s->h = h;
+    s->fmt = format;
+    s->owned = false;
+    *out = s;
+    return SMR_OK;
+}
+
+void smr_surface_destroy(smr_ctx *ctx, smr_surface *s) {
+    if (!s) return;
+    if (s->owned && s->ptr) {
+        if (ctx) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        (void)hipFree(s->ptr);
+    }
+    delete s;
+}
+
+int smr_surface_info_get(const smr_surface *s, smr_surface_info *out) {
+    if (!s || !out) return SMR_ERR_INVALID;
+    out->width = s->w;
+    out->height = s->h;
+    out->format = s->fmt;
+    out->owned = s->owned ? 1 : 0;
+    out->pitch = s->pitch;
+    out->dptr = s->ptr;
+    return SMR_OK;
+}
+
+int smr_surface_upload(smr_ctx *ctx, smr_surface *s, const void *host, size_t host_pitch) {
+    if (!ctx || !s || !host) return SMR_ERR_INVALID;
+    size_t row = (size_t)s->w * bytes_per_px(s->fmt);
+    if (host_pitch == 0) host_pitch = row;
+    if (host_pitch < row) return smr_fail(ctx, SMR_ERR_INVALID, "smr_surface_upload: host pitch too small");
+    SMR_HIP(ctx, hipMemcpy2DAsync(s->ptr, s->pitch, host, host_pitch, row, s->h, hipMemcpyHostToDevice, ctx->stream));
+    // the host buffer is pageable caller memory: make the call safe to return from
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SMR_OK;
+}
+
+int smr_surface_download(smr_ctx *ctx, const smr_surface *s, void *host, size_t host_pitch) {
+    if (!ctx || !s || !host) return SMR_ERR_INVALID;
+    size_t row = (size_t)s->w * bytes_per_px(s->fmt);
+    if (host_pitch == 0) host_pitch = row;
+    if (host_pitch < row) return smr_fail(ctx, SMR_ERR_INVALID, "smr_surface_download: host pitch too small");
+    SMR_HIP(ctx, hipMemcpy2DAsync(host, host_pitch, s->ptr, s->pitch, row, s->h, hipMemcpyDeviceToHost, ctx->stream));
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SMR_OK;
+}
+
+int smr_surface_clear(smr_ctx *ctx, smr_surface *s) {
+    if (!ctx || !s) return SMR_ERR_INVALID;
+    SMR_HIP(ctx, hipMemsetAsync(s->ptr, 0, s->pitch * s->h, ctx->stream));
+    return SMR_OK;
+}
+
+// ------------------------------------------------------------------------------ frames
+// plane geometry per FrameData variant (wgpu/texture/planar_yuv.rs:65-84, nv12.rs,
+// interleaved_yuv422.rs, bgra_linear.rs, argb_linear.rs)
+static int plane_geometry(u32 format, u32 w, u32 h, u32 pw[3], u32 ph[3], u32 pf[3]) {
+    for (int i = 0; i < 3; i++) pw[i] = ph[i] = 0, pf[i] = SMR_PX_R8;
+    switch (format) {
+    case SMR_FRAME_PLANAR_YUV420:
+    case SMR_FRAME_PLANAR_YUVJ420:
+        pw[0] = w; ph[0] = h; pw[1] = pw[2] = w / 2; ph[1] = ph[2] = h / 2; return 3;
+    case SMR_FRAME_PLANAR_YUV422:
+        pw[0] = w; ph[0] = h; pw[1] = pw[2] = w / 2; ph[1] = ph[2] = h; return 3;
+    case SMR_FRAME_PLANAR_YUV444:
+        pw[0] = w; ph[0] = h; pw[1] = pw[2] = w; ph[1] = ph[2] = h; return 3;
+    case SMR_FRAME_NV12:
+        pw[0] = w; ph[0] = h; pw[1] = w / 2; ph[1] = h / 2; pf[1] = SMR_PX_RG8; return 2;
+    case SMR_FRAME_UYVY422:
+    case SMR_FRAME_YUYV422:
+        pw[0] = w / 2; ph[0] = h; pf[0] = SMR_PX_RGBA8; return 1;
+    case SMR_FRAME_BGRA:
+    case SMR_FRAME_ARGB:
+    case SMR_FRAME_RGBA:
+        pw[0] = w; ph[0] = h; pf[0] = SMR_PX_RGBA8; return 1;
+    default: return 0;
+    }
+}
+
+int smr_frame_create(smr_ctx *ctx, uint32_t format, uint32_t w, uint32_t h, smr_frame *out) {
+    if (!ctx || !out) return SMR_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    u32 pw[3], ph[3], pf[3];
+    int n = plane_geometry(format, w, h, pw, ph, pf);
+    if (n == 0) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_create: unknown frame format %u", format);
+    out->format = format;
+    out->width = w;
+    out->height = h;
+    for (int i = 0; i < n; i++) {
+        // chroma planes of 1-pixel-wide/high frames would be empty: keep a 1x1 plane so kernels stay valid
+        int rc = smr_surface_create(ctx, pw[i] ? pw[i] : 1, ph[i] ? ph[i] : 1, pf[i], &out->planes[i]);
+        if (rc != SMR_OK) {
+            smr_frame_destroy(ctx, out);
+            return rc;
+        }
+    }
+    return SMR_OK;
+}
+
+void smr_frame_destroy(smr_ctx *ctx, smr_frame *f) {
+    if (!f) return;
+    for (int i = 0; i < 3; i++) {
+        if (f->planes[i]) smr_surface_destroy(ctx, f->planes[i]);
+        f->planes[i] = nullptr;
+    }
+}
+
+int smr_frame_upload(smr_ctx *ctx, const smr_frame *f, const void *const host_planes[3]) {
+    if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
+    u32 pw[3], ph[3], pf[3];
+    int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);
+    for (int i = 0; i < n; i++) {
+        if (!f->planes[i] || !host_planes[i]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_upload: missing plane %d", i);
+        if (pw[i] == 0 || ph[i] == 0) continue;
+        const smr_surface *s = f->planes[i];
+        size_t row = (size_t)pw[i] * bytes_per_px(pf[i]);
+        SMR_HIP(ctx, hipMemcpy2DAsync(s->ptr, s->pitch, host_planes[i], row, row, ph[i], hipMemcpyHostToDevice, ctx->stream));
+    }
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SMR_OK;
+}
+
+int smr_frame_download(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]) {
+    if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
+    u32 pw[3], ph[3], pf[3];
+    int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);
+    for (int i = 0; i < n; i++) {
+        if (!f->planes[i] || !host_planes[i]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_download: missing plane %d", i);
+        if (pw[i] == 0 || ph[i] == 0) continue;
+        const smr_surface *s = f->planes[i];
+        size_t row = (size_t)pw[i] * bytes_per_px(pf[i]);
+        SMR_HIP(ctx, hipMemcpy2DAsync(host_planes[i], row, s->ptr, s->pitch, row, ph[i], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SMR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+// smr_internal.h — shared host/device definitions of libsmr_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "smr.h"
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+
+#define SMR_NUM_STAGES 8
+enum {
+    SMR_STAGE_INGEST = 0,
+    SMR_STAGE_RESAMPLE = 1,
+    SMR_STAGE_LAYOUT = 2,
+    SMR_STAGE_OUTPUT = 3,
+    SMR_STAGE_FUSED_INGEST = 4,
+    SMR_STAGE_FUSED_COMPOSE = 5,
+};
+
+struct smr_surface {
+    void *ptr = nullptr;
+    size_t pitch = 0;
+    u32 w = 0, h = 0, fmt = 0;
+    bool owned = false;
+};
+
+// Device-side view of a surface.
+struct SurfView {
+    u8 *ptr;
+    u32 pitch;
+    int w, h;
+};
+
+// one pinned-host + device staging slot of the per-call layout parameter ring
+struct LayoutSlot {
+    void *host = nullptr;
+    void *dev = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+struct StagePending {
+    hipEvent_t a, b;
+    int stage;
+};
+
+struct smr_ctx {
+    int device = 0;
+    u32 mode = 0;
+    u32 max_layouts = SMR_DEFAULT_MAX_LAYOUTS;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // device tables: [0..255] sRGB decode, [256..512] encode thresholds (257 entries)
+    float *d_tables = nullptr;
+
+    // timers
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool profiling = false;
+    std::vector<StagePending> pending;
+    std::vector<hipEvent_t> event_pool;
+    float stage_ms[SMR_NUM_STAGES] = {0};
+    u32 stage_launches[SMR_NUM_STAGES] = {0};
+
+    // per-call layout parameters travel through a ring of pinned staging slots
+    std::vector<LayoutSlot> layout_ring;
+    size_t layout_ring_next = 0;
+    // scratch owned by the ctx (resampler intermediates, fused tiles)
+    struct Scratch { void *ptr = nullptr; size_t bytes = 0; };
+    std::vector<Scratch> scratch;  // indexed slots, grown on demand
+
+    // size-keyed reusable surfaces (NodeTexture::ensure_size, state/node_texture.rs:22-42)
+    std::vector<smr_surface *> surf_cache;
+
+    // device-resident Lanczos weight tables, keyed by (scale, offset, n); see smr_fused.hip
+    struct WeightTable {
+        float scale = 0.f, offset = 0.f;
+        int n = 0, taps = 0;
+        void *dev = nullptr;  // int first[n]; float wsum[n]; float w[n * taps]
+        size_t bytes = 0;
+        uint64_t last_use = 0;
+    };
+    std::vector<WeightTable> weight_tables;
+    uint64_t weight_clock = 0;
+    int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
+
+    bool srgb() const { return mode == SMR_MODE_GPU_OPTIMIZED; }
+};
+
+// ctx-owned surface for `slot`, (re)allocated when the requested geometry changes; nullptr on error
+smr_surface *smr_cached_surface(smr_ctx *ctx, size_t slot, u32 w, u32 h, u32 fmt);
+
+int smr_fail(smr_ctx *ctx, int code, const char *fmt, ...);
+int smr_check_hip(smr_ctx *ctx, hipError_t e, const char *what);
+void *smr_scratch(smr_ctx *ctx, int slot, size_t bytes);  // nullptr on OOM (error set)
+
+// stage-timing helper: brackets kernel launches of one class with HIP events when profiling.
+struct StageScope {
+    smr_ctx *ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(smr_ctx *c, int s);
+    ~StageScope();
+};
+
+#define SMR_HIP(ctx, call)                                                    \
+    do {                                                                      \
+        hipError_t e__ = (call);                                              \
+        if (e__ != hipSuccess) return smr_check_hip((ctx), e__, #call);       \
+    } while (0)
+
+static inline SurfView view_of(const smr_surface *s) {
+    SurfView v;
+    v.ptr = (u8 *)s->ptr;
+    v.pitch = (u32)s->pitch;
+    v.w = (int)s->w;
+    v.h = (int)s->h;
+    return v;
+}
+
+static inline u32 bytes_per_px(u32 fmt) {
+    switch (fmt) {
+    case SMR_PX_RGBA8: return 4;
+    case SMR_PX_RGBA16F: return 8;
+    case SMR_PX_R8: return 1;
+    case SMR_PX_RG8: return 2;
+    default: return 0;
+    }
+}
+
+// ------------------------------------------------------------------ device helpers
+#ifdef __HIPCC__
+
+// Pixel interpretation used by filter kernels (same numbering as the oracle).
+enum { PXI_RGBA8_SRGB = 0, PXI_RGBA8_UNORM = 1, PXI_RGBA16F = 2 };
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) {
+    // WGSL clamp: min(max(x, lo), hi); NaN -> lo
+    if (!(x > lo)) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+__device__ __forceinline__ u32 unorm8(float x) {
+    x = clampf(x, 0.0f, 1.0f);
+    return (u32)(int)(x * 255.0f + 0.5f);
+}
+
+// sRGB encode as the monotone step function u8 = #{i : thr[i] <= x}; thr has 257 entries
+// (thr[0] = -inf, thr[256] = +inf).  A fast estimate followed by an exact fix-up.
+__device__ __forceinline__ u32 srgb_encode8(float x, const float *__restrict__ thr) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 1.0f) return 255u;
+    float e = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(x, 0.41666666f) - 0.055f;
+    int c = (int)(e * 255.0f + 0.5f);
+    c = clampi(c, 0, 255);
+    while (thr[c] > x) c--;
+    while (thr[c + 1] <= x) c++;
+    return (u32)c;
+}
+
+__device__ __forceinline__ float subtexel(float f) { return floorf(f * 256.0f + 0.5f) / 256.0f; }
+
+__device__ __forceinline__ float4 load_texel(const SurfView &s, int pxi, int x, int y, const float *__restrict__ dec) {
+    float4 o;
+    if (pxi == PXI_RGBA16F) {
+        const uint2 raw = *(const uint2 *)(s.ptr + (size_t)y * s.pitch + (size_t)x * 8);
+        __half2 lo = *(const __half2 *)&raw.x, hi = *(const __half2 *)&raw.y;
+        float2 a = __half22float2(lo), b = __half22float2(hi);
+        o = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+        const u32 raw = *(const u32 *)(s.ptr + (size_t)y * s.pitch + (size_t)x * 4);
+        u32 r = raw & 0xff, g = (raw >> 8) & 0xff, b = (raw >> 16) & 0xff, a = raw >> 24;
+        if (pxi == PXI_RGBA8_SRGB) {
+            o.x = dec[r]; o.y = dec[g]; o.z = dec[b];
+        } else {
+            o.x = (float)r / 255.0f; o.y = (float)g / 255.0f; o.z = (float)b / 255.0f;
+        }
+        o.w = (float)a / 255.0f;
+    }
+    return o;
+}
+
+__device__ __forceinline__ void store_texel(const SurfView &s, int pxi, int x, int y, float4 v,
+                                            const float *__restrict__ thr) {
+    if (pxi == PXI_RGBA16F) {
+        __half2 lo = __floats2half2_rn(v.x, v.y), hi = __floats2half2_rn(v.z, v.w);
+        uint2 raw;
+        raw.x = *(const u32 *)&lo;
+        raw.y = *(const u32 *)&hi;
+        *(uint2 *)(s.ptr + (size_t)y * s.pitch + (size_t)x * 8) = raw;
+    } else {
+        u32 r, g, b;
+        if (pxi == PXI_RGBA8_SRGB) {
+            r = srgb_encode8(v.x, thr); g = srgb_encode8(v.y, thr); b = srgb_encode8(v.z, thr);
+        } else {
+            r = unorm8(v.x); g = unorm8(v.y); b = unorm8(v.z);
+        }
+        u32 a = unorm8(v.w);
+        *(u32 *)(s.ptr + (size_t)y * s.pitch + (size_t)x * 4) = r | (g << 8) | (b << 16) | (a << 24);
+    }
+}
+
+// textureSample of one channel of an 8-bit plane (comps interleaved channels), bilinear,
+// clamp-to-edge, 8-bit sub-texel weights.  Returns the unorm value.
+__device__ __forceinline__ float sample_plane_bilinear(const SurfView &p, int comps, int c, float u, float v) {
+    float sx = u * (float)p.w - 0.5f;
+    float sy = v * (float)p.h - 0.5f;
+    float fx0 = floorf(sx), fy0 = floorf(sy);
+    float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
+    int x0 = clampi((int)fx0, 0, p.w - 1), x1 = clampi((int)fx0 + 1, 0, p.w - 1);
+    int y0 = clampi((int)fy0, 0, p.h - 1), y1 = clampi((int)fy0 + 1, 0, p.h - 1);
+    const u8 *r0 = p.ptr + (size_t)y0 * p.pitch, *r1 = p.ptr + (size_t)y1 * p.pitch;
+    float a = (float)r0[x0 * comps + c] / 255.0f;
+    float b = (float)r0[x1 * comps + c] / 255.0f;
+    float cc = (float)r1[x0 * comps + c] / 255.0f;
+    float d = (float)r1[x1 * comps + c] / 255.0f;
+    float top = a * (1.0f - fx) + b * fx;
+    float bot = cc * (1.0f - fx) + d * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+// textureSample of an RGBA8 (or RGBA16F) surface, bilinear + clamp, texels decoded per `pxi`.
+__device__ __forceinline__ float4 sample_rgba_bilinear(const SurfView &s, int pxi, float u, float v,
+                                                       const float *__restrict__ dec) {
+    float sx = u * (float)s.w - 0.5f, sy = v * (float)s.h - 0.5f;
+    float fx0 = floorf(sx), fy0 = floorf(sy);
+    float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
+    int x0 = clampi((int)fx0, 0, s.w - 1), x1 = clampi((int)fx0 + 1, 0, s.w - 1);
+    int y0 = clampi((int)fy0, 0, s.h - 1), y1 = clampi((int)fy0 + 1, 0, s.h - 1);
+    float4 a = load_texel(s, pxi, x0, y0, dec), b = load_texel(s, pxi, x1, y0, dec);
+    float4 c = load_texel(s, pxi, x0, y1, dec), d = load_texel(s, pxi, x1, y1, dec);
+    float4 o;
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    o.x = (a.x * gx + b.x * fx) * gy + (c.x * gx + d.x * fx) * fy;
+    o.y = (a.y * gx + b.y * fx) * gy + (c.y * gx + d.y * fx) * fy;
+    o.z = (a.z * gx + b.z * fx) * gy + (c.z * gx + d.z * fx) * fy;
+    o.w = (a.w * gx + b.w * fx) * gy + (c.w * gx + d.w * fx) * fy;
+    return o;
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,182 @@
+// smr_layout.hip — the layout compositor.
+//
+// Replaces LayoutShader::render (smelter-render/src/transformations/layout/shader.rs:93-167),
+// ParamsBindGroups::update (layout/params.rs:169-334) and apply_layouts.wgsl:127-377.
+//
+// The reference clears the target and issues one full-pipeline draw per layout, each a
+// read-modify-write of the RGBA8 target.  Here ALL layouts are applied in ONE launch:
+// every 32x8-pixel workgroup bins the layout list against its tile (bit mask in LDS),
+// then each thread walks the surviving layouts back to front with the running colour
+// held in a register.  The colour is re-quantised to RGBA8 (sRGB-encoded in
+// GpuOptimized mode) after every layout, exactly where the reference's render-target
+// store would quantise it, so results are identical to N separate draws while the
+// target is written once and never read.
+#include "smr_layout_dev.h"
+
+namespace {
+
+__global__ __launch_bounds__(LAYOUT_TILE_W *LAYOUT_TILE_H) void k_apply_layouts(SurfView target, const DevLayout *__restrict__ layouts,
+                                                                               const smr_mask *__restrict__ masks, int n,
+                                                                               int srgb, const float *__restrict__ tables) {
+    __shared__ u32 s_bits[MAX_LAYOUT_WORDS];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * LAYOUT_TILE_W, ty0 = blockIdx.y * LAYOUT_TILE_H;
+    bin_layouts(s_bits, layouts, n, tx0, ty0, tx0 + LAYOUT_TILE_W, ty0 + LAYOUT_TILE_H, tid, LAYOUT_TILE_W * LAYOUT_TILE_H);
+
+    const int px = tx0 + (tid % LAYOUT_TILE_W), py = ty0 + (tid / LAYOUT_TILE_W);
+    if (px >= target.w || py >= target.h) return;
+
+    const float *dec = tables, *thr = tables + 256;
+    u32 acc = 0;  // RGBA8 of the cleared target (wgpu::Color::TRANSPARENT, shader.rs:135)
+    const int words = (n + 31) >> 5;
+    for (int wi = 0; wi < words; wi++) {
+        u32 bits = s_bits[wi];
+        while (bits) {
+            const int li = (wi << 5) + __builtin_ctz(bits);
+            bits &= bits - 1;
+            acc = composite_layout(acc, layouts[li], masks, px, py, srgb, dec, thr);
+        }
+    }
+    *(u32 *)(target.ptr + (size_t)py * target.pitch + (size_t)px * 4) = acc;
+}
+
+}  // namespace
+
+// Packs the POD layout list into the compact device form (rotation, quad and bounding box
+// precomputed on the host in f32, as the vertex stage does per draw: apply_layouts.wgsl:127-157).
+int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfView *src_views, const int *src_kind,
+                     u32 n_sources, int out_w, int out_h, size_t extra_bytes, PackedLayouts *out) {
+    if (n > ctx->max_layouts) n = ctx->max_layouts;  // params.rs:176-182: extra layouts are skipped
+    if (n > MAX_LAYOUT_WORDS * 32) n = MAX_LAYOUT_WORDS * 32;
+    size_t total_masks = 0;
+    for (u32 i = 0; i < n; i++) total_masks += layouts[i].masks_len > SMR_MAX_MASKS ? SMR_MAX_MASKS : layouts[i].masks_len;
+    const size_t lay_bytes = ((size_t)n * sizeof(DevLayout) + 255) & ~(size_t)255;
+    const size_t mask_bytes = (total_masks * sizeof(smr_mask) + 255) & ~(size_t)255;
+    const size_t bytes = lay_bytes + mask_bytes + extra_bytes + 256;
+
+    // ring of pinned staging slots; a slot is reusable once the kernel that read its device copy is done
+    if (ctx->layout_ring.empty()) ctx->layout_ring.resize(8);
+    LayoutSlot &slot = ctx->layout_ring[ctx->layout_ring_next];
+    ctx->layout_ring_next = (ctx->layout_ring_next + 1) % ctx->layout_ring.size();
+    if (slot.busy) {
+        SMR_HIP(ctx, hipEventSynchronize(slot.done));
+        slot.busy = false;
+    }
+    if (slot.bytes < bytes) {
+        if (slot.host) (void)hipHostFree(slot.host);
+        if (slot.dev) (void)hipFree(slot.dev);
+        slot.host = nullptr;
+        slot.dev = nullptr;
+        slot.bytes = 0;
+        size_t want = (bytes + 65535) & ~(size_t)65535;
+        SMR_HIP(ctx, hipHostMalloc(&slot.host, want, hipHostMallocDefault));
+        SMR_HIP(ctx, hipMalloc(&slot.dev, want));
+        slot.bytes = want;
+    }
+    if (!slot.done) SMR_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+
+    DevLayout *hl = (DevLayout *)slot.host;
+    smr_mask *hm = (smr_mask *)((u8 *)slot.host + lay_bytes);
+    const float DEG = 0.017453292519943295f;
+    u32 mo = 0;
+    for (u32 i = 0; i < n; i++) {
+        const smr_layout &L = layouts[i];
+        DevLayout &D = hl[i];
+        memset(&D, 0, sizeof(D));
+        D.top = L.top; D.left = L.left; D.width = L.width; D.height = L.height;
+        for (int k = 0; k < 4; k++) {
+            D.radius[k] = L.border_radius[k];
+            D.color[k] = L.color[k];
+            D.border_color[k] = L.border_color[k];
+            D.crop[k] = L.crop[k];
+        }
+        D.type = L.type;
+        D.border_width = L.border_width;
+        D.blur = L.blur_radius;
+        D.masks_off = mo;
+        D.masks_len = L.masks_len > SMR_MAX_MASKS ? SMR_MAX_MASKS : L.masks_len;
+        for (u32 m = 0; m < D.masks_len; m++) hm[mo++] = L.masks[m];
+        float qleft = L.left, qtop = L.top, qw = L.width, qh = L.height;
+        if (L.type == 2) {  // box shadow quad grown by blur on each side (apply_layouts.wgsl:216-229)
+            qleft = L.left - L.blur_radius; qtop = L.top - L.blur_radius;
+            qw = L.width + 2.0f * L.blur_radius; qh = L.height + 2.0f * L.blur_radius;
+        }
+        D.qw = qw; D.qh = qh;
+        D.cx = qleft + qw / 2.0f; D.cy = qtop + qh / 2.0f;
+        float ang = L.rotation_degrees * DEG;
+        D.cs = cosf(ang); D.sn = sinf(ang);
+        D.src_kind = 0;
+        D.tex_w = 1; D.tex_h = 1;
+        D.src_index = -1;
+        if (L.type == 0 && L.source_index < n_sources && src_kind[L.source_index] != 0) {
+            D.src = src_views[L.source_index];
+            D.src_kind = src_kind[L.source_index];
+            D.tex_w = D.src.w; D.tex_h = D.src.h;
+            D.src_index = (int)L.source_index;
+        }
+        if (!(qw > 0.0f) || !(qh > 0.0f) || L.type > 2) {
+            D.bx0 = D.by0 = 0; D.bx1 = D.by1 = -1;  // never binned
+        } else {
+            float ex = fabsf(D.cs) * qw / 2.0f + fabsf(D.sn) * qh / 2.0f;
+            float ey = fabsf(D.sn) * qw / 2.0f + fabsf(D.cs) * qh / 2.0f;
+            auto clampi_h = [](float v, int lo, int hi) { return v < (float)lo ? lo : (v > (float)hi ? hi : (int)v); };
+            D.bx0 = clampi_h(floorf(D.cx - ex - 1.0f), 0, out_w);
+            D.bx1 = clampi_h(ceilf(D.cx + ex + 1.0f), 0, out_w);
+            D.by0 = clampi_h(floorf(D.cy - ey - 1.0f), 0, out_h);
+            D.by1 = clampi_h(ceilf(D.cy + ey + 1.0f), 0, out_h);
+        }
+    }
+    out->layouts = (const DevLayout *)slot.dev;
+    out->masks = (const smr_mask *)((u8 *)slot.dev + lay_bytes);
+    out->host_layouts = hl;
+    out->n = (int)n;
+    out->slot = &slot;
+    out->extra_host = (u8 *)slot.host + lay_bytes + mask_bytes;
+    out->extra_dev = (u8 *)slot.dev + lay_bytes + mask_bytes;
+    out->copy_bytes = lay_bytes + mask_bytes + extra_bytes;
+    return SMR_OK;
+}
+
+// host -> device copy of the packed slot (after the caller filled the extra region)
+int smr_pack_commit(smr_ctx *ctx, PackedLayouts *p) {
+    SMR_HIP(ctx, hipMemcpyAsync(p->slot->dev, p->slot->host, p->copy_bytes, hipMemcpyHostToDevice, ctx->stream));
+    return SMR_OK;
+}
+
+int smr_pack_done(smr_ctx *ctx, PackedLayouts *p) {
+    SMR_HIP(ctx, hipEventRecord(p->slot->done, ctx->stream));
+    p->slot->busy = true;
+    return SMR_OK;
+}
+
+extern "C" int smr_apply_layouts(smr_ctx *ctx, smr_surface *target, const smr_layout *layouts, uint32_t n,
+                                 const smr_surface *const *sources, uint32_t n_sources) {
+    if (!ctx || !target || (n && !layouts)) return SMR_ERR_INVALID;
+    if (target->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_apply_layouts: target must be RGBA8");
+    std::vector<SurfView> views(n_sources ? n_sources : 1);
+    std::vector<int> kinds(n_sources ? n_sources : 1, 0);
+    for (u32 i = 0; i < n_sources; i++) {
+        if (sources && sources[i]) {
+            if (sources[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_apply_layouts: source %u is not RGBA8", i);
+            views[i] = view_of(sources[i]);
+            kinds[i] = 1;
+        }
+    }
+    PackedLayouts packed;
+    int rc = smr_pack_layouts(ctx, layouts, n, views.data(), kinds.data(), n_sources, (int)target->w, (int)target->h, 0, &packed);
+    if (rc != SMR_OK) return rc;
+    rc = smr_pack_commit(ctx, &packed);
+    if (rc != SMR_OK) return rc;
+    rc = smr_launch_apply_layouts(ctx, target, &packed);
+    if (rc != SMR_OK) return rc;
+    return smr_pack_done(ctx, &packed);
+}
+
+int smr_launch_apply_layouts(smr_ctx *ctx, smr_surface *target, const PackedLayouts *p) {
+    StageScope scope(ctx, SMR_STAGE_LAYOUT);
+    dim3 grid((target->w + LAYOUT_TILE_W - 1) / LAYOUT_TILE_W, (target->h + LAYOUT_TILE_H - 1) / LAYOUT_TILE_H, 1);
+    hipLaunchKernelGGL(k_apply_layouts, grid, dim3(LAYOUT_TILE_W * LAYOUT_TILE_H), 0, ctx->stream, view_of(target), p->layouts,
+                       p->masks, p->n, ctx->srgb() ? 1 : 0, ctx->d_tables);
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}

@@ -1,0 +1,186 @@
+// smr_layout_dev.h — device-side layout evaluation shared by the general compositor
+// (smr_layout.hip) and the fused compose+output kernel (smr_fused.hip).
+//
+// Mirrors apply_layouts.wgsl:127-377 one-for-one; see the oracle (oracle/smr_oracle.c,
+// layout_fragment / orc_apply_layouts) for the same maths on the CPU.
+#pragma once
+
+#include "smr_internal.h"
+
+constexpr int LAYOUT_TILE_W = 32;
+constexpr int LAYOUT_TILE_H = 8;
+constexpr int MAX_LAYOUT_WORDS = 32;  // up to 1024 layouts per node
+
+// Compact per-layout record consumed by the kernels (wave-uniform: read through scalar loads).
+struct DevLayout {
+    float top, left, width, height;
+    float cs, sn;         // cos / sin of rotation_degrees (vertex stage, wgsl:99-110)
+    float radius[4];      // tl, tr, br, bl
+    float color[4];
+    float border_color[4];
+    float crop[4];        // top, left, width, height
+    float border_width, blur;
+    float qw, qh, cx, cy; // rasterised quad: size and centre (shadow quads are grown by blur)
+    u32 type;
+    u32 masks_off, masks_len;
+    int bx0, by0, bx1, by1;  // pixel bounding box [x0,x1) x [y0,y1)
+    int src_kind;         // 0 none (1x1 transparent), 1 RGBA8 surface, 2 tile produced by the fused resampler
+    int src_index;
+    int tex_w, tex_h;
+    SurfView src;
+};
+
+struct PackedLayouts {
+    const DevLayout *layouts = nullptr;  // device
+    const smr_mask *masks = nullptr;     // device
+    DevLayout *host_layouts = nullptr;   // pinned host copy (valid until the slot is reused)
+    int n = 0;
+    LayoutSlot *slot = nullptr;
+    void *extra_host = nullptr;  // caller-defined parameter block riding in the same slot
+    void *extra_dev = nullptr;
+    size_t copy_bytes = 0;
+};
+
+int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfView *src_views, const int *src_kind,
+                     u32 n_sources, int out_w, int out_h, size_t extra_bytes, PackedLayouts *out);
+int smr_pack_commit(smr_ctx *ctx, PackedLayouts *p);
+// launches the general compositor kernel over a committed parameter pack
+int smr_launch_apply_layouts(smr_ctx *ctx, smr_surface *target, const PackedLayouts *p);
+int smr_pack_done(smr_ctx *ctx, PackedLayouts *p);
+
+#ifdef __HIPCC__
+
+// Cooperative binning: set bit i when layout i's bounding box touches the tile.
+__device__ __forceinline__ void bin_layouts(u32 *s_bits, const DevLayout *__restrict__ layouts, int n, int x0, int y0, int x1,
+                                            int y1, int tid, int nthreads) {
+    if (tid < MAX_LAYOUT_WORDS) s_bits[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += nthreads) {
+        const DevLayout &L = layouts[i];
+        if (L.bx0 < x1 && L.bx1 > x0 && L.by0 < y1 && L.by1 > y0) atomicOr(&s_bits[i >> 5], 1u << (i & 31));
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
+    if (e0 == e1) return x >= e1 ? 1.0f : 0.0f;  // degenerate edge (blur 0): step
+    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+// roundedRectSDF, apply_layouts.wgsl:246-256
+__device__ __forceinline__ float rounded_rect_sdf(float dx, float dy, float sw, float sh, const float *radius) {
+    float hx = sw / 2.0f, hy = sh / 2.0f;
+    float rx, ry;
+    if (dx < 0.0f) { rx = radius[0]; ry = radius[3]; } else { rx = radius[1]; ry = radius[2]; }
+    float r = (dy < 0.0f) ? ry : rx;
+    float qx = fabsf(dx) - hx + r, qy = fabsf(dy) - hy + r;
+    float mx = qx > 0.0f ? qx : 0.0f, my = qy > 0.0f ? qy : 0.0f;
+    float m = qx > qy ? qx : qy;
+    float inner = m < 0.0f ? m : 0.0f;
+    return inner + sqrtf(mx * mx + my * my) - r;
+}
+
+// Is pixel (px,py) inside layout L's quad?  Outputs the interpolated varyings.
+__device__ __forceinline__ bool layout_covers(const DevLayout &L, int px, int py, float &fx, float &fy, float &lx, float &ly) {
+    fx = (float)px + 0.5f;
+    fy = (float)py + 0.5f;
+    float dx = fx - L.cx, dy = -(fy - L.cy);
+    lx = L.cs * dx + L.sn * dy;
+    ly = -L.sn * dx + L.cs * dy;
+    if (!(lx >= -L.qw / 2.0f && lx < L.qw / 2.0f)) return false;
+    if (!(-ly >= -L.qh / 2.0f && -ly < L.qh / 2.0f)) return false;
+    return true;
+}
+
+// Fragment stage (apply_layouts.wgsl:258-377).  `sample` is fetched by the caller for texture layouts.
+__device__ __forceinline__ float4 layout_fragment(const DevLayout &L, const smr_mask *__restrict__ masks, float fx, float fy,
+                                                  float lx, float ly, float4 sample) {
+    float mask_alpha = 1.0f;
+    for (u32 i = 0; i < L.masks_len; i++) {
+        const smr_mask &m = masks[L.masks_off + i];
+        float dx = m.left + (m.width / 2.0f) - fx;
+        float dy = m.top + (m.height / 2.0f) - fy;
+        float dist = rounded_rect_sdf(dx, dy, m.width, m.height, m.radius);
+        mask_alpha = mask_alpha * smoothstepf(-0.5f, 0.5f, -dist);
+    }
+    float edge_distance = -rounded_rect_sdf(lx, ly, L.width, L.height, L.radius);
+    const float bw = L.border_width;
+    float4 o;
+    if (L.type == 0) {
+        if (bw < 1.0f) {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            o = make_float4(sample.x * ca * mask_alpha, sample.y * ca * mask_alpha, sample.z * ca * mask_alpha,
+                            sample.w * ca * mask_alpha);
+        } else if (mask_alpha < 0.01f) {
+            o = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (edge_distance > bw / 2.0f) {
+            float ba = smoothstepf(bw - 0.5f, bw + 0.5f, edge_distance);
+            float ia = 1.0f - ba;
+            o = make_float4((L.border_color[0] * ia + sample.x * ba) * mask_alpha, (L.border_color[1] * ia + sample.y * ba) * mask_alpha,
+                            (L.border_color[2] * ia + sample.z * ba) * mask_alpha, (L.border_color[3] * ia + sample.w * ba) * mask_alpha);
+        } else {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            o = make_float4(L.border_color[0] * ca * mask_alpha, L.border_color[1] * ca * mask_alpha,
+                            L.border_color[2] * ca * mask_alpha, L.border_color[3] * ca * mask_alpha);
+        }
+    } else if (L.type == 1) {
+        if (bw < 1.0f) {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            o = make_float4(L.color[0] * ca * mask_alpha, L.color[1] * ca * mask_alpha, L.color[2] * ca * mask_alpha,
+                            L.color[3] * ca * mask_alpha);
+        } else if (edge_distance > bw / 2.0f) {
+            float ba = smoothstepf(bw, bw + 1.0f, edge_distance);
+            float ia = 1.0f - ba;
+            o = make_float4((L.border_color[0] * ia + L.color[0] * ba) * mask_alpha, (L.border_color[1] * ia + L.color[1] * ba) * mask_alpha,
+                            (L.border_color[2] * ia + L.color[2] * ba) * mask_alpha, (L.border_color[3] * ia + L.color[3] * ba) * mask_alpha);
+        } else {
+            float ca = smoothstepf(-0.5f, 0.5f, edge_distance);
+            o = make_float4(L.border_color[0] * ca * mask_alpha, L.border_color[1] * ca * mask_alpha,
+                            L.border_color[2] * ca * mask_alpha, L.border_color[3] * ca * mask_alpha);
+        }
+    } else {
+        float ba = smoothstepf(-L.blur / 2.0f, L.blur / 2.0f, edge_distance) * mask_alpha;
+        o = make_float4(L.color[0] * ba, L.color[1] * ba, L.color[2] * ba, L.color[3] * ba);
+    }
+    return o;
+}
+
+// PREMULTIPLIED_ALPHA_BLENDING (wgpu/common_pipeline.rs:125) onto an RGBA8 target texel,
+// re-encoded the way the render-target store does (sRGB in GpuOptimized mode).
+__device__ __forceinline__ u32 blend_store(u32 acc, float4 frag, int srgb, const float *__restrict__ dec,
+                                           const float *__restrict__ thr) {
+    if (frag.x == 0.0f && frag.y == 0.0f && frag.z == 0.0f && frag.w == 0.0f) return acc;  // dst*1 + 0: bytes unchanged
+    const float inv = 1.0f - frag.w;
+    const u32 r8 = acc & 0xff, g8 = (acc >> 8) & 0xff, b8 = (acc >> 16) & 0xff, a8 = acc >> 24;
+    u32 r, g, b;
+    if (srgb) {
+        r = srgb_encode8(frag.x + dec[r8] * inv, thr);
+        g = srgb_encode8(frag.y + dec[g8] * inv, thr);
+        b = srgb_encode8(frag.z + dec[b8] * inv, thr);
+    } else {
+        r = unorm8(frag.x + ((float)r8 / 255.0f) * inv);
+        g = unorm8(frag.y + ((float)g8 / 255.0f) * inv);
+        b = unorm8(frag.z + ((float)b8 / 255.0f) * inv);
+    }
+    const u32 a = unorm8(frag.w + ((float)a8 / 255.0f) * inv);
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+// One layout applied to one pixel: coverage, varyings, texture fetch, fragment, blend.
+__device__ __forceinline__ u32 composite_layout(u32 acc, const DevLayout &L, const smr_mask *__restrict__ masks, int px, int py,
+                                                int srgb, const float *__restrict__ dec, const float *__restrict__ thr) {
+    float fx, fy, lx, ly;
+    if (!layout_covers(L, px, py, fx, fy, lx, ly)) return acc;
+    float4 sample = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (L.type == 0 && L.src_kind != 0) {
+        float u01 = lx / L.qw + 0.5f, v01 = 0.5f - ly / L.qh;
+        float tu = (L.crop[1] + u01 * L.crop[2]) / (float)L.tex_w;
+        float tv = (L.crop[0] + v01 * L.crop[3]) / (float)L.tex_h;
+        sample = sample_rgba_bilinear(L.src, srgb ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM, tu, tv, dec);
+    }
+    float4 frag = layout_fragment(L, masks, fx, fy, lx, ly, sample);
+    return blend_store(acc, frag, srgb, dec, thr);
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,277 @@
+// smr_resample.hip — Lanczos3 separable resampler, box pre-decimation, bilinear rescale.
+//
+// Replaces smelter-render/src/transformations/layout/resampler.rs (pass planning and
+// ResampledChild::render), resample.wgsl, downsample.wgsl, and wgpu/format/rgba_rescale.wgsl.
+//
+// These are the general, pass-per-launch kernels (any source format, any crop, any plan);
+// the hot configuration (YUV frame -> scaled tile) runs through smr_fused.hip instead.
+// Weights follow resample.wgsl:50-86 exactly: sin/cos rotation recurrence in f32, one
+// weight table per output coordinate, built once per workgroup in LDS and shared by the
+// 64 threads that walk the perpendicular axis.
+#include "smr_resample_dev.h"
+
+#include <cmath>
+
+namespace {
+
+// One workgroup = 64 x 4 output pixels (lanes run along x so every global access is row-contiguous).
+// Horizontal pass: 64 weight tables (one per x); vertical pass: 4 tables (one per y).
+constexpr int TILE_X = 64;
+constexpr int TILE_Y = 4;
+
+struct PassParams {
+    int axis;  // 0 horizontal, 1 vertical
+    float scale, offset;
+    int perp_offset;
+    int src_pxi, dst_pxi;
+};
+
+__global__ __launch_bounds__(TILE_X *TILE_Y) void k_resample_pass(SurfView src, SurfView dst, PassParams p,
+                                                                  const float *__restrict__ tables) {
+    __shared__ float s_w[TILE_X][MAX_TAPS + 1];  // +1: conflict-free per-lane rows
+    __shared__ float s_wsum[TILE_X];
+    __shared__ int s_first[TILE_X];
+
+    const float *dec = tables, *thr = tables + 256;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x = blockIdx.x * TILE_X + lx;
+    const int y = blockIdx.y * TILE_Y + ly;
+    const int o_idx = p.axis == 0 ? lx : ly;            // which weight table this thread uses
+    const int out_coord = p.axis == 0 ? x : y;
+    const int out_len = p.axis == 0 ? dst.w : dst.h;
+
+    const int taps = lanczos_taps(p.scale);
+
+    // --- weight tables: one thread per output coordinate (resample.wgsl:44-86) ---
+    const bool builder = p.axis == 0 ? (ly == 0) : (lx == 0);
+    if (builder && out_coord < out_len) {
+        float wsum;
+        s_first[o_idx] = lanczos_weights(out_coord, p.scale, p.offset, taps, s_w[o_idx], &wsum);
+        s_wsum[o_idx] = wsum;
+    }
+    __syncthreads();
+    if (x >= dst.w || y >= dst.h) return;
+
+    const int first = s_first[o_idx];
+    const int max_src = (p.axis == 1 ? src.h : src.w) - 1;
+    const int perp = clampi((p.axis == 1 ? x : y) + p.perp_offset, 0, (p.axis == 1 ? src.w : src.h) - 1);
+
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < taps; t++) {
+        float wgt = s_w[o_idx][t];
+        int s = clampi(first + t, 0, max_src);
+        float4 tx = (p.axis == 1) ? load_texel(src, p.src_pxi, perp, s, dec) : load_texel(src, p.src_pxi, s, perp, dec);
+        sum.x = sum.x + tx.x * wgt;
+        sum.y = sum.y + tx.y * wgt;
+        sum.z = sum.z + tx.z * wgt;
+        sum.w = sum.w + tx.w * wgt;
+    }
+    const float ws = s_wsum[o_idx];
+    store_texel(dst, p.dst_pxi, x, y, make_float4(sum.x / ws, sum.y / ws, sum.z / ws, sum.w / ws), thr);
+}
+
+// downsample.wgsl:27-40 — 2^k x 2^l box mean into Rgba16Float
+__global__ __launch_bounds__(256) void k_downsample(SurfView src, SurfView dst, int fx, int fy, int src_pxi,
+                                                    const float *__restrict__ tables) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dst.w || y >= dst.h) return;
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy = 0; dy < fy; dy++) {
+        for (int dx = 0; dx < fx; dx++) {
+            int sx = clampi(x * fx + dx, 0, src.w - 1);
+            int sy = clampi(y * fy + dy, 0, src.h - 1);
+            float4 t = load_texel(src, src_pxi, sx, sy, tables);
+            sum.x = sum.x + t.x; sum.y = sum.y + t.y; sum.z = sum.z + t.z; sum.w = sum.w + t.w;
+        }
+    }
+    float n = (float)(unsigned)(fx * fy);
+    store_texel(dst, PXI_RGBA16F, x, y, make_float4(sum.x / n, sum.y / n, sum.z / n, sum.w / n), tables + 256);
+}
+
+// rgba_rescale.wgsl:24-27
+__global__ __launch_bounds__(256) void k_rescale_bilinear(SurfView src, SurfView dst, int pxi, const float *__restrict__ tables) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dst.w || y >= dst.h) return;
+    float4 o = sample_rgba_bilinear(src, pxi, ((float)x + 0.5f) / (float)dst.w, ((float)y + 0.5f) / (float)dst.h, tables);
+    store_texel(dst, pxi, x, y, o, tables + 256);
+}
+
+// ---- pass planning (host): smelter-render/src/transformations/layout/resampler.rs:36-145 ----
+struct AxisMapping {
+    int axis;
+    float crop_offset, crop_len;
+    int dst_len;
+    float scale() const { return crop_len / (float)dst_len; }
+};
+
+int predecimate_levels(const AxisMapping &m) {
+    // ((scale / KERNEL_BUDGET).log2().ceil().max(0.0) as u32).min(MAX_PREDECIMATE_LEVELS)
+    float v = ceilf(log2f(m.scale() / 4.0f));
+    if (std::isnan(v)) v = 0.0f;
+    if (v < 0.0f) v = 0.0f;
+    unsigned u = v >= 4294967296.0f ? 0xffffffffu : (unsigned)v;
+    return u > 16 ? 16 : (int)u;
+}
+
+bool is_same_px(float a, float b) { return fabsf(a - b) < 0.001f; }
+
+bool as_direct(const AxisMapping &m, int *perp) {
+    bool direct = is_same_px(m.crop_len, (float)m.dst_len) && is_same_px(m.crop_offset, roundf(m.crop_offset));
+    if (direct) *perp = (int)roundf(m.crop_offset);
+    return direct;
+}
+
+int plan_passes(const AxisMapping maps[2], smr_resample_plan *p) {
+    int ph = 0, pv = 0;
+    bool dh = as_direct(maps[0], &ph), dv = as_direct(maps[1], &pv);
+    if (dh && dv) return 0;
+    auto set = [&](int slot, const AxisMapping &m, int perp) {
+        p->axis[slot] = m.axis;
+        p->scale[slot] = m.scale();
+        p->offset[slot] = m.crop_offset;
+        p->perp_offset[slot] = perp;
+    };
+    if (!dh && dv) { set(0, maps[0], pv); return 1; }
+    if (dh && !dv) { set(0, maps[1], ph); return 1; }
+    // stronger shrink first, to minimise the intermediate size and tap count
+    int first = maps[1].scale() > maps[0].scale() ? 1 : 0;
+    set(0, maps[first], 0);
+    set(1, maps[1 - first], 0);
+    return 2;
+}
+
+int pxi_of(const smr_ctx *ctx, const smr_surface *s) {
+    if (s->fmt == SMR_PX_RGBA16F) return PXI_RGBA16F;
+    return ctx->srgb() ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM;
+}
+
+int launch_pass(smr_ctx *ctx, const smr_surface *src, int axis, float scale, float offset, int perp_offset, smr_surface *dst) {
+    PassParams p;
+    p.axis = axis;
+    p.scale = scale;
+    p.offset = offset;
+    p.perp_offset = perp_offset;
+    p.src_pxi = pxi_of(ctx, src);
+    p.dst_pxi = pxi_of(ctx, dst);
+    dim3 grid((dst->w + TILE_X - 1) / TILE_X, (dst->h + TILE_Y - 1) / TILE_Y, 1);
+    hipLaunchKernelGGL(k_resample_pass, grid, dim3(TILE_X * TILE_Y), 0, ctx->stream, view_of(src), view_of(dst), p, ctx->d_tables);
+    return smr_check_hip(ctx, hipGetLastError(), "k_resample_pass");
+}
+
+}  // namespace
+
+extern "C" {
+
+int smr_resample_plan_make(uint32_t src_w, uint32_t src_h, const float crop[4], uint32_t dst_w, uint32_t dst_h,
+                           smr_resample_plan *p) {
+    if (!crop || !p || dst_w == 0 || dst_h == 0) return SMR_ERR_INVALID;
+    memset(p, 0, sizeof(*p));
+    AxisMapping maps[2] = {{0, crop[1], crop[2], (int)dst_w}, {1, crop[0], crop[3], (int)dst_h}};
+    p->reduced_w = (int)src_w;
+    p->reduced_h = (int)src_h;
+    smr_resample_plan tmp;
+    memset(&tmp, 0, sizeof(tmp));
+    if (plan_passes(maps, &tmp) == 0) return 0;  // ResampledChild::is_needed == false
+    for (int a = 0; a < 2; a++) p->levels[a] = predecimate_levels(maps[a]);
+    const int fx = 1 << p->levels[0], fy = 1 << p->levels[1];
+    if (fx != 1 || fy != 1) {
+        p->reduced_w = ((int)src_w + fx - 1) / fx;
+        p->reduced_h = ((int)src_h + fy - 1) / fy;
+    }
+    AxisMapping residual[2];
+    for (int a = 0; a < 2; a++) {
+        float factor = (float)(1u << p->levels[a]);
+        residual[a] = maps[a];
+        residual[a].crop_offset = maps[a].crop_offset / factor;
+        residual[a].crop_len = maps[a].crop_len / factor;
+    }
+    p->kind = plan_passes(residual, p);
+    if (p->kind == 0) return SMR_ERR_INTERNAL;  // the reference panics here (resampler.rs:345-346)
+    if (p->kind == 2) {
+        if (p->axis[0] == 0) { p->mid_w = residual[0].dst_len; p->mid_h = p->reduced_h; }
+        else { p->mid_w = p->reduced_w; p->mid_h = residual[1].dst_len; }
+    }
+    return p->kind;
+}
+
+int smr_resample_pass(smr_ctx *ctx, const smr_surface *src, int axis, float scale, float offset, int perp_offset,
+                      smr_surface *dst) {
+    if (!ctx || !src || !dst) return SMR_ERR_INVALID;
+    if ((src->fmt != SMR_PX_RGBA8 && src->fmt != SMR_PX_RGBA16F) || (dst->fmt != SMR_PX_RGBA8 && dst->fmt != SMR_PX_RGBA16F))
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_resample_pass: surfaces must be RGBA8 or RGBA16F");
+    if (axis != 0 && axis != 1) return smr_fail(ctx, SMR_ERR_INVALID, "smr_resample_pass: bad axis %d", axis);
+    if (!(scale > 0.0f) || ceilf(6.0f * fmaxf(scale, 1.0f)) + 1 > MAX_TAPS)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_resample_pass: scale %f outside (0, %f]", scale, (MAX_TAPS - 1) / 6.0);
+    StageScope scope(ctx, SMR_STAGE_RESAMPLE);
+    return launch_pass(ctx, src, axis, scale, offset, perp_offset, dst);
+}
+
+int smr_downsample(smr_ctx *ctx, const smr_surface *src, uint32_t fx, uint32_t fy, smr_surface *dst) {
+    if (!ctx || !src || !dst || fx == 0 || fy == 0) return SMR_ERR_INVALID;
+    if (dst->fmt != SMR_PX_RGBA16F || (src->fmt != SMR_PX_RGBA8 && src->fmt != SMR_PX_RGBA16F))
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_downsample: src RGBA8/RGBA16F, dst RGBA16F");
+    if (dst->w != (src->w + fx - 1) / fx || dst->h != (src->h + fy - 1) / fy)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_downsample: dst must be ceil(src / factor)");
+    StageScope scope(ctx, SMR_STAGE_RESAMPLE);
+    dim3 grid((dst->w + 63) / 64, (dst->h + 3) / 4, 1);
+    hipLaunchKernelGGL(k_downsample, grid, dim3(256), 0, ctx->stream, view_of(src), view_of(dst), (int)fx, (int)fy,
+                       pxi_of(ctx, src), ctx->d_tables);
+    return smr_check_hip(ctx, hipGetLastError(), "k_downsample");
+}
+
+int smr_resample(smr_ctx *ctx, const smr_surface *src, const float crop[4], smr_surface *dst) {
+    if (!ctx || !src || !crop || !dst) return SMR_ERR_INVALID;
+    if (src->fmt != SMR_PX_RGBA8 || dst->fmt != SMR_PX_RGBA8)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_resample: node surfaces must be RGBA8");
+    smr_resample_plan plan;
+    int kind = smr_resample_plan_make(src->w, src->h, crop, dst->w, dst->h, &plan);
+    if (kind < 0) return smr_fail(ctx, kind, "smr_resample: box reduction left no residual scale");
+    if (kind == 0) return 0;
+    StageScope scope(ctx, SMR_STAGE_RESAMPLE);
+    const smr_surface *cur = src;
+    smr_surface reduced, mid;
+    const int fx = 1 << plan.levels[0], fy = 1 << plan.levels[1];
+    if (fx != 1 || fy != 1) {
+        reduced.w = (u32)plan.reduced_w;
+        reduced.h = (u32)plan.reduced_h;
+        reduced.fmt = SMR_PX_RGBA16F;
+        reduced.pitch = ((size_t)reduced.w * 8 + 255) & ~(size_t)255;
+        reduced.ptr = smr_scratch(ctx, 0, reduced.pitch * reduced.h);
+        if (!reduced.ptr) return SMR_ERR_OOM;
+        dim3 grid((reduced.w + 63) / 64, (reduced.h + 3) / 4, 1);
+        hipLaunchKernelGGL(k_downsample, grid, dim3(256), 0, ctx->stream, view_of(src), view_of(&reduced), fx, fy,
+                           pxi_of(ctx, src), ctx->d_tables);
+        cur = &reduced;
+    }
+    int last = 0;
+    if (kind == 2) {
+        mid.w = (u32)plan.mid_w;
+        mid.h = (u32)plan.mid_h;
+        mid.fmt = SMR_PX_RGBA16F;
+        mid.pitch = ((size_t)mid.w * 8 + 255) & ~(size_t)255;
+        mid.ptr = smr_scratch(ctx, 1, mid.pitch * mid.h);
+        if (!mid.ptr) return SMR_ERR_OOM;
+        int rc = launch_pass(ctx, cur, plan.axis[0], plan.scale[0], plan.offset[0], plan.perp_offset[0], &mid);
+        if (rc != SMR_OK) return rc;
+        cur = &mid;
+        last = 1;
+    }
+    int rc = launch_pass(ctx, cur, plan.axis[last], plan.scale[last], plan.offset[last], plan.perp_offset[last], dst);
+    if (rc != SMR_OK) return rc;
+    return kind;
+}
+
+int smr_rescale_bilinear(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) {
+    if (!ctx || !src || !dst) return SMR_ERR_INVALID;
+    if (src->fmt != SMR_PX_RGBA8 || dst->fmt != SMR_PX_RGBA8)
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_rescale_bilinear: surfaces must be RGBA8");
+    StageScope scope(ctx, SMR_STAGE_RESAMPLE);
+    dim3 grid((dst->w + 63) / 64, (dst->h + 3) / 4, 1);
+    hipLaunchKernelGGL(k_rescale_bilinear, grid, dim3(256), 0, ctx->stream, view_of(src), view_of(dst), pxi_of(ctx, src),
+                       ctx->d_tables);
+    return smr_check_hip(ctx, hipGetLastError(), "k_rescale_bilinear");
+}
+
+}  // extern "C"

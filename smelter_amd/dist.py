@@ -1,0 +1,127 @@
+"""Multi-GPU path: inputs sharded across ranks, one exchange step (tile gather to the root), root composes.
+
+The reference has no multi-GPU support (single wgpu device); this is the MI355X-native
+scaling axis named by BASELINE.json: per-input work (colour conversion + Lanczos to the on-screen size)
+is independent per input (smelter-render/src/state/render_loop.rs:24-41, transformations/layout.rs:250-275),
+so input i lives on GPU i % world; every frame each rank turns its inputs into dst-sized RGBA8 tiles and
+sends them point-to-point to rank 0 (RCCL send/recv: each peer uses its own xGMI link to the root, so the
+gather is per-link bound, not ring bound); rank 0 runs the single compose+output kernel.
+
+The exchange logic is backend-agnostic (torch.distributed): `nccl` (= RCCL) on GPUs, `gloo` in the CPU tests.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, replace
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def rust_round(x: float) -> int:
+    """f32::round — half away from zero (layout.rs:258-261)."""
+    x = float(np.float32(x))
+    return int(np.floor(abs(x) + 0.5)) * (1 if x >= 0 else -1)
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    n_inputs: int
+    world: int
+    root: int = 0
+
+    def owner(self, input_idx: int) -> int:
+        return input_idx % self.world
+
+    def inputs_of(self, rank: int) -> List[int]:
+        return [i for i in range(self.n_inputs) if self.owner(i) == rank]
+
+    def remote_inputs(self) -> List[int]:
+        return [i for i in range(self.n_inputs) if self.owner(i) != self.root]
+
+
+def pitch_of(width_px: int) -> int:
+    return (width_px * 4 + 255) & ~255
+
+
+def gather_tiles(dist, plan: ShardPlan, rank: int, tiles: Dict[int, "object"]):
+    """One exchange step.  `tiles[i]` is the tile tensor of input i: filled on owner(i), receive buffer on the root.
+    Non-root ranks send their tiles to the root; the root receives every remote tile. Returns the list of work handles
+    (already waited on: the current stream is ordered after completion)."""
+    ops = []
+    if rank == plan.root:
+        for i in plan.remote_inputs():
+            if i in tiles:
+                ops.append(dist.P2POp(dist.irecv, tiles[i], plan.owner(i), tag=i))
+    else:
+        for i in plan.inputs_of(rank):
+            if i in tiles:
+                ops.append(dist.P2POp(dist.isend, tiles[i], plan.root, tag=i))
+    if not ops:
+        return []
+    works = dist.batch_isend_irecv(ops)
+    for w in works:
+        w.wait()
+    return works
+
+
+class ShardedCompositor:
+    """Per-frame driver of the sharded path for one output scene."""
+
+    def __init__(self, ctx, hip, plan: ShardPlan, rank: int, layouts, res, input_source_slot: Sequence[int], label_surface,
+                 torch, dist, ingest_fn: Optional[Callable] = None, compose_fn: Optional[Callable] = None, device=None):
+        self.ctx, self.hip, self.plan, self.rank, self.dist, self.torch = ctx, hip, plan, rank, dist, torch
+        self.layouts = list(layouts)
+        self.res = list(res)
+        self.slot_of_input = list(input_source_slot)
+        self.input_of_slot = {s: k for k, s in enumerate(self.slot_of_input)}
+        self.label = label_surface
+        device = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu")
+        # geometry of every input's tile: the layout that samples it (resample_scaled_children, layout.rs:238-278)
+        self.tile_geom: Dict[int, tuple] = {}
+        for L in self.layouts:
+            if L.type == 0 and L.source_index in self.input_of_slot:
+                k = self.input_of_slot[L.source_index]
+                self.tile_geom[k] = (max(rust_round(L.width), 1), max(rust_round(L.height), 1), tuple(L.crop))
+        needed = plan.inputs_of(rank) if rank != plan.root else list(range(plan.n_inputs))
+        self.tiles = {}
+        self.tile_surfaces = {}
+        for k in needed:
+            if k not in self.tile_geom:
+                continue
+            dw, dh, _ = self.tile_geom[k]
+            t = torch.zeros((dh, pitch_of(dw)), dtype=torch.uint8, device=device)
+            self.tiles[k] = t
+            if ctx is not None:
+                self.tile_surfaces[k] = ctx.wrap(t.data_ptr(), pitch_of(dw), dw, dh)
+        self.ingest_fn = ingest_fn or self._ingest
+        self.compose_fn = compose_fn or self._compose
+        if rank == plan.root:
+            # root-side layout list: inputs are replaced by their (already resampled) tiles, crop = whole tile
+            self.root_layouts = []
+            for L in self.layouts:
+                if L.type == 0 and L.source_index in self.input_of_slot:
+                    dw, dh, _ = self.tile_geom[self.input_of_slot[L.source_index]]
+                    L = replace(L, crop=(0.0, 0.0, float(dw), float(dh)))
+                self.root_layouts.append(L)
+            self.root_packed = hip.pack_layouts(self.root_layouts) if hip is not None else None
+
+    # -- default device implementations
+    def _ingest(self, k, frame, tile_tensor):
+        dw, dh, crop = self.tile_geom[k]
+        kind = self.ctx.ingest_resample(frame, crop, self.tile_surfaces[k])
+        if kind == 0:
+            raise RuntimeError("sharded path expects scaled inputs (direct 1:1 inputs need no resample shard)")
+
+    def _compose(self, tiles, out):
+        srcs = []
+        for slot, r in enumerate(self.res):
+            srcs.append(self.tile_surfaces[self.input_of_slot[slot]] if slot in self.input_of_slot else self.label)
+        self.ctx.render_layouts(self.root_layouts, srcs, out.w, out.h, out=out, packed=self.root_packed)
+
+    def step(self, frames_row: Dict[int, object], out):
+        for k in self.plan.inputs_of(self.rank):
+            if k in self.tile_geom:
+                self.ingest_fn(k, frames_row[k], self.tiles[k])
+        gather_tiles(self.dist, self.plan, self.rank, self.tiles)
+        if self.rank == self.plan.root:
+            self.compose_fn(self.tiles, out)

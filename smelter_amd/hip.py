@@ -1,0 +1,286 @@
+"""Thin object layer over the C ABI (include/smr.h) used by tests, bench.py and the host mirror.
+
+Everything here calls straight into libsmr_hip.so through ctypes; numpy arrays only carry
+host bytes in and out.  There is no CPU implementation behind these classes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import (FRAME_ARGB, FRAME_BGRA, FRAME_NV12, FRAME_PLANAR_YUV420, FRAME_PLANAR_YUV422, FRAME_PLANAR_YUV444,
+                   FRAME_PLANAR_YUVJ420, FRAME_RGBA, FRAME_UYVY422, FRAME_YUYV422, MODE_CPU_OPTIMIZED, MODE_GPU_OPTIMIZED,
+                   PX_R8, PX_RG8, PX_RGBA8, PX_RGBA16F)
+
+STAGE_NAMES = {0: "ingest", 1: "resample", 2: "layouts", 3: "output", 4: "fused_ingest_resample", 5: "fused_compose_output"}
+
+
+class SmrError(RuntimeError):
+    """Mirrors RenderSceneError::WgpuError(WgpuError::{Validation, OutOfMemory, Internal}(String))."""
+
+    def __init__(self, code: int, message: str):
+        kind = {-1: "Validation", -2: "OutOfMemory", -3: "Internal"}.get(code, str(code))
+        super().__init__(f"{kind}: {message}")
+        self.code = code
+
+
+class Surface:
+    def __init__(self, ctx: "Context", handle, w: int, h: int, fmt: int):
+        self.ctx, self.handle, self.w, self.h, self.fmt = ctx, handle, w, h, fmt
+
+    def _shape_dtype(self):
+        if self.fmt == PX_RGBA8:
+            return (self.h, self.w, 4), np.uint8
+        if self.fmt == PX_RGBA16F:
+            return (self.h, self.w, 4), np.uint16
+        if self.fmt == PX_RG8:
+            return (self.h, self.w, 2), np.uint8
+        return (self.h, self.w), np.uint8
+
+    def upload(self, arr) -> "Surface":
+        shape, dt = self._shape_dtype()
+        a = np.ascontiguousarray(arr, dtype=dt).reshape(shape)
+        self.ctx._check(self.ctx.lib.smr_surface_upload(self.ctx.handle, self.handle, a.ctypes.data, 0))
+        return self
+
+    def download(self) -> np.ndarray:
+        shape, dt = self._shape_dtype()
+        out = np.empty(shape, dt)
+        self.ctx._check(self.ctx.lib.smr_surface_download(self.ctx.handle, self.handle, out.ctypes.data, 0))
+        return out
+
+    def info(self) -> _ffi.SurfaceInfo:
+        inf = _ffi.SurfaceInfo()
+        self.ctx._check(self.ctx.lib.smr_surface_info_get(self.handle, C.byref(inf)))
+        return inf
+
+    def destroy(self):
+        if self.handle:
+            self.ctx.lib.smr_surface_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+
+class DeviceFrame:
+    """A video frame resident in HBM (smr_frame)."""
+
+    def __init__(self, ctx: "Context", fmt: int, w: int, h: int):
+        self.ctx, self.fmt, self.w, self.h = ctx, fmt, w, h
+        self.c = _ffi.Frame()
+        ctx._check(ctx.lib.smr_frame_create(ctx.handle, fmt, w, h, C.byref(self.c)))
+
+    def plane_shapes(self):
+        w, h, f = self.w, self.h, self.fmt
+        if f in (FRAME_PLANAR_YUV420, FRAME_PLANAR_YUVJ420):
+            return [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+        if f == FRAME_PLANAR_YUV422:
+            return [(h, w), (h, w // 2), (h, w // 2)]
+        if f == FRAME_PLANAR_YUV444:
+            return [(h, w), (h, w), (h, w)]
+        if f == FRAME_NV12:
+            return [(h, w), (h // 2, w // 2, 2)]
+        if f in (FRAME_UYVY422, FRAME_YUYV422):
+            return [(h, w // 2, 4)]
+        return [(h, w, 4)]
+
+    def upload(self, planes: Sequence[np.ndarray]) -> "DeviceFrame":
+        shapes = self.plane_shapes()
+        keep = [np.ascontiguousarray(p, dtype=np.uint8).reshape(s) for p, s in zip(planes, shapes)]
+        ptrs = (C.c_void_p * 3)(*[k.ctypes.data for k in keep] + [None] * (3 - len(keep)))
+        self.ctx._check(self.ctx.lib.smr_frame_upload(self.ctx.handle, C.byref(self.c), ptrs))
+        return self
+
+    def download(self) -> List[np.ndarray]:
+        outs = [np.empty(s, np.uint8) for s in self.plane_shapes()]
+        ptrs = (C.c_void_p * 3)(*[o.ctypes.data for o in outs] + [None] * (3 - len(outs)))
+        self.ctx._check(self.ctx.lib.smr_frame_download(self.ctx.handle, C.byref(self.c), ptrs))
+        return outs
+
+    def destroy(self):
+        self.ctx.lib.smr_frame_destroy(self.ctx.handle, C.byref(self.c))
+
+
+def pack_layouts(layouts) -> "C.Array":
+    """Accepts oracle-style Layout dataclasses (duck-typed) and fills smr_layout[]."""
+    arr = (_ffi.Layout * max(len(layouts), 1))()
+    for i, L in enumerate(layouts):
+        s = arr[i]
+        s.top, s.left, s.width, s.height = L.top, L.left, L.width, L.height
+        s.rotation_degrees = L.rotation_degrees
+        s.border_radius[:] = list(L.border_radius)
+        s.type = L.type
+        s.source_index = L.source_index
+        s.color[:] = list(L.color)
+        s.border_color[:] = list(L.border_color)
+        s.border_width = L.border_width
+        s.crop[:] = list(L.crop)
+        s.blur_radius = L.blur_radius
+        s.masks_len = len(L.masks)
+        for j, m in enumerate(L.masks[: _ffi.MAX_MASKS]):
+            s.masks[j].radius[:] = list(m.radius)
+            s.masks[j].top, s.masks[j].left, s.masks[j].width, s.masks[j].height = m.top, m.left, m.width, m.height
+    return arr
+
+
+class Context:
+    def __init__(self, device: int = 0, mode: int = MODE_GPU_OPTIMIZED, max_layouts: int = 100, stream: Optional[int] = None):
+        self.lib = _ffi.load()
+        h = C.c_void_p()
+        rc = self.lib.smr_ctx_create(device, mode, max_layouts, C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise SmrError(rc, f"smr_ctx_create(device={device}) failed — is a HIP device visible?")
+        self.handle = h
+        self.mode = mode
+        self.device = device
+
+    # -- plumbing
+    def _check(self, rc: int) -> int:
+        if rc < 0:
+            raise SmrError(rc, self.lib.smr_last_error(self.handle).decode())
+        return rc
+
+    def close(self):
+        if self.handle:
+            self.lib.smr_ctx_destroy(self.handle)
+            self.handle = None
+
+    def sync(self):
+        self._check(self.lib.smr_sync(self.handle))
+
+    def timer_start(self):
+        self._check(self.lib.smr_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.smr_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on: bool):
+        self._check(self.lib.smr_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        self._check(self.lib.smr_profile_reset(self.handle))
+
+    def profile_read(self):
+        out = {}
+        for sid, name in STAGE_NAMES.items():
+            ms, n = C.c_float(), C.c_uint32()
+            self._check(self.lib.smr_profile_read(self.handle, sid, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    # -- resources
+    def surface(self, w: int, h: int, fmt: int = PX_RGBA8) -> Surface:
+        h_ = C.c_void_p()
+        self._check(self.lib.smr_surface_create(self.handle, w, h, fmt, C.byref(h_)))
+        return Surface(self, h_, w, h, fmt)
+
+    def wrap(self, dptr: int, pitch: int, w: int, h: int, fmt: int = PX_RGBA8) -> Surface:
+        h_ = C.c_void_p()
+        self._check(self.lib.smr_surface_wrap(self.handle, C.c_void_p(dptr), pitch, w, h, fmt, C.byref(h_)))
+        return Surface(self, h_, w, h, fmt)
+
+    def surface_from(self, arr, fmt: int = PX_RGBA8) -> Surface:
+        a = np.asarray(arr)
+        return self.surface(a.shape[1], a.shape[0], fmt).upload(a)
+
+    def frame(self, fmt: int, w: int, h: int, planes: Optional[Sequence[np.ndarray]] = None) -> DeviceFrame:
+        f = DeviceFrame(self, fmt, w, h)
+        if planes is not None:
+            f.upload(planes)
+        return f
+
+    # -- passes
+    def frame_to_rgba(self, frame: DeviceFrame, node: Optional[Surface] = None) -> Surface:
+        node = node or self.surface(frame.w, frame.h, PX_RGBA8)
+        self._check(self.lib.smr_frame_to_rgba(self.handle, C.byref(frame.c), node.handle))
+        return node
+
+    def add_premultiplied_alpha(self, src: Surface, dst: Optional[Surface] = None) -> Surface:
+        dst = dst or self.surface(src.w, src.h)
+        self._check(self.lib.smr_add_premultiplied_alpha(self.handle, src.handle, dst.handle))
+        return dst
+
+    def remove_premultiplied_alpha(self, src: Surface, dst: Optional[Surface] = None) -> Surface:
+        dst = dst or self.surface(src.w, src.h)
+        self._check(self.lib.smr_remove_premultiplied_alpha(self.handle, src.handle, dst.handle))
+        return dst
+
+    def rgba_to_frame(self, node: Surface, fmt: int, out: Optional[DeviceFrame] = None) -> DeviceFrame:
+        out = out or self.frame(fmt, node.w, node.h)
+        self._check(self.lib.smr_rgba_to_frame(self.handle, node.handle, C.byref(out.c)))
+        return out
+
+    def fill_black(self, out: DeviceFrame):
+        self._check(self.lib.smr_frame_fill_black(self.handle, C.byref(out.c)))
+
+    def resample_plan(self, src_w, src_h, crop, dst_w, dst_h) -> _ffi.ResamplePlan:
+        p = _ffi.ResamplePlan()
+        c = (C.c_float * 4)(*[float(x) for x in crop])
+        rc = self.lib.smr_resample_plan_make(src_w, src_h, c, dst_w, dst_h, C.byref(p))
+        if rc < 0:
+            raise SmrError(rc, "smr_resample_plan_make")
+        return p
+
+    def resample(self, src: Surface, crop, dst: Surface) -> int:
+        c = (C.c_float * 4)(*[float(x) for x in crop])
+        return self._check(self.lib.smr_resample(self.handle, src.handle, c, dst.handle))
+
+    def resample_pass(self, src: Surface, axis: int, scale: float, offset: float, perp_offset: int, dst: Surface):
+        self._check(self.lib.smr_resample_pass(self.handle, src.handle, axis, scale, offset, perp_offset, dst.handle))
+
+    def downsample(self, src: Surface, fx: int, fy: int, dst: Surface):
+        self._check(self.lib.smr_downsample(self.handle, src.handle, fx, fy, dst.handle))
+
+    def rescale_bilinear(self, src: Surface, dst: Surface):
+        self._check(self.lib.smr_rescale_bilinear(self.handle, src.handle, dst.handle))
+
+    def apply_layouts(self, target: Surface, layouts, sources: Sequence[Optional[Surface]]):
+        arr = pack_layouts(layouts)
+        n_src = len(sources)
+        ptrs = (C.c_void_p * max(n_src, 1))(*[(s.handle if s is not None else None) for s in sources])
+        self._check(self.lib.smr_apply_layouts(self.handle, target.handle, arr, len(layouts), ptrs, n_src))
+
+    def render_layouts(self, layouts, sources, out_w: int, out_h: int, out: Optional[DeviceFrame] = None,
+                       out_rgba: Optional[Surface] = None, packed=None):
+        """sources: sequence of Surface | DeviceFrame | None."""
+        arr = packed if packed is not None else pack_layouts(layouts)
+        n = len(layouts)
+        srcs = (_ffi.Source * max(len(sources), 1))()
+        for i, s in enumerate(sources):
+            if s is None:
+                srcs[i].kind = _ffi.SOURCE_NONE
+            elif isinstance(s, DeviceFrame):
+                srcs[i].kind = _ffi.SOURCE_FRAME
+                srcs[i].frame = C.pointer(s.c)
+            else:
+                srcs[i].kind = _ffi.SOURCE_SURFACE
+                srcs[i].surface = s.handle
+        self._check(self.lib.smr_render_layouts(self.handle, arr, n, srcs, len(sources), out_w, out_h,
+                                                C.byref(out.c) if out is not None else None,
+                                                out_rgba.handle if out_rgba is not None else None))
+
+    def ingest_resample(self, frame: DeviceFrame, crop, dst: Surface) -> int:
+        c = (C.c_float * 4)(*[float(x) for x in crop])
+        return self._check(self.lib.smr_ingest_resample(self.handle, C.byref(frame.c), c, dst.handle))
+
+    def blit_glyphs(self, target: Surface, bg, glyphs, atlas: np.ndarray):
+        atlas = np.ascontiguousarray(atlas, dtype=np.uint8)
+        garr = (_ffi.Glyph * max(len(glyphs), 1))()
+        for i, g in enumerate(glyphs):
+            garr[i].dst_x, garr[i].dst_y, garr[i].w, garr[i].h = g.dst_x, g.dst_y, g.w, g.h
+            garr[i].atlas_x, garr[i].atlas_y = g.atlas_x, g.atlas_y
+            garr[i].color[:] = list(g.color)
+        bgc = (C.c_float * 4)(*[float(x) for x in bg])
+        self._check(self.lib.smr_blit_glyphs(self.handle, target.handle, bgc, garr, len(glyphs), atlas.ctypes.data,
+                                             atlas.shape[1], atlas.shape[0]))
+
+    def gaussian_blur(self, src: Surface, sigma: float, dst: Optional[Surface] = None) -> Surface:
+        dst = dst or self.surface(src.w, src.h)
+        p = _ffi.GaussianBlurParams(sigma)
+        ptrs = (C.c_void_p * 1)(src.handle)
+        self._check(self.lib.smr_builtin_shader(self.handle, _ffi.SHADER_GAUSSIAN_BLUR, C.byref(p), C.sizeof(p), ptrs, 1,
+                                                dst.handle, 0.0))
+        return dst

@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: libsmr_hip.so loads and exports every symbol that
+include/smr.h declares, struct layouts agree across C / ctypes / oracle, and — with no GPU in the
+container — context creation fails loudly instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from smelter_amd import _ffi
+    return _ffi.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "smr.h")).read()
+    declared = set(re.findall(r"SMR_API\s+[\w\s\*]+?\b(smr_\w+)\s*\(", hdr))
+    assert len(declared) >= 30
+    from smelter_amd import _ffi
+    assert declared == set(_ffi.EXPORTS), declared ^ set(_ffi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"libsmr_hip.so does not export {name}"
+
+
+def test_struct_layouts_agree(lib):
+    from smelter_amd import _ffi
+    from oracle import oracle
+    assert lib.smr_sizeof_layout() == C.sizeof(_ffi.Layout) == C.sizeof(oracle._Layout) == 744
+    assert C.sizeof(_ffi.Mask) == 32
+    assert lib.smr_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from smelter_amd import hip
+    with pytest.raises(hip.SmrError):
+        hip.Context(0)
+
+
+def test_plan_make_is_host_only_and_matches_oracle(lib):
+    # smr_resample_plan_make is a pure host function: usable without a device
+    from smelter_amd import _ffi
+    from oracle import oracle
+    cases = [((0, 0, 640, 360), (640, 360), (640, 360)), ((40, 100, 640, 360), (640, 360), (1920, 1080)),
+             ((0, 100, 640, 360), (640, 300), (1920, 1080)), ((0, 100.5, 640, 360), (640, 300), (1920, 1080)),
+             ((0, 0, 1920, 1080), (960, 270), (1920, 1080)), ((0, 0, 5760, 3240), (640, 360), (5760, 3240)),
+             ((0, 0, 3840, 2160), (960, 540), (3840, 2160)), ((0, 0, 1920, 1080), (1266, 712), (1920, 1080)),
+             ((3.5, 7.25, 301.5, 200.0), (97, 411), (640, 360))]
+    for crop, dst, src in cases:
+        p = _ffi.ResamplePlan()
+        c = (C.c_float * 4)(*crop)
+        kind = lib.smr_resample_plan_make(src[0], src[1], c, dst[0], dst[1], C.byref(p))
+        o = oracle.resample_plan(src[0], src[1], crop, dst[0], dst[1])
+        assert kind == o.kind == p.kind
+        if kind:
+            assert tuple(p.levels) == o.levels and (p.reduced_w, p.reduced_h) == o.reduced
+            n = 2 if kind == 2 else 1
+            assert tuple(p.axis)[:n] == o.axis[:n] and tuple(p.perp_offset)[:n] == o.perp_offset[:n]
+            assert tuple(p.scale)[:n] == o.scale[:n] and tuple(p.offset)[:n] == o.offset[:n]
+            if kind == 2:
+                assert (p.mid_w, p.mid_h) == o.mid

@@ -1,0 +1,198 @@
+"""The fused hot path (smr_render_layouts): (1) bit-identical to the pass-per-launch path on the
+same device, (2) within 1 LSB of the CPU oracle's restatement of the reference's pass sequence,
+(3) size-independent properties at BASELINE.json's full sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import scene as S
+from tests import refpipe, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from smelter_amd import hip as h
+    return h
+
+
+@pytest.fixture(scope="module")
+def ctx(hip):
+    c = hip.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx_unfused(hip):
+    os.environ["SMR_DISABLE_FUSED"] = "1"
+    c = hip.Context(0)
+    # force the env read now
+    t = c.surface(2, 2)
+    c.render_layouts([], [], 2, 2, out_rgba=t)
+    del os.environ["SMR_DISABLE_FUSED"]
+    yield c
+    c.close()
+
+
+def _inputs(ctx, hip, n, w, h, seed=1234):
+    planes, frames = [], []
+    for i in range(n):
+        y, u, v = scenes.test_input(i, w, h, noise_seed=seed + i)
+        planes.append((y, u, v))
+        frames.append(ctx.frame(hip.FRAME_PLANAR_YUV420, w, h, [y, u, v]))
+    return planes, frames
+
+
+def _label_surfaces(ctx, n):
+    atlas, glyphs = scenes.label_glyphs("CAM 3 LIVE", 3)
+    bg = orc.color_to_shader((0, 0, 0, 0), True)
+    t = ctx.surface(scenes.LABEL_W, scenes.LABEL_H)
+    ctx.blit_glyphs(t, bg, glyphs, atlas)
+    host = t.download()
+    return t, host
+
+
+def _render(ctx, hip, layouts, sources, W, H):
+    out = ctx.frame(hip.FRAME_PLANAR_YUV420, W, H)
+    ctx.render_layouts(layouts, sources, W, H, out=out)
+    return out.download()
+
+
+SMALL_CASES = [
+    ("cfg2_small", lambda: scenes.cfg2_scene(320, 180, 320, 180, 4), 320, 180, 320, 180),
+    ("cfg3_small", lambda: scenes.cfg3_scene(480, 270, 960, 540, 8), 480, 270, 960, 540),
+    ("cfg3_odd", lambda: scenes.cfg3_scene(482, 274, 1000, 562, 5), 482, 274, 1000, 562),
+    ("upscale", lambda: scenes.cfg2_scene(160, 90, 640, 360, 2), 160, 90, 640, 360),
+    ("downscale4", lambda: scenes.cfg2_scene(1280, 720, 320, 180, 4), 1280, 720, 320, 180),   # k = 8 -> box pre-reduce
+]
+
+
+@pytest.mark.parametrize("name,mk,iw,ih,W,H", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+def test_fused_equals_unfused_and_oracle(ctx, ctx_unfused, hip, name, mk, iw, ih, W, H):
+    layouts, res = mk()
+    n_in = sum(1 for r in res if r == (iw, ih))
+    planes, _ = _inputs(ctx, hip, n_in, iw, ih)
+    label_t, label_host = _label_surfaces(ctx, 1)
+
+    def sources_for(c):
+        srcs, k = [], 0
+        lt = c.surface_from(label_host)
+        for r in res:
+            if r == (iw, ih):
+                y, u, v = planes[k]
+                k += 1
+                srcs.append(c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, [y, u, v]))
+            else:
+                srcs.append(lt)
+        return srcs
+
+    got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
+    got_unfused = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
+    for a, b in zip(got, got_unfused):
+        assert (a == b).all(), f"{name}: fused and unfused paths differ on the same device"
+    # oracle
+    nodes, k = [], 0
+    for r in res:
+        if r == (iw, ih):
+            y, u, v = planes[k]
+            k += 1
+            nodes.append(orc.planar_yuv_to_rgba(y, u, v, iw, ih))
+        else:
+            nodes.append(label_host)
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+    for g, w_, pl in zip(got, want, "YUV"):
+        d = refpipe.max_diff(g, w_)
+        ex = refpipe.exact_fraction(g, w_)
+        assert d <= 1, f"{name} plane {pl}: {d} LSB off the oracle"
+        assert ex >= 0.995, f"{name} plane {pl}: only {ex:.4f} identical"
+
+
+def test_nv12_and_rgba_outputs(ctx, ctx_unfused, hip):
+    layouts, res = scenes.cfg2_scene(320, 180, 640, 360, 4)
+    planes, frames = _inputs(ctx, hip, 4, 320, 180)
+    nodes = refpipe.nodes_from_yuv420(planes)
+    rgba_want = refpipe.layout_node_render(layouts, nodes, 640, 360)
+    out = ctx.frame(hip.FRAME_NV12, 640, 360)
+    ctx.render_layouts(layouts, frames, 640, 360, out=out)
+    y, uv = out.download()
+    wy, wuv = orc.rgba_to_nv12(rgba_want)
+    assert refpipe.max_diff(y, wy) <= 1 and refpipe.max_diff(uv, wuv) <= 1
+    t = ctx.surface(640, 360)
+    ctx.render_layouts(layouts, frames, 640, 360, out_rgba=t)
+    assert refpipe.max_diff(t.download(), rgba_want) <= 1
+    for fmt, ov in ((hip.FRAME_PLANAR_YUV422, orc.YUV422), (hip.FRAME_PLANAR_YUV444, orc.YUV444)):
+        o = ctx.frame(fmt, 640, 360)
+        ctx.render_layouts(layouts, frames, 640, 360, out=o)
+        for g, w_ in zip(o.download(), orc.rgba_to_planar_yuv(rgba_want, ov)):
+            assert refpipe.max_diff(g, w_) <= 1
+
+
+def test_missing_input_renders_like_the_reference(ctx, hip):
+    # stale / missing input: node texture None -> InputStream size 0x0 -> layout culled (scene/layout.rs:109-115)
+    root = S.Tiles(children=[S.InputStream(0), S.InputStream(1)], background_color=(10, 20, 30, 255))
+    res = [(320, 180), None]
+    layouts = S.scene_layouts(root, 640, 360, res)
+    planes, frames = _inputs(ctx, hip, 1, 320, 180)
+    got = _render(ctx, hip, layouts, [frames[0], None], 640, 360)
+    want, _ = refpipe.render_yuv420(layouts, [refpipe.nodes_from_yuv420(planes)[0], None], 640, 360)
+    for g, w_ in zip(got, want):
+        assert refpipe.max_diff(g, w_) <= 1
+
+
+def test_empty_scene_is_transparent_black(ctx, hip):
+    out = ctx.frame(hip.FRAME_PLANAR_YUV420, 64, 36)
+    ctx.render_layouts([], [], 64, 36, out=out)
+    y, u, v = out.download()
+    # cleared transparent target -> RGBA (0,0,0,0) -> Y=16, U=V=128
+    assert (y == 16).all() and (u == 128).all() and (v == 128).all()
+
+
+# ---- BASELINE.json full sizes: properties that do not need the oracle at 4K ----------------------
+def test_full_size_properties(ctx, ctx_unfused, hip):
+    iw, ih, W, H, n = 1920, 1080, 3840, 2160, 8
+    layouts, res = scenes.cfg3_scene(iw, ih, W, H, n)
+    label_t, label_host = _label_surfaces(ctx, 1)
+    planes, frames = _inputs(ctx, hip, n, iw, ih)
+
+    def srcs(c, fr):
+        lt = c.surface_from(label_host)
+        out, k = [], 0
+        for r in res:
+            if r == (iw, ih):
+                out.append(fr[k]); k += 1
+            else:
+                out.append(lt)
+        return out
+
+    a = _render(ctx, hip, layouts, srcs(ctx, frames), W, H)
+    # idempotence: same inputs, same bytes
+    b = _render(ctx, hip, layouts, srcs(ctx, frames), W, H)
+    for p, q in zip(a, b):
+        assert (p == q).all()
+    # fused == unfused at full size
+    fr_u = [ctx_unfused.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes]
+    c = _render(ctx_unfused, hip, layouts, srcs(ctx_unfused, fr_u), W, H)
+    for p, q in zip(a, c):
+        assert (p == q).all()
+    # tile independence: permuting which input feeds which tile permutes the tiles (linearity of placement)
+    perm = [3, 0, 1, 2, 7, 4, 5, 6]
+    d = _render(ctx, hip, layouts, srcs(ctx, [frames[i] for i in perm]), W, H)
+    tiles = S.tiles_positions(S.Tiles(), n, W, H)
+    for slot, src_idx in enumerate(perm):
+        t0, l0, tw, th = [int(round(float(v))) for v in tiles[slot]]
+        t1, l1, _, _ = [int(round(float(v))) for v in tiles[src_idx]]
+        # interior of the tile (away from labels/borders which are identical anyway)
+        ys, xs = slice(t0 + 64, t0 + 256), slice(l0 + 400, l0 + 900)
+        ys1, xs1 = slice(t1 + 64, t1 + 256), slice(l1 + 400, l1 + 900)
+        assert (d[0][ys, xs] == a[0][ys1, xs1]).all()
+    # oracle check of one full-resolution tile crop (cheap: a 2-input sub-scene at the same geometry)
+    sub_layouts, sub_res = scenes.cfg3_scene(iw, ih, 2560, 720, 2)
+    sub = _render(ctx, hip, sub_layouts, srcs(ctx, frames)[:4], 2560, 720)
+    nodes = [refpipe.nodes_from_yuv420([planes[0]], omp=True)[0], label_host, refpipe.nodes_from_yuv420([planes[1]], omp=True)[0], label_host]
+    want, _ = refpipe.render_yuv420(sub_layouts, nodes, 2560, 720, omp=True)
+    for g, w_ in zip(sub, want):
+        assert refpipe.max_diff(g, w_) <= 1
