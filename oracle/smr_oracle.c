@@ -509,7 +509,10 @@ ORC_API void orc_resample_pass(const void *src, int src_fmt, int sw, int sh, int
                 float tx[4];
                 if (axis == 1) load_texel(src, src_fmt, sw, perp, s, tx);
                 else load_texel(src, src_fmt, sw, s, perp, tx);
-                for (int c = 0; c < 4; c++) sum[c] = sum[c] + tx[c] * weight;
+                /* `sum += textureLoad(..) * weight` — WGSL lets the implementation contract a*b+c and every
+                 * driver the reference runs on does (SPIR-V "contraction" is on unless NoContraction is set,
+                 * which naga does not emit), so the tap accumulation is a fused multiply-add here. */
+                for (int c = 0; c < 4; c++) sum[c] = fmaf(tx[c], weight, sum[c]);
                 weight_sum = weight_sum + weight;
 
                 float ns1 = s1 * cd1 + c1 * sd1;

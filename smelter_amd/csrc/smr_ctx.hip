@@ -129,11 +129,32 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         }
         ctx->own_stream = true;
     }
-    float tables[256 + 257];
+    static float tables[SMR_TABLE_FLOATS];
+    memset(tables, 0, sizeof(tables));
     for (int i = 0; i < 256; i++) tables[i] = (float)srgb_to_linear_f64((double)i / 255.0);
-    tables[256] = -INFINITY;
-    for (int i = 1; i < 256; i++) tables[256 + i] = (float)srgb_to_linear_f64(((double)i - 0.5) / 255.0);
-    tables[256 + 256] = INFINITY;
+    float *thr = tables + 256;
+    thr[0] = -INFINITY;
+    for (int i = 1; i < 256; i++) thr[i] = (float)srgb_to_linear_f64(((double)i - 0.5) / 255.0);
+    thr[256] = INFINITY;
+    {
+        // encode estimate table: code of the lowest float of every (exponent, 7-bit mantissa) bucket in [2^-13, 1)
+        u8 *enc = (u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
+        auto code_of = [&](float x) {
+            int c = 0;
+            while (c < 255 && thr[c + 1] <= x) c++;
+            return c;
+        };
+        for (u32 idx = 0; idx < SMR_ENC_ENTRIES; idx++) {
+            u32 lo_bits = 0x39000000u + (idx << 16), hi_bits = lo_bits + 0xffffu;
+            float lo, hi;
+            memcpy(&lo, &lo_bits, 4);
+            memcpy(&hi, &hi_bits, 4);
+            int cl = code_of(lo), chh = code_of(hi);
+            if (chh - cl > 1) return SMR_ERR_INTERNAL;  // the one-step fix-up in srgb_encode8 would not suffice
+            enc[idx] = (u8)cl;
+        }
+    }
+    memcpy(ctx->h_tables, tables, sizeof(tables));
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {

@@ -17,6 +17,11 @@ typedef uint8_t u8;
 typedef uint16_t u16;
 typedef uint32_t u32;
 
+// sRGB table block (layout documented at srgb_encode8 below)
+#define SMR_TABLE_FLOATS 932
+#define SMR_ENC_OFFSET_FROM_THR 260
+#define SMR_ENC_ENTRIES 1664
+
 #define SMR_NUM_STAGES 8
 enum {
     SMR_STAGE_INGEST = 0,
@@ -65,6 +70,7 @@ struct smr_ctx {
 
     // device tables: [0..255] sRGB decode, [256..512] encode thresholds (257 entries)
     float *d_tables = nullptr;
+    float h_tables[SMR_TABLE_FLOATS] = {0};  // host copy (colour pre-encoding in the layout packer)
 
     // timers
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -159,17 +165,19 @@ __device__ __forceinline__ u32 unorm8(float x) {
     return (u32)(int)(x * 255.0f + 0.5f);
 }
 
-// sRGB encode as the monotone step function u8 = #{i : thr[i] <= x}; thr has 257 entries
-// (thr[0] = -inf, thr[256] = +inf).  A fast estimate followed by an exact fix-up.
+// sRGB encode as the monotone step function u8 = #{i : thr[i] <= x}.  Table block layout
+// (SMR_TABLE_FLOATS floats, built in smr_ctx_create, copied to LDS by the hot kernels):
+//   [0,256)    decode LUT            [256,513)  thr[0..256] (thr[0] = -inf, thr[256] = +inf)
+//   [516,932)  enc: 1664 bytes, enc[((bits(x) - bits(2^-13)) >> 16)] = code of the bucket's lowest x
+// A bucket (7 mantissa bits) straddles at most two thresholds (checked when the table is built),
+// so the estimate needs at most two upward fix-up steps: exact, branch-free, no transcendental.
 __device__ __forceinline__ u32 srgb_encode8(float x, const float *__restrict__ thr) {
-    if (!(x > 0.0f)) return 0u;
+    if (!(x >= 1.220703125e-4f)) return 0u;  // < 2^-13 (< thr[1]); also NaN and negatives
     if (x >= 1.0f) return 255u;
-    float e = x <= 0.0031308f ? 12.92f * x : 1.055f * __powf(x, 0.41666666f) - 0.055f;
-    int c = (int)(e * 255.0f + 0.5f);
-    c = clampi(c, 0, 255);
-    while (thr[c] > x) c--;
-    while (thr[c + 1] <= x) c++;
-    return (u32)c;
+    const u8 *enc = (const u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
+    u32 c = enc[(__float_as_uint(x) - 0x39000000u) >> 16];
+    c += thr[c + 1] <= x ? 1u : 0u;
+    return c;
 }
 
 __device__ __forceinline__ float subtexel(float f) { return floorf(f * 256.0f + 0.5f) / 256.0f; }

@@ -114,6 +114,35 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
             D.tex_w = D.src.w; D.tex_h = D.src.h;
             D.src_index = (int)L.source_index;
         }
+        // ---- classification helpers for the fused compose kernel
+        D.flags = (D.cs == 1.0f && D.sn == 0.0f) ? DL_UNROTATED : 0;
+        float rmax = fmaxf(fmaxf(L.border_radius[0], L.border_radius[1]), fmaxf(L.border_radius[2], L.border_radius[3]));
+        D.inset = rmax + 1.0f;
+        if (L.type != 2 && L.border_width >= 1.0f) D.inset += L.border_width;
+        // (shadow radii already include blur/2, flatten.rs:354; ed >= blur/2 needs another blur/2)
+        if (L.type == 2) D.inset += L.blur_radius / 2.0f;
+        if (L.type == 0 && D.src_kind != 0 && (D.flags & DL_UNROTATED) && L.crop[0] == 0.0f && L.crop[1] == 0.0f &&
+            L.crop[2] == (float)D.tex_w && L.crop[3] == (float)D.tex_h && L.width == (float)D.tex_w && L.height == (float)D.tex_h &&
+            L.left == floorf(L.left) && L.top == floorf(L.top) && fabsf(L.left) < 65536.0f && fabsf(L.top) < 65536.0f) {
+            D.flags |= DL_ALIGNED;
+            D.ix = (int)L.left;
+            D.iy = (int)L.top;
+        }
+        if (L.type != 0 && L.color[3] == 1.0f) {
+            D.flags |= DL_COLOR_OPAQUE;
+            const float *thr = ctx->h_tables + 256;
+            auto enc = [&](float x) -> u32 {
+                if (ctx->srgb()) {
+                    if (!(x > 0.0f)) return 0u;
+                    u32 c = 0;
+                    while (c < 255 && thr[c + 1] <= x) c++;
+                    return c;
+                }
+                x = !(x > 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x);
+                return (u32)(int)(x * 255.0f + 0.5f);
+            };
+            D.solid_px = enc(L.color[0]) | (enc(L.color[1]) << 8) | (enc(L.color[2]) << 16) | (255u << 24);
+        }
         if (!(qw > 0.0f) || !(qh > 0.0f) || L.type > 2) {
             D.bx0 = D.by0 = 0; D.bx1 = D.by1 = -1;  // never binned
         } else {

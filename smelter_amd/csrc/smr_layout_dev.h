@@ -24,10 +24,21 @@ struct DevLayout {
     u32 type;
     u32 masks_off, masks_len;
     int bx0, by0, bx1, by1;  // pixel bounding box [x0,x1) x [y0,y1)
-    int src_kind;         // 0 none (1x1 transparent), 1 RGBA8 surface, 2 tile produced by the fused resampler
+    int src_kind;         // 0 none (1x1 transparent), 1 RGBA8 surface, 2 RGBA8 surface known to be fully opaque
     int src_index;
     int tex_w, tex_h;
     SurfView src;
+    // --- tile-classification helpers (fused compose kernel)
+    int flags;            // DL_* below
+    float inset;          // inside the rect inset by this much the fragment equals its base value (no AA / border / radius)
+    int ix, iy;           // DL_ALIGNED: texel = pixel - (ix, iy)
+    u32 solid_px;         // DL_COLOR_OPAQUE: the colour as the render-target store would encode it
+};
+
+enum {
+    DL_UNROTATED = 1,     // rotation is exactly 0 (cs == 1, sn == 0)
+    DL_ALIGNED = 2,       // texture layout that is a 1:1 texel-aligned blit (bilinear weights are exactly (1,0))
+    DL_COLOR_OPAQUE = 4,  // colour / shadow layout whose premultiplied colour has alpha == 1
 };
 
 struct PackedLayouts {

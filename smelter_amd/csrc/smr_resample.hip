@@ -61,10 +61,11 @@ __global__ __launch_bounds__(TILE_X *TILE_Y) void k_resample_pass(SurfView src, 
         float wgt = s_w[o_idx][t];
         int s = clampi(first + t, 0, max_src);
         float4 tx = (p.axis == 1) ? load_texel(src, p.src_pxi, perp, s, dec) : load_texel(src, p.src_pxi, s, perp, dec);
-        sum.x = sum.x + tx.x * wgt;
-        sum.y = sum.y + tx.y * wgt;
-        sum.z = sum.z + tx.z * wgt;
-        sum.w = sum.w + tx.w * wgt;
+        // contracted multiply-add, as the reference's drivers compile `sum += texel * weight`
+        sum.x = __builtin_fmaf(tx.x, wgt, sum.x);
+        sum.y = __builtin_fmaf(tx.y, wgt, sum.y);
+        sum.z = __builtin_fmaf(tx.z, wgt, sum.z);
+        sum.w = __builtin_fmaf(tx.w, wgt, sum.w);
     }
     const float ws = s_wsum[o_idx];
     store_texel(dst, p.dst_pxi, x, y, make_float4(sum.x / ws, sum.y / ws, sum.z / ws, sum.w / ws), thr);
