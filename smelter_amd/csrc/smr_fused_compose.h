@@ -1,0 +1,164 @@
+// smr_fused_compose.h — wave B of the hot path: k_compose_output (included by smr_fused.hip only).
+//
+// LayoutShader::render + RgbaToYuvConverter / RgbaToNv12Converter in one launch.  A 256-thread workgroup
+// owns a 128x16 pixel tile; each thread a 4x2 pixel block (one u32 of Y per row, two chroma samples).
+// Per tile the layout list is classified once (one thread per layout):
+//   touch — bounding box intersects the tile
+//   solid — for every pixel of the tile the fragment equals the layout's base value (its colour, or the
+//           texture sample): the tile lies inside the unrotated rect inset past radius / border / AA and
+//           inside every parent mask, so coverage, SDF and smoothstep all evaluate to exactly 1
+//   start — the last solid layout whose base value is opaque: every earlier layout is overwritten by it
+//           (dst * (1 - 1) == 0 exactly), so compositing starts there.
+// A tile whose start layer is a 1:1 texel-aligned opaque texture (the resampled video tile) or an opaque colour
+// and that no later layout touches is a pure copy: texels -> Y'CbCr, no tables, no blending arithmetic.
+// Everything else runs the same per-pixel code as the general compositor (smr_layout_dev.h).
+#pragma once
+
+#include "smr_convert_dev.h"
+#include "smr_layout_dev.h"
+
+namespace {
+
+constexpr int B_TILE_W = 128, B_TILE_H = 16;  // pixels; 32 x 8 threads, one 4x2 pixel block each
+
+__device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int *s_start, const DevLayout *__restrict__ layouts,
+                                                 const smr_mask *__restrict__ masks, int n, int x0, int y0, int x1, int y1, int tid,
+                                                 int nthreads) {
+    if (tid < MAX_LAYOUT_WORDS) { s_touch[tid] = 0; s_solid[tid] = 0; }
+    if (tid == 0) *s_start = -1;
+    __syncthreads();
+    const float cx0 = (float)x0 + 0.5f, cx1 = (float)x1 - 0.5f, cy0 = (float)y0 + 0.5f, cy1 = (float)y1 - 0.5f;
+    for (int i = tid; i < n; i += nthreads) {
+        const DevLayout &L = layouts[i];
+        if (!(L.bx0 < x1 && L.bx1 > x0 && L.by0 < y1 && L.by1 > y0)) continue;
+        atomicOr(&s_touch[i >> 5], 1u << (i & 31));
+        if (!(L.flags & DL_UNROTATED)) continue;
+        bool solid = L.left + L.inset <= cx0 && cx1 <= L.left + L.width - L.inset && L.top + L.inset <= cy0 &&
+                     cy1 <= L.top + L.height - L.inset;
+        for (u32 m = 0; solid && m < L.masks_len; m++) {
+            const smr_mask &K = masks[L.masks_off + m];
+            const float mi = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3])) + 1.0f;
+            solid = K.left + mi <= cx0 && cx1 <= K.left + K.width - mi && K.top + mi <= cy0 && cy1 <= K.top + K.height - mi;
+        }
+        if (!solid) continue;
+        atomicOr(&s_solid[i >> 5], 1u << (i & 31));
+        const bool opaque = (L.type == 0) ? (L.src_kind == 2) : ((L.flags & DL_COLOR_OPAQUE) != 0);
+        if (opaque) atomicMax(s_start, i);
+    }
+    __syncthreads();
+}
+
+// NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV)
+template <int NV>
+__global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
+                                                        const DevLayout *__restrict__ layouts, const smr_mask *__restrict__ masks,
+                                                        int n, int srgb, const float *__restrict__ tables) {
+    __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
+    __shared__ int s_start, s_general;
+    __shared__ float s_tab[SMR_TABLE_FLOATS];
+    const int tid = threadIdx.x;
+    const int tx0 = blockIdx.x * B_TILE_W, ty0 = blockIdx.y * B_TILE_H;
+    if (tid == 0) s_general = 0;
+    classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + B_TILE_H, H), tid, 256);
+    const int start = s_start;
+    // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
+    for (int i = tid; i < n; i += 256) {
+        if (!((s_touch[i >> 5] >> (i & 31)) & 1u) || i < start) continue;
+        const DevLayout &L = layouts[i];
+        const bool copy_layer = i == start && (L.type != 0 || (L.flags & DL_ALIGNED));
+        if (!copy_layer) s_general = 1;
+    }
+    __syncthreads();
+    const bool general = s_general != 0;
+    if (general) {
+        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
+        __syncthreads();
+    }
+    const float *dec = s_tab, *thr = s_tab + 256;
+
+    const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);
+    if (px0 >= W || py0 >= H) return;  // W % 4 == 0, H % 2 == 0: a block is entirely inside or outside
+
+    u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // [row][col]: acc[r * 4 + c]
+    const int words = (n + 31) >> 5;
+    for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
+        u32 bits = s_touch[wi];
+        if (start >= 0 && wi == (start >> 5)) bits &= ~((1u << (start & 31)) - 1u);
+        const u32 solid_bits = s_solid[wi];
+        while (bits) {
+            const int b = __builtin_ctz(bits);
+            const int li = (wi << 5) + b;
+            bits &= bits - 1;
+            const DevLayout &L = layouts[li];
+            const bool solid = (solid_bits >> b) & 1u;
+            if (li == start) {
+                // opaque base layer: dst is irrelevant (dst * (1 - 1) == 0 exactly)
+                if (L.type != 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
+                } else if (L.flags & DL_ALIGNED) {
+                    // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
+                    const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
+                    const u8 *r1 = r0 + L.src.pitch;
+                    if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
+                        const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
+                        acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+                        acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) acc[k] = composite_layout(0u, L, masks, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+                }
+                continue;
+            }
+            if (solid && L.type != 0) {
+                // fragment == colour everywhere in this tile: skip coverage / SDF / masks
+                const float4 frag = make_float4(L.color[0], L.color[1], L.color[2], L.color[3]);
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[k] = blend_store(acc[k], frag, srgb, dec, thr);
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = composite_layout(acc[k], L, masks, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+        }
+    }
+
+    // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52
+    float4 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c[k] = unpack_unorm(acc[k]);
+    u32 yrow0 = 0, yrow1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        yrow0 |= unorm8(yuv_component(c[k], 0)) << (8 * k);
+        yrow1 |= unorm8(yuv_component(c[4 + k], 0)) << (8 * k);
+    }
+    *(u32 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = yrow0;
+    *(u32 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = yrow1;
+    // chroma: the bilinear tap at the chroma texel centre = weights (1/2, 1/2) x (1/2, 1/2)
+    const float fx = 0.5f, gx = 1.0f - fx, fy = 0.5f, gy = 1.0f - fy;
+    u32 uv[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float4 &p00 = c[2 * j], &p01 = c[2 * j + 1], &p10 = c[4 + 2 * j], &p11 = c[4 + 2 * j + 1];
+        float4 m;
+        m.x = (p00.x * gx + p01.x * fx) * gy + (p10.x * gx + p11.x * fx) * fy;
+        m.y = (p00.y * gx + p01.y * fx) * gy + (p10.y * gx + p11.y * fx) * fy;
+        m.z = (p00.z * gx + p01.z * fx) * gy + (p10.z * gx + p11.z * fx) * fy;
+        m.w = 0.0f;
+        uv[j][0] = unorm8(yuv_component(m, 1));
+        uv[j][1] = unorm8(yuv_component(m, 2));
+    }
+    const int cx = px0 >> 1, cy = py0 >> 1;
+    if (NV == 0) {
+        *(u16 *)(up.ptr + (size_t)cy * up.pitch + cx) = (u16)(uv[0][0] | (uv[1][0] << 8));
+        *(u16 *)(vp.ptr + (size_t)cy * vp.pitch + cx) = (u16)(uv[0][1] | (uv[1][1] << 8));
+    } else {
+        *(u32 *)(up.ptr + (size_t)cy * up.pitch + (size_t)cx * 2) = uv[0][0] | (uv[0][1] << 8) | (uv[1][0] << 16) | (uv[1][1] << 24);
+    }
+}
+
+}  // namespace
