@@ -2,15 +2,12 @@
 //
 // LayoutShader::render + RgbaToYuvConverter / RgbaToNv12Converter in one launch.  A 256-thread workgroup
 // owns a 128x16 pixel tile; each thread a 4x2 pixel block (one u32 of Y per row, two chroma samples).
-// Per tile the layout list is classified once (one thread per layout):
-//   touch — bounding box intersects the tile
-//   solid — for every pixel of the tile the fragment equals the layout's base value (its colour, or the
-//           texture sample): the tile lies inside the unrotated rect inset past radius / border / AA and
-//           inside every parent mask, so coverage, SDF and smoothstep all evaluate to exactly 1
-//   start — the last solid layout whose base value is opaque: every earlier layout is overwritten by it
-//           (dst * (1 - 1) == 0 exactly), so compositing starts there.
-// A tile whose start layer is a 1:1 texel-aligned opaque texture (the resampled video tile) or an opaque colour
-// and that no later layout touches is a pure copy: texels -> Y'CbCr, no tables, no blending arithmetic.
+// The layout list is classified twice, both times with the exact "solid region" test of smr_layout_dev.h:
+//   per tile   (one thread per layout): touch / solid / start = last solid layer whose base value is opaque;
+//   per thread (its 4x2 block): the start search continues above the tile's start layer.
+// Compositing begins at the start layer — every earlier layer is overwritten (dst * (1 - 1) == 0 exactly).
+// A start layer that is a 1:1 texel-aligned opaque texture (the resampled video tile) is a byte copy; a tile
+// that nothing else touches needs no tables and no blending arithmetic: texels -> Y'CbCr.
 // Everything else runs the same per-pixel code as the general compositor (smr_layout_dev.h).
 #pragma once
 
@@ -32,20 +29,35 @@ __device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int
         const DevLayout &L = layouts[i];
         if (!(L.bx0 < x1 && L.bx1 > x0 && L.by0 < y1 && L.by1 > y0)) continue;
         atomicOr(&s_touch[i >> 5], 1u << (i & 31));
-        if (!(L.flags & DL_UNROTATED)) continue;
-        bool solid = L.left + L.inset <= cx0 && cx1 <= L.left + L.width - L.inset && L.top + L.inset <= cy0 &&
-                     cy1 <= L.top + L.height - L.inset;
-        for (u32 m = 0; solid && m < L.masks_len; m++) {
-            const smr_mask &K = masks[L.masks_off + m];
-            const float mi = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3])) + 1.0f;
-            solid = K.left + mi <= cx0 && cx1 <= K.left + K.width - mi && K.top + mi <= cy0 && cy1 <= K.top + K.height - mi;
-        }
-        if (!solid) continue;
+        if (!layout_solid_box(L, masks, cx0, cy0, cx1, cy1)) continue;
         atomicOr(&s_solid[i >> 5], 1u << (i & 31));
-        const bool opaque = (L.type == 0) ? (L.src_kind == 2) : ((L.flags & DL_COLOR_OPAQUE) != 0);
-        if (opaque) atomicMax(s_start, i);
+        if (layout_base_opaque(L)) atomicMax(s_start, i);
     }
     __syncthreads();
+}
+
+// fills the 4x2 block from an opaque base layer (dst is irrelevant)
+__device__ __forceinline__ void fill_from_base(u32 acc[8], const DevLayout &L, int px0, int py0, int srgb, const float *__restrict__ dec,
+                                               const float *__restrict__ thr) {
+    if (L.type != 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
+    } else if (L.flags & DL_ALIGNED) {
+        // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
+        const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
+        const u8 *r1 = r0 + L.src.pitch;
+        if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
+            const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
+            acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+            acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(0u, L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+    }
 }
 
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV)
@@ -81,48 +93,40 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
 
     u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // [row][col]: acc[r * 4 + c]
     const int words = (n + 31) >> 5;
-    for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
+    // ---- per-thread start: the topmost layer above the tile's start whose solid region contains this 4x2 block
+    int start_t = start;
+    if (general) {
+        const float bx0 = (float)px0 + 0.5f, bx1 = (float)px0 + 3.5f, by0 = (float)py0 + 0.5f, by1 = (float)py0 + 1.5f;
+        for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)) && start_t == start; wi--) {
+            u32 bits = s_touch[wi];
+            if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
+            while (bits) {
+                const int b = 31 - __builtin_clz(bits);
+                bits &= ~(1u << b);
+                const int li = (wi << 5) + b;
+                const DevLayout &L = layouts[li];
+                if (layout_base_opaque(L) && layout_solid_box(L, masks, bx0, by0, bx1, by1)) { start_t = li; break; }
+            }
+        }
+    }
+    for (int wi = start_t < 0 ? 0 : (start_t >> 5); wi < words; wi++) {
         u32 bits = s_touch[wi];
-        if (start >= 0 && wi == (start >> 5)) bits &= ~((1u << (start & 31)) - 1u);
+        if (start_t >= 0 && wi == (start_t >> 5)) bits &= ~((1u << (start_t & 31)) - 1u);
         const u32 solid_bits = s_solid[wi];
         while (bits) {
             const int b = __builtin_ctz(bits);
             const int li = (wi << 5) + b;
             bits &= bits - 1;
             const DevLayout &L = layouts[li];
-            const bool solid = (solid_bits >> b) & 1u;
-            if (li == start) {
-                // opaque base layer: dst is irrelevant (dst * (1 - 1) == 0 exactly)
-                if (L.type != 0) {
+            if (li == start_t) {
+                fill_from_base(acc, L, px0, py0, srgb, dec, thr);
+            } else if ((solid_bits >> b) & 1u) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
-                } else if (L.flags & DL_ALIGNED) {
-                    // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
-                    const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
-                    const u8 *r1 = r0 + L.src.pitch;
-                    if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
-                        const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
-                        acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
-                        acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
-                    } else {
+                for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(acc[k], L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+            } else {
 #pragma unroll
-                        for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
-                    }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; k++) acc[k] = composite_layout(0u, L, masks, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
-                }
-                continue;
+                for (int k = 0; k < 8; k++) acc[k] = composite_layout(acc[k], L, masks, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
             }
-            if (solid && L.type != 0) {
-                // fragment == colour everywhere in this tile: skip coverage / SDF / masks
-                const float4 frag = make_float4(L.color[0], L.color[1], L.color[2], L.color[3]);
-#pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] = blend_store(acc[k], frag, srgb, dec, thr);
-                continue;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] = composite_layout(acc[k], L, masks, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
         }
     }
 

@@ -2,11 +2,14 @@
 //
 // One launch covers every scaled planar-YUV input of the frame (blockIdx.z = job).  A 512-thread
 // workgroup produces one 64x32 tile of the dst-sized RGBA8 tile surface:
-//   * each of the 8 waves runs its own pipeline over the tile's source footprint, two source rows
-//     at a time: convert (YUV -> RGBA8 bytes -> sRGB-decoded linear f32, 2x2 quads for 4:2:0) into a
-//     wave-private LDS strip, then the horizontal Lanczos of exactly those two rows into the shared
-//     f16 intermediate M (LDS).  No workgroup barrier separates the two — only the wave's own
-//     in-order LDS stream — so conversion latency of one wave overlaps filter arithmetic of others.
+//   * prologue: the tile's raw Y/U/V source footprint (~10 KB), the weight tables of its 64 columns /
+//     32 rows and the sRGB tables are pulled into LDS with one round of loads — the only global-memory
+//     latency the workgroup is exposed to;
+//   * each of the 8 waves then runs its own pipeline over the footprint, two source rows at a time:
+//     convert (YUV -> RGBA8 bytes -> sRGB-decoded linear f32; 2x2 quads sharing one chroma neighbourhood
+//     for 4:2:0) into a wave-private LDS strip, then the horizontal Lanczos of exactly those two rows
+//     into the shared f16 intermediate M (LDS).  No workgroup barrier separates the two — only the
+//     wave's own in-order LDS stream;
 //   * one barrier, then the vertical Lanczos over M, sRGB encode, one coalesced 256 B row store per wave.
 // The node texture (RGBA8, input-sized) and the Rgba16Float intermediate of the reference never exist
 // in HBM; their quantisation (u8, f16) is applied in registers at the same points.
@@ -27,6 +30,10 @@ __device__ __forceinline__ float div_cr(float a, float b, float rb) {
     float r = __builtin_fmaf(-q0, b, a);
     return __builtin_fmaf(r, rb, q0);
 }
+
+// clamp for values that are never NaN (one v_med3_f32)
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+__device__ __forceinline__ u32 unorm8_fast(float x) { return (u32)(int)(clamp01(x) * 255.0f + 0.5f); }
 
 // ------------------------------------------------------------------ weight tables (device cache)
 __global__ __launch_bounds__(64) void k_build_weights(float scale, float offset, int taps, int n, int *__restrict__ first,
@@ -98,7 +105,7 @@ int get_weights(smr_ctx *ctx, float scale, float offset, int n, WeightPtrs *out)
 
 // ------------------------------------------------------------------ kernel
 constexpr int TW = 64;          // output tile width  (one lane per column)
-constexpr int TH = 32;          // output tile height
+constexpr int TH = 24;          // output tile height (keeps LDS at ~74 KB for k = 1.5: two workgroups per CU)
 constexpr int A_WAVES = 8;
 constexpr int A_THREADS = A_WAVES * 64;
 
@@ -107,13 +114,18 @@ struct IngestJob {
     SurfView dst;         // RGBA8 tile, dst-sized
     int src_w, src_h;
     int full_range;
-    int fast420;          // 4:2:0 with even luma size: 2x2-quad conversion path
+    int fast420;          // 4:2:0 with even luma size: LDS-staged 2x2-quad conversion path
     int taps_h, taps_v;
     const int *first_h; const float *wsum_h; const float *w_h;
     const int *first_v; const float *wsum_v; const float *w_v;
     int tiles_x, tiles_y;
     int nc_max, nr_max;   // LDS capacity: columns of a source strip, rows of M (even)
 };
+
+// raw-footprint staging geometry (bytes)
+__host__ __device__ inline int raw_y_stride(int nc_max) { return (nc_max + 8 + 3) & ~3; }
+__host__ __device__ inline int raw_c_stride(int nc_max) { return ((nc_max >> 1) + 4 + 3) & ~3; }
+__host__ __device__ inline int raw_c_rows(int nr_max) { return (nr_max >> 1) + 2; }
 
 __device__ __forceinline__ float4 half4_to_float4(uint2 raw) {
     __half2 lo = *(const __half2 *)&raw.x, hi = *(const __half2 *)&raw.y;
@@ -135,13 +147,13 @@ __device__ __forceinline__ float4 yuv_expanded_to_linear(float y, float u, float
     float r = y + 1.5748f * (v - 0.5f);
     float g = y - 0.1873f * (u - 0.5f) - 0.4681f * (v - 0.5f);
     float b = y + 1.8556f * (u - 0.5f);
-    return make_float4(s_dec[unorm8(r)], s_dec[unorm8(g)], s_dec[unorm8(b)], 1.0f);
+    return make_float4(s_dec[unorm8_fast(r)], s_dec[unorm8_fast(g)], s_dec[unorm8_fast(b)], 1.0f);
 }
 
 __device__ __forceinline__ float expand_chroma(float u) {
     // clamp((u - 16/255) / 0.87843137254, 0, 1) — planar_yuv_to_rgba.wgsl:49-50
     const float C = 0.87843137254f;
-    return clampf(div_cr(u - (16.0f / 255.0f), C, 1.0f / C), 0.0f, 1.0f);
+    return clamp01(div_cr(u - (16.0f / 255.0f), C, 1.0f / C));
 }
 
 __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *__restrict__ jobs, const float *__restrict__ tables) {
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
     const int tw = min(TW, J.dst.w - tx0), th = min(TH, J.dst.h - ty0);
     const int taps_h = J.taps_h, taps_v = J.taps_v;
     const int ncm = J.nc_max;
+    const int sw = J.src_w, sh = J.src_h;
 
     // ---- LDS carve (every region is a multiple of 16 B)
     float *s_tab = (float *)smem;                          // SMR_TABLE_FLOATS: dec | thr | enc
@@ -169,7 +182,27 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
     float *s_rsv = s_wsv + TH;                             // [TH]
     float4 *S_all = (float4 *)(s_rsv + TH);                // [A_WAVES][2][nc_max] linear RGBA, wave-private strips
     uint2 *M = (uint2 *)(S_all + (size_t)A_WAVES * 2 * ncm);  // [nr_max][TW] half4
+    u8 *rawY = (u8 *)(M + (size_t)J.nr_max * TW);          // [nr_max][ys]        (fast420 only)
+    const int ys = raw_y_stride(ncm), cs = raw_c_stride(ncm), crows = raw_c_rows(J.nr_max);
+    u8 *rawU = rawY + (size_t)J.nr_max * ys;               // [crows][cs]
+    u8 *rawV = rawU + (size_t)crows * cs;
 
+    // ---- the tile's source footprint (first[] is non-decreasing in the output coordinate)
+    int c_lo = clampi(J.first_h[tx0], 0, sw - 1);
+    const int c_hi = clampi(J.first_h[tx0 + tw - 1] + taps_h - 1, 0, sw - 1);
+    int r_lo = clampi(J.first_v[ty0], 0, sh - 1);
+    const int r_hi = clampi(J.first_v[ty0 + th - 1] + taps_v - 1, 0, sh - 1);
+    if (J.fast420) {
+        // 2x2 conversion quads start on odd luma coordinates (they share one 2x2 chroma neighbourhood)
+        c_lo -= (c_lo & 1) ^ 1;
+        r_lo -= (r_lo & 1) ^ 1;
+    }
+    const int NC = c_hi - c_lo + 1, NR = r_hi - r_lo + 1;
+    const int n_pairs = (NR + 1) >> 1;
+    const int cbase = max(c_lo, 0) & ~3;          // luma staging keeps global dword alignment
+    const int qx0 = (c_lo + 1) >> 1, qy0 = (r_lo + 1) >> 1;  // chroma index of the first quad column / row
+
+    // ---- prologue: one round of global loads
     for (int i = tid; i < SMR_TABLE_FLOATS; i += A_THREADS) s_tab[i] = tables[i];
     if (tid < 256) {
         // u8 -> f32 conversions done once per table entry with the same IEEE operations the per-pixel path uses
@@ -194,40 +227,42 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
         s_wsv[tid - 64] = ws;
         s_rsv[tid - 64] = 1.0f / ws;
     }
+    if (J.fast420) {
+        // luma: aligned dwords of rows [max(r_lo,0), r_hi], columns [cbase, c_hi]
+        const int ndw = ((c_hi - cbase) >> 2) + 1;
+        const int row0 = max(r_lo, 0);
+        for (int i = tid; i < (r_hi - row0 + 1) * ndw; i += A_THREADS) {
+            const int rr = i / ndw, d = i - rr * ndw;
+            const int gy = row0 + rr;
+            // rows are pitched to 256 B, so reading the last dword of a row never leaves the allocation
+            const u32 v = *(const u32 *)(J.yp.ptr + (size_t)gy * J.yp.pitch + cbase + 4 * d);
+            *(u32 *)(rawY + (size_t)(gy - r_lo) * ys + 4 * d) = v;
+        }
+        // chroma: rows qy0-1 .. qy0+n_pairs-1 (+1), columns qx0-1 .. qx0+nq, edge clamp baked in
+        const int nq = (NC + 1) >> 1;
+        const int ccols = nq + 1, crw = n_pairs + 1;
+        for (int i = tid; i < crw * ccols; i += A_THREADS) {
+            const int j = i / ccols, k = i - j * ccols;
+            const int cy = clampi(qy0 - 1 + j, 0, J.up.h - 1), cx = clampi(qx0 - 1 + k, 0, J.up.w - 1);
+            rawU[j * cs + k] = J.up.ptr[(size_t)cy * J.up.pitch + cx];
+            rawV[j * cs + k] = J.vp.ptr[(size_t)cy * J.vp.pitch + cx];
+        }
+    }
     __syncthreads();
     const float *s_dec = s_tab, *s_thr = s_tab + 256;
-
-    const int sw = J.src_w, sh = J.src_h;
-    // first[] is non-decreasing in the output coordinate, so the tile's source footprint is:
-    int c_lo = clampi(s_fh[0], 0, sw - 1);
-    const int c_hi = clampi(s_fh[tw - 1] + taps_h - 1, 0, sw - 1);
-    int r_lo = clampi(s_fv[0], 0, sh - 1);
-    const int r_hi = clampi(s_fv[th - 1] + taps_v - 1, 0, sh - 1);
-    if (J.fast420) {
-        // 2x2 conversion quads start on odd luma coordinates (they share one 2x2 chroma neighbourhood)
-        c_lo -= (c_lo & 1) ^ 1;
-        r_lo -= (r_lo & 1) ^ 1;
-    }
-    const int NC = c_hi - c_lo + 1, NR = r_hi - r_lo + 1;
-    const int n_pairs = (NR + 1) >> 1;
     float4 *S = S_all + (size_t)wave * 2 * ncm;  // this wave's two-row strip
 
     for (int pr = wave; pr < n_pairs; pr += A_WAVES) {
         const int y0 = r_lo + 2 * pr, y1 = y0 + 1;
         // ---- convert the two source rows: YUV -> RGBA8 (node texture bytes) -> sRGB-decoded linear f32
         if (J.fast420) {
-            const int qy = y1 >> 1;  // y0 odd (or -1), y1 even
-            const int cya = clampi(qy - 1, 0, J.up.h - 1), cyb = clampi(qy, 0, J.up.h - 1);
-            const u8 *ua = J.up.ptr + (size_t)cya * J.up.pitch, *ub = J.up.ptr + (size_t)cyb * J.up.pitch;
-            const u8 *va = J.vp.ptr + (size_t)cya * J.vp.pitch, *vb = J.vp.ptr + (size_t)cyb * J.vp.pitch;
-            const u8 *yr0 = J.yp.ptr + (size_t)max(y0, 0) * J.yp.pitch, *yr1 = J.yp.ptr + (size_t)min(y1, sh - 1) * J.yp.pitch;
+            const u8 *ua = rawU + pr * cs, *ub = ua + cs, *va = rawV + pr * cs, *vb = va + cs;
+            const u8 *yr0 = rawY + (size_t)(2 * pr) * ys - cbase, *yr1 = yr0 + ys;  // index by absolute x
             const bool ok0 = y0 >= 0, ok1 = y1 <= r_hi;
             for (int qc = lane; qc < ((NC + 1) >> 1); qc += 64) {
                 const int x0 = c_lo + 2 * qc, x1 = x0 + 1;  // x0 odd (or -1), x1 even
-                const int qx = x1 >> 1;
-                const int cxa = clampi(qx - 1, 0, J.up.w - 1), cxb = clampi(qx, 0, J.up.w - 1);
-                const float u00 = s_n255[ua[cxa]], u01 = s_n255[ua[cxb]], u10 = s_n255[ub[cxa]], u11 = s_n255[ub[cxb]];
-                const float v00 = s_n255[va[cxa]], v01 = s_n255[va[cxb]], v10 = s_n255[vb[cxa]], v11 = s_n255[vb[cxb]];
+                const float u00 = s_n255[ua[qc]], u01 = s_n255[ua[qc + 1]], u10 = s_n255[ub[qc]], u11 = s_n255[ub[qc + 1]];
+                const float v00 = s_n255[va[qc]], v01 = s_n255[va[qc + 1]], v10 = s_n255[vb[qc]], v11 = s_n255[vb[qc + 1]];
                 // bilinear weights of the chroma tap: odd coordinate -> 1/4, even -> 3/4 (planar_yuv_to_rgba.wgsl:37-39)
 #pragma unroll
                 for (int ix = 0; ix < 2; ix++) {
@@ -276,15 +311,29 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
             const int fh = s_fh[lane];
             const float wsh = s_wsh[lane], rsh = s_rsh[lane];
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 *Sa = S - c_lo, *Sb = S + ncm - c_lo;
-            for (int t = 0; t < taps_h; t++) {
-                const float wgt = s_wh[t * TW + lane];
-                const int s = clampi(fh + t, 0, sw - 1);
-                const float4 ta = Sa[s], tb = Sb[s];
-                a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
-                a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
-                b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
-                b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+            const float *wcol = s_wh + lane;
+            if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
+                // interior: no edge clamp, consecutive texels
+                const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
+                for (int t = 0; t < taps_h; t++) {
+                    const float wgt = wcol[t * TW];
+                    const float4 ta = pa[t], tb = pb[t];
+                    a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                    a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                    b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
+                    b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                }
+            } else {
+                const float4 *Sa = S - c_lo, *Sb = S + ncm - c_lo;
+                for (int t = 0; t < taps_h; t++) {
+                    const float wgt = wcol[t * TW];
+                    const int s = clampi(fh + t, 0, sw - 1);
+                    const float4 ta = Sa[s], tb = Sb[s];
+                    a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                    a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                    b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
+                    b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                }
             }
             if (y0 >= 0) M[(size_t)(2 * pr) * TW + lane] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
             if (y1 <= r_hi) M[(size_t)(2 * pr + 1) * TW + lane] = float4_to_half4(div_cr(b.x, wsh, rsh), div_cr(b.y, wsh, rsh), div_cr(b.z, wsh, rsh), div_cr(b.w, wsh, rsh));
@@ -301,11 +350,20 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
             const int fv = s_fv[y];
             float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
             const float *wv = s_wv + y * taps_v;
-            for (int t = 0; t < taps_v; t++) {
-                const float wgt = wv[t];
-                const int r = clampi(fv + t, 0, sh - 1) - r_lo;
-                const float4 m = half4_to_float4(M[(size_t)r * TW + lane]);
-                sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
+            if (fv >= 0 && fv + taps_v - 1 <= sh - 1) {
+                const uint2 *pm = M + (size_t)(fv - r_lo) * TW + lane;
+                for (int t = 0; t < taps_v; t++) {
+                    const float wgt = wv[t];
+                    const float4 m = half4_to_float4(pm[(size_t)t * TW]);
+                    sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
+                }
+            } else {
+                for (int t = 0; t < taps_v; t++) {
+                    const float wgt = wv[t];
+                    const int r = clampi(fv + t, 0, sh - 1) - r_lo;
+                    const float4 m = half4_to_float4(M[(size_t)r * TW + lane]);
+                    sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
+                }
             }
             const float ws = s_wsv[y], rs = s_rsv[y];
             const u32 r8 = srgb_encode8(div_cr(sx_, ws, rs), s_thr), g8 = srgb_encode8(div_cr(sy_, ws, rs), s_thr),
@@ -318,7 +376,9 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
 size_t ingest_lds_bytes(const IngestJob &J) {
     size_t floats = SMR_TABLE_FLOATS + 256 + 256 + (size_t)((J.taps_h * TW + 3) & ~3) + (size_t)((TH * J.taps_v + 3) & ~3) + TW + TH +
                     2 * TW + 2 * TH;
-    return floats * 4 + (size_t)A_WAVES * 2 * J.nc_max * 16 + (size_t)J.nr_max * TW * 8;
+    size_t bytes = floats * 4 + (size_t)A_WAVES * 2 * J.nc_max * 16 + (size_t)J.nr_max * TW * 8;
+    if (J.fast420) bytes += (size_t)J.nr_max * raw_y_stride(J.nc_max) + 2 * (size_t)raw_c_rows(J.nr_max) * raw_c_stride(J.nc_max);
+    return (bytes + 15) & ~(size_t)15;
 }
 
 bool is_planar_yuv(u32 fmt) { return fmt <= SMR_FRAME_PLANAR_YUVJ420; }
@@ -340,8 +400,10 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     J.dst = view_of(tile);
     J.src_w = (int)f->width; J.src_h = (int)f->height;
     J.full_range = f->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
+    // the staged path reads whole dwords of luma rows: needs the 256 B row pitch of smr_frame_create / a 4 B-aligned pitch
     J.fast420 = ((f->format == SMR_FRAME_PLANAR_YUV420 || f->format == SMR_FRAME_PLANAR_YUVJ420) && f->width % 2 == 0 &&
-                 f->height % 2 == 0 && f->width >= 2 && f->height >= 2) ? 1 : 0;
+                 f->height % 2 == 0 && f->width >= 2 && f->height >= 2 && (J.yp.pitch % 4) == 0 && (((uintptr_t)J.yp.ptr) % 4) == 0 &&
+                 J.yp.pitch >= ((f->width + 3u) & ~3u)) ? 1 : 0;
     J.taps_h = wh.taps; J.taps_v = wv.taps;
     J.first_h = wh.first; J.wsum_h = wh.wsum; J.w_h = wh.w;
     J.first_v = wv.first; J.wsum_v = wv.wsum; J.w_v = wv.w;

@@ -116,11 +116,17 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         }
         // ---- classification helpers for the fused compose kernel
         D.flags = (D.cs == 1.0f && D.sn == 0.0f) ? DL_UNROTATED : 0;
+        // Solid region: inside the rect inset by m >= radius on every side the SDF is <= -m, i.e. edge_distance >= m.
+        // m must also reach the point where every smoothstep saturates at exactly 1:
+        //   no border: smoothstep(-.5,.5,ed) -> ed >= .5;  texture border: smoothstep(bw-.5,bw+.5,ed) -> ed >= bw+.5;
+        //   colour border: smoothstep(bw,bw+1,ed) -> ed >= bw+1;  shadow: smoothstep(-b/2,b/2,ed) -> ed >= b/2.
         float rmax = fmaxf(fmaxf(L.border_radius[0], L.border_radius[1]), fmaxf(L.border_radius[2], L.border_radius[3]));
-        D.inset = rmax + 1.0f;
-        if (L.type != 2 && L.border_width >= 1.0f) D.inset += L.border_width;
-        // (shadow radii already include blur/2, flatten.rs:354; ed >= blur/2 needs another blur/2)
-        if (L.type == 2) D.inset += L.blur_radius / 2.0f;
+        float need = 0.5f;
+        if (L.type == 2) need = L.blur_radius / 2.0f;
+        else if (L.border_width >= 1.0f) need = L.border_width + (L.type == 0 ? 0.5f : 1.0f);
+        auto half_int = [](float v) { return v * 2.0f == floorf(v * 2.0f) && fabsf(v) < 32768.0f; };
+        const bool exact = rmax == 0.0f && half_int(L.left) && half_int(L.top) && half_int(L.width) && half_int(L.height) && half_int(need);
+        D.inset = fmaxf(rmax, need) + (exact ? 0.0f : 0.015625f);  // 1/64 px of slack for f32 rounding in the SDF
         if (L.type == 0 && D.src_kind != 0 && (D.flags & DL_UNROTATED) && L.crop[0] == 0.0f && L.crop[1] == 0.0f &&
             L.crop[2] == (float)D.tex_w && L.crop[3] == (float)D.tex_h && L.width == (float)D.tex_w && L.height == (float)D.tex_h &&
             L.left == floorf(L.left) && L.top == floorf(L.top) && fabsf(L.left) < 65536.0f && fabsf(L.top) < 65536.0f) {

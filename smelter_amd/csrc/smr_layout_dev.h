@@ -97,8 +97,13 @@ __device__ __forceinline__ bool layout_covers(const DevLayout &L, int px, int py
     fx = (float)px + 0.5f;
     fy = (float)py + 0.5f;
     float dx = fx - L.cx, dy = -(fy - L.cy);
-    lx = L.cs * dx + L.sn * dy;
-    ly = -L.sn * dx + L.cs * dy;
+    if (L.flags & DL_UNROTATED) {  // cs == 1, sn == 0: 1*dx + 0*dy == dx exactly
+        lx = dx;
+        ly = dy;
+    } else {
+        lx = L.cs * dx + L.sn * dy;
+        ly = -L.sn * dx + L.cs * dy;
+    }
     if (!(lx >= -L.qw / 2.0f && lx < L.qw / 2.0f)) return false;
     if (!(-ly >= -L.qh / 2.0f && -ly < L.qh / 2.0f)) return false;
     return true;
@@ -178,20 +183,62 @@ __device__ __forceinline__ u32 blend_store(u32 acc, float4 frag, int srgb, const
     return r | (g << 8) | (b << 16) | (a << 24);
 }
 
+// textureSample of a texture layout at the interpolated tex_coords (vertex stage crop transform, wgsl:159-172)
+__device__ __forceinline__ float4 layout_texture_sample(const DevLayout &L, float lx, float ly, int srgb, const float *__restrict__ dec) {
+    if (L.src_kind == 0) return make_float4(0.f, 0.f, 0.f, 0.f);
+    float u01 = lx / L.qw + 0.5f, v01 = 0.5f - ly / L.qh;
+    float tu = (L.crop[1] + u01 * L.crop[2]) / (float)L.tex_w;
+    float tv = (L.crop[0] + v01 * L.crop[3]) / (float)L.tex_h;
+    return sample_rgba_bilinear(L.src, srgb ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM, tu, tv, dec);
+}
+
 // One layout applied to one pixel: coverage, varyings, texture fetch, fragment, blend.
 __device__ __forceinline__ u32 composite_layout(u32 acc, const DevLayout &L, const smr_mask *__restrict__ masks, int px, int py,
                                                 int srgb, const float *__restrict__ dec, const float *__restrict__ thr) {
     float fx, fy, lx, ly;
     if (!layout_covers(L, px, py, fx, fy, lx, ly)) return acc;
     float4 sample = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (L.type == 0 && L.src_kind != 0) {
-        float u01 = lx / L.qw + 0.5f, v01 = 0.5f - ly / L.qh;
-        float tu = (L.crop[1] + u01 * L.crop[2]) / (float)L.tex_w;
-        float tv = (L.crop[0] + v01 * L.crop[3]) / (float)L.tex_h;
-        sample = sample_rgba_bilinear(L.src, srgb ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM, tu, tv, dec);
-    }
+    if (L.type == 0) sample = layout_texture_sample(L, lx, ly, srgb, dec);
     float4 frag = layout_fragment(L, masks, fx, fy, lx, ly, sample);
     return blend_store(acc, frag, srgb, dec, thr);
+}
+
+// The same for a pixel known to lie in the layout's "solid" region: coverage, SDF, border and masks all
+// evaluate to exactly 1, so the fragment is the base value (colour or texture sample) itself.
+__device__ __forceinline__ u32 composite_layout_solid(u32 acc, const DevLayout &L, int px, int py, int srgb,
+                                                      const float *__restrict__ dec, const float *__restrict__ thr) {
+    float4 frag;
+    if (L.type == 0) {
+        float fx, fy, lx, ly;
+        layout_covers(L, px, py, fx, fy, lx, ly);
+        frag = layout_texture_sample(L, lx, ly, srgb, dec);
+    } else {
+        frag = make_float4(L.color[0], L.color[1], L.color[2], L.color[3]);
+    }
+    return blend_store(acc, frag, srgb, dec, thr);
+}
+
+// Does the axis-aligned box of pixel centres [cx0,cx1] x [cy0,cy1] lie in the solid region of L?
+// Inside a rect inset by m >= radius on every side the SDF is <= -m; m also covers the border / blur band,
+// plus 1/64 px of slack for f32 rounding unless every quantity is exactly representable (L.inset, host).
+__device__ __forceinline__ bool layout_solid_box(const DevLayout &L, const smr_mask *__restrict__ masks, float cx0, float cy0,
+                                                 float cx1, float cy1) {
+    if (!(L.flags & DL_UNROTATED)) return false;
+    bool solid = L.left + L.inset <= cx0 && cx1 <= L.left + L.width - L.inset && L.top + L.inset <= cy0 &&
+                 cy1 <= L.top + L.height - L.inset;
+    for (u32 m = 0; solid && m < L.masks_len; m++) {
+        const smr_mask &K = masks[L.masks_off + m];
+        const float rmax = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3]));
+        const bool exact = rmax == 0.0f && K.left * 2.0f == floorf(K.left * 2.0f) && K.top * 2.0f == floorf(K.top * 2.0f) &&
+                           K.width * 2.0f == floorf(K.width * 2.0f) && K.height * 2.0f == floorf(K.height * 2.0f);
+        const float mi = fmaxf(rmax, 0.5f) + (exact ? 0.0f : 0.015625f);
+        solid = K.left + mi <= cx0 && cx1 <= K.left + K.width - mi && K.top + mi <= cy0 && cy1 <= K.top + K.height - mi;
+    }
+    return solid;
+}
+
+__device__ __forceinline__ bool layout_base_opaque(const DevLayout &L) {
+    return (L.type == 0) ? (L.src_kind == 2) : ((L.flags & DL_COLOR_OPAQUE) != 0);
 }
 
 #endif  // __HIPCC__
