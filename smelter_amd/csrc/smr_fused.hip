@@ -30,6 +30,8 @@ bool fused_disabled(smr_ctx *ctx) {
     if (ctx->fused_disabled < 0) {
         const char *e = getenv("SMR_DISABLE_FUSED");
         ctx->fused_disabled = (e && e[0] && e[0] != '0') ? 1 : 0;
+        const char *a = getenv("SMR_ABLATE");
+        ctx->ablate = a ? atoi(a) : 0;
     }
     return ctx->fused_disabled == 1;
 }
@@ -147,16 +149,14 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
 
     // ---- parameters -> device (one pinned staging slot, one copy)
     PackedLayouts packed;
-    int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h,
-                              jobs.size() * sizeof(IngestJob), &packed);
+    int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, 0, &packed);
     if (rc != SMR_OK) return rc;
-    if (!jobs.empty()) memcpy(packed.extra_host, jobs.data(), jobs.size() * sizeof(IngestJob));
     rc = smr_pack_commit(ctx, &packed);
     if (rc != SMR_OK) return rc;
 
-    // ---- wave A
+    // ---- wave A (job descriptors ride in the kernel arguments)
     if (!jobs.empty()) {
-        rc = launch_ingest(ctx, jobs, packed.extra_dev);
+        rc = launch_ingest(ctx, jobs);
         if (rc != SMR_OK) return rc;
     }
 
@@ -204,15 +204,7 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
         std::vector<IngestJob> jobs(1);
         int rc = make_ingest_job(ctx, in, plan, dst, &jobs[0]);
         if (rc != SMR_OK) return rc;
-        PackedLayouts packed;
-        rc = smr_pack_layouts(ctx, nullptr, 0, nullptr, nullptr, 0, 1, 1, sizeof(IngestJob), &packed);
-        if (rc != SMR_OK) return rc;
-        memcpy(packed.extra_host, jobs.data(), sizeof(IngestJob));
-        rc = smr_pack_commit(ctx, &packed);
-        if (rc != SMR_OK) return rc;
-        rc = launch_ingest(ctx, jobs, packed.extra_dev);
-        if (rc != SMR_OK) return rc;
-        rc = smr_pack_done(ctx, &packed);
+        rc = launch_ingest(ctx, jobs);
         return rc == SMR_OK ? kind : rc;
     }
     smr_surface *node = smr_cached_surface(ctx, SLOT_INGEST_NODE, in->width, in->height, SMR_PX_RGBA8);

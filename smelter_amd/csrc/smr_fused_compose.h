@@ -19,7 +19,7 @@ namespace {
 constexpr int B_TILE_W = 128, B_TILE_H = 16;  // pixels; 32 x 8 threads, one 4x2 pixel block each
 
 __device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int *s_start, const DevLayout *__restrict__ layouts,
-                                                 const smr_mask *__restrict__ masks, int n, int x0, int y0, int x1, int y1, int tid,
+                                                 const DevMask *__restrict__ masks, int n, int x0, int y0, int x1, int y1, int tid,
                                                  int nthreads) {
     if (tid < MAX_LAYOUT_WORDS) { s_touch[tid] = 0; s_solid[tid] = 0; }
     if (tid == 0) *s_start = -1;
@@ -63,7 +63,7 @@ __device__ __forceinline__ void fill_from_base(u32 acc[8], const DevLayout &L, i
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV)
 template <int NV>
 __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
-                                                        const DevLayout *__restrict__ layouts, const smr_mask *__restrict__ masks,
+                                                        const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks,
                                                         int n, int srgb, const float *__restrict__ tables) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;

@@ -23,14 +23,6 @@
 
 namespace {
 
-// a / b, correctly rounded, from rb = RN(1/b): q0 = RN(a*rb); r = a - q0*b (exact, FMA); q = RN(q0 + r*rb)
-// (Markstein; holds for normal operands unless b's significand is all ones).
-__device__ __forceinline__ float div_cr(float a, float b, float rb) {
-    float q0 = a * rb;
-    float r = __builtin_fmaf(-q0, b, a);
-    return __builtin_fmaf(r, rb, q0);
-}
-
 // clamp for values that are never NaN (one v_med3_f32)
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 __device__ __forceinline__ u32 unorm8_fast(float x) { return (u32)(int)(clamp01(x) * 255.0f + 0.5f); }
@@ -44,7 +36,7 @@ __global__ __launch_bounds__(64) void k_build_weights(float scale, float offset,
     float s;
     first[i] = lanczos_weights(i, scale, offset, taps, tmp, &s);
     wsum[i] = s;
-    for (int t = 0; t < taps; t++) w[(size_t)i * taps + t] = tmp[t];
+    for (int t = 0; t < taps; t++) w[(size_t)t * n + i] = tmp[t];  // tap-major: a tile reads contiguous runs
 }
 
 struct WeightPtrs {
@@ -115,9 +107,11 @@ struct IngestJob {
     int src_w, src_h;
     int full_range;
     int fast420;          // 4:2:0 with even luma size: LDS-staged 2x2-quad conversion path
+    int ablate;           // profiling only (SMR_ABLATE): 1 skip convert, 2 skip H taps, 4 skip V taps, 8 skip staging
     int taps_h, taps_v;
-    const int *first_h; const float *wsum_h; const float *w_h;
-    const int *first_v; const float *wsum_v; const float *w_v;
+    float scale_h, off_h, scale_v, off_v;  // axis mappings (resampler.rs:36-48): source texels per output texel, crop offset
+    const float *wsum_h; const float *w_h;  // device weight tables: wsum[n], w[taps][n] (tap-major)
+    const float *wsum_v; const float *w_v;
     int tiles_x, tiles_y;
     int nc_max, nr_max;   // LDS capacity: columns of a source strip, rows of M (even)
 };
@@ -156,9 +150,15 @@ __device__ __forceinline__ float expand_chroma(float u) {
     return clamp01(div_cr(u - (16.0f / 255.0f), C, 1.0f / C));
 }
 
-__global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *__restrict__ jobs, const float *__restrict__ tables) {
+// Job descriptors travel in the kernel-argument segment (scalar loads, no dependent global round trip).
+constexpr int MAX_JOBS_PER_LAUNCH = 16;
+struct IngestArgs {
+    IngestJob jobs[MAX_JOBS_PER_LAUNCH];
+};
+
+__global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs args, const float *__restrict__ tables) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const IngestJob &J = jobs[blockIdx.z];
+    const IngestJob &J = args.jobs[blockIdx.z];
     if ((int)blockIdx.x >= J.tiles_x || (int)blockIdx.y >= J.tiles_y) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -188,10 +188,11 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
     u8 *rawV = rawU + (size_t)crows * cs;
 
     // ---- the tile's source footprint (first[] is non-decreasing in the output coordinate)
-    int c_lo = clampi(J.first_h[tx0], 0, sw - 1);
-    const int c_hi = clampi(J.first_h[tx0 + tw - 1] + taps_h - 1, 0, sw - 1);
-    int r_lo = clampi(J.first_v[ty0], 0, sh - 1);
-    const int r_hi = clampi(J.first_v[ty0 + th - 1] + taps_v - 1, 0, sh - 1);
+    //      computed from the mapping itself (same f32 sequence as the weight tables) — no dependent load
+    int c_lo = clampi(lanczos_first(tx0, J.scale_h, J.off_h), 0, sw - 1);
+    const int c_hi = clampi(lanczos_first(tx0 + tw - 1, J.scale_h, J.off_h) + taps_h - 1, 0, sw - 1);
+    int r_lo = clampi(lanczos_first(ty0, J.scale_v, J.off_v), 0, sh - 1);
+    const int r_hi = clampi(lanczos_first(ty0 + th - 1, J.scale_v, J.off_v) + taps_v - 1, 0, sh - 1);
     if (J.fast420) {
         // 2x2 conversion quads start on odd luma coordinates (they share one 2x2 chroma neighbourhood)
         c_lo -= (c_lo & 1) ^ 1;
@@ -210,42 +211,72 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
         s_n255[tid] = v;
         s_ylut[tid] = J.full_range ? v : clampf((v - (16.0f / 255.0f)) / 0.85882352941f, 0.0f, 1.0f);
     }
+    // weight tables are stored tap-major in global memory (w[t * n + i]): a tile's slice of every tap is contiguous
     for (int i = tid; i < taps_h * TW; i += A_THREADS) {
         int t = i / TW, x = i - t * TW;
-        s_wh[i] = x < tw ? J.w_h[(size_t)(tx0 + x) * taps_h + t] : 0.0f;
+        s_wh[i] = x < tw ? J.w_h[(size_t)t * J.dst.w + tx0 + x] : 0.0f;
     }
-    for (int i = tid; i < th * taps_v; i += A_THREADS) s_wv[i] = J.w_v[(size_t)ty0 * taps_v + i];
+    for (int i = tid; i < taps_v * TH; i += A_THREADS) {
+        int t = i / TH, y = i - t * TH;
+        if (y < th) s_wv[y * taps_v + t] = J.w_v[(size_t)t * J.dst.h + ty0 + y];
+    }
     if (tid < tw) {
-        s_fh[tid] = J.first_h[tx0 + tid];
+        s_fh[tid] = lanczos_first(tx0 + tid, J.scale_h, J.off_h);
         const float ws = J.wsum_h[tx0 + tid];
         s_wsh[tid] = ws;
         s_rsh[tid] = 1.0f / ws;
     }
     if (tid >= 64 && tid - 64 < th) {
-        s_fv[tid - 64] = J.first_v[ty0 + tid - 64];
+        s_fv[tid - 64] = lanczos_first(ty0 + tid - 64, J.scale_v, J.off_v);
         const float ws = J.wsum_v[ty0 + tid - 64];
         s_wsv[tid - 64] = ws;
         s_rsv[tid - 64] = 1.0f / ws;
     }
-    if (J.fast420) {
-        // luma: aligned dwords of rows [max(r_lo,0), r_hi], columns [cbase, c_hi]
+    if (J.fast420 && !(J.ablate & 8)) {
+        // luma: aligned dwords of rows [max(r_lo,0), r_hi], columns [cbase, c_hi].  Half a wave per row (32 dwords =
+        // 128 B), 16 rows per sweep; every sweep's loads are issued before the first LDS store waits on them.
         const int ndw = ((c_hi - cbase) >> 2) + 1;
         const int row0 = max(r_lo, 0);
-        for (int i = tid; i < (r_hi - row0 + 1) * ndw; i += A_THREADS) {
-            const int rr = i / ndw, d = i - rr * ndw;
-            const int gy = row0 + rr;
-            // rows are pitched to 256 B, so reading the last dword of a row never leaves the allocation
-            const u32 v = *(const u32 *)(J.yp.ptr + (size_t)gy * J.yp.pitch + cbase + 4 * d);
-            *(u32 *)(rawY + (size_t)(gy - r_lo) * ys + 4 * d) = v;
+        const int nrows = r_hi - row0 + 1;
+        for (int d0 = 0; d0 < ndw; d0 += 32) {
+            const int d = d0 + (lane & 31);
+            constexpr int SWEEPS = 4;  // 64 rows per outer iteration
+            for (int rbase = 0; rbase < nrows; rbase += 16 * SWEEPS) {
+                u32 v[SWEEPS];
+#pragma unroll
+                for (int s = 0; s < SWEEPS; s++) {
+                    const int rr = rbase + s * 16 + wave * 2 + (lane >> 5);
+                    // rows are pitched to >= 4 B multiples, so reading the last dword of a row never leaves the allocation
+                    v[s] = (rr < nrows && d < ndw) ? *(const u32 *)(J.yp.ptr + (size_t)(row0 + rr) * J.yp.pitch + cbase + 4 * d) : 0u;
+                }
+#pragma unroll
+                for (int s = 0; s < SWEEPS; s++) {
+                    const int rr = rbase + s * 16 + wave * 2 + (lane >> 5);
+                    if (rr < nrows && d < ndw) *(u32 *)(rawY + (size_t)(row0 + rr - r_lo) * ys + 4 * d) = v[s];
+                }
+            }
         }
         // chroma: rows qy0-1 .. qy0+n_pairs-1 (+1), columns qx0-1 .. qx0+nq, edge clamp baked in
         const int nq = (NC + 1) >> 1;
         const int ccols = nq + 1, crw = n_pairs + 1;
-        for (int i = tid; i < crw * ccols; i += A_THREADS) {
-            const int j = i / ccols, k = i - j * ccols;
-            const int cy = clampi(qy0 - 1 + j, 0, J.up.h - 1), cx = clampi(qx0 - 1 + k, 0, J.up.w - 1);
-            rawU[j * cs + k] = J.up.ptr[(size_t)cy * J.up.pitch + cx];
-            rawV[j * cs + k] = J.vp.ptr[(size_t)cy * J.vp.pitch + cx];
+        for (int k = lane; k < ccols; k += 64) {
+            const int cx = clampi(qx0 - 1 + k, 0, J.up.w - 1);
+            constexpr int CS = 4;  // 32 chroma rows per outer iteration, all loads issued before the stores
+            for (int jbase = 0; jbase < crw; jbase += A_WAVES * CS) {
+                u8 bu[CS], bv[CS];
+#pragma unroll
+                for (int s = 0; s < CS; s++) {
+                    const int j = jbase + s * A_WAVES + wave;
+                    const int cy = clampi(qy0 - 1 + j, 0, J.up.h - 1);
+                    bu[s] = j < crw ? J.up.ptr[(size_t)cy * J.up.pitch + cx] : (u8)0;
+                    bv[s] = j < crw ? J.vp.ptr[(size_t)cy * J.vp.pitch + cx] : (u8)0;
+                }
+#pragma unroll
+                for (int s = 0; s < CS; s++) {
+                    const int j = jbase + s * A_WAVES + wave;
+                    if (j < crw) { rawU[j * cs + k] = bu[s]; rawV[j * cs + k] = bv[s]; }
+                }
+            }
         }
     }
     __syncthreads();
@@ -255,7 +286,8 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
     for (int pr = wave; pr < n_pairs; pr += A_WAVES) {
         const int y0 = r_lo + 2 * pr, y1 = y0 + 1;
         // ---- convert the two source rows: YUV -> RGBA8 (node texture bytes) -> sRGB-decoded linear f32
-        if (J.fast420) {
+        if (J.ablate & 1) {
+        } else if (J.fast420) {
             const u8 *ua = rawU + pr * cs, *ub = ua + cs, *va = rawV + pr * cs, *vb = va + cs;
             const u8 *yr0 = rawY + (size_t)(2 * pr) * ys - cbase, *yr1 = yr0 + ys;  // index by absolute x
             const bool ok0 = y0 >= 0, ok1 = y1 <= r_hi;
@@ -312,7 +344,8 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
             const float wsh = s_wsh[lane], rsh = s_rsh[lane];
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             const float *wcol = s_wh + lane;
-            if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
+            if (J.ablate & 2) {
+            } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
                 // interior: no edge clamp, consecutive texels
                 const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
                 for (int t = 0; t < taps_h; t++) {
@@ -350,7 +383,8 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestJob *
             const int fv = s_fv[y];
             float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
             const float *wv = s_wv + y * taps_v;
-            if (fv >= 0 && fv + taps_v - 1 <= sh - 1) {
+            if (J.ablate & 4) {
+            } else if (fv >= 0 && fv + taps_v - 1 <= sh - 1) {
                 const uint2 *pm = M + (size_t)(fv - r_lo) * TW + lane;
                 for (int t = 0; t < taps_v; t++) {
                     const float wgt = wv[t];
@@ -404,9 +438,12 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     J.fast420 = ((f->format == SMR_FRAME_PLANAR_YUV420 || f->format == SMR_FRAME_PLANAR_YUVJ420) && f->width % 2 == 0 &&
                  f->height % 2 == 0 && f->width >= 2 && f->height >= 2 && (J.yp.pitch % 4) == 0 && (((uintptr_t)J.yp.ptr) % 4) == 0 &&
                  J.yp.pitch >= ((f->width + 3u) & ~3u)) ? 1 : 0;
+    J.ablate = ctx->ablate;
     J.taps_h = wh.taps; J.taps_v = wv.taps;
-    J.first_h = wh.first; J.wsum_h = wh.wsum; J.w_h = wh.w;
-    J.first_v = wv.first; J.wsum_v = wv.wsum; J.w_v = wv.w;
+    J.scale_h = plan.scale[0]; J.off_h = plan.offset[0];
+    J.scale_v = plan.scale[1]; J.off_v = plan.offset[1];
+    J.wsum_h = wh.wsum; J.w_h = wh.w;
+    J.wsum_v = wv.wsum; J.w_v = wv.w;
     J.tiles_x = ((int)tile->w + TW - 1) / TW; J.tiles_y = ((int)tile->h + TH - 1) / TH;
     // +1: the quad path aligns the footprint start down to an odd coordinate
     J.nc_max = (int)ceilf((float)TW * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
@@ -417,25 +454,32 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     return SMR_OK;
 }
 
-int launch_ingest(smr_ctx *ctx, const std::vector<IngestJob> &jobs, const void *jobs_dev) {
-    int gx = 0, gy = 0;
-    size_t lds = 0;
-    for (auto &J : jobs) {
-        gx = J.tiles_x > gx ? J.tiles_x : gx;
-        gy = J.tiles_y > gy ? J.tiles_y : gy;
-        size_t b = ingest_lds_bytes(J);
-        lds = b > lds ? b : lds;
-    }
-    if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_resample: %zu B of LDS needed", lds);
+int launch_ingest(smr_ctx *ctx, const std::vector<IngestJob> &jobs) {
     static bool attr_set = false;
     if (!attr_set) {
         SMR_HIP(ctx, hipFuncSetAttribute((const void *)k_ingest_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
-    hipLaunchKernelGGL(k_ingest_resample, dim3((unsigned)gx, (unsigned)gy, (unsigned)jobs.size()), dim3(A_THREADS), lds, ctx->stream,
-                       (const IngestJob *)jobs_dev, ctx->d_tables);
-    SMR_HIP(ctx, hipGetLastError());
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_JOBS_PER_LAUNCH) {
+        const size_t nj = jobs.size() - j0 < (size_t)MAX_JOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_JOBS_PER_LAUNCH;
+        IngestArgs args;
+        memset(&args, 0, sizeof(args));
+        int gx = 0, gy = 0;
+        size_t lds = 0;
+        for (size_t j = 0; j < nj; j++) {
+            const IngestJob &J = jobs[j0 + j];
+            args.jobs[j] = J;
+            gx = J.tiles_x > gx ? J.tiles_x : gx;
+            gy = J.tiles_y > gy ? J.tiles_y : gy;
+            size_t b = ingest_lds_bytes(J);
+            lds = b > lds ? b : lds;
+        }
+        if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_resample: %zu B of LDS needed", lds);
+        hipLaunchKernelGGL(k_ingest_resample, dim3((unsigned)gx, (unsigned)gy, (unsigned)nj), dim3(A_THREADS), lds, ctx->stream, args,
+                           ctx->d_tables);
+        SMR_HIP(ctx, hipGetLastError());
+    }
     return SMR_OK;
 }
 

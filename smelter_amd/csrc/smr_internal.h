@@ -101,6 +101,7 @@ struct smr_ctx {
     std::vector<WeightTable> weight_tables;
     uint64_t weight_clock = 0;
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
+    int ablate = 0;           // SMR_ABLATE (profiling experiments only)
 
     bool srgb() const { return mode == SMR_MODE_GPU_OPTIMIZED; }
 };
@@ -178,6 +179,14 @@ __device__ __forceinline__ u32 srgb_encode8(float x, const float *__restrict__ t
     u32 c = enc[(__float_as_uint(x) - 0x39000000u) >> 16];
     c += thr[c + 1] <= x ? 1u : 0u;
     return c;
+}
+
+// a / b, correctly rounded, from rb = RN(1/b): q0 = RN(a*rb); r = a - q0*b (exact, FMA); q = RN(q0 + r*rb)
+// (Markstein; holds for normal operands unless b's significand is all ones).
+__device__ __forceinline__ float div_cr(float a, float b, float rb) {
+    float q0 = a * rb;
+    float r = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(r, rb, q0);
 }
 
 __device__ __forceinline__ float subtexel(float f) { return floorf(f * 256.0f + 0.5f) / 256.0f; }

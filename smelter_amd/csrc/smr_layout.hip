@@ -16,7 +16,7 @@
 namespace {
 
 __global__ __launch_bounds__(LAYOUT_TILE_W *LAYOUT_TILE_H) void k_apply_layouts(SurfView target, const DevLayout *__restrict__ layouts,
-                                                                               const smr_mask *__restrict__ masks, int n,
+                                                                               const DevMask *__restrict__ masks, int n,
                                                                                int srgb, const float *__restrict__ tables) {
     __shared__ u32 s_bits[MAX_LAYOUT_WORDS];
     const int tid = threadIdx.x;
@@ -51,7 +51,7 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
     size_t total_masks = 0;
     for (u32 i = 0; i < n; i++) total_masks += layouts[i].masks_len > SMR_MAX_MASKS ? SMR_MAX_MASKS : layouts[i].masks_len;
     const size_t lay_bytes = ((size_t)n * sizeof(DevLayout) + 255) & ~(size_t)255;
-    const size_t mask_bytes = (total_masks * sizeof(smr_mask) + 255) & ~(size_t)255;
+    const size_t mask_bytes = (total_masks * sizeof(DevMask) + 255) & ~(size_t)255;
     const size_t bytes = lay_bytes + mask_bytes + extra_bytes + 256;
 
     // ring of pinned staging slots; a slot is reusable once the kernel that read its device copy is done
@@ -76,7 +76,7 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
     if (!slot.done) SMR_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
 
     DevLayout *hl = (DevLayout *)slot.host;
-    smr_mask *hm = (smr_mask *)((u8 *)slot.host + lay_bytes);
+    DevMask *hm = (DevMask *)((u8 *)slot.host + lay_bytes);
     const float DEG = 0.017453292519943295f;
     u32 mo = 0;
     for (u32 i = 0; i < n; i++) {
@@ -95,7 +95,18 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         D.blur = L.blur_radius;
         D.masks_off = mo;
         D.masks_len = L.masks_len > SMR_MAX_MASKS ? SMR_MAX_MASKS : L.masks_len;
-        for (u32 m = 0; m < D.masks_len; m++) hm[mo++] = L.masks[m];
+        for (u32 m = 0; m < D.masks_len; m++) {
+            const smr_mask &K = L.masks[m];
+            DevMask &DM = hm[mo++];
+            memset(&DM, 0, sizeof(DM));
+            for (int k = 0; k < 4; k++) DM.radius[k] = K.radius[k];
+            DM.top = K.top; DM.left = K.left; DM.width = K.width; DM.height = K.height;
+            // solid region of smoothstep(-.5, .5, -sdf): inset by max(radius, .5) (+ rounding slack unless exactly representable)
+            const float mr = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3]));
+            auto hi = [](float v) { return v * 2.0f == floorf(v * 2.0f) && fabsf(v) < 32768.0f; };
+            const bool mexact = mr == 0.0f && hi(K.left) && hi(K.top) && hi(K.width) && hi(K.height);
+            DM.inset = fmaxf(mr, 0.5f) + (mexact ? 0.0f : 0.015625f);
+        }
         float qleft = L.left, qtop = L.top, qw = L.width, qh = L.height;
         if (L.type == 2) {  // box shadow quad grown by blur on each side (apply_layouts.wgsl:216-229)
             qleft = L.left - L.blur_radius; qtop = L.top - L.blur_radius;
@@ -114,6 +125,8 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
             D.tex_w = D.src.w; D.tex_h = D.src.h;
             D.src_index = (int)L.source_index;
         }
+        D.rqw = 1.0f / D.qw; D.rqh = 1.0f / D.qh;
+        D.rtw = 1.0f / (float)D.tex_w; D.rth = 1.0f / (float)D.tex_h;
         // ---- classification helpers for the fused compose kernel
         D.flags = (D.cs == 1.0f && D.sn == 0.0f) ? DL_UNROTATED : 0;
         // Solid region: inside the rect inset by m >= radius on every side the SDF is <= -m, i.e. edge_distance >= m.
@@ -162,7 +175,7 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         }
     }
     out->layouts = (const DevLayout *)slot.dev;
-    out->masks = (const smr_mask *)((u8 *)slot.dev + lay_bytes);
+    out->masks = (const DevMask *)((u8 *)slot.dev + lay_bytes);
     out->host_layouts = hl;
     out->n = (int)n;
     out->slot = &slot;

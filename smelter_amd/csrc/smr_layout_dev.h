@@ -1,8 +1,13 @@
 // smr_layout_dev.h — device-side layout evaluation shared by the general compositor
-// (smr_layout.hip) and the fused compose+output kernel (smr_fused.hip).
+// (smr_layout.hip) and the fused compose+output kernel (smr_fused_compose.h).
 //
 // Mirrors apply_layouts.wgsl:127-377 one-for-one; see the oracle (oracle/smr_oracle.c,
-// layout_fragment / orc_apply_layouts) for the same maths on the CPU.
+// layout_fragment / orc_apply_layouts) for the same maths on the CPU.  Shortcuts taken here are exact:
+//   * "solid region" test — inside the rect (and every parent mask) inset past radius / border / AA band, every
+//     smoothstep of the fragment stage evaluates to exactly 1, so the fragment is the base value itself;
+//   * texel-aligned 1:1 blits have bilinear weights of exactly (1,0): one fetch instead of four;
+//   * x / b is evaluated as the correctly rounded quotient from a precomputed RN(1/b) and two FMAs;
+//   * sqrt(m*m) == m, and (x - e0) / 1 == x - e0.
 #pragma once
 
 #include "smr_internal.h"
@@ -10,6 +15,14 @@
 constexpr int LAYOUT_TILE_W = 32;
 constexpr int LAYOUT_TILE_H = 8;
 constexpr int MAX_LAYOUT_WORDS = 32;  // up to 1024 layouts per node
+
+// parent mask + the inset of its solid region
+struct DevMask {
+    float radius[4];  // tl, tr, br, bl
+    float top, left, width, height;
+    float inset;      // inside the mask rect inset by this much smoothstep(-.5,.5,-sdf) == 1 exactly
+    float pad[3];
+};
 
 // Compact per-layout record consumed by the kernels (wave-uniform: read through scalar loads).
 struct DevLayout {
@@ -21,6 +34,8 @@ struct DevLayout {
     float crop[4];        // top, left, width, height
     float border_width, blur;
     float qw, qh, cx, cy; // rasterised quad: size and centre (shadow quads are grown by blur)
+    float rqw, rqh;       // RN(1/qw), RN(1/qh)
+    float rtw, rth;       // RN(1/tex_w), RN(1/tex_h)
     u32 type;
     u32 masks_off, masks_len;
     int bx0, by0, bx1, by1;  // pixel bounding box [x0,x1) x [y0,y1)
@@ -28,7 +43,6 @@ struct DevLayout {
     int src_index;
     int tex_w, tex_h;
     SurfView src;
-    // --- tile-classification helpers (fused compose kernel)
     int flags;            // DL_* below
     float inset;          // inside the rect inset by this much the fragment equals its base value (no AA / border / radius)
     int ix, iy;           // DL_ALIGNED: texel = pixel - (ix, iy)
@@ -43,7 +57,7 @@ enum {
 
 struct PackedLayouts {
     const DevLayout *layouts = nullptr;  // device
-    const smr_mask *masks = nullptr;     // device
+    const DevMask *masks = nullptr;      // device
     DevLayout *host_layouts = nullptr;   // pinned host copy (valid until the slot is reused)
     int n = 0;
     LayoutSlot *slot = nullptr;
@@ -75,7 +89,9 @@ __device__ __forceinline__ void bin_layouts(u32 *s_bits, const DevLayout *__rest
 
 __device__ __forceinline__ float smoothstepf(float e0, float e1, float x) {
     if (e0 == e1) return x >= e1 ? 1.0f : 0.0f;  // degenerate edge (blur 0): step
-    float t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    const float d = e1 - e0;
+    float t = (d == 1.0f) ? (x - e0) : (x - e0) / d;  // v / 1 == v
+    t = clampf(t, 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
 
@@ -89,7 +105,9 @@ __device__ __forceinline__ float rounded_rect_sdf(float dx, float dy, float sw, 
     float mx = qx > 0.0f ? qx : 0.0f, my = qy > 0.0f ? qy : 0.0f;
     float m = qx > qy ? qx : qy;
     float inner = m < 0.0f ? m : 0.0f;
-    return inner + sqrtf(mx * mx + my * my) - r;
+    // length(max(q, 0)): with one component zero, sqrt(m*m + 0) == m exactly (correctly rounded sqrt of a rounded square)
+    float len = (my == 0.0f) ? mx : ((mx == 0.0f) ? my : sqrtf(mx * mx + my * my));
+    return inner + len - r;
 }
 
 // Is pixel (px,py) inside layout L's quad?  Outputs the interpolated varyings.
@@ -109,12 +127,34 @@ __device__ __forceinline__ bool layout_covers(const DevLayout &L, int px, int py
     return true;
 }
 
+// Does the axis-aligned box of pixel centres [cx0,cx1] x [cy0,cy1] lie in the solid region of L?
+// Inside a rect inset by m >= radius on every side the SDF is <= -m; m also covers the border / blur band,
+// plus 1/64 px of slack for f32 rounding unless every quantity is exactly representable (host: smr_pack_layouts).
+__device__ __forceinline__ bool layout_solid_box(const DevLayout &L, const DevMask *__restrict__ masks, float cx0, float cy0,
+                                                 float cx1, float cy1) {
+    if (!(L.flags & DL_UNROTATED)) return false;
+    bool solid = L.left + L.inset <= cx0 && cx1 <= L.left + L.width - L.inset && L.top + L.inset <= cy0 &&
+                 cy1 <= L.top + L.height - L.inset;
+    for (u32 m = 0; solid && m < L.masks_len; m++) {
+        const DevMask &K = masks[L.masks_off + m];
+        solid = K.left + K.inset <= cx0 && cx1 <= K.left + K.width - K.inset && K.top + K.inset <= cy0 &&
+                cy1 <= K.top + K.height - K.inset;
+    }
+    return solid;
+}
+
+__device__ __forceinline__ bool layout_base_opaque(const DevLayout &L) {
+    return (L.type == 0) ? (L.src_kind == 2) : ((L.flags & DL_COLOR_OPAQUE) != 0);
+}
+
 // Fragment stage (apply_layouts.wgsl:258-377).  `sample` is fetched by the caller for texture layouts.
-__device__ __forceinline__ float4 layout_fragment(const DevLayout &L, const smr_mask *__restrict__ masks, float fx, float fy,
+__device__ __forceinline__ float4 layout_fragment(const DevLayout &L, const DevMask *__restrict__ masks, float fx, float fy,
                                                   float lx, float ly, float4 sample) {
     float mask_alpha = 1.0f;
     for (u32 i = 0; i < L.masks_len; i++) {
-        const smr_mask &m = masks[L.masks_off + i];
+        const DevMask &m = masks[L.masks_off + i];
+        // inside the mask's solid region the factor is exactly 1
+        if (m.left + m.inset <= fx && fx <= m.left + m.width - m.inset && m.top + m.inset <= fy && fy <= m.top + m.height - m.inset) continue;
         float dx = m.left + (m.width / 2.0f) - fx;
         float dy = m.top + (m.height / 2.0f) - fy;
         float dist = rounded_rect_sdf(dx, dy, m.width, m.height, m.radius);
@@ -184,61 +224,50 @@ __device__ __forceinline__ u32 blend_store(u32 acc, float4 frag, int srgb, const
 }
 
 // textureSample of a texture layout at the interpolated tex_coords (vertex stage crop transform, wgsl:159-172)
-__device__ __forceinline__ float4 layout_texture_sample(const DevLayout &L, float lx, float ly, int srgb, const float *__restrict__ dec) {
+__device__ __forceinline__ float4 layout_texture_sample(const DevLayout &L, int px, int py, float lx, float ly, int srgb,
+                                                        const float *__restrict__ dec) {
     if (L.src_kind == 0) return make_float4(0.f, 0.f, 0.f, 0.f);
-    float u01 = lx / L.qw + 0.5f, v01 = 0.5f - ly / L.qh;
-    float tu = (L.crop[1] + u01 * L.crop[2]) / (float)L.tex_w;
-    float tv = (L.crop[0] + v01 * L.crop[3]) / (float)L.tex_h;
-    return sample_rgba_bilinear(L.src, srgb ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM, tu, tv, dec);
+    const int pxi = srgb ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM;
+    if (L.flags & DL_ALIGNED) {
+        // 1:1 blit on whole texels: the sample position is a texel centre, bilinear weights are exactly (1,0)
+        return load_texel(L.src, pxi, clampi(px - L.ix, 0, L.tex_w - 1), clampi(py - L.iy, 0, L.tex_h - 1), dec);
+    }
+    float u01 = div_cr(lx, L.qw, L.rqw) + 0.5f, v01 = 0.5f - div_cr(ly, L.qh, L.rqh);
+    float tu = div_cr(L.crop[1] + u01 * L.crop[2], (float)L.tex_w, L.rtw);
+    float tv = div_cr(L.crop[0] + v01 * L.crop[3], (float)L.tex_h, L.rth);
+    return sample_rgba_bilinear(L.src, pxi, tu, tv, dec);
 }
 
 // One layout applied to one pixel: coverage, varyings, texture fetch, fragment, blend.
-__device__ __forceinline__ u32 composite_layout(u32 acc, const DevLayout &L, const smr_mask *__restrict__ masks, int px, int py,
+__device__ __forceinline__ u32 composite_layout(u32 acc, const DevLayout &L, const DevMask *__restrict__ masks, int px, int py,
                                                 int srgb, const float *__restrict__ dec, const float *__restrict__ thr) {
     float fx, fy, lx, ly;
     if (!layout_covers(L, px, py, fx, fy, lx, ly)) return acc;
-    float4 sample = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (L.type == 0) sample = layout_texture_sample(L, lx, ly, srgb, dec);
-    float4 frag = layout_fragment(L, masks, fx, fy, lx, ly, sample);
+    float4 frag;
+    if (layout_solid_box(L, masks, fx, fy, fx, fy)) {
+        // every smoothstep of the fragment stage is exactly 1 here: the fragment is the base value
+        frag = (L.type == 0) ? layout_texture_sample(L, px, py, lx, ly, srgb, dec)
+                             : make_float4(L.color[0], L.color[1], L.color[2], L.color[3]);
+    } else {
+        float4 sample = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (L.type == 0) sample = layout_texture_sample(L, px, py, lx, ly, srgb, dec);
+        frag = layout_fragment(L, masks, fx, fy, lx, ly, sample);
+    }
     return blend_store(acc, frag, srgb, dec, thr);
 }
 
-// The same for a pixel known to lie in the layout's "solid" region: coverage, SDF, border and masks all
-// evaluate to exactly 1, so the fragment is the base value (colour or texture sample) itself.
+// The same for a pixel known to lie in the layout's solid region.
 __device__ __forceinline__ u32 composite_layout_solid(u32 acc, const DevLayout &L, int px, int py, int srgb,
                                                       const float *__restrict__ dec, const float *__restrict__ thr) {
     float4 frag;
     if (L.type == 0) {
         float fx, fy, lx, ly;
         layout_covers(L, px, py, fx, fy, lx, ly);
-        frag = layout_texture_sample(L, lx, ly, srgb, dec);
+        frag = layout_texture_sample(L, px, py, lx, ly, srgb, dec);
     } else {
         frag = make_float4(L.color[0], L.color[1], L.color[2], L.color[3]);
     }
     return blend_store(acc, frag, srgb, dec, thr);
-}
-
-// Does the axis-aligned box of pixel centres [cx0,cx1] x [cy0,cy1] lie in the solid region of L?
-// Inside a rect inset by m >= radius on every side the SDF is <= -m; m also covers the border / blur band,
-// plus 1/64 px of slack for f32 rounding unless every quantity is exactly representable (L.inset, host).
-__device__ __forceinline__ bool layout_solid_box(const DevLayout &L, const smr_mask *__restrict__ masks, float cx0, float cy0,
-                                                 float cx1, float cy1) {
-    if (!(L.flags & DL_UNROTATED)) return false;
-    bool solid = L.left + L.inset <= cx0 && cx1 <= L.left + L.width - L.inset && L.top + L.inset <= cy0 &&
-                 cy1 <= L.top + L.height - L.inset;
-    for (u32 m = 0; solid && m < L.masks_len; m++) {
-        const smr_mask &K = masks[L.masks_off + m];
-        const float rmax = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3]));
-        const bool exact = rmax == 0.0f && K.left * 2.0f == floorf(K.left * 2.0f) && K.top * 2.0f == floorf(K.top * 2.0f) &&
-                           K.width * 2.0f == floorf(K.width * 2.0f) && K.height * 2.0f == floorf(K.height * 2.0f);
-        const float mi = fmaxf(rmax, 0.5f) + (exact ? 0.0f : 0.015625f);
-        solid = K.left + mi <= cx0 && cx1 <= K.left + K.width - mi && K.top + mi <= cy0 && cy1 <= K.top + K.height - mi;
-    }
-    return solid;
-}
-
-__device__ __forceinline__ bool layout_base_opaque(const DevLayout &L) {
-    return (L.type == 0) ? (L.src_kind == 2) : ((L.flags & DL_COLOR_OPAQUE) != 0);
 }
 
 #endif  // __HIPCC__

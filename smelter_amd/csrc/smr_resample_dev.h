@@ -15,6 +15,14 @@ __device__ __forceinline__ int lanczos_taps(float scale) {
     return taps > MAX_TAPS ? MAX_TAPS : taps;
 }
 
+// first source texel of output coordinate `out_coord` (resample.wgsl:47-49) — the same f32 sequence as lanczos_weights
+__device__ __forceinline__ int lanczos_first(int out_coord, float scale, float offset) {
+    float kernel_scale = scale > 1.0f ? scale : 1.0f;
+    float support = 3.0f * kernel_scale;
+    float center = offset + ((float)out_coord + 0.5f) * scale - 0.5f;
+    return (int)ceilf(center - support);
+}
+
 // Weights of output coordinate `out_coord`: w[0..taps), returns first source index; *wsum = sum of weights.
 __device__ __forceinline__ int lanczos_weights(int out_coord, float scale, float offset, int taps, float *w, float *wsum) {
     const float PI = 3.14159265359f;
