@@ -162,7 +162,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
 
     // ---- wave B (or the general compositor + output converters)
     const bool fuse_out = fused && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
-                          (out_w % 4 == 0) && (out_h % 2 == 0) && out->planes[0] && out->planes[1] &&
+                          (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= B_MAX_LAYOUTS && packed.n_masks <= B_MAX_MASKS &&
+                          out->planes[0] && out->planes[1] &&
                           (out->format == SMR_FRAME_NV12 || out->planes[2]);
     if (fuse_out) {
         StageScope scope(ctx, SMR_STAGE_FUSED_COMPOSE);
@@ -170,10 +171,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
         if (out->format == SMR_FRAME_NV12) {
             hipLaunchKernelGGL(k_compose_output<1>, grid, dim3(256), 0, ctx->stream, yp, up, up, (int)out_w, (int)out_h, packed.layouts,
-                               packed.masks, packed.n, ctx->srgb() ? 1 : 0, ctx->d_tables);
+                               packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables);
         } else {
             hipLaunchKernelGGL(k_compose_output<0>, grid, dim3(256), 0, ctx->stream, yp, up, view_of(out->planes[2]), (int)out_w, (int)out_h,
-                               packed.layouts, packed.masks, packed.n, ctx->srgb() ? 1 : 0, ctx->d_tables);
+                               packed.layouts, packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables);
         }
         SMR_HIP(ctx, hipGetLastError());
         return smr_pack_done(ctx, &packed);

@@ -17,6 +17,9 @@
 namespace {
 
 constexpr int B_TILE_W = 128, B_TILE_H = 16;  // pixels; 32 x 8 threads, one 4x2 pixel block each
+constexpr int B_MAX_LAYOUTS = 48;             // LDS-resident layout list (larger lists take the general compositor)
+constexpr int B_MAX_MASKS = 96;
+static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS copies move 16 B words");
 
 __device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int *s_start, const DevLayout *__restrict__ layouts,
                                                  const DevMask *__restrict__ masks, int n, int x0, int y0, int x1, int y1, int tid,
@@ -63,11 +66,29 @@ __device__ __forceinline__ void fill_from_base(u32 acc[8], const DevLayout &L, i
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV)
 template <int NV>
 __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
-                                                        const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks,
-                                                        int n, int srgb, const float *__restrict__ tables) {
+                                                        const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
+                                                        int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;
     __shared__ float s_tab[SMR_TABLE_FLOATS];
+    // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
+    // dependent scalar-memory round trip per field per layer per wave
+    __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
+    __shared__ __attribute__((aligned(16))) DevMask s_mask[B_MAX_MASKS];
+    {
+        const uint4 *gl = (const uint4 *)layouts_g;
+        uint4 *ll = (uint4 *)s_lay;
+        for (int i = threadIdx.x; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
+        const uint4 *gm = (const uint4 *)masks_g;
+        uint4 *lm = (uint4 *)s_mask;
+        for (int i = threadIdx.x; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
+    }
+    const DevLayout *layouts = s_lay;
+    const DevMask *masks = s_mask;
+    const int srgb = srgb_and_ablate & 1;
+    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only,
+                                              // 4 no per-thread start search, 8 base layer only
+    if (ablate & 1) return;
     const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * B_TILE_W, ty0 = blockIdx.y * B_TILE_H;
     if (tid == 0) s_general = 0;
@@ -87,6 +108,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         __syncthreads();
     }
     const float *dec = s_tab, *thr = s_tab + 256;
+    if (ablate & 2) return;
 
     const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);
     if (px0 >= W || py0 >= H) return;  // W % 4 == 0, H % 2 == 0: a block is entirely inside or outside
@@ -95,7 +117,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     const int words = (n + 31) >> 5;
     // ---- per-thread start: the topmost layer above the tile's start whose solid region contains this 4x2 block
     int start_t = start;
-    if (general) {
+    if (general && !(ablate & 4)) {
         const float bx0 = (float)px0 + 0.5f, bx1 = (float)px0 + 3.5f, by0 = (float)py0 + 0.5f, by1 = (float)py0 + 1.5f;
         for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)) && start_t == start; wi--) {
             u32 bits = s_touch[wi];
@@ -120,6 +142,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
             const DevLayout &L = layouts[li];
             if (li == start_t) {
                 fill_from_base(acc, L, px0, py0, srgb, dec, thr);
+            } else if (ablate & 8) {
             } else if ((solid_bits >> b) & 1u) {
 #pragma unroll
                 for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(acc[k], L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const IngestJob &J = args.jobs[blockIdx.z];
     if ((int)blockIdx.x >= J.tiles_x || (int)blockIdx.y >= J.tiles_y) return;
+    if (J.ablate & 16) return;  // profiling: pure dispatch cost of this grid
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
@@ -204,8 +205,9 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
     const int qx0 = (c_lo + 1) >> 1, qy0 = (r_lo + 1) >> 1;  // chroma index of the first quad column / row
 
     // ---- prologue: one round of global loads
+    if (!(J.ablate & 32))
     for (int i = tid; i < SMR_TABLE_FLOATS; i += A_THREADS) s_tab[i] = tables[i];
-    if (tid < 256) {
+    if (tid < 256 && !(J.ablate & 64)) {
         // u8 -> f32 conversions done once per table entry with the same IEEE operations the per-pixel path uses
         const float v = (float)tid / 255.0f;
         s_n255[tid] = v;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
     __syncthreads();
 
     // ---- vertical Lanczos (pass 2) + sRGB encode + store
-    if (lane < tw) {
+    if (lane < tw && !(J.ablate & 128)) {
         for (int y = wave; y < th; y += A_WAVES) {
             const int fv = s_fv[y];
             float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;

@@ -178,6 +178,7 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
     out->masks = (const DevMask *)((u8 *)slot.dev + lay_bytes);
     out->host_layouts = hl;
     out->n = (int)n;
+    out->n_masks = (int)mo;
     out->slot = &slot;
     out->extra_host = (u8 *)slot.host + lay_bytes + mask_bytes;
     out->extra_dev = (u8 *)slot.dev + lay_bytes + mask_bytes;

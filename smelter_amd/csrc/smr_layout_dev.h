@@ -25,7 +25,7 @@ struct DevMask {
 };
 
 // Compact per-layout record consumed by the kernels (wave-uniform: read through scalar loads).
-struct DevLayout {
+struct alignas(16) DevLayout {
     float top, left, width, height;
     float cs, sn;         // cos / sin of rotation_degrees (vertex stage, wgsl:99-110)
     float radius[4];      // tl, tr, br, bl
@@ -60,6 +60,7 @@ struct PackedLayouts {
     const DevMask *masks = nullptr;      // device
     DevLayout *host_layouts = nullptr;   // pinned host copy (valid until the slot is reused)
     int n = 0;
+    int n_masks = 0;
     LayoutSlot *slot = nullptr;
     void *extra_host = nullptr;  // caller-defined parameter block riding in the same slot
     void *extra_dev = nullptr;
