@@ -1,14 +1,16 @@
 // smr_fused_compose.h — wave B of the hot path: k_compose_output (included by smr_fused.hip only).
 //
 // LayoutShader::render + RgbaToYuvConverter / RgbaToNv12Converter in one launch.  A 256-thread workgroup
-// owns a 128x16 pixel tile; each thread a 4x2 pixel block (one u32 of Y per row, two chroma samples).
-// The layout list is classified twice, both times with the exact "solid region" test of smr_layout_dev.h:
-//   per tile   (one thread per layout): touch / solid / start = last solid layer whose base value is opaque;
-//   per thread (its 4x2 block): the start search continues above the tile's start layer.
-// Compositing begins at the start layer — every earlier layer is overwritten (dst * (1 - 1) == 0 exactly).
-// A start layer that is a 1:1 texel-aligned opaque texture (the resampled video tile) is a byte copy; a tile
-// that nothing else touches needs no tables and no blending arithmetic: texels -> Y'CbCr.
-// Everything else runs the same per-pixel code as the general compositor (smr_layout_dev.h).
+// owns a 128x16 pixel tile.  The layout list (copied once into LDS) is classified per tile with the exact
+// "solid region" test of smr_layout_dev.h (one thread per layout): touch / solid / start = last solid layer whose
+// base value is opaque — every earlier layer is overwritten by it (dst * (1 - 1) == 0 exactly).
+//   * copy tiles — the start layer is a 1:1 texel-aligned opaque texture (the resampled video tile) or an opaque
+//     colour and nothing above it touches the tile: each thread moves a 4x2 pixel block straight from the
+//     source texels to Y'CbCr.  No tables, no blending arithmetic.
+//   * general tiles — one pixel per thread, eight sweeps of the tile: per-pixel start search (topmost opaque
+//     solid layer at that pixel), then the same per-pixel code as the general compositor; results go to an
+//     8 KB RGBA8 tile in LDS, from which the 4x2 Y'CbCr conversion runs.  (One inlined copy of the compositor
+//     keeps the kernel inside the instruction cache — eight unrolled copies did not.)
 #pragma once
 
 #include "smr_convert_dev.h"
@@ -39,28 +41,56 @@ __device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int
     __syncthreads();
 }
 
-// fills the 4x2 block from an opaque base layer (dst is irrelevant)
-__device__ __forceinline__ void fill_from_base(u32 acc[8], const DevLayout &L, int px0, int py0, int srgb, const float *__restrict__ dec,
-                                               const float *__restrict__ thr) {
+// Wave-uniform copy of a record (LDS or global) into scalar registers: the dword loads are issued back to back
+// (one wait), v_readfirstlane moves them to SGPRs, and every later use is a scalar operand / a uniform branch.
+template <typename T>
+__device__ __forceinline__ T load_uniform(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "dword records only");
+    T out;
+    const u32 *s = (const u32 *)p;
+    u32 *d = (u32 *)&out;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = __builtin_amdgcn_readfirstlane(s[i]);
+    return out;
+}
+
+__device__ __forceinline__ float4 decode_texel(u32 raw, int srgb, const float *__restrict__ dec) {
+    const u32 r = raw & 0xff, g = (raw >> 8) & 0xff, b = (raw >> 16) & 0xff, a = raw >> 24;
+    float4 o;
+    if (srgb) { o.x = dec[r]; o.y = dec[g]; o.z = dec[b]; }
+    else { o.x = (float)r / 255.0f; o.y = (float)g / 255.0f; o.z = (float)b / 255.0f; }
+    o.w = div_cr((float)a, 255.0f, 1.0f / 255.0f);
+    return o;
+}
+
+// composite_layout() for one pixel with the exact shortcuts the fused kernel can take:
+//   * an opaque colour in its solid region stores its pre-encoded bytes (dst * 0 vanishes);
+//   * an aligned opaque texel whose fragment came out equal to the sample (coverage, border and every mask evaluated
+//     to exactly 1) stores its own bytes: encode(decode(b)) == b;
+//   * `is_base`: the caller established that this layer is opaque and solid at the pixel.
+__device__ __forceinline__ u32 compose_px(u32 a, const DevLayout &L, const DevMask *__restrict__ masks, int px, int py, bool is_base,
+                                          int srgb, const float *__restrict__ dec, const float *__restrict__ thr) {
+    float fx, fy, lx, ly;
+    if (!layout_covers(L, px, py, fx, fy, lx, ly)) return a;
+    const bool solid = is_base || layout_solid_box(L, masks, fx, fy, fx, fy);
     if (L.type != 0) {
-#pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
-    } else if (L.flags & DL_ALIGNED) {
-        // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
-        const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
-        const u8 *r1 = r0 + L.src.pitch;
-        if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
-            const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
-            acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
-            acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(0u, L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+        if (solid && (L.flags & DL_COLOR_OPAQUE)) return L.solid_px;
+        const float4 frag = solid ? make_float4(L.color[0], L.color[1], L.color[2], L.color[3])
+                                  : layout_fragment(L, masks, fx, fy, lx, ly, make_float4(0.f, 0.f, 0.f, 0.f));
+        return blend_store(a, frag, srgb, dec, thr);
     }
+    const bool aligned = (L.flags & DL_ALIGNED) && L.src_kind != 0;
+    u32 raw = 0u;
+    float4 sample;
+    if (aligned) {
+        raw = *(const u32 *)(L.src.ptr + (size_t)clampi(py - L.iy, 0, L.tex_h - 1) * L.src.pitch + (size_t)clampi(px - L.ix, 0, L.tex_w - 1) * 4);
+        sample = decode_texel(raw, srgb, dec);
+    } else {
+        sample = layout_texture_sample(L, px, py, lx, ly, srgb, dec);
+    }
+    const float4 frag = solid ? sample : layout_fragment(L, masks, fx, fy, lx, ly, sample);
+    if (aligned && (raw >> 24) == 255u && frag.x == sample.x && frag.y == sample.y && frag.z == sample.z && frag.w == sample.w) return raw;
+    return blend_store(a, frag, srgb, dec, thr);
 }
 
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV)
@@ -71,25 +101,25 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;
     __shared__ float s_tab[SMR_TABLE_FLOATS];
+    __shared__ u32 s_px[B_TILE_W * B_TILE_H];  // general tiles: composited RGBA8
     // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
     // dependent scalar-memory round trip per field per layer per wave
     __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
     __shared__ __attribute__((aligned(16))) DevMask s_mask[B_MAX_MASKS];
+    const int tid = threadIdx.x;
     {
         const uint4 *gl = (const uint4 *)layouts_g;
         uint4 *ll = (uint4 *)s_lay;
-        for (int i = threadIdx.x; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
+        for (int i = tid; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
         const uint4 *gm = (const uint4 *)masks_g;
         uint4 *lm = (uint4 *)s_mask;
-        for (int i = threadIdx.x; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
+        for (int i = tid; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
     }
     const DevLayout *layouts = s_lay;
     const DevMask *masks = s_mask;
     const int srgb = srgb_and_ablate & 1;
-    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only,
-                                              // 4 no per-thread start search, 8 base layer only
+    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
     if (ablate & 1) return;
-    const int tid = threadIdx.x;
     const int tx0 = blockIdx.x * B_TILE_W, ty0 = blockIdx.y * B_TILE_H;
     if (tid == 0) s_general = 0;
     classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + B_TILE_H, H), tid, 256);
@@ -103,52 +133,89 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     }
     __syncthreads();
     const bool general = s_general != 0;
+    if (ablate & 2) return;
+    if ((ablate & 16) && general) return;   // profiling: copy tiles only
+    if ((ablate & 32) && !general) return;  // profiling: general tiles only
+    const int words = (n + 31) >> 5;
+    const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);  // this thread's 4x2 output block
+    u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};                     // [row][col]: acc[r * 4 + c]
+
     if (general) {
         for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
         __syncthreads();
-    }
-    const float *dec = s_tab, *thr = s_tab + 256;
-    if (ablate & 2) return;
-
-    const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);
-    if (px0 >= W || py0 >= H) return;  // W % 4 == 0, H % 2 == 0: a block is entirely inside or outside
-
-    u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // [row][col]: acc[r * 4 + c]
-    const int words = (n + 31) >> 5;
-    // ---- per-thread start: the topmost layer above the tile's start whose solid region contains this 4x2 block
-    int start_t = start;
-    if (general && !(ablate & 4)) {
-        const float bx0 = (float)px0 + 0.5f, bx1 = (float)px0 + 3.5f, by0 = (float)py0 + 0.5f, by1 = (float)py0 + 1.5f;
-        for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)) && start_t == start; wi--) {
-            u32 bits = s_touch[wi];
+        const float *dec = s_tab, *thr = s_tab + 256;
+        // ---- one pixel per thread and sweep (a wave covers 64 consecutive pixels of one row); layers are the OUTER loop:
+        //      a layer's record is pulled into scalar registers once per wave and then applied to the wave's 8 sweeps.
+        //      Per-pixel state lives in LDS: s_px = running RGBA8, s_sp = per-pixel start layer.
+        constexpr int SWEEPS = (B_TILE_W * B_TILE_H) / 256;
+        __shared__ short s_sp[B_TILE_W * B_TILE_H];
+#pragma unroll 1
+        for (int sweep = 0; sweep < SWEEPS; sweep++) {
+            s_px[sweep * 256 + tid] = 0u;
+            s_sp[sweep * 256 + tid] = (short)start;
+        }
+        // (each thread only ever touches its own 8 pixels of s_px / s_sp: no barrier needed until the conversion phase)
+        // -- per-pixel start: the topmost touched layer above the tile's start whose solid region holds the pixel
+        for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {
+            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
             if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
             while (bits) {
                 const int b = 31 - __builtin_clz(bits);
                 bits &= ~(1u << b);
                 const int li = (wi << 5) + b;
-                const DevLayout &L = layouts[li];
-                if (layout_base_opaque(L) && layout_solid_box(L, masks, bx0, by0, bx1, by1)) { start_t = li; break; }
+                const DevLayout L = load_uniform(&layouts[li]);
+                if (!layout_base_opaque(L) || !(L.flags & DL_UNROTATED)) continue;
+#pragma unroll 1
+                for (int sweep = 0; sweep < SWEEPS; sweep++) {
+                    const int idx = sweep * 256 + tid;
+                    const float fx = (float)(tx0 + (idx & (B_TILE_W - 1))) + 0.5f, fy = (float)(ty0 + (idx >> 7)) + 0.5f;
+                    if (s_sp[idx] == (short)start && layout_solid_box(L, masks, fx, fy, fx, fy)) s_sp[idx] = (short)li;
+                }
             }
         }
-    }
-    for (int wi = start_t < 0 ? 0 : (start_t >> 5); wi < words; wi++) {
-        u32 bits = s_touch[wi];
-        if (start_t >= 0 && wi == (start_t >> 5)) bits &= ~((1u << (start_t & 31)) - 1u);
-        const u32 solid_bits = s_solid[wi];
-        while (bits) {
-            const int b = __builtin_ctz(bits);
-            const int li = (wi << 5) + b;
-            bits &= bits - 1;
-            const DevLayout &L = layouts[li];
-            if (li == start_t) {
-                fill_from_base(acc, L, px0, py0, srgb, dec, thr);
-            } else if (ablate & 8) {
-            } else if ((solid_bits >> b) & 1u) {
+        // -- composite upwards from the tile's start; a pixel joins at its own start layer
+        for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
+            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
+            if (start >= 0 && wi == (start >> 5)) bits &= ~((1u << (start & 31)) - 1u);
+            while (bits) {
+                const int li = (wi << 5) + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const DevLayout L = load_uniform(&layouts[li]);
+#pragma unroll 1
+                for (int sweep = 0; sweep < SWEEPS; sweep++) {
+                    const int idx = sweep * 256 + tid;
+                    const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
+                    const int sp = s_sp[idx];
+                    if (px < W && py < H && li >= sp && !((ablate & 8) && li != sp))
+                        s_px[idx] = compose_px(s_px[idx], L, masks, px, py, li == sp, srgb, dec, thr);
+                }
+            }
+        }
+        __syncthreads();
+        if (px0 >= W || py0 >= H) return;
+        const int lx0 = px0 - tx0, ly0 = py0 - ty0;
+        const uint4 t0 = *(const uint4 *)&s_px[ly0 * B_TILE_W + lx0], t1 = *(const uint4 *)&s_px[(ly0 + 1) * B_TILE_W + lx0];
+        acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+        acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+    } else {
+        if (px0 >= W || py0 >= H) return;  // W % 4 == 0, H % 2 == 0: a block is entirely inside or outside
+        if (start >= 0) {
+            const DevLayout &L = layouts[start];
+            if (L.type != 0) {
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(acc[k], L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+                for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
             } else {
+                // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
+                const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
+                const u8 *r1 = r0 + L.src.pitch;
+                if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
+                    const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
+                    acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+                    acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+                } else {
 #pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] = composite_layout(acc[k], L, masks, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+                    for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
+                }
             }
         }
     }

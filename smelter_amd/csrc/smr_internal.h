@@ -173,10 +173,12 @@ __device__ __forceinline__ u32 unorm8(float x) {
 // A bucket (7 mantissa bits) straddles at most two thresholds (checked when the table is built),
 // so the estimate needs at most two upward fix-up steps: exact, branch-free, no transcendental.
 __device__ __forceinline__ u32 srgb_encode8(float x, const float *__restrict__ thr) {
-    if (!(x >= 1.220703125e-4f)) return 0u;  // < 2^-13 (< thr[1]); also NaN and negatives
-    if (x >= 1.0f) return 255u;
+    // branch-free (independent encodes overlap their table latencies): the estimate index is taken from x clamped
+    // into [2^-13, 1); below 2^-13 (< thr[1]; also NaN, negatives) the bucket code is 0 and no threshold is reached,
+    // at and above 1 the last bucket's code steps up to 255 through thr[255] (thr[256] = +inf ends the count).
     const u8 *enc = (const u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
-    u32 c = enc[(__float_as_uint(x) - 0x39000000u) >> 16];
+    const float xc = fminf(fmaxf(x, 1.220703125e-4f), 0.99999994f);
+    u32 c = enc[(__float_as_uint(xc) - 0x39000000u) >> 16];
     c += thr[c + 1] <= x ? 1u : 0u;
     return c;
 }

@@ -207,7 +207,7 @@ __device__ __forceinline__ float4 layout_fragment(const DevLayout &L, const DevM
 // re-encoded the way the render-target store does (sRGB in GpuOptimized mode).
 __device__ __forceinline__ u32 blend_store(u32 acc, float4 frag, int srgb, const float *__restrict__ dec,
                                            const float *__restrict__ thr) {
-    if (frag.x == 0.0f && frag.y == 0.0f && frag.z == 0.0f && frag.w == 0.0f) return acc;  // dst*1 + 0: bytes unchanged
+    // (a zero fragment leaves the bytes unchanged: encode(decode(b) * 1 + 0) == b, so no early-out is needed)
     const float inv = 1.0f - frag.w;
     const u32 r8 = acc & 0xff, g8 = (acc >> 8) & 0xff, b8 = (acc >> 16) & 0xff, a8 = acc >> 24;
     u32 r, g, b;
