@@ -236,6 +236,56 @@ typedef struct smr_gaussian_blur_params { float sigma; } smr_gaussian_blur_param
 SMR_API int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t params_size,
                                const smr_surface *const *src, uint32_t n_src, smr_surface *dst, float time_s);
 
+/* ---- a5/a6: host scene engine (no GPU work) ------------------------------------------
+ * Scene JSON (the smelter-api component schema, smelter-api/src/video/component.rs) -> stateful
+ * component tree with transitions (smelter-render/src/scene/scene_state.rs:74-127) -> render graph
+ * (IntermediateNode::build_tree, scene_state.rs:148-196) -> per frame the flattened smr_layout list
+ * of one layout node (LayoutProvider::layouts + NestedLayout::flatten, transformations/layout.rs:176-184,
+ * layout/flatten.rs:10-22).  One smr_scene == one output of the reference's SceneState. */
+typedef struct smr_scene smr_scene;
+
+typedef enum smr_node_kind {
+    SMR_NODE_INPUT_STREAM = 0, /* NodeParams::InputStream */
+    SMR_NODE_LAYOUT = 1,       /* NodeParams::Layout (View / Rescaler / Tiles root) */
+    SMR_NODE_TEXT = 2,         /* NodeParams::Text */
+    SMR_NODE_IMAGE = 3,        /* NodeParams::Image */
+    SMR_NODE_SHADER = 4        /* NodeParams::Shader */
+} smr_node_kind;
+
+typedef struct smr_scene_node {
+    uint32_t kind;        /* smr_node_kind */
+    int32_t parent;       /* -1 for the root */
+    uint32_t n_children;
+    uint32_t width, height; /* intrinsic size (0,0 for an input stream that has not rendered yet) */
+    const char *ref_id;   /* input_id / image_id / shader_id, "" for layouts and text; valid until the next update */
+    const char *id;       /* component id or "" */
+    const char *payload;  /* Text: the string; otherwise "" */
+} smr_scene_node;
+
+#define SMR_NO_RESOLUTION 0xffffffffu /* child_wh width: the child has no texture (node_texture.rs state() == None) */
+
+SMR_API int smr_scene_create(smr_scene **out);
+SMR_API void smr_scene_destroy(smr_scene *scene);
+SMR_API const char *smr_scene_last_error(const smr_scene *scene);
+/* Renderer::register_renderer(Image) as far as sizing goes (scene/image_component.rs) */
+SMR_API int smr_scene_register_image(smr_scene *scene, const char *image_id, uint32_t width, uint32_t height);
+/* Renderer::update_scene (state.rs:177-189).  On error the previous scene stays active. */
+SMR_API int smr_scene_update(smr_scene *scene, const char *scene_json, uint32_t out_width, uint32_t out_height);
+SMR_API int smr_scene_node_count(const smr_scene *scene); /* nodes in pre-order, 0 is the root */
+SMR_API int smr_scene_node_info(const smr_scene *scene, int node, smr_scene_node *out);
+SMR_API int smr_scene_node_children(const smr_scene *scene, int node, int32_t *out, uint32_t cap);
+/* LayoutNode::render up to the flattened list.  child_wh = {w0,h0,w1,h1,...} one pair per child node in order
+ * (w == SMR_NO_RESOLUTION: no texture).  mode selects convert_to_shader_color's sRGB handling (wgpu/utils.rs:51-72).
+ * Writes min(*n_out, cap) layouts; also advances the scene clock used by the next smr_scene_update
+ * (SceneState::register_render_event, scene_state.rs:59-67). */
+SMR_API int smr_scene_node_layouts(smr_scene *scene, int node, int64_t pts_ns, const uint32_t *child_wh, uint32_t n_children,
+                                   uint32_t mode, smr_layout *out, uint32_t cap, uint32_t *n_out, uint32_t *out_width,
+                                   uint32_t *out_height);
+/* scene/transition/{cubic_bezier,bounce}.rs and smelter-api/src/video/color.rs, exported for the parity tests */
+SMR_API double smr_cubic_bezier_easing(double progress, double x1, double y1, double x2, double y2);
+SMR_API double smr_bounce_easing(double progress);
+SMR_API int smr_parse_color(const char *text, uint8_t rgba[4]);
+
 SMR_API uint32_t smr_abi_version(void);
 SMR_API uint32_t smr_sizeof_layout(void);
 

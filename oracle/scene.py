@@ -28,6 +28,21 @@ def f(x) -> np.float32:
     return np.float32(x)
 
 
+def _fmin(a, b):
+    """Rust's f32::min: a NaN operand is ignored (IEEE minNum) — Python's builtin is order dependent."""
+    return a if b != b else b if a != a else (b if b < a else a)
+
+
+def _fmax(a, b=None):
+    """Rust's f32::max; with one argument the maximum of a non-empty list."""
+    if b is None:
+        acc = a[0]
+        for x in a[1:]:
+            acc = _fmax(acc, x)
+        return acc
+    return a if b != b else b if a != a else (b if b > a else a)
+
+
 # ----------------------------------------------------------------------------- components
 @dataclass
 class BoxShadow:
@@ -117,6 +132,7 @@ class Tiles:
     padding: float = 0.0
     horizontal_align: str = "center"
     vertical_align: str = "center"
+    absolute: None = None  # Tiles are always statically positioned (tiles_component.rs:77-82)
 
 
 def _is_layout(c) -> bool:
@@ -153,14 +169,27 @@ def update_state(c, input_resolutions) -> None:
             off += 1
 
 
+def _external(c, v, horizontal: bool):
+    """Position::with_border / with_padding (scene/components/position.rs:5-53): the external size of a View includes
+    its border and padding, a Rescaler's its border (view_component.rs:61-66, rescaler_component.rs:74-77)."""
+    if v is None:
+        return None
+    v = f(v)
+    if isinstance(c, (View, Rescaler)):
+        v = v + F(2) * f(c.border_width)
+    if isinstance(c, View):
+        v = v + (c.padding.horizontal() if horizontal else c.padding.vertical())
+    return v
+
+
 def _width(c):
     if isinstance(c, InputStream):
         return f(c.size[0])
     if isinstance(c, NodeChild):
         return f(c.width)
     if c.absolute is not None:
-        return None if c.absolute.width is None else f(c.absolute.width)
-    return None if c.width is None else f(c.width)
+        return _external(c, c.absolute.width, True)
+    return _external(c, c.width, True)
 
 
 def _height(c):
@@ -169,8 +198,8 @@ def _height(c):
     if isinstance(c, NodeChild):
         return f(c.height)
     if c.absolute is not None:
-        return None if c.absolute.height is None else f(c.absolute.height)
-    return None if c.height is None else f(c.height)
+        return _external(c, c.absolute.height, False)
+    return _external(c, c.height, False)
 
 
 # ----------------------------------------------------------------------------- nested layout
@@ -208,12 +237,12 @@ def _radius(r) -> np.ndarray:
 
 
 def _clip_radius(r: np.ndarray, w, h) -> np.ndarray:
-    mx = max(F(0), min(f(w), f(h)) / F(2))
-    return np.array([min(max(x, F(0)), mx) for x in r], F)
+    mx = _fmax(F(0), _fmin(f(w), f(h)) / F(2))
+    return np.array([F(0) if x < F(0) else mx if x > mx else x for x in r], F)  # f32::clamp keeps a NaN
 
 
 def _radius_add(r: np.ndarray, d) -> np.ndarray:
-    return np.array([max(x + F(d), F(0)) for x in r], F)
+    return np.array([_fmax(x + F(d), F(0)) for x in r], F)
 
 
 def _layout_content(c, index=0):
@@ -245,8 +274,8 @@ def _wrap_layout_child(ch, top, left, w, h, rot=F(0)) -> Nested:
 
 def _absolute_child(ch, pos: AbsolutePosition, pw, ph) -> Nested:
     """layout_absolute_position_child, scene/layout.rs:164-239."""
-    w = pw if pos.width is None else f(pos.width)
-    h = ph if pos.height is None else f(pos.height)
+    w = pw if pos.width is None else _external(ch, pos.width, True)
+    h = ph if pos.height is None else _external(ch, pos.height, False)
     top = (ph - f(pos.bottom) - h) if pos.bottom is not None else f(pos.top if pos.top is not None else 0.0)
     left = (pw - f(pos.right) - w) if pos.right is not None else f(pos.left if pos.left is not None else 0.0)
     rot = f(pos.rotation_degrees)
@@ -269,23 +298,23 @@ def _sum_static(c: View):
 
 def _view_layout(c: View, w, h) -> Nested:
     bw = f(c.border_width)
-    cw = max(w - F(2) * bw, F(0))
-    chh = max(h - F(2) * bw, F(0))
+    cw = _fmax(w - F(2) * bw, F(0))
+    chh = _fmax(h - F(2) * bw, F(0))
     radius = _clip_radius(_radius(c.border_radius), w, h)
     # static_child_size (view_component/layout.rs:205-231)
     max_size = (cw - c.padding.horizontal()) if c.direction == "row" else (chh - c.padding.vertical())
     unknown = sum(1 for ch in _static_children(c) if (_width(ch) if c.direction == "row" else _height(ch)) is None)
-    static_child_size = F(0) if unknown == 0 else max(F(0), (max_size - _sum_static(c)) / F(unknown))
+    static_child_size = F(0) if unknown == 0 else _fmax(F(0), (max_size - _sum_static(c)) / F(unknown))
     mask = None
     scale = F(1)
     if c.overflow in ("hidden", "fit"):
         mask = NMask(_radius_add(radius, -bw), bw, bw, cw, chh)
     if c.overflow == "fit":
-        sum_size = max(_sum_static(c), F(0.000000001))
+        sum_size = _fmax(_sum_static(c), F(0.000000001))
         mx, alt = (cw, chh) if c.direction == "row" else (chh, cw)
         alts = [((_height(ch) if c.direction == "row" else _width(ch)) or F(0)) for ch in _static_children(c)]
-        max_alt = max(max(alts) if alts else F(0), F(0.000000001))
-        scale = min(F(1), min(mx / sum_size, alt / max_alt))
+        max_alt = _fmax(_fmax(alts) if alts else F(0), F(0.000000001))
+        scale = _fmin(F(1), _fmin(mx / sum_size, alt / max_alt))
     static_offset = bw / scale
     parent_bw = bw / scale
     kids = []
@@ -317,8 +346,8 @@ def _view_layout(c: View, w, h) -> Nested:
 
 def _rescaler_layout(c: Rescaler, w, h) -> Nested:
     bw = f(c.border_width)
-    cw = max(w - F(2) * bw, F(0))
-    chh = max(h - F(2) * bw, F(0))
+    cw = _fmax(w - F(2) * bw, F(0))
+    chh = _fmax(h - F(2) * bw, F(0))
     child = c.child
     kw, kh = _width(child), _height(child)
     radius = _clip_radius(_radius(c.border_radius), w, h)
@@ -329,7 +358,7 @@ def _rescaler_layout(c: Rescaler, w, h) -> Nested:
     elif kh is None:
         scale = cw / kw
     else:
-        scale = min(cw / kw, chh / kh) if c.mode == "fit" else max(cw / kw, chh / kh)
+        scale = _fmin(cw / kw, chh / kh) if c.mode == "fit" else _fmax(cw / kw, chh / kh)
     if _is_layout(child):
         inner = layout(child, kw if kw is not None else cw / scale, kh if kh is not None else chh / scale)
         content, children, count = ("none",), [inner], inner.child_nodes_count
@@ -362,8 +391,8 @@ def _tile_size(c: Tiles, rows, cols, w, h):
     y_padding = F(rows) * F(2) * pad
     x_margin = (F(cols) + F(1)) * mar
     y_margin = (F(rows) + F(1)) * mar
-    xs = max(w - x_padding - x_margin, F(0)) / F(cols) / F(c.tile_aspect_ratio[0])
-    ys = max(h - y_padding - y_margin, F(0)) / F(rows) / F(c.tile_aspect_ratio[1])
+    xs = _fmax(w - x_padding - x_margin, F(0)) / F(cols) / F(c.tile_aspect_ratio[0])
+    ys = _fmax(h - y_padding - y_margin, F(0)) / F(rows) / F(c.tile_aspect_ratio[1])
     s = xs if xs < ys else ys
     return F(c.tile_aspect_ratio[0]) * s, F(c.tile_aspect_ratio[1]) * s
 
@@ -421,7 +450,7 @@ def _tiles_layout(c: Tiles, w, h) -> Nested:
             # fit_into_tile (tiles_component/layout.rs:114-135)
             kw, kh = _width(ch), _height(ch)
             if kw is not None and kh is not None:
-                s = min(tw / kw, th / kh)
+                s = _fmin(tw / kw, th / kh)
                 top, left, tw, th = top + (th - s * kh) / F(2), left + (tw - s * kw) / F(2), s * kw, s * kh
             kids.append(Nested(top, left, tw, th, content=_layout_content(ch), child_nodes_count=1))
     return Nested(F(0), F(0), w, h, content=("color", tuple(c.background_color)), children=kids,
@@ -448,19 +477,19 @@ class RL:  # RenderLayout (layout.rs:58-96)
 
 
 def _child_parent_masks(n: Nested, masks):
-    s = min(n.scale_x, n.scale_y)
+    s = _fmin(n.scale_x, n.scale_y)
     return [NMask(m.radius * (F(1) / s), (m.top - n.top) / n.scale_y, (m.left - n.left) / n.scale_x, m.width / n.scale_x,
                   m.height / n.scale_y) for m in masks]
 
 
 def _parent_parent_masks(n: Nested, masks):
-    s = min(n.scale_x, n.scale_y)
+    s = _fmin(n.scale_x, n.scale_y)
     return [NMask(m.radius * s, (m.top * n.scale_y) + n.top, (m.left * n.scale_x) + n.left, m.width * n.scale_x,
                   m.height * n.scale_y) for m in masks]
 
 
 def _flatten_child(n: Nested, c: RL) -> RL:
-    us = min(n.scale_x, n.scale_y)
+    us = _fmin(n.scale_x, n.scale_y)
     bw = c.border_width
     blur = c.blur_radius
     if n.crop is None:
@@ -471,17 +500,17 @@ def _flatten_child(n: Nested, c: RL) -> RL:
         blur = blur * us
     else:
         ct, cl, cwid, chei = n.crop
-        cropped_top = max(c.top - ct, F(0))
-        cropped_left = max(c.left - cl, F(0))
-        cropped_bottom = min(c.top + c.height - ct, chei)
-        cropped_right = min(c.left + c.width - cl, cwid)
+        cropped_top = _fmax(c.top - ct, F(0))
+        cropped_left = _fmax(c.left - cl, F(0))
+        cropped_bottom = _fmin(c.top + c.height - ct, chei)
+        cropped_right = _fmin(c.left + c.width - cl, cwid)
         cw_, ch_ = cropped_right - cropped_left, cropped_bottom - cropped_top
         top, left = n.top + (cropped_top * n.scale_y), n.left + (cropped_left * n.scale_x)
         width, height = cw_ * n.scale_x, ch_ * n.scale_y
         crop = c.crop
         if c.kind == "child":
-            top_diff = max(ct - c.top, F(0))
-            left_diff = max(cl - c.left, F(0))
+            top_diff = _fmax(ct - c.top, F(0))
+            left_diff = _fmax(cl - c.left, F(0))
             hs = c.crop[2] / c.width
             vs = c.crop[3] / c.height
             crop = (c.crop[0] + (top_diff * vs), c.crop[1] + (left_diff * hs), cw_ * hs, ch_ * vs)
@@ -547,10 +576,10 @@ def _fix_final(l: RL) -> RL:
         l.border_width = F(0)
     keep = []
     for m in l.masks:
-        mt = max(m.radius[0], m.radius[1])
-        mb = max(m.radius[3], m.radius[2])
-        ml = max(m.radius[0], m.radius[3])
-        mr = max(m.radius[1], m.radius[2])
+        mt = _fmax(m.radius[0], m.radius[1])
+        mb = _fmax(m.radius[3], m.radius[2])
+        ml = _fmax(m.radius[0], m.radius[3])
+        mr = _fmax(m.radius[1], m.radius[2])
         skip = (m.top + mt <= l.top and m.left + ml <= l.left and m.left + m.width - mr >= l.left + l.width
                 and m.top + m.height - mb >= l.top + l.height)
         if not skip:

@@ -32,8 +32,18 @@ EXPORTS = [
     "smr_rgba_to_frame", "smr_frame_fill_black",
     "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear",
     "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_blit_glyphs", "smr_builtin_shader",
+    "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update",
+    "smr_scene_node_count", "smr_scene_node_info", "smr_scene_node_children", "smr_scene_node_layouts",
+    "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color",
     "smr_abi_version", "smr_sizeof_layout",
 ]
+NO_RESOLUTION = 0xFFFFFFFF
+NODE_INPUT_STREAM, NODE_LAYOUT, NODE_TEXT, NODE_IMAGE, NODE_SHADER = 0, 1, 2, 3, 4
+
+
+class SceneNode(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("parent", C.c_int32), ("n_children", C.c_uint32), ("width", C.c_uint32),
+                ("height", C.c_uint32), ("ref_id", C.c_char_p), ("id", C.c_char_p), ("payload", C.c_char_p)]
 
 
 class Mask(C.Structure):
@@ -140,6 +150,19 @@ def load():
         "smr_ingest_resample": ([P, C.POINTER(Frame), C.POINTER(F), P], I),
         "smr_blit_glyphs": ([P, P, C.POINTER(F), C.POINTER(Glyph), U, P, U, U], I),
         "smr_builtin_shader": ([P, U, P, C.c_size_t, PP, U, P, F], I),
+        "smr_scene_create": ([PP], I),
+        "smr_scene_destroy": ([P], None),
+        "smr_scene_last_error": ([P], C.c_char_p),
+        "smr_scene_register_image": ([P, C.c_char_p, U, U], I),
+        "smr_scene_update": ([P, C.c_char_p, U, U], I),
+        "smr_scene_node_count": ([P], I),
+        "smr_scene_node_info": ([P, I, C.POINTER(SceneNode)], I),
+        "smr_scene_node_children": ([P, I, C.POINTER(C.c_int32), U], I),
+        "smr_scene_node_layouts": ([P, I, C.c_int64, C.POINTER(U), U, U, C.POINTER(Layout), U, C.POINTER(U), C.POINTER(U),
+                                    C.POINTER(U)], I),
+        "smr_cubic_bezier_easing": ([C.c_double] * 5, C.c_double),
+        "smr_bounce_easing": ([C.c_double], C.c_double),
+        "smr_parse_color": ([C.c_char_p, C.POINTER(C.c_uint8)], I),
         "smr_abi_version": ([], U),
         "smr_sizeof_layout": ([], U),
     }

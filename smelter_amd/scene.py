@@ -1,0 +1,106 @@
+"""Host scene engine binding: scene JSON -> render graph -> flattened smr_layout list per frame.
+
+Mirrors the reference's `Renderer::update_scene` / `LayoutNode::render` up to the draw list
+(smelter-render/src/state.rs:177-189, scene/scene_state.rs:74-127, transformations/layout.rs:176-184); the engine itself
+is C++ (smelter_amd/csrc/host/scene*.cpp) behind the `smr_scene_*` entry points of include/smr.h.  No GPU is needed here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+from . import _ffi
+
+MODE_GPU_OPTIMIZED, MODE_CPU_OPTIMIZED = 0, 1
+
+
+class SceneError(ValueError):
+    """TypeError / SceneError of the reference (smelter-api TypeError, scene.rs:188-231)."""
+
+
+@dataclass
+class Node:
+    index: int
+    kind: int            # _ffi.NODE_*
+    parent: int
+    children: List[int]
+    width: int
+    height: int
+    ref_id: str          # input_id / image_id / shader_id
+    id: str
+    payload: str
+
+
+class Scene:
+    def __init__(self):
+        self._lib = _ffi.load()
+        h = C.c_void_p()
+        if self._lib.smr_scene_create(C.byref(h)) != 0:
+            raise SceneError("smr_scene_create failed")
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self._lib.smr_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc < 0:
+            raise SceneError(self._lib.smr_scene_last_error(self._h).decode())
+        return rc
+
+    def register_image(self, image_id: str, width: int, height: int):
+        self._check(self._lib.smr_scene_register_image(self._h, image_id.encode(), width, height))
+
+    def update(self, scene: Union[str, dict], out_w: int, out_h: int) -> List[Node]:
+        text = scene if isinstance(scene, str) else json.dumps(scene)
+        self._check(self._lib.smr_scene_update(self._h, text.encode(), out_w, out_h))
+        return self.nodes()
+
+    def nodes(self) -> List[Node]:
+        out = []
+        for i in range(self._check(self._lib.smr_scene_node_count(self._h))):
+            info = _ffi.SceneNode()
+            self._check(self._lib.smr_scene_node_info(self._h, i, C.byref(info)))
+            kids = (C.c_int32 * max(1, info.n_children))()
+            self._check(self._lib.smr_scene_node_children(self._h, i, kids, info.n_children))
+            out.append(Node(i, info.kind, info.parent, list(kids[:info.n_children]), info.width, info.height,
+                            (info.ref_id or b"").decode(), (info.id or b"").decode(), (info.payload or b"").decode()))
+        return out
+
+    def node_layouts(self, node: int, pts_ns: int, child_resolutions: Sequence[Optional[Tuple[int, int]]],
+                     mode: int = MODE_GPU_OPTIMIZED, cap: int = 512):
+        """-> (ctypes array of smr_layout, count, out_w, out_h) for layout node `node` at `pts_ns`."""
+        n = len(child_resolutions)
+        wh = (C.c_uint32 * max(1, 2 * n))()
+        for i, r in enumerate(child_resolutions):
+            wh[2 * i], wh[2 * i + 1] = (_ffi.NO_RESOLUTION, 0) if r is None else (int(r[0]), int(r[1]))
+        arr = (_ffi.Layout * cap)()
+        cnt, w, h = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._lib.smr_scene_node_layouts(self._h, node, int(pts_ns), wh, n, mode, arr, cap, C.byref(cnt), C.byref(w), C.byref(h)))
+        if cnt.value > cap:
+            return self.node_layouts(node, pts_ns, child_resolutions, mode, cnt.value)
+        return arr, cnt.value, w.value, h.value
+
+
+def cubic_bezier_easing(progress: float, x1: float, y1: float, x2: float, y2: float) -> float:
+    return _ffi.load().smr_cubic_bezier_easing(progress, x1, y1, x2, y2)
+
+
+def bounce_easing(progress: float) -> float:
+    return _ffi.load().smr_bounce_easing(progress)
+
+
+def parse_color(text: str) -> Tuple[int, int, int, int]:
+    out = (C.c_uint8 * 4)()
+    if _ffi.load().smr_parse_color(text.encode(), out) != 0:
+        raise SceneError(f"invalid color {text!r}")
+    return tuple(out)
