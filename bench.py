@@ -39,53 +39,63 @@ def yuv420_bytes(w, h):
 ALGO_BYTES_PER_FRAME = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H)  # 37 324 800
 
 
-def build_scene():
-    """The scene as *data*: POD layout list + per-source resolutions (the scene maths is host-side
-    and outside the timed region; see tests/scenes.py)."""
-    from tests import scenes
-    from oracle import scene as S
-    kids, res = [], []
+LABEL_W, LABEL_H = 176, 32
+
+
+def scene_json():
+    """configs[2] as the scene JSON the reference's API takes (smelter-api/src/video/component.rs)."""
+    kids = []
     for i in range(N_IN):
-        label = S.View(children=[S.NodeChild(scenes.LABEL_W, scenes.LABEL_H)], background_color=(0, 0, 0, 128), border_radius=8.0,
-                       absolute=S.AbsolutePosition(width=scenes.LABEL_W + 16.0, height=scenes.LABEL_H + 8.0, left=24.0, bottom=24.0),
-                       padding=S.Padding(4.0, 8.0, 4.0, 8.0))
-        kids.append(S.View(children=[S.Rescaler(child=S.InputStream(i), border_radius=24.0), label], background_color=(16, 16, 24, 255)))
-        res += [(IN_W, IN_H), (scenes.LABEL_W, scenes.LABEL_H)]
-    root = S.Tiles(children=kids, background_color=(32, 32, 48, 255))
-    return S.scene_layouts(root, OUT_W, OUT_H, res), res
+        label = {"type": "view", "background_color": "#00000080", "border_radius": 8.0, "width": float(LABEL_W), "height": float(LABEL_H),
+                 "left": 24.0, "bottom": 24.0, "padding_vertical": 4.0, "padding_horizontal": 8.0,
+                 "children": [{"type": "text", "text": "CAM 3 LIVE", "font_size": 24.0, "width": float(LABEL_W), "height": float(LABEL_H)}]}
+        kids.append({"type": "view", "background_color": "#101018FF",
+                     "children": [{"type": "rescaler", "border_radius": 24.0, "child": {"type": "input_stream", "input_id": f"input_{i}"}}, label]})
+    return {"type": "tiles", "background_color": "#202030FF", "children": kids}
+
+
+def build_scene():
+    """Scene JSON -> flattened layout list + per-source resolutions through the host scene engine
+    (smelter_amd/csrc/host/scene*.cpp; outside the timed region: the scene does not change between frames)."""
+    from smelter_amd import _ffi
+    from smelter_amd.scene import Scene
+    sc = Scene()
+    nodes = sc.update(scene_json(), OUT_W, OUT_H)
+    res = [(IN_W, IN_H) if nodes[k].kind == _ffi.NODE_INPUT_STREAM else (nodes[k].width, nodes[k].height) for k in nodes[0].children]
+    return sc.layouts(0, 0, res), res
 
 
 def make_inputs(ctx, hip, frame_sets, input_ids):
     """frame_sets x len(input_ids) device frames of synthetic 1080p YUV420 (TestInput pattern + seeded noise + shift)."""
-    from tests import scenes
+    from smelter_amd import synth
     ring = []
     for s in range(frame_sets):
         row = {}
         for i in input_ids:
-            y, u, v = scenes.test_input(i, IN_W, IN_H, noise_seed=1234 + i + 100 * s, shift=s * 7)
+            y, u, v = synth.test_input(i, IN_W, IN_H, noise_seed=1234 + i + 100 * s, shift=s * 7)
             row[i] = ctx.frame(hip.FRAME_PLANAR_YUV420, IN_W, IN_H, [y, u, v])
         ring.append(row)
     return ring
 
 
 def make_label(ctx):
-    from tests import scenes
-    from oracle.oracle import color_to_shader
-    atlas, glyphs = scenes.label_glyphs("CAM 3 LIVE", 3)
-    t = ctx.surface(scenes.LABEL_W, scenes.LABEL_H)
-    ctx.blit_glyphs(t, color_to_shader((0, 0, 0, 0), True), glyphs, atlas)
+    from smelter_amd import synth
+    atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
+    t = ctx.surface(LABEL_W, LABEL_H)
+    ctx.blit_glyphs(t, (0.0, 0.0, 0.0, 0.0), glyphs, atlas)  # transparent background (text_renderer.rs default)
     return t
 
 
 def cpu_baseline(layouts, res):
     """The CPU restatement of the reference renderer (oracle, kind 'port') on the same workload:
     ONE composited frame (8 x 1080p YUV420 -> 4K YUV420), all passes, OpenMP on all host cores."""
-    from tests import refpipe, scenes
+    from tests import refpipe
     from oracle import oracle as orc
+    from smelter_amd import synth
     orc.build()
-    planes = [scenes.test_input(i, IN_W, IN_H, noise_seed=1234 + i) for i in range(N_IN)]
-    atlas, glyphs = scenes.label_glyphs("CAM 3 LIVE", 3)
-    label = orc.blit_glyphs(scenes.LABEL_W, scenes.LABEL_H, orc.color_to_shader((0, 0, 0, 0), True), glyphs, atlas)
+    planes = [synth.test_input(i, IN_W, IN_H, noise_seed=1234 + i) for i in range(N_IN)]
+    atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
+    label = orc.blit_glyphs(LABEL_W, LABEL_H, orc.color_to_shader((0, 0, 0, 0), True), glyphs, atlas)
     cores = orc.num_threads(omp=True)
     t0 = time.perf_counter()
     nodes, k = [], 0

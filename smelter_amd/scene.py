@@ -91,6 +91,46 @@ class Scene:
         return arr, cnt.value, w.value, h.value
 
 
+    def layouts(self, node: int, pts_ns: int, child_resolutions, mode: int = MODE_GPU_OPTIMIZED) -> List["Layout"]:
+        """node_layouts as plain Python records (what hip.pack_layouts / dist.ShardedCompositor take)."""
+        arr, n, _, _ = self.node_layouts(node, pts_ns, child_resolutions, mode)
+        return [Layout.from_c(arr[i]) for i in range(n)]
+
+
+@dataclass
+class Mask:
+    radius: List[float]
+    top: float
+    left: float
+    width: float
+    height: float
+
+
+@dataclass
+class Layout:
+    """smr_layout as a Python record (field names of include/smr.h)."""
+    top: float
+    left: float
+    width: float
+    height: float
+    rotation_degrees: float
+    border_radius: List[float]
+    type: int
+    source_index: int
+    color: List[float]
+    border_color: List[float]
+    border_width: float
+    crop: List[float]
+    blur_radius: float
+    masks: List[Mask]
+
+    @staticmethod
+    def from_c(s: "_ffi.Layout") -> "Layout":
+        masks = [Mask(list(m.radius), m.top, m.left, m.width, m.height) for m in s.masks[: s.masks_len]]
+        return Layout(s.top, s.left, s.width, s.height, s.rotation_degrees, list(s.border_radius), s.type, s.source_index,
+                      list(s.color), list(s.border_color), s.border_width, list(s.crop), s.blur_radius, masks)
+
+
 def cubic_bezier_easing(progress: float, x1: float, y1: float, x2: float, y2: float) -> float:
     return _ffi.load().smr_cubic_bezier_easing(progress, x1, y1, x2, y2)
 
