@@ -271,6 +271,11 @@ SMR_API const char *smr_scene_last_error(const smr_scene *scene);
 SMR_API int smr_scene_register_image(smr_scene *scene, const char *image_id, uint32_t width, uint32_t height);
 /* Renderer::update_scene (state.rs:177-189).  On error the previous scene stays active. */
 SMR_API int smr_scene_update(smr_scene *scene, const char *scene_json, uint32_t out_width, uint32_t out_height);
+/* The API-to-scene conversion alone: `impl TryFrom<Component> for scene::Component`
+ * (smelter-api/src/video/component_into.rs:8-432) with its defaults, validation and error strings.  *out_json is the
+ * converted component tree as canonical JSON (owned by the scene, valid until the next call); the active scene is untouched.
+ * Pinned by smelter-api/tests/scene_deserialization.rs (tests/golden/scene_api_vectors.json). */
+SMR_API int smr_scene_parse(smr_scene *scene, const char *scene_json, const char **out_json);
 SMR_API int smr_scene_node_count(const smr_scene *scene); /* nodes in pre-order, 0 is the root */
 SMR_API int smr_scene_node_info(const smr_scene *scene, int node, smr_scene_node *out);
 SMR_API int smr_scene_node_children(const smr_scene *scene, int node, int32_t *out, uint32_t cap);

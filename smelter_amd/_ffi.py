@@ -32,7 +32,7 @@ EXPORTS = [
     "smr_rgba_to_frame", "smr_frame_fill_black",
     "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear",
     "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_blit_glyphs", "smr_builtin_shader",
-    "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update",
+    "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update", "smr_scene_parse",
     "smr_scene_node_count", "smr_scene_node_info", "smr_scene_node_children", "smr_scene_node_layouts",
     "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color",
     "smr_abi_version", "smr_sizeof_layout",
@@ -155,6 +155,7 @@ def load():
         "smr_scene_last_error": ([P], C.c_char_p),
         "smr_scene_register_image": ([P, C.c_char_p, U, U], I),
         "smr_scene_update": ([P, C.c_char_p, U, U], I),
+        "smr_scene_parse": ([P, C.c_char_p, C.POINTER(C.c_char_p)], I),
         "smr_scene_node_count": ([P], I),
         "smr_scene_node_info": ([P, I, C.POINTER(SceneNode)], I),
         "smr_scene_node_children": ([P, I, C.POINTER(C.c_int32), U], I),

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <memory>
@@ -25,6 +26,56 @@ struct Json {
         return nullptr;
     }
     bool is_null() const { return kind == Null; }
+
+    static Json number(double v) { Json j; j.kind = Number; j.num = v; return j; }
+    static Json string(const std::string &v) { Json j; j.kind = String; j.str = v; return j; }
+    static Json boolean(bool v) { Json j; j.kind = Bool; j.b = v; return j; }
+    static Json array(std::vector<Json> v = {}) { Json j; j.kind = Array; j.arr = std::move(v); return j; }
+    static Json object() { Json j; j.kind = Object; return j; }
+    Json &set(const std::string &key, Json v) { obj.emplace_back(key, std::move(v)); return *this; }
+
+    void dump(std::string &out) const {
+        switch (kind) {
+        case Null: out += "null"; break;
+        case Bool: out += b ? "true" : "false"; break;
+        case Number: {
+            if (!std::isfinite(num)) { out += "null"; break; }
+            char buf[40];
+            snprintf(buf, sizeof(buf), "%.17g", num);
+            out += buf;
+            break;
+        }
+        case String: dump_string(str, out); break;
+        case Array:
+            out += '[';
+            for (size_t i = 0; i < arr.size(); i++) { if (i) out += ','; arr[i].dump(out); }
+            out += ']';
+            break;
+        case Object:
+            out += '{';
+            for (size_t i = 0; i < obj.size(); i++) {
+                if (i) out += ',';
+                dump_string(obj[i].first, out);
+                out += ':';
+                obj[i].second.dump(out);
+            }
+            out += '}';
+            break;
+        }
+    }
+    static void dump_string(const std::string &s, std::string &out) {
+        out += '"';
+        for (unsigned char c : s) {
+            if (c == '"') out += "\\\"";
+            else if (c == '\\') out += "\\\\";
+            else if (c == '\n') out += "\\n";
+            else if (c == '\r') out += "\\r";
+            else if (c == '\t') out += "\\t";
+            else if (c < 0x20) { char buf[8]; snprintf(buf, sizeof(buf), "\\u%04x", c); out += buf; }
+            else out += (char)c;
+        }
+        out += '"';
+    }
 };
 
 class JsonParser {

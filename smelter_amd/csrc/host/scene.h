@@ -124,6 +124,7 @@ struct Stateful {
     Size leaf_size;              // InputStream: filled by update_state; Text/Image/Shader: intrinsic
     std::string text;            // Text payload (passed through to the caller)
     Json shader_param;
+    Json desc;                   // the converted component (scene::Component) as canonical JSON, see Scene::parse
     // layouts
     ViewParam view_end; std::optional<ViewParam> view_start;
     RescalerParam resc_end; std::optional<RescalerParam> resc_start;
@@ -189,6 +190,9 @@ class Scene {
   public:
     // Renderer::update_scene (state.rs:177-189, scene/scene_state.rs:74-127)
     bool update(const std::string &json, uint32_t out_w, uint32_t out_h, std::string &err);
+    // The smelter-api conversion alone (TryFrom<Component> for scene::Component, smelter-api/src/video/component_into.rs):
+    // validates and returns the converted component tree as canonical JSON; the active scene is untouched.
+    bool parse(const std::string &json, std::string &out, std::string &err) const;
     void register_image(const std::string &image_id, float w, float h) { images_[image_id] = Size{w, h}; }
     const std::vector<GraphNode> &nodes() const { return nodes_; }
     // LayoutProvider::layouts + NestedLayout::flatten for one layout node (transformations/layout.rs:176-184);

@@ -103,10 +103,55 @@ struct BuildCtx {
     const std::map<std::string, Size> *input_resolutions = nullptr;
     const std::map<std::string, Size> *images = nullptr;
     std::set<std::string> ids;  // validate_component_ids_uniqueness
+    bool api_only = false;      // stop after the smelter-api conversion (TryFrom<Component>): no renderer registry, no shaper
     std::string err;
 };
 
 bool fail(BuildCtx &c, const std::string &msg) { c.err = msg; return false; }
+
+// canonical description of the converted component (scene::Component's Debug shape as JSON), see Scene::parse
+Json jopt(const OptF &v) { return v ? Json::number(*v) : Json(); }
+Json jcolor(RGBA c) { return Json::array({Json::number(c.r), Json::number(c.g), Json::number(c.b), Json::number(c.a)}); }
+Json jid(const Stateful &s) { return s.has_id ? Json::string(s.id) : Json(); }
+Json jradius(const BorderRadius &r) { return Json::array({Json::number(r.tl), Json::number(r.tr), Json::number(r.br), Json::number(r.bl)}); }
+Json jposition(const Position &p) {
+    Json j = Json::object();
+    j.set("kind", Json::string(p.absolute ? "Absolute" : "Static")).set("width", jopt(p.width)).set("height", jopt(p.height));
+    if (p.absolute) {
+        j.set("horizontal", Json::array({Json::string(p.from_right ? "Right" : "Left"), Json::number(p.h_offset)}));
+        j.set("vertical", Json::array({Json::string(p.from_bottom ? "Bottom" : "Top"), Json::number(p.v_offset)}));
+        j.set("rotation_degrees", Json::number(p.rotation_degrees));
+    }
+    return j;
+}
+Json jtransition(const std::optional<Transition> &t) {
+    if (!t) return Json();
+    Json j = Json::object();
+    j.set("duration_ns", Json::number((double)t->duration_ns));
+    if (t->interp.kind == InterpKind::CubicBezier)
+        j.set("interpolation", Json::array({Json::string("CubicBezier"), Json::number(t->interp.x1), Json::number(t->interp.y1),
+                                            Json::number(t->interp.x2), Json::number(t->interp.y2)}));
+    else j.set("interpolation", Json::string(t->interp.kind == InterpKind::Linear ? "Linear" : "Bounce"));
+    j.set("should_interrupt", Json::boolean(t->should_interrupt));
+    return j;
+}
+Json jshadows(const std::vector<BoxShadow> &v) {
+    Json a = Json::array();
+    for (auto &s : v) {
+        Json j = Json::object();
+        j.set("offset_x", Json::number(s.offset_x)).set("offset_y", Json::number(s.offset_y)).set("blur_radius", Json::number(s.blur_radius))
+            .set("color", jcolor(s.color));
+        a.arr.push_back(j);
+    }
+    return a;
+}
+Json jchildren(const std::vector<std::unique_ptr<Stateful>> &v) {
+    Json a = Json::array();
+    for (auto &k : v) a.arr.push_back(k->desc);
+    return a;
+}
+const char *halign_name(HAlign a) { return a == HAlign::Left ? "Left" : a == HAlign::Right ? "Right" : a == HAlign::Justified ? "Justified" : "Center"; }
+const char *valign_name(VAlign a) { return a == VAlign::Top ? "Top" : a == VAlign::Bottom ? "Bottom" : a == VAlign::Justified ? "Justified" : "Center"; }
 
 bool check_fields(const Json &j, const char *type_name, std::initializer_list<const char *> allowed, BuildCtx &c) {
     for (auto &kv : j.obj) {
@@ -196,9 +241,11 @@ bool get_transition(const Json &j, std::optional<Transition> &out, BuildCtx &c) 
         } else return fail(c, "unknown variant `" + fn->str + "`, expected one of `linear`, `bounce`, `cubic_bezier`");
     }
     double s = d->num / 1000.0;  // Duration::try_from_secs_f64
-    if (!(s >= 0.0) || !std::isfinite(s) || s > 1.8e19) return fail(c, "Invalid duration. cannot convert float seconds to Duration: value is negative, overflows or is not finite");
+    if (s < 0.0) return fail(c, "Invalid duration. cannot convert float seconds to Duration: value is negative");
+    if (!(s < 1.8446744073709552e19)) return fail(c, "Invalid duration. cannot convert float seconds to Duration: value is either too big or NaN");
     double whole = std::floor(s);
-    t.duration_ns = (int64_t)whole * 1000000000LL + (int64_t)std::llround((s - whole) * 1e9);
+    t.duration_ns = s > 2.0e9 ? INT64_MAX / 4  // > 63 years: saturate (the reference's u64 seconds never matter at that range)
+                              : (int64_t)whole * 1000000000LL + (int64_t)std::llround((s - whole) * 1e9);
     const Json *si = v->get("should_interrupt");
     if (si && si->kind == Json::Bool) t.should_interrupt = si->b;
     out = t;
@@ -225,6 +272,42 @@ bool get_position(const Json &j, const char *type_name, Position &pos, BuildCtx 
 }
 
 std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c);
+
+// ShaderParam (smelter-api/src/video/component.rs:300-324): {"type": f32|u32|i32|list|struct, "value": ...}
+bool shader_param(const Json &j, bool struct_field, Json &out, BuildCtx &c) {
+    if (j.kind != Json::Object) return fail(c, "shader_param: expected an object");
+    for (auto &kv : j.obj)
+        if (kv.first != "type" && kv.first != "value" && !(struct_field && kv.first == "field_name"))
+            return fail(c, "unknown field `" + kv.first + "` in shader_param");
+    const Json *ty = j.get("type"), *v = j.get("value");
+    if (!ty || ty->kind != Json::String) return fail(c, "shader_param: missing field `type`");
+    if (!v) return fail(c, "shader_param: missing field `value`");
+    auto integer = [&](double lo, double hi) { return v->kind == Json::Number && v->num == std::floor(v->num) && v->num >= lo && v->num <= hi; };
+    if (ty->str == "f32") {
+        if (v->kind != Json::Number) return fail(c, "shader_param: f32 value has to be a number");
+        out = Json::array({Json::string("F32"), Json::number((float)v->num)});
+    } else if (ty->str == "u32") {
+        if (!integer(0.0, 4294967295.0)) return fail(c, "shader_param: u32 value out of range");
+        out = Json::array({Json::string("U32"), Json::number(v->num)});
+    } else if (ty->str == "i32") {
+        if (!integer(-2147483648.0, 2147483647.0)) return fail(c, "shader_param: i32 value out of range");
+        out = Json::array({Json::string("I32"), Json::number(v->num)});
+    } else if (ty->str == "list" || ty->str == "struct") {
+        if (v->kind != Json::Array) return fail(c, "shader_param: list/struct value has to be an array");
+        Json items = Json::array();
+        for (const Json &e : v->arr) {
+            Json p;
+            if (!shader_param(e, ty->str == "struct", p, c)) return false;
+            if (ty->str == "struct") {
+                const Json *name = e.get("field_name");
+                if (!name || name->kind != Json::String) return fail(c, "shader_param: missing field `field_name`");
+                items.arr.push_back(Json::array({Json::string(name->str), p}));
+            } else items.arr.push_back(p);
+        }
+        out = Json::array({Json::string(ty->str == "list" ? "List" : "Struct"), items});
+    } else return fail(c, "shader_param: unknown variant `" + ty->str + "`");
+    return true;
+}
 
 bool build_children(const Json &j, std::vector<std::unique_ptr<Stateful>> &out, BuildCtx &c) {
     const Json *ch = j.get("children");
@@ -262,6 +345,9 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
         s->kind = Kind::InputStream;
         if (!check_fields(j, "InputStream", {"id", "input_id"}, c) || !get_str(j, "input_id", s->ref_id, present, c)) return nullptr;
         if (!present) { fail(c, "missing field `input_id`"); return nullptr; }
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("InputStream")).set("id", jid(*s)).set("input_id", Json::string(s->ref_id));
+        if (c.api_only) return s;
         auto it = c.input_resolutions->find(s->ref_id);
         s->leaf_size = it != c.input_resolutions->end() ? it->second : Size{0.0f, 0.0f};
         return s;
@@ -300,6 +386,14 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
         bool changed = prev ? !(prev->view_end == v) : false;
         s->transition = TransitionState::make(tr, prev ? prev->transition : std::nullopt, changed, tr ? tr->should_interrupt : false, c.last_pts);
         if (!build_children(j, s->children, c)) return nullptr;
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("View")).set("id", jid(*s)).set("children", jchildren(s->children))
+            .set("direction", Json::string(v.column ? "Column" : "Row")).set("position", jposition(v.position)).set("transition", jtransition(tr))
+            .set("overflow", Json::string(v.overflow == 0 ? "Visible" : v.overflow == 1 ? "Hidden" : "Fit"))
+            .set("background_color", jcolor(v.background_color)).set("border_radius", jradius(v.border_radius))
+            .set("border_width", Json::number(v.border_width)).set("border_color", jcolor(v.border_color)).set("box_shadow", jshadows(v.box_shadow))
+            .set("padding", Json::array({Json::number(v.padding.top), Json::number(v.padding.right), Json::number(v.padding.bottom),
+                                         Json::number(v.padding.left)}));
         return s;
     }
     if (t == "rescaler") {
@@ -332,6 +426,12 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
         auto k = build(*child, c);
         if (!k) return nullptr;
         s->children.push_back(std::move(k));
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("Rescaler")).set("id", jid(*s)).set("child", s->children[0]->desc).set("position", jposition(r.position))
+            .set("transition", jtransition(tr)).set("mode", Json::string(r.fill ? "Fill" : "Fit"))
+            .set("horizontal_align", Json::string(halign_name(r.horizontal_align))).set("vertical_align", Json::string(valign_name(r.vertical_align)))
+            .set("border_radius", jradius(r.border_radius)).set("border_width", Json::number(r.border_width))
+            .set("border_color", jcolor(r.border_color)).set("box_shadow", jshadows(r.box_shadow));
         return s;
     }
     if (t == "tiles") {
@@ -388,6 +488,12 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             }
         }
         s->transition = TransitionState::make(tr, prev ? prev->transition : std::nullopt, changed, tr ? tr->should_interrupt : false, c.last_pts);
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("Tiles")).set("id", jid(*s)).set("width", jopt(tp.width)).set("height", jopt(tp.height))
+            .set("margin", Json::number(tp.margin)).set("padding", Json::number(tp.padding)).set("children", jchildren(s->children))
+            .set("transition", jtransition(tr)).set("vertical_align", Json::string(valign_name(tp.vertical_align)))
+            .set("horizontal_align", Json::string(halign_name(tp.horizontal_align))).set("background_color", jcolor(tp.background_color))
+            .set("tile_aspect_ratio", Json::array({Json::number(tp.ar_w), Json::number(tp.ar_h)}));
         return s;
     }
     if (t == "image") {  // image_component.rs
@@ -397,6 +503,9 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             !get_f32(j, "width", w, c) || !get_f32(j, "height", h, c))
             return nullptr;
         if (!present) { fail(c, "missing field `image_id`"); return nullptr; }
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("Image")).set("id", jid(*s)).set("image_id", Json::string(s->ref_id)).set("width", jopt(w)).set("height", jopt(h));
+        if (c.api_only) return s;
         auto it = c.images->find(s->ref_id);
         if (it == c.images->end()) {
             fail(c, "Image \"" + s->ref_id + "\" does not exist. You have to register it first before using it in the scene definition.");
@@ -415,17 +524,45 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
     }
     if (t == "text") {  // text_component.rs; only TextDimensions::Fixed can be sized without the text shaper
         s->kind = Kind::Text;
-        OptF w, h, fs, lh;
+        OptF w, h, mw, mh, fs, lh;
+        std::string family = "Verdana", style, wrap, weight;
+        bool has_family;
+        HAlign align;
+        RGBA color, bg;
         if (!check_fields(j, "Text", {"id", "text", "width", "height", "max_width", "max_height", "font_size", "line_height", "color",
                                       "background_color", "font_family", "style", "align", "wrap", "weight"}, c) ||
             !get_str(j, "text", s->text, present, c) || !get_f32(j, "width", w, c) || !get_f32(j, "height", h, c) ||
-            !get_f32(j, "font_size", fs, c) || !get_f32(j, "line_height", lh, c))
+            !get_f32(j, "max_width", mw, c) || !get_f32(j, "max_height", mh, c) || !get_f32(j, "font_size", fs, c) ||
+            !get_f32(j, "line_height", lh, c))
             return nullptr;
         if (!present) { fail(c, "missing field `text`"); return nullptr; }
         if (!fs) { fail(c, "missing field `font_size`"); return nullptr; }
+        std::string fam;
+        if (!get_str(j, "font_family", fam, has_family, c) ||
+            !get_enum<std::string>(j, "style", {{"normal", "Normal"}, {"italic", "Italic"}, {"oblique", "Oblique"}}, "Normal", style, c) ||
+            !get_enum<std::string>(j, "wrap", {{"none", "None"}, {"glyph", "Glyph"}, {"word", "Word"}}, "None", wrap, c) ||
+            !get_enum<std::string>(j, "weight", {{"thin", "Thin"}, {"extra_light", "ExtraLight"}, {"light", "Light"}, {"normal", "Normal"},
+                                                 {"medium", "Medium"}, {"semi_bold", "SemiBold"}, {"bold", "Bold"}, {"extra_bold", "ExtraBold"},
+                                                 {"black", "Black"}}, "Normal", weight, c) ||
+            !get_enum<HAlign>(j, "align", {{"left", HAlign::Left}, {"right", HAlign::Right}, {"justified", HAlign::Justified}, {"center", HAlign::Center}},
+                              HAlign::Left, align, c))
+            return nullptr;
+        if (has_family) family = fam;
+        // component_into.rs:285-320 — the dimensions are resolved before font_size / line_height are validated, colours last
         if (!w && h) { fail(c, "\"height\" property on a Text component can only be provided if \"width\" is also defined."); return nullptr; }
         if (*fs <= 0.0f) { fail(c, "\"font_size\" property has to be larger than 0"); return nullptr; }
         if (lh.value_or(*fs) <= 0.0f) { fail(c, "\"line_height\" property has to be larger than 0"); return nullptr; }
+        if (!get_color(j, "color", RGBA{255, 255, 255, 255}, color, c) || !get_color(j, "background_color", RGBA{0, 0, 0, 0}, bg, c)) return nullptr;
+        const float MAX_W = 7682.0f, MAX_H = 4320.0f;  // MAX_NODE_RESOLUTION (smelter-render/src/types.rs:146-149)
+        Json dims = w && h ? Json::array({Json::string("Fixed"), Json::number(*w), Json::number(*h)})
+                    : w    ? Json::array({Json::string("FittedColumn"), Json::number(*w), Json::number(mh.value_or(MAX_H))})
+                           : Json::array({Json::string("Fitted"), Json::number(mw.value_or(MAX_W)), Json::number(mh.value_or(MAX_H))});
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("Text")).set("id", jid(*s)).set("text", Json::string(s->text)).set("font_size", Json::number(*fs))
+            .set("line_height", Json::number(lh.value_or(*fs))).set("color", jcolor(color)).set("font_family", Json::string(family))
+            .set("style", Json::string(style)).set("align", Json::string(halign_name(align))).set("weight", Json::string(weight))
+            .set("wrap", Json::string(wrap)).set("background_color", jcolor(bg)).set("dimensions", dims);
+        if (c.api_only) return s;
         if (!w || !h) {
             fail(c, "Text components need \"width\" and \"height\" here: fitted text is measured by the caller's text shaper (SURVEY.md §8 a12)");
             return nullptr;
@@ -447,11 +584,28 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             return nullptr;
         }
         s->leaf_size = {(float)(size_t)rw->num, (float)(size_t)rh->num};
-        if (const Json *p = j.get("shader_param")) s->shader_param = *p;
+        Json param;
+        if (const Json *p = j.get("shader_param")) {
+            s->shader_param = *p;
+            if (!p->is_null() && !shader_param(*p, false, param, c)) return nullptr;
+        }
         if (!build_children(j, s->children, c)) return nullptr;
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("Shader")).set("id", jid(*s)).set("shader_id", Json::string(s->ref_id)).set("shader_param", param)
+            .set("size", Json::array({Json::number(s->leaf_size.width), Json::number(s->leaf_size.height)})).set("children", jchildren(s->children));
         return s;
     }
-    if (t == "web_view") { fail(c, "WebView components are not supported (SURVEY.md §8: out of scope)"); return nullptr; }
+    if (t == "web_view") {  // parsed for API parity; there is no browser to render it (out of scope)
+        std::string instance;
+        if (!check_fields(j, "WebView", {"id", "children", "instance_id"}, c) || !get_str(j, "instance_id", instance, present, c)) return nullptr;
+        if (!present) { fail(c, "missing field `instance_id`"); return nullptr; }
+        if (!c.api_only) { fail(c, "Instance of web renderer \"" + instance + "\" does not exist. You have to register it first before using it in the scene definition."); return nullptr; }
+        s->kind = Kind::Shader;
+        if (!build_children(j, s->children, c)) return nullptr;
+        s->desc = Json::object();
+        s->desc.set("type", Json::string("WebView")).set("id", jid(*s)).set("children", jchildren(s->children)).set("instance_id", Json::string(instance));
+        return s;
+    }
     fail(c, "unknown variant `" + t + "`, expected one of `input_stream`, `view`, `web_view`, `shader`, `image`, `text`, `tiles`, `rescaler`");
     return nullptr;
 }
@@ -524,6 +678,21 @@ bool Scene::update(const std::string &json, uint32_t out_w, uint32_t out_h, std:
     root_ = std::move(root);
     nodes_ = std::move(nodes);
     out_w_ = out_w; out_h_ = out_h;
+    return true;
+}
+
+bool Scene::parse(const std::string &json, std::string &out, std::string &err) const {
+    Json j;
+    JsonParser parser(json);
+    if (!parser.parse(j, err)) return false;
+    BuildCtx ctx;
+    ctx.api_only = true;
+    ctx.input_resolutions = &input_resolutions_;
+    ctx.images = &images_;
+    std::unique_ptr<Stateful> root = build(j, ctx);
+    if (!root) { err = ctx.err; return false; }
+    out.clear();
+    root->desc.dump(out);
     return true;
 }
 

@@ -8,6 +8,7 @@ using namespace smr_host;
 struct smr_scene {
     Scene scene;
     std::string err;
+    std::string parsed;  // storage behind smr_scene_parse's out_json
 };
 
 static int set_err(smr_scene *s, const std::string &msg) {
@@ -35,6 +36,14 @@ SMR_API int smr_scene_update(smr_scene *scene, const char *scene_json, uint32_t 
     if (!scene || !scene_json) return set_err(scene, "smr_scene_update: null argument");
     std::string err;
     if (!scene->scene.update(scene_json, out_width, out_height, err)) return set_err(scene, err);
+    return 0;
+}
+
+SMR_API int smr_scene_parse(smr_scene *scene, const char *scene_json, const char **out_json) {
+    if (!scene || !scene_json || !out_json) return set_err(scene, "smr_scene_parse: null argument");
+    std::string err;
+    if (!scene->scene.parse(scene_json, scene->parsed, err)) return set_err(scene, err);
+    *out_json = scene->parsed.c_str();
     return 0;
 }
 

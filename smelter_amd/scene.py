@@ -65,6 +65,13 @@ class Scene:
         self._check(self._lib.smr_scene_update(self._h, text.encode(), out_w, out_h))
         return self.nodes()
 
+    def parse(self, scene: Union[str, dict]) -> dict:
+        """The smelter-api -> scene::Component conversion alone; returns the converted tree (canonical form)."""
+        text = scene if isinstance(scene, str) else json.dumps(scene)
+        out = C.c_char_p()
+        self._check(self._lib.smr_scene_parse(self._h, text.encode(), C.byref(out)))
+        return json.loads(out.value.decode())
+
     def nodes(self) -> List[Node]:
         out = []
         for i in range(self._check(self._lib.smr_scene_node_count(self._h))):

@@ -58,6 +58,29 @@ def test_cpu_optimized_colors():
     assert_same_layouts(arr, n, want)
 
 
+# ----------------------------------------------------------------------------- the reference's own API test vectors
+def _api_vectors():
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scene_api_vectors.json")
+    return json.load(open(path))["vectors"]
+
+
+@pytest.mark.parametrize("vec", _api_vectors(), ids=lambda v: v["name"])
+def test_scene_api_reference_vectors(vec):
+    """smelter-api/tests/scene_deserialization.rs, extracted by tests/golden/gen_scene_api_vectors.py: the JSON -> scene::Component
+    conversion (defaults, validation, exact error strings)."""
+    sc = Scene()
+    if vec["kind"] == "ok":
+        assert sc.parse(vec["scene"]) == vec["expected"]
+    elif vec["kind"] == "err":
+        with pytest.raises(SceneError) as e:
+            sc.parse(vec["scene"])
+        assert str(e.value) == vec["message"]
+    else:
+        with pytest.raises(SceneError):
+            sc.parse(vec["scene"])
+
+
 # ----------------------------------------------------------------------------- random trees, both restatements
 def _hex(c):
     return "#%02X%02X%02X%02X" % tuple(c)
