@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-frames", type=int, default=500)
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight on one GPU (renderer contexts / HIP streams)")
     args = ap.parse_args()
 
     import torch
@@ -152,9 +153,15 @@ def main():
     plan = smr_dist.ShardPlan(n_inputs=N_IN, world=world)
     my_inputs = plan.inputs_of(rank)
     ring = make_inputs(ctx, hip, RING, my_inputs)
-    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(4)] if rank == 0 else []
+    n_lanes = max(1, args.inflight) if world == 1 else 1
+    # two output frames per lane: a lane's frames are stream-ordered, lanes never share an output frame
+    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2 * n_lanes)] if rank == 0 else []
+
+    def out_for(step):
+        return outs[(step % n_lanes) + n_lanes * ((step // n_lanes) % 2)]
     input_source_slot = [i for i, r in enumerate(res) if r == (IN_W, IN_H)]  # source index of input k
 
+    lanes = [ctx]
     if world == 1:
         def sources_for(step):
             row = ring[step % RING]
@@ -166,19 +173,25 @@ def main():
                     srcs.append(label)
             return srcs
         src_cache = [sources_for(s) for s in range(RING)]
+        # frames in flight: consecutive frames go to separate renderer contexts (own HIP stream, own tile / parameter scratch),
+        # so the latency-bound tail of one frame's compose kernel overlaps the next frame's ingest kernel.  Frames are
+        # independent (inputs read-only, distinct output frames), exactly like two outputs of the reference's pipeline.
+        lanes += [hip.Context(local_rank) for _ in range(n_lanes - 1)]
 
-        def step_fn(step):
-            ctx.render_layouts(layouts, src_cache[step % RING], OUT_W, OUT_H, out=outs[step % len(outs)], packed=packed)
+        def step_fn(step, lane=None):
+            c = lanes[step % n_lanes] if lane is None else lane
+            c.render_layouts(layouts, src_cache[step % RING], OUT_W, OUT_H, out=out_for(step) if lane is None else outs[0], packed=packed)
     else:
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
 
         def step_fn(step):
-            sharded.step(ring[step % RING], outs[step % len(outs)] if rank == 0 else None)
+            sharded.step(ring[step % RING], out_for(step) if rank == 0 else None)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        ctx.sync()
+        for c in lanes:
+            c.sync()
         torch.cuda.synchronize()
 
     for s in range(args.warmup):
@@ -205,7 +218,7 @@ def main():
             "config": {"workload": "configs[2]: 8x1080p YUV420 inputs tiled -> 3840x2160 YUV420, Tiles + Rescaler(border_radius 24) "
                                    "+ text label per tile, GpuOptimized (linear-light Lanczos3 + blend)",
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
-                       "layouts": len(layouts), "input_ring": RING,
+                       "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
                        "parallelism": "single GPU" if world == 1 else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
             "frame": {"algorithmic_bytes": ALGO_BYTES_PER_FRAME, "achieved_GBps": round(ALGO_BYTES_PER_FRAME * fps / 1e9, 2),
                       "frac_of_hbm_peak": round(ALGO_BYTES_PER_FRAME * fps / 1e9 / HBM_PEAK_GBPS, 5)},
@@ -217,7 +230,7 @@ def main():
         ctx.profile_reset()
         ctx.profile_enable(True)
         for s in range(min(args.steps, 200)):
-            step_fn(s)
+            step_fn(s, ctx)
         ctx.sync()
         prof = ctx.profile_read()
         ctx.profile_enable(False)
@@ -242,7 +255,7 @@ def main():
         lat = []
         for s in range(args.latency_frames):
             t1 = time.perf_counter()
-            step_fn(s)
+            step_fn(s, ctx)
             ctx.sync()
             lat.append(time.perf_counter() - t1)
         lat = np.array(lat) * 1e3
@@ -256,6 +269,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    for c in lanes[1:]:
+        c.close()
     ctx.close()
 
 

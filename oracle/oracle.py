@@ -383,6 +383,17 @@ def pack_layouts(layouts: Sequence[Layout], struct=_Layout, mask_struct=_Mask):
     return arr
 
 
+def layout_fragments(W, H, layout: Layout) -> np.ndarray:
+    """Fragment-stage output (f32, premultiplied) of one colour / shadow layout per pixel; NaN where the quad does not cover."""
+    arr = pack_layouts([layout])
+    out = np.empty((H, W, 4), np.float32)
+    lib = _load()
+    lib.orc_layout_fragments.restype = None
+    lib.orc_layout_fragments.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.orc_layout_fragments(out.ctypes.data, W, H, C.addressof(arr))
+    return out
+
+
 def apply_layouts(W, H, layouts: Sequence[Layout], sources: Sequence[Optional[np.ndarray]], srgb=True, omp=False) -> np.ndarray:
     arr = pack_layouts(layouts)
     srcs = (_Source * max(len(sources), 1))()

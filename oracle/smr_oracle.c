@@ -811,6 +811,35 @@ static void layout_fragment(const orc_layout *L, const orc_source *src, int srgb
     }
 }
 
+/* Test hook: the fragment stage alone for ONE colour / shadow layout — out[(py*W+px)*4..] = fragment output (premultiplied
+ * f32) where the quad covers the pixel centre, NaN elsewhere.  Used to check the kernels' "solid region" claim (the set of
+ * pixels where the fragment equals the base colour bit for bit) against the full SDF evaluation. */
+ORC_API void orc_layout_fragments(float *out, int W, int H, const orc_layout *L) {
+    orc_init();
+    const float DEG = 0.017453292519943295f;
+    for (size_t i = 0; i < (size_t)W * H * 4; i++) out[i] = NAN;
+    float qleft = L->left, qtop = L->top, qw = L->width, qh = L->height;
+    if (L->type == 2) {
+        qleft = L->left - L->blur_radius; qtop = L->top - L->blur_radius;
+        qw = L->width + 2.0f * L->blur_radius; qh = L->height + 2.0f * L->blur_radius;
+    }
+    if (!(qw > 0.0f) || !(qh > 0.0f) || L->type == 0) return;
+    float cx = qleft + qw / 2.0f, cy = qtop + qh / 2.0f;
+    float ang = L->rotation_degrees * DEG;
+    float cs = cosf(ang), sn = sinf(ang);
+    for (int py = 0; py < H; py++) {
+        for (int px = 0; px < W; px++) {
+            float fx = (float)px + 0.5f, fy = (float)py + 0.5f;
+            float dx = fx - cx, dy = -(fy - cy);
+            float lx = cs * dx + sn * dy;
+            float ly = -sn * dx + cs * dy;
+            if (!(lx >= -qw / 2.0f && lx < qw / 2.0f)) continue;
+            if (!(-ly >= -qh / 2.0f && -ly < qh / 2.0f)) continue;
+            layout_fragment(L, NULL, 1, fx, fy, lx, ly, 0.0f, 0.0f, out + ((size_t)py * W + px) * 4);
+        }
+    }
+}
+
 /* LayoutShader::render (layout/shader.rs:93-167): clear to transparent, then one
  * quad per layout, back to front, PREMULTIPLIED_ALPHA blending, target re-quantised
  * to RGBA8 after every draw (sRGB-encoded when srgb != 0: GpuOptimized).

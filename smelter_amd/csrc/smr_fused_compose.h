@@ -68,8 +68,13 @@ __device__ __forceinline__ float4 decode_texel(u32 raw, int srgb, const float *_
 //   * an aligned opaque texel whose fragment came out equal to the sample (coverage, border and every mask evaluated
 //     to exactly 1) stores its own bytes: encode(decode(b)) == b;
 //   * `is_base`: the caller established that this layer is opaque and solid at the pixel.
+__device__ __forceinline__ u32 aligned_texel(const DevLayout &L, int px, int py) {
+    return *(const u32 *)(L.src.ptr + (size_t)clampi(py - L.iy, 0, L.tex_h - 1) * L.src.pitch + (size_t)clampi(px - L.ix, 0, L.tex_w - 1) * 4);
+}
+
+// `raw_pre`: the texel of an aligned texture layer, fetched by the caller ahead of the arithmetic (aligned_texel)
 __device__ __forceinline__ u32 compose_px(u32 a, const DevLayout &L, const DevMask *__restrict__ masks, int px, int py, bool is_base,
-                                          int srgb, const float *__restrict__ dec, const float *__restrict__ thr) {
+                                          u32 raw_pre, int srgb, const float *__restrict__ dec, const float *__restrict__ thr) {
     float fx, fy, lx, ly;
     if (!layout_covers(L, px, py, fx, fy, lx, ly)) return a;
     const bool solid = is_base || layout_solid_box(L, masks, fx, fy, fx, fy);
@@ -83,7 +88,7 @@ __device__ __forceinline__ u32 compose_px(u32 a, const DevLayout &L, const DevMa
     u32 raw = 0u;
     float4 sample;
     if (aligned) {
-        raw = *(const u32 *)(L.src.ptr + (size_t)clampi(py - L.iy, 0, L.tex_h - 1) * L.src.pitch + (size_t)clampi(px - L.ix, 0, L.tex_w - 1) * 4);
+        raw = raw_pre;
         sample = decode_texel(raw, srgb, dec);
     } else {
         sample = layout_texture_sample(L, px, py, lx, ly, srgb, dec);
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         //      Per-pixel state lives in LDS: s_px = running RGBA8, s_sp = per-pixel start layer.
         constexpr int SWEEPS = (B_TILE_W * B_TILE_H) / 256;
         __shared__ short s_sp[B_TILE_W * B_TILE_H];
+        __shared__ u32 s_raw[B_TILE_W * B_TILE_H];  // prefetched texels of the aligned texture layer being applied
 #pragma unroll 1
         for (int sweep = 0; sweep < SWEEPS; sweep++) {
             s_px[sweep * 256 + tid] = 0u;
@@ -181,13 +187,25 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
                 const int li = (wi << 5) + __builtin_ctz(bits);
                 bits &= bits - 1;
                 const DevLayout L = load_uniform(&layouts[li]);
+                if (L.type == 0 && (L.flags & DL_ALIGNED) && L.src_kind != 0) {
+                    // aligned texture layer: all eight texel fetches of this thread are in flight together instead of one
+                    // exposed global-memory round trip per sweep (the addresses are clamped, so every lane may load)
+                    u32 pre[SWEEPS];
+#pragma unroll
+                    for (int sweep = 0; sweep < SWEEPS; sweep++) {
+                        const int idx = sweep * 256 + tid;
+                        pre[sweep] = aligned_texel(L, tx0 + (idx & (B_TILE_W - 1)), ty0 + (idx >> 7));
+                    }
+#pragma unroll
+                    for (int sweep = 0; sweep < SWEEPS; sweep++) s_raw[sweep * 256 + tid] = pre[sweep];
+                }
 #pragma unroll 1
                 for (int sweep = 0; sweep < SWEEPS; sweep++) {
                     const int idx = sweep * 256 + tid;
                     const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
                     const int sp = s_sp[idx];
                     if (px < W && py < H && li >= sp && !((ablate & 8) && li != sp))
-                        s_px[idx] = compose_px(s_px[idx], L, masks, px, py, li == sp, srgb, dec, thr);
+                        s_px[idx] = compose_px(s_px[idx], L, masks, px, py, li == sp, s_raw[idx], srgb, dec, thr);
                 }
             }
         }

@@ -101,11 +101,15 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
             memset(&DM, 0, sizeof(DM));
             for (int k = 0; k < 4; k++) DM.radius[k] = K.radius[k];
             DM.top = K.top; DM.left = K.left; DM.width = K.width; DM.height = K.height;
-            // solid region of smoothstep(-.5, .5, -sdf): inset by max(radius, .5) (+ rounding slack unless exactly representable)
+            // solid region of smoothstep(-.5, .5, -sdf): the rect inset by .5 minus the four corner squares of side max radius
+            // (+ rounding slack unless every quantity is a multiple of 1/2 below 2^15: then each f32 operation of the SDF is exact)
             const float mr = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3]));
             auto hi = [](float v) { return v * 2.0f == floorf(v * 2.0f) && fabsf(v) < 32768.0f; };
-            const bool mexact = mr == 0.0f && hi(K.left) && hi(K.top) && hi(K.width) && hi(K.height);
-            DM.inset = fmaxf(mr, 0.5f) + (mexact ? 0.0f : 0.015625f);
+            const bool mexact = hi(K.radius[0]) && hi(K.radius[1]) && hi(K.radius[2]) && hi(K.radius[3]) && hi(K.left) && hi(K.top) &&
+                                hi(K.width) && hi(K.height);
+            const float mslack = mexact ? 0.0f : 0.015625f;
+            DM.inset = 0.5f + mslack;
+            DM.corner = (mr + mslack > DM.inset) ? mr + mslack : 0.0f;
         }
         float qleft = L.left, qtop = L.top, qw = L.width, qh = L.height;
         if (L.type == 2) {  // box shadow quad grown by blur on each side (apply_layouts.wgsl:216-229)
@@ -135,11 +139,17 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         //   colour border: smoothstep(bw,bw+1,ed) -> ed >= bw+1;  shadow: smoothstep(-b/2,b/2,ed) -> ed >= b/2.
         float rmax = fmaxf(fmaxf(L.border_radius[0], L.border_radius[1]), fmaxf(L.border_radius[2], L.border_radius[3]));
         float need = 0.5f;
-        if (L.type == 2) need = L.blur_radius / 2.0f;
+        if (L.type == 2) need = fmaxf(L.blur_radius / 2.0f, 0.5f);  // >= .5 keeps the region inside the half-open quad coverage
         else if (L.border_width >= 1.0f) need = L.border_width + (L.type == 0 ? 0.5f : 1.0f);
+        // Outside the four corner squares (side = max radius) the SDF is the plain distance to the nearest straight edge
+        // (smr_layout_dev.h, rect_solid_box), so only those squares and the `need` band along the edges are not solid.
         auto half_int = [](float v) { return v * 2.0f == floorf(v * 2.0f) && fabsf(v) < 32768.0f; };
-        const bool exact = rmax == 0.0f && half_int(L.left) && half_int(L.top) && half_int(L.width) && half_int(L.height) && half_int(need);
-        D.inset = fmaxf(rmax, need) + (exact ? 0.0f : 0.015625f);  // 1/64 px of slack for f32 rounding in the SDF
+        const bool exact = half_int(L.border_radius[0]) && half_int(L.border_radius[1]) && half_int(L.border_radius[2]) &&
+                           half_int(L.border_radius[3]) && half_int(L.left) && half_int(L.top) && half_int(L.width) && half_int(L.height) &&
+                           half_int(need) && half_int(qleft) && half_int(qw) && half_int(qtop) && half_int(qh);
+        const float slack = exact ? 0.0f : 0.015625f;  // 1/64 px for f32 rounding in the SDF
+        D.inset = need + slack;
+        D.corner = (rmax + slack > D.inset) ? rmax + slack : 0.0f;
         if (L.type == 0 && D.src_kind != 0 && (D.flags & DL_UNROTATED) && L.crop[0] == 0.0f && L.crop[1] == 0.0f &&
             L.crop[2] == (float)D.tex_w && L.crop[3] == (float)D.tex_h && L.width == (float)D.tex_w && L.height == (float)D.tex_h &&
             L.left == floorf(L.left) && L.top == floorf(L.top) && fabsf(L.left) < 65536.0f && fabsf(L.top) < 65536.0f) {
@@ -164,6 +174,16 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         }
         if (!(qw > 0.0f) || !(qh > 0.0f) || L.type > 2) {
             D.bx0 = D.by0 = 0; D.bx1 = D.by1 = -1;  // never binned
+        } else if (D.flags & DL_UNROTATED) {
+            // pixel x is covered iff qleft <= x + .5 < qleft + qw (layout_covers), i.e. qleft - .5 <= x < qleft + qw - .5.
+            // Tight bounds matter: a one-pixel margin makes every neighbour of a tile-aligned rect "touch" the next tile column.
+            // 1/64 px of slack unless the quad is on half-integers (then the coverage arithmetic is exact in f32).
+            const float s = (half_int(qleft) && half_int(qtop) && half_int(qw) && half_int(qh)) ? 0.0f : 0.015625f;
+            auto clampi_h = [](float v, int lo, int hi) { return v < (float)lo ? lo : (v > (float)hi ? hi : (int)v); };
+            D.bx0 = clampi_h(ceilf(qleft - 0.5f - s), 0, out_w);
+            D.bx1 = clampi_h(ceilf(qleft + qw - 0.5f + s), 0, out_w);
+            D.by0 = clampi_h(ceilf(qtop - 0.5f - s), 0, out_h);
+            D.by1 = clampi_h(ceilf(qtop + qh - 0.5f + s), 0, out_h);
         } else {
             float ex = fabsf(D.cs) * qw / 2.0f + fabsf(D.sn) * qh / 2.0f;
             float ey = fabsf(D.sn) * qw / 2.0f + fabsf(D.cs) * qh / 2.0f;

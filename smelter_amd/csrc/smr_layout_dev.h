@@ -20,8 +20,9 @@ constexpr int MAX_LAYOUT_WORDS = 32;  // up to 1024 layouts per node
 struct DevMask {
     float radius[4];  // tl, tr, br, bl
     float top, left, width, height;
-    float inset;      // inside the mask rect inset by this much smoothstep(-.5,.5,-sdf) == 1 exactly
-    float pad[3];
+    float inset;      // inside the mask rect inset by this much (corner squares excepted) smoothstep(-.5,.5,-sdf) == 1 exactly
+    float corner;     // side of the four corner squares in which the SDF is curved (0: none beyond the inset band)
+    float pad[2];
 };
 
 // Compact per-layout record consumed by the kernels (wave-uniform: read through scalar loads).
@@ -44,9 +45,10 @@ struct alignas(16) DevLayout {
     int tex_w, tex_h;
     SurfView src;
     int flags;            // DL_* below
-    float inset;          // inside the rect inset by this much the fragment equals its base value (no AA / border / radius)
+    float inset;          // inside the rect inset by this much (corner squares excepted) the fragment equals its base value
     int ix, iy;           // DL_ALIGNED: texel = pixel - (ix, iy)
     u32 solid_px;         // DL_COLOR_OPAQUE: the colour as the render-target store would encode it
+    float corner;         // side of the four corner squares in which the SDF is curved (0: none beyond the inset band)
 };
 
 enum {
@@ -128,18 +130,31 @@ __device__ __forceinline__ bool layout_covers(const DevLayout &L, int px, int py
     return true;
 }
 
-// Does the axis-aligned box of pixel centres [cx0,cx1] x [cy0,cy1] lie in the solid region of L?
-// Inside a rect inset by m >= radius on every side the SDF is <= -m; m also covers the border / blur band,
-// plus 1/64 px of slack for f32 rounding unless every quantity is exactly representable (host: smr_pack_layouts).
+// Solid region of a rounded rect for the box of pixel centres [cx0,cx1] x [cy0,cy1].
+// roundedRectSDF with q = |d| - half + r:  outside the four r x r corner squares at least one of q.x, q.y is <= 0, the
+// length() term collapses to the other component (or 0) and the SDF is the plain distance to the nearest straight edge:
+// edge_distance = min(half_w - |dx|, half_h - |dy|).  So inside the rect inset by `inset` (the distance at which every
+// smoothstep of the fragment stage saturates at exactly 1) and outside the corner squares the fragment is the base value.
+// Both carry 1/64 px of slack for f32 rounding unless every quantity is exactly representable (host: smr_pack_layouts).
+__device__ __forceinline__ bool rect_solid_box(float left, float top, float width, float height, float inset, float corner,
+                                               float cx0, float cy0, float cx1, float cy1) {
+    if (!(left + inset <= cx0 && cx1 <= left + width - inset && top + inset <= cy0 && cy1 <= top + height - inset)) return false;
+    if (corner > 0.0f) {
+        const bool near_x = cx0 < left + corner || cx1 > left + width - corner;
+        const bool near_y = cy0 < top + corner || cy1 > top + height - corner;
+        if (near_x && near_y) return false;
+    }
+    return true;
+}
+
+// Does the axis-aligned box of pixel centres [cx0,cx1] x [cy0,cy1] lie in the solid region of L and of all its masks?
 __device__ __forceinline__ bool layout_solid_box(const DevLayout &L, const DevMask *__restrict__ masks, float cx0, float cy0,
                                                  float cx1, float cy1) {
     if (!(L.flags & DL_UNROTATED)) return false;
-    bool solid = L.left + L.inset <= cx0 && cx1 <= L.left + L.width - L.inset && L.top + L.inset <= cy0 &&
-                 cy1 <= L.top + L.height - L.inset;
+    bool solid = rect_solid_box(L.left, L.top, L.width, L.height, L.inset, L.corner, cx0, cy0, cx1, cy1);
     for (u32 m = 0; solid && m < L.masks_len; m++) {
         const DevMask &K = masks[L.masks_off + m];
-        solid = K.left + K.inset <= cx0 && cx1 <= K.left + K.width - K.inset && K.top + K.inset <= cy0 &&
-                cy1 <= K.top + K.height - K.inset;
+        solid = rect_solid_box(K.left, K.top, K.width, K.height, K.inset, K.corner, cx0, cy0, cx1, cy1);
     }
     return solid;
 }
@@ -155,7 +170,7 @@ __device__ __forceinline__ float4 layout_fragment(const DevLayout &L, const DevM
     for (u32 i = 0; i < L.masks_len; i++) {
         const DevMask &m = masks[L.masks_off + i];
         // inside the mask's solid region the factor is exactly 1
-        if (m.left + m.inset <= fx && fx <= m.left + m.width - m.inset && m.top + m.inset <= fy && fy <= m.top + m.height - m.inset) continue;
+        if (rect_solid_box(m.left, m.top, m.width, m.height, m.inset, m.corner, fx, fy, fx, fy)) continue;
         float dx = m.left + (m.width / 2.0f) - fx;
         float dy = m.top + (m.height / 2.0f) - fy;
         float dist = rounded_rect_sdf(dx, dy, m.width, m.height, m.radius);
