@@ -120,6 +120,8 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     ctx->device = hip_device;
     ctx->mode = mode;
     ctx->max_layouts = max_layouts ? max_layouts : SMR_DEFAULT_MAX_LAYOUTS;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, hip_device) == hipSuccess && cus > 0) ctx->cu_count = cus;
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
     } else {

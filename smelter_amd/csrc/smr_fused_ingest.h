@@ -1,18 +1,18 @@
 // smr_fused_ingest.h — wave A of the hot path: k_ingest_resample (included by smr_fused.hip only).
 //
-// One launch covers every scaled planar-YUV input of the frame (blockIdx.z = job).  A 512-thread
-// workgroup produces one 64x32 tile of the dst-sized RGBA8 tile surface:
-//   * prologue: the tile's raw Y/U/V source footprint (~10 KB), the weight tables of its 64 columns /
-//     32 rows and the sRGB tables are pulled into LDS with one round of loads — the only global-memory
-//     latency the workgroup is exposed to;
-//   * each of the 8 waves then runs its own pipeline over the footprint, two source rows at a time:
-//     convert (YUV -> RGBA8 bytes -> sRGB-decoded linear f32; 2x2 quads sharing one chroma neighbourhood
-//     for 4:2:0) into a wave-private LDS strip, then the horizontal Lanczos of exactly those two rows
-//     into the shared f16 intermediate M (LDS).  No workgroup barrier separates the two — only the
-//     wave's own in-order LDS stream;
-//   * one barrier, then the vertical Lanczos over M, sRGB encode, one coalesced 256 B row store per wave.
-// The node texture (RGBA8, input-sized) and the Rgba16Float intermediate of the reference never exist
-// in HBM; their quantisation (u8, f16) is applied in registers at the same points.
+// One launch covers every scaled planar-YUV input of the frame (blockIdx.z = job).  A 512-thread workgroup owns a
+// 64-column strip of the dst-sized RGBA8 tile surface over a segment of its rows and streams the matching source rows
+// through LDS in chunks of 16 (one row pair per wave):
+//   * stage   — the chunk's raw Y/U/V footprint (aligned dwords) into LDS;
+//   * convert — per wave: YUV -> RGBA8 bytes -> sRGB-decoded linear f32 (2x2 quads sharing one chroma neighbourhood for
+//               4:2:0) into a wave-private LDS strip, then the horizontal Lanczos of exactly those two rows into a ring of
+//               f16 rows M (LDS) — no barrier between the two, only the wave's own in-order LDS stream;
+//   * resolve — every output row whose vertical window is now complete: vertical Lanczos over M, sRGB encode, one coalesced
+//               256 B row store per wave.
+// A source row is converted and filtered horizontally exactly once per strip (no vertical halo), the per-block setup
+// (tables, horizontal weights) is paid once per ~240 output rows.  The node texture (RGBA8, input-sized) and the
+// Rgba16Float intermediate of the reference never exist in HBM; their quantisation (u8, f16) is applied in registers at
+// the same points.
 #pragma once
 
 #include "smr_convert_dev.h"
@@ -96,30 +96,35 @@ int get_weights(smr_ctx *ctx, float scale, float offset, int n, WeightPtrs *out)
 }
 
 // ------------------------------------------------------------------ kernel
-constexpr int TW = 64;          // output tile width  (one lane per column)
-constexpr int TH = 24;          // output tile height (keeps LDS at ~74 KB for k = 1.5: two workgroups per CU)
+constexpr int TW = 64;          // strip width (one lane per output column)
+constexpr int CH = 16;          // source rows per chunk: one row pair per wave
+constexpr int MR = 64;          // rows of the f16 intermediate ring (power of two)
 constexpr int A_WAVES = 8;
 constexpr int A_THREADS = A_WAVES * 64;
+constexpr int VR_MAX = 64;      // output rows whose vertical weights are resident per chunk (one ballot wide)
+static_assert(CH == 2 * A_WAVES, "one row pair per wave and chunk");
 
 struct IngestJob {
     SurfView yp, up, vp;  // planar source planes (chroma views carry the logical chroma size)
     SurfView dst;         // RGBA8 tile, dst-sized
     int src_w, src_h;
     int full_range;
-    int fast420;          // 4:2:0 with even luma size: LDS-staged 2x2-quad conversion path
-    int ablate;           // profiling only (SMR_ABLATE): 1 skip convert, 2 skip H taps, 4 skip V taps, 8 skip staging
+    int fast420;          // 4:2:0 with even luma size and dword-aligned planes: LDS-staged 2x2-quad conversion path
+    int ablate;           // profiling only (SMR_ABLATE): 1 skip convert, 2 skip H taps, 4 skip V taps, 8 skip staging, 16 dispatch only
     int taps_h, taps_v;
     float scale_h, off_h, scale_v, off_v;  // axis mappings (resampler.rs:36-48): source texels per output texel, crop offset
     const float *wsum_h; const float *w_h;  // device weight tables: wsum[n], w[taps][n] (tap-major)
     const float *wsum_v; const float *w_v;
-    int tiles_x, tiles_y;
-    int nc_max, nr_max;   // LDS capacity: columns of a source strip, rows of M (even)
+    int strips_x, segs_y, seg_h;  // grid: 64-column strips x row segments of seg_h output rows
+    int nc_max;           // LDS capacity: columns of a source strip
+    int vr;               // output rows with resident vertical weights per chunk
+    int defer8;           // resolve output rows in multiples of 8 (one per wave) while the ring has room for the stragglers
 };
 
 // raw-footprint staging geometry (bytes)
 __host__ __device__ inline int raw_y_stride(int nc_max) { return (nc_max + 8 + 3) & ~3; }
-__host__ __device__ inline int raw_c_stride(int nc_max) { return ((nc_max >> 1) + 4 + 3) & ~3; }
-__host__ __device__ inline int raw_c_rows(int nr_max) { return (nr_max >> 1) + 2; }
+__host__ __device__ inline int raw_c_stride(int nc_max) { return ((nc_max >> 1) + 12 + 3) & ~3; }
+constexpr int RAW_C_ROWS = CH / 2 + 2;
 
 __device__ __forceinline__ float4 half4_to_float4(uint2 raw) {
     __half2 lo = *(const __half2 *)&raw.x, hi = *(const __half2 *)&raw.y;
@@ -159,68 +164,69 @@ struct IngestArgs {
 __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs args, const float *__restrict__ tables) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const IngestJob &J = args.jobs[blockIdx.z];
-    if ((int)blockIdx.x >= J.tiles_x || (int)blockIdx.y >= J.tiles_y) return;
+    if ((int)blockIdx.x >= J.strips_x || (int)blockIdx.y >= J.segs_y) return;
     if (J.ablate & 16) return;  // profiling: pure dispatch cost of this grid
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
-    const int tw = min(TW, J.dst.w - tx0), th = min(TH, J.dst.h - ty0);
+    const int tx0 = blockIdx.x * TW;
+    const int tw = min(TW, J.dst.w - tx0);
+    const int oy0 = blockIdx.y * J.seg_h, oy1 = min(oy0 + J.seg_h, J.dst.h);
+    if (oy0 >= oy1) return;
     const int taps_h = J.taps_h, taps_v = J.taps_v;
     const int ncm = J.nc_max;
     const int sw = J.src_w, sh = J.src_h;
+    const int VR = J.vr, VRa = (VR + 3) & ~3;
 
     // ---- LDS carve (every region is a multiple of 16 B)
     float *s_tab = (float *)smem;                          // SMR_TABLE_FLOATS: dec | thr | enc
     float *s_n255 = s_tab + SMR_TABLE_FLOATS;              // 256: u8 / 255
     float *s_ylut = s_n255 + 256;                          // 256: luma u8 -> range-expanded y
     float *s_wh = s_ylut + 256;                            // [taps_h][TW]
-    float *s_wv = s_wh + ((taps_h * TW + 3) & ~3);         // [TH][taps_v]
-    int *s_fh = (int *)(s_wv + ((TH * taps_v + 3) & ~3));  // [TW]
-    int *s_fv = s_fh + TW;                                 // [TH]
-    float *s_wsh = (float *)(s_fv + TH);                   // [TW]   wsum
+    float *s_wsh = s_wh + ((taps_h * TW + 3) & ~3);        // [TW]   wsum
     float *s_rsh = s_wsh + TW;                             // [TW]   1 / wsum
-    float *s_wsv = s_rsh + TW;                             // [TH]
-    float *s_rsv = s_wsv + TH;                             // [TH]
-    float4 *S_all = (float4 *)(s_rsv + TH);                // [A_WAVES][2][nc_max] linear RGBA, wave-private strips
-    uint2 *M = (uint2 *)(S_all + (size_t)A_WAVES * 2 * ncm);  // [nr_max][TW] half4
-    u8 *rawY = (u8 *)(M + (size_t)J.nr_max * TW);          // [nr_max][ys]        (fast420 only)
-    const int ys = raw_y_stride(ncm), cs = raw_c_stride(ncm), crows = raw_c_rows(J.nr_max);
-    u8 *rawU = rawY + (size_t)J.nr_max * ys;               // [crows][cs]
-    u8 *rawV = rawU + (size_t)crows * cs;
+    int *s_fh = (int *)(s_rsh + TW);                       // [TW]
+    float *s_wv = (float *)(s_fh + TW);                    // [3][taps_v][VRp]  (tap-major like the global table; three chunks deep)
+    const int VRp = VR <= 32 ? 32 : 64;
+    const int wv_sz = taps_v * VRp;
+    int *s_fv = (int *)(s_wv + 3 * wv_sz);                 // [3][VRa]
+    float *s_wsv = (float *)(s_fv + 3 * VRa);              // [3][VRa]
+    float *s_rsv = s_wsv + 3 * VRa;                        // [3][VRa]
+    float4 *S_all = (float4 *)(s_rsv + 3 * VRa);           // [A_WAVES][2][nc_max] linear RGBA, wave-private strips
+    uint2 *M = (uint2 *)(S_all + (size_t)A_WAVES * 2 * ncm);  // [MR][TW] half4 ring, row r lives in slot (r - R_lo) & (MR - 1)
+    u8 *raw0 = (u8 *)(M + (size_t)MR * TW);                // [2]{ Y [CH][ys], U [RAW_C_ROWS][cs], V [RAW_C_ROWS][cs] }  (fast420 only)
+    const int ys = raw_y_stride(ncm), cs = raw_c_stride(ncm);
+    const int raw_sz = CH * ys + 2 * RAW_C_ROWS * cs;
 
-    // ---- the tile's source footprint (first[] is non-decreasing in the output coordinate)
-    //      computed from the mapping itself (same f32 sequence as the weight tables) — no dependent load
+    // ---- the strip's source footprint (first[] is non-decreasing in the output coordinate), computed from the mapping
+    //      itself (same f32 sequence as the weight tables) — no dependent load
     int c_lo = clampi(lanczos_first(tx0, J.scale_h, J.off_h), 0, sw - 1);
     const int c_hi = clampi(lanczos_first(tx0 + tw - 1, J.scale_h, J.off_h) + taps_h - 1, 0, sw - 1);
-    int r_lo = clampi(lanczos_first(ty0, J.scale_v, J.off_v), 0, sh - 1);
-    const int r_hi = clampi(lanczos_first(ty0 + th - 1, J.scale_v, J.off_v) + taps_v - 1, 0, sh - 1);
+    int R_lo = clampi(lanczos_first(oy0, J.scale_v, J.off_v), 0, sh - 1);
+    const int R_hi = clampi(lanczos_first(oy1 - 1, J.scale_v, J.off_v) + taps_v - 1, 0, sh - 1);
     if (J.fast420) {
         // 2x2 conversion quads start on odd luma coordinates (they share one 2x2 chroma neighbourhood)
         c_lo -= (c_lo & 1) ^ 1;
-        r_lo -= (r_lo & 1) ^ 1;
+        R_lo -= (R_lo & 1) ^ 1;
     }
-    const int NC = c_hi - c_lo + 1, NR = r_hi - r_lo + 1;
-    const int n_pairs = (NR + 1) >> 1;
-    const int cbase = max(c_lo, 0) & ~3;          // luma staging keeps global dword alignment
-    const int qx0 = (c_lo + 1) >> 1, qy0 = (r_lo + 1) >> 1;  // chroma index of the first quad column / row
+    const int NC = c_hi - c_lo + 1;
+    const int nq = (NC + 1) >> 1;                          // quad columns
+    const int cbase = max(c_lo, 0) & ~3;                   // luma staging keeps global dword alignment
+    const int qx0 = (c_lo + 1) >> 1;                       // chroma index of the first quad column
+    const int cb = max(qx0 - 1, 0) & ~3;                   // first staged chroma column (dword aligned)
+    const int chi = min(qx0 + nq - 1, J.up.w - 1);         // last chroma column any quad reads
 
-    // ---- prologue: one round of global loads
-    if (!(J.ablate & 32))
+    // ---- prologue: tables and the horizontal weights of the strip (once per block)
     for (int i = tid; i < SMR_TABLE_FLOATS; i += A_THREADS) s_tab[i] = tables[i];
-    if (tid < 256 && !(J.ablate & 64)) {
+    if (tid < 256) {
         // u8 -> f32 conversions done once per table entry with the same IEEE operations the per-pixel path uses
         const float v = (float)tid / 255.0f;
         s_n255[tid] = v;
         s_ylut[tid] = J.full_range ? v : clampf((v - (16.0f / 255.0f)) / 0.85882352941f, 0.0f, 1.0f);
     }
-    // weight tables are stored tap-major in global memory (w[t * n + i]): a tile's slice of every tap is contiguous
+    // weight tables are stored tap-major in global memory (w[t * n + i]): a strip's slice of every tap is contiguous
     for (int i = tid; i < taps_h * TW; i += A_THREADS) {
-        int t = i / TW, x = i - t * TW;
+        const int t = i >> 6, x = i & 63;
         s_wh[i] = x < tw ? J.w_h[(size_t)t * J.dst.w + tx0 + x] : 0.0f;
-    }
-    for (int i = tid; i < taps_v * TH; i += A_THREADS) {
-        int t = i / TH, y = i - t * TH;
-        if (y < th) s_wv[y * taps_v + t] = J.w_v[(size_t)t * J.dst.h + ty0 + y];
     }
     if (tid < tw) {
         s_fh[tid] = lanczos_first(tx0 + tid, J.scale_h, J.off_h);
@@ -228,201 +234,281 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
         s_wsh[tid] = ws;
         s_rsh[tid] = 1.0f / ws;
     }
-    if (tid >= 64 && tid - 64 < th) {
-        s_fv[tid - 64] = lanczos_first(ty0 + tid - 64, J.scale_v, J.off_v);
-        const float ws = J.wsum_v[ty0 + tid - 64];
-        s_wsv[tid - 64] = ws;
-        s_rsv[tid - 64] = 1.0f / ws;
-    }
-    if (J.fast420 && !(J.ablate & 8)) {
-        // luma: aligned dwords of rows [max(r_lo,0), r_hi], columns [cbase, c_hi].  Half a wave per row (32 dwords =
-        // 128 B), 16 rows per sweep; every sweep's loads are issued before the first LDS store waits on them.
-        const int ndw = ((c_hi - cbase) >> 2) + 1;
-        const int row0 = max(r_lo, 0);
-        const int nrows = r_hi - row0 + 1;
-        for (int d0 = 0; d0 < ndw; d0 += 32) {
-            const int d = d0 + (lane & 31);
-            constexpr int SWEEPS = 4;  // 64 rows per outer iteration
-            for (int rbase = 0; rbase < nrows; rbase += 16 * SWEEPS) {
-                u32 v[SWEEPS];
-#pragma unroll
-                for (int s = 0; s < SWEEPS; s++) {
-                    const int rr = rbase + s * 16 + wave * 2 + (lane >> 5);
-                    // rows are pitched to >= 4 B multiples, so reading the last dword of a row never leaves the allocation
-                    v[s] = (rr < nrows && d < ndw) ? *(const u32 *)(J.yp.ptr + (size_t)(row0 + rr) * J.yp.pitch + cbase + 4 * d) : 0u;
-                }
-#pragma unroll
-                for (int s = 0; s < SWEEPS; s++) {
-                    const int rr = rbase + s * 16 + wave * 2 + (lane >> 5);
-                    if (rr < nrows && d < ndw) *(u32 *)(rawY + (size_t)(row0 + rr - r_lo) * ys + 4 * d) = v[s];
-                }
-            }
-        }
-        // chroma: rows qy0-1 .. qy0+n_pairs-1 (+1), columns qx0-1 .. qx0+nq, edge clamp baked in
-        const int nq = (NC + 1) >> 1;
-        const int ccols = nq + 1, crw = n_pairs + 1;
-        for (int k = lane; k < ccols; k += 64) {
-            const int cx = clampi(qx0 - 1 + k, 0, J.up.w - 1);
-            constexpr int CS = 4;  // 32 chroma rows per outer iteration, all loads issued before the stores
-            for (int jbase = 0; jbase < crw; jbase += A_WAVES * CS) {
-                u8 bu[CS], bv[CS];
-#pragma unroll
-                for (int s = 0; s < CS; s++) {
-                    const int j = jbase + s * A_WAVES + wave;
-                    const int cy = clampi(qy0 - 1 + j, 0, J.up.h - 1);
-                    bu[s] = j < crw ? J.up.ptr[(size_t)cy * J.up.pitch + cx] : (u8)0;
-                    bv[s] = j < crw ? J.vp.ptr[(size_t)cy * J.vp.pitch + cx] : (u8)0;
-                }
-#pragma unroll
-                for (int s = 0; s < CS; s++) {
-                    const int j = jbase + s * A_WAVES + wave;
-                    if (j < crw) { rawU[j * cs + k] = bu[s]; rawV[j * cs + k] = bv[s]; }
-                }
-            }
-        }
-    }
-    __syncthreads();
     const float *s_dec = s_tab, *s_thr = s_tab + 256;
     float4 *S = S_all + (size_t)wave * 2 * ncm;  // this wave's two-row strip
 
-    for (int pr = wave; pr < n_pairs; pr += A_WAVES) {
-        const int y0 = r_lo + 2 * pr, y1 = y0 + 1;
-        // ---- convert the two source rows: YUV -> RGBA8 (node texture bytes) -> sRGB-decoded linear f32
-        if (J.ablate & 1) {
-        } else if (J.fast420) {
-            const u8 *ua = rawU + pr * cs, *ub = ua + cs, *va = rawV + pr * cs, *vb = va + cs;
-            const u8 *yr0 = rawY + (size_t)(2 * pr) * ys - cbase, *yr1 = yr0 + ys;  // index by absolute x
-            const bool ok0 = y0 >= 0, ok1 = y1 <= r_hi;
-            for (int qc = lane; qc < ((NC + 1) >> 1); qc += 64) {
-                const int x0 = c_lo + 2 * qc, x1 = x0 + 1;  // x0 odd (or -1), x1 even
-                const float u00 = s_n255[ua[qc]], u01 = s_n255[ua[qc + 1]], u10 = s_n255[ub[qc]], u11 = s_n255[ub[qc + 1]];
-                const float v00 = s_n255[va[qc]], v01 = s_n255[va[qc + 1]], v10 = s_n255[vb[qc]], v11 = s_n255[vb[qc + 1]];
-                // bilinear weights of the chroma tap: odd coordinate -> 1/4, even -> 3/4 (planar_yuv_to_rgba.wgsl:37-39)
-#pragma unroll
-                for (int ix = 0; ix < 2; ix++) {
-                    const int sx = ix ? x1 : x0;
-                    if (sx < 0 || sx > c_hi) continue;
-                    const float fx = ix ? 0.75f : 0.25f, gx = 1.0f - fx;
-                    const float ut = u00 * gx + u01 * fx, ubt = u10 * gx + u11 * fx;
-                    const float vt = v00 * gx + v01 * fx, vbt = v10 * gx + v11 * fx;
-                    if (ok0) {
-                        const float uu = ut * 0.75f + ubt * 0.25f, vv = vt * 0.75f + vbt * 0.25f;
-                        const float ue = J.full_range ? uu : expand_chroma(uu), ve = J.full_range ? vv : expand_chroma(vv);
-                        S[sx - c_lo] = yuv_expanded_to_linear(s_ylut[yr0[sx]], ue, ve, s_dec);
-                    }
-                    if (ok1) {
-                        const float uu = ut * 0.25f + ubt * 0.75f, vv = vt * 0.25f + vbt * 0.75f;
-                        const float ue = J.full_range ? uu : expand_chroma(uu), ve = J.full_range ? vv : expand_chroma(vv);
-                        S[ncm + sx - c_lo] = yuv_expanded_to_linear(s_ylut[yr1[sx]], ue, ve, s_dec);
-                    }
-                }
+    // ---- staging geometry (block-uniform) and the software pipeline
+    //      The global loads of chunk k+1 are issued before chunk k's arithmetic and land in LDS after it.  One dword of luma,
+    //      one of each chroma plane and one vertical weight per thread cover the usual footprints; larger ones
+    //      (ndw > 32, ndc > 16, taps_v * VRp > 512) take the unpipelined path.
+    const int ndw = ((c_hi - cbase) >> 2) + 1;  // luma dwords per row: columns [cbase, c_hi]
+    const int ndc = ((chi - cb) >> 2) + 1;      // chroma dwords per row: columns [cb, chi]
+    const bool stage = J.fast420 && !(J.ablate & 8);
+    const bool piped = ndw <= 32 && ndc <= 16 && wv_sz <= A_THREADS;
+    const int vsh = VRp == 32 ? 5 : 6;
+    u32 py = 0u, pu = 0u, pv = 0u;
+    float pw = 0.0f, pws = 1.0f;
+    u8 *rawY = raw0, *rawU = rawY + CH * ys, *rawV = rawU + RAW_C_ROWS * cs;  // the current chunk's raw buffer (re-pointed per chunk)
+    // rows are pitched to >= 4 B multiples (fast420), so reading the last dword of a row never leaves the allocation
+    auto issue = [&](int base, int y_next) {
+        const int e = min(base + CH - 1, R_hi);
+        const int np = (e - base + 2) >> 1;
+        if (stage) {
+            const int rr = wave * 2 + (lane >> 5), row = base + rr, d = lane & 31;  // luma: half a wave per row (128 B)
+            if (row >= 0 && row <= e && d < ndw) py = *(const u32 *)(J.yp.ptr + (size_t)row * J.yp.pitch + cbase + 4 * d);
+            const int j = tid >> 4, d2 = tid & 15;                                   // chroma: 16 lanes per row, np + 1 <= 9 rows
+            if (j <= np && d2 < ndc) {
+                const int cy = clampi(((base + 1) >> 1) - 1 + j, 0, J.up.h - 1);
+                pu = *(const u32 *)(J.up.ptr + (size_t)cy * J.up.pitch + cb + 4 * d2);
+                pv = *(const u32 *)(J.vp.ptr + (size_t)cy * J.vp.pitch + cb + 4 * d2);
             }
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int sy = rr ? y1 : y0;
-                if (sy > r_hi) continue;
-                const float tv = ((float)sy + 0.5f) / (float)sh;
-                const u8 *yrow = J.yp.ptr + (size_t)sy * J.yp.pitch;
-                for (int col = lane; col < NC; col += 64) {
-                    const int sx = c_lo + col;
-                    const float tu = ((float)sx + 0.5f) / (float)sw;
-                    const float yy = (float)yrow[sx] / 255.0f;
-                    const float uu = sample_plane_bilinear(J.up, 1, 0, tu, tv);
-                    const float vv = sample_plane_bilinear(J.vp, 1, 0, tu, tv);
-                    const u32 p = yuv_to_rgb_px(yy, uu, vv, J.full_range != 0);
-                    S[rr * ncm + col] = make_float4(s_dec[p & 0xff], s_dec[(p >> 8) & 0xff], s_dec[(p >> 16) & 0xff], 1.0f);
+        }
+        const int nv = min(VR, oy1 - y_next);
+        const int t = tid >> vsh, j = tid & (VRp - 1);
+        if (tid < wv_sz && j < nv) pw = J.w_v[(size_t)t * J.dst.h + y_next + j];
+        if (wave == A_WAVES - 1 && lane < nv) pws = J.wsum_v[y_next + lane];
+    };
+    auto land = [&](int base, int nv, float *wvb, float *wsvb, float *rsvb) {
+        const int e = min(base + CH - 1, R_hi);
+        const int np = (e - base + 2) >> 1;
+        if (stage) {
+            const int rr = wave * 2 + (lane >> 5), row = base + rr, d = lane & 31;
+            if (row >= 0 && row <= e && d < ndw) *(u32 *)(rawY + (size_t)rr * ys + 4 * d) = py;
+            const int j = tid >> 4, d2 = tid & 15;
+            if (j <= np && d2 < ndc) {
+                *(u32 *)(rawU + j * cs + 4 * d2) = pu;
+                *(u32 *)(rawV + j * cs + 4 * d2) = pv;
+            }
+        }
+        if (tid < wv_sz && (tid & (VRp - 1)) < nv) wvb[tid] = pw;
+        if (wave == A_WAVES - 1 && lane < nv) { wsvb[lane] = pws; rsvb[lane] = 1.0f / pws; }
+    };
+    auto stage_unpiped = [&](int base, int y_next, int nv, float *wvb, float *wsvb, float *rsvb) {
+        const int e = min(base + CH - 1, R_hi);
+        const int np = (e - base + 2) >> 1;
+        if (stage) {
+            const int rr = wave * 2 + (lane >> 5), row = base + rr;
+            for (int d = lane & 31; d < ndw; d += 32)
+                if (row >= 0 && row <= e) *(u32 *)(rawY + (size_t)rr * ys + 4 * d) = *(const u32 *)(J.yp.ptr + (size_t)row * J.yp.pitch + cbase + 4 * d);
+            const int j = tid >> 4;
+            if (j <= np) {
+                const int cy = clampi(((base + 1) >> 1) - 1 + j, 0, J.up.h - 1);
+                for (int d = tid & 15; d < ndc; d += 16) {
+                    *(u32 *)(rawU + j * cs + 4 * d) = *(const u32 *)(J.up.ptr + (size_t)cy * J.up.pitch + cb + 4 * d);
+                    *(u32 *)(rawV + j * cs + 4 * d) = *(const u32 *)(J.vp.ptr + (size_t)cy * J.vp.pitch + cb + 4 * d);
                 }
             }
         }
-        // the strip is private to this wave and a wave's LDS operations complete in order: a fence is all that is needed
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- horizontal Lanczos of the two rows into the f16 intermediate (pass 1 of the separable plan).
-        //      All four channels ride in packed FMAs; alpha comes out as (sum w)/(sum w) == 1 exactly.
-        if (lane < tw) {
-            const int fh = s_fh[lane];
-            const float wsh = s_wsh[lane], rsh = s_rsh[lane];
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float *wcol = s_wh + lane;
-            if (J.ablate & 2) {
-            } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
-                // interior: no edge clamp, consecutive texels
-                const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
-                for (int t = 0; t < taps_h; t++) {
-                    const float wgt = wcol[t * TW];
-                    const float4 ta = pa[t], tb = pb[t];
-                    a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
-                    a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
-                    b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
-                    b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
-                }
-            } else {
-                const float4 *Sa = S - c_lo, *Sb = S + ncm - c_lo;
-                for (int t = 0; t < taps_h; t++) {
-                    const float wgt = wcol[t * TW];
-                    const int s = clampi(fh + t, 0, sw - 1);
-                    const float4 ta = Sa[s], tb = Sb[s];
-                    a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
-                    a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
-                    b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
-                    b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
-                }
-            }
-            if (y0 >= 0) M[(size_t)(2 * pr) * TW + lane] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
-            if (y1 <= r_hi) M[(size_t)(2 * pr + 1) * TW + lane] = float4_to_half4(div_cr(b.x, wsh, rsh), div_cr(b.y, wsh, rsh), div_cr(b.z, wsh, rsh), div_cr(b.w, wsh, rsh));
+        for (int i = tid; i < wv_sz; i += A_THREADS) {
+            const int t = i >> vsh, j = i & (VRp - 1);
+            if (j < nv) wvb[i] = J.w_v[(size_t)t * J.dst.h + y_next + j];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    __syncthreads();
+        if (wave == A_WAVES - 1 && lane < nv) {
+            const float ws = J.wsum_v[y_next + lane];
+            wsvb[lane] = ws;
+            rsvb[lane] = 1.0f / ws;
+        }
+    };
 
-    // ---- vertical Lanczos (pass 2) + sRGB encode + store
-    if (lane < tw && !(J.ablate & 128)) {
-        for (int y = wave; y < th; y += A_WAVES) {
-            const int fv = s_fv[y];
+    // resolve: vertical Lanczos (pass 2) over the ring + sRGB encode + store of output rows [yr, yr + n); weights in buffer b
+    auto resolve = [&](int yr, int n, int b) {
+        if (J.ablate & 128) return;
+        const float *wvb = s_wv + b * wv_sz;
+        const int *fvb = s_fv + b * VRa;
+        const float *wsvb = s_wsv + b * VRa, *rsvb = s_rsv + b * VRa;
+        for (int j = wave; j < n; j += A_WAVES) {
+            const int y = yr + j;
+            const int fv = fvb[j];
             float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
-            const float *wv = s_wv + y * taps_v;
-            if (J.ablate & 4) {
-            } else if (fv >= 0 && fv + taps_v - 1 <= sh - 1) {
-                const uint2 *pm = M + (size_t)(fv - r_lo) * TW + lane;
+            const float *wv = wvb + j;  // tap t at wv[t * VRp]
+            const int s0 = (fv - R_lo) & (MR - 1);
+            if (lane >= tw || (J.ablate & 4)) {
+            } else if (fv >= 0 && fv + taps_v - 1 <= sh - 1 && s0 + taps_v <= MR) {
+                const uint2 *pm = M + (size_t)s0 * TW + lane;  // the window is contiguous in the ring
                 for (int t = 0; t < taps_v; t++) {
-                    const float wgt = wv[t];
+                    const float wgt = wv[t * VRp];
                     const float4 m = half4_to_float4(pm[(size_t)t * TW]);
                     sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
                 }
             } else {
                 for (int t = 0; t < taps_v; t++) {
-                    const float wgt = wv[t];
-                    const int r = clampi(fv + t, 0, sh - 1) - r_lo;
+                    const float wgt = wv[t * VRp];
+                    const int r = (clampi(fv + t, 0, sh - 1) - R_lo) & (MR - 1);
                     const float4 m = half4_to_float4(M[(size_t)r * TW + lane]);
                     sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
                 }
             }
-            const float ws = s_wsv[y], rs = s_rsv[y];
-            const u32 r8 = srgb_encode8(div_cr(sx_, ws, rs), s_thr), g8 = srgb_encode8(div_cr(sy_, ws, rs), s_thr),
-                      b8 = srgb_encode8(div_cr(sz_, ws, rs), s_thr);
-            *(u32 *)(J.dst.ptr + (size_t)(ty0 + y) * J.dst.pitch + (size_t)(tx0 + lane) * 4) = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+            if (lane < tw) {
+                const float ws = wsvb[j], rs = rsvb[j];
+                const u32 r8 = srgb_encode8(div_cr(sx_, ws, rs), s_thr), g8 = srgb_encode8(div_cr(sy_, ws, rs), s_thr),
+                          b8 = srgb_encode8(div_cr(sz_, ws, rs), s_thr);
+                *(u32 *)(J.dst.ptr + (size_t)y * J.dst.pitch + (size_t)(tx0 + lane) * 4) = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+            }
         }
+    };
+
+    // One barrier per chunk.  Phase k (between barriers k and k+1): every wave converts + filters its row pair of chunk k into
+    // the ring AND resolves its share of the output rows that chunk k-1 completed (their window lies in rows <= e_{k-1}, all
+    // written before barrier k).  Slower waves may still be in phase k-1 while a fast wave prepares chunk k+1, hence the raw
+    // footprint is double-buffered and the vertical weights are kept three chunks deep.
+    int y_done = oy0;  // next output row without a resolve slot (uniform across the block: every wave derives the same counts)
+    int chunk = 0, vb = 0;
+    int pend_y = oy0, pend_n = 0, pend_vb = 0;  // rows completed by the previous chunk, resolved in this phase
+    if (piped) issue(R_lo, oy0);
+    for (int base = R_lo; base <= R_hi; base += CH, chunk++, vb = vb == 2 ? 0 : vb + 1) {
+        const int e = min(base + CH - 1, R_hi);  // last source row this chunk produces
+        const int np = (e - base + 2) >> 1;      // row pairs
+        rawY = raw0 + (chunk & 1) * raw_sz; rawU = rawY + CH * ys; rawV = rawU + RAW_C_ROWS * cs;
+        float *wvb = s_wv + vb * wv_sz;
+        int *fvb = s_fv + vb * VRa;
+        float *wsvb = s_wsv + vb * VRa, *rsvb = s_rsv + vb * VRa;
+        const int nv = min(VR, oy1 - y_done);    // candidate output rows of this chunk
+
+        // ---- (a) which candidates does this chunk complete?  first[] is non-decreasing, so the ready rows are a prefix:
+        //      every lane evaluates the mapping of one candidate, one ballot counts them (no LDS, known before the arithmetic)
+        const int fv_l = lanczos_first(y_done + (lane < nv ? lane : 0), J.scale_v, J.off_v);
+        const bool ready = lane < nv && min(fv_l + taps_v - 1, sh - 1) <= e;
+        const unsigned long long rdy = __ballot(ready);
+        int n_emit = rdy == ~0ull ? 64 : __builtin_ctzll(~rdy);
+        if (e < R_hi && J.defer8) n_emit &= ~7;  // stragglers wait for the next chunk (one row per wave keeps the waves level)
+        // ---- (b) this chunk's raw footprint and vertical weights reach LDS
+        if (piped) land(base, nv, wvb, wsvb, rsvb);
+        else stage_unpiped(base, y_done, nv, wvb, wsvb, rsvb);
+        if (wave == A_WAVES - 1 && lane < nv) fvb[lane] = fv_l;
+        __syncthreads();
+        if (piped && base + CH <= R_hi) issue(base + CH, y_done + n_emit);
+
+
+        // ---- (c) convert + horizontal Lanczos: one row pair per wave
+        // odd waves resolve first, even waves last: the LDS-bound filter loops of one half overlap the VALU-bound conversion
+        // of the other half instead of all eight waves hitting the same unit in the same phase
+        if (wave & 1) resolve(pend_y, pend_n, pend_vb);
+        const int pr = wave;
+        if (pr < np) {
+            const int y0 = base + 2 * pr, y1 = y0 + 1;
+            if (J.ablate & 1) {
+            } else if (J.fast420) {
+                const u8 *ua = rawU + pr * cs - cb, *ub = ua + cs, *va = rawV + pr * cs - cb, *vbp = va + cs;  // index by chroma x
+                const u8 *yr0 = rawY + (size_t)(2 * pr) * ys - cbase, *yr1 = yr0 + ys;                        // index by luma x
+                const bool ok0 = y0 >= 0, ok1 = y1 <= e;
+                const int cw1 = J.up.w - 1;
+                for (int qc = lane; qc < nq; qc += 64) {
+                    const int x0 = c_lo + 2 * qc, x1 = x0 + 1;  // x0 odd (or -1), x1 even
+                    const int i0 = max(qx0 - 1 + qc, 0), i1 = min(qx0 + qc, cw1);  // clamp-to-edge chroma taps
+                    const float u00 = s_n255[ua[i0]], u01 = s_n255[ua[i1]], u10 = s_n255[ub[i0]], u11 = s_n255[ub[i1]];
+                    const float v00 = s_n255[va[i0]], v01 = s_n255[va[i1]], v10 = s_n255[vbp[i0]], v11 = s_n255[vbp[i1]];
+                    // bilinear weights of the chroma tap: odd coordinate -> 1/4, even -> 3/4 (planar_yuv_to_rgba.wgsl:37-39)
+#pragma unroll
+                    for (int ix = 0; ix < 2; ix++) {
+                        const int sx = ix ? x1 : x0;
+                        if (sx < 0 || sx > c_hi) continue;
+                        const float fx = ix ? 0.75f : 0.25f, gx = 1.0f - fx;
+                        const float ut = u00 * gx + u01 * fx, ubt = u10 * gx + u11 * fx;
+                        const float vt = v00 * gx + v01 * fx, vbt = v10 * gx + v11 * fx;
+                        if (ok0) {
+                            const float uu = ut * 0.75f + ubt * 0.25f, vv = vt * 0.75f + vbt * 0.25f;
+                            const float ue = J.full_range ? uu : expand_chroma(uu), ve = J.full_range ? vv : expand_chroma(vv);
+                            S[sx - c_lo] = yuv_expanded_to_linear(s_ylut[yr0[sx]], ue, ve, s_dec);
+                        }
+                        if (ok1) {
+                            const float uu = ut * 0.25f + ubt * 0.75f, vv = vt * 0.25f + vbt * 0.75f;
+                            const float ue = J.full_range ? uu : expand_chroma(uu), ve = J.full_range ? vv : expand_chroma(vv);
+                            S[ncm + sx - c_lo] = yuv_expanded_to_linear(s_ylut[yr1[sx]], ue, ve, s_dec);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int sy = rr ? y1 : y0;
+                    if (sy < 0 || sy > e) continue;
+                    const float tv = ((float)sy + 0.5f) / (float)sh;
+                    const u8 *yrow = J.yp.ptr + (size_t)sy * J.yp.pitch;
+                    for (int col = lane; col < NC; col += 64) {
+                        const int sx = c_lo + col;
+                        const float tu = ((float)sx + 0.5f) / (float)sw;
+                        const float yy = (float)yrow[sx] / 255.0f;
+                        const float uu = sample_plane_bilinear(J.up, 1, 0, tu, tv);
+                        const float vv = sample_plane_bilinear(J.vp, 1, 0, tu, tv);
+                        const u32 p = yuv_to_rgb_px(yy, uu, vv, J.full_range != 0);
+                        S[rr * ncm + col] = make_float4(s_dec[p & 0xff], s_dec[(p >> 8) & 0xff], s_dec[(p >> 16) & 0xff], 1.0f);
+                    }
+                }
+            }
+            // the strip is private to this wave and a wave's LDS operations complete in order: a fence is all that is needed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- horizontal Lanczos of the two rows into the f16 ring (pass 1 of the separable plan).
+            //      All four channels ride in packed FMAs; alpha comes out as (sum w)/(sum w) == 1 exactly.
+            if (lane < tw) {
+                const int fh = s_fh[lane];
+                const float wsh = s_wsh[lane], rsh = s_rsh[lane];
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float *wcol = s_wh + lane;
+                if (J.ablate & 2) {
+                } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
+                    // interior: no edge clamp, consecutive texels
+                    const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
+                    for (int t = 0; t < taps_h; t++) {
+                        const float wgt = wcol[t * TW];
+                        const float4 ta = pa[t], tb = pb[t];
+                        a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                        a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                        b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
+                        b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                    }
+                } else {
+                    const float4 *Sa = S - c_lo, *Sb = S + ncm - c_lo;
+                    for (int t = 0; t < taps_h; t++) {
+                        const float wgt = wcol[t * TW];
+                        const int s = clampi(fh + t, 0, sw - 1);
+                        const float4 ta = Sa[s], tb = Sb[s];
+                        a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                        a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                        b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
+                        b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                    }
+                }
+                if (y0 >= 0) M[(size_t)((y0 - R_lo) & (MR - 1)) * TW + lane] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
+                if (y1 <= e) M[(size_t)((y1 - R_lo) & (MR - 1)) * TW + lane] = float4_to_half4(div_cr(b.x, wsh, rsh), div_cr(b.y, wsh, rsh), div_cr(b.z, wsh, rsh), div_cr(b.w, wsh, rsh));
+            }
+        }
+        // ---- (d) this wave's share of the rows the previous chunk completed
+        if (!(wave & 1)) resolve(pend_y, pend_n, pend_vb);
+        pend_y = y_done; pend_n = n_emit; pend_vb = vb;
+        y_done += n_emit;
     }
+    __syncthreads();
+    resolve(pend_y, pend_n, pend_vb);  // rows completed by the last chunk
+}
+
+int ingest_vr(float scale_v) {
+    // rows that become ready per chunk (<= CH / scale + 1) plus the stragglers deferred from the previous one (<= 7)
+    const float s = scale_v > 0.0f ? scale_v : 1.0f;
+    return (int)ceilf((float)CH / s) + 9;
 }
 
 size_t ingest_lds_bytes(const IngestJob &J) {
-    size_t floats = SMR_TABLE_FLOATS + 256 + 256 + (size_t)((J.taps_h * TW + 3) & ~3) + (size_t)((TH * J.taps_v + 3) & ~3) + TW + TH +
-                    2 * TW + 2 * TH;
-    size_t bytes = floats * 4 + (size_t)A_WAVES * 2 * J.nc_max * 16 + (size_t)J.nr_max * TW * 8;
-    if (J.fast420) bytes += (size_t)J.nr_max * raw_y_stride(J.nc_max) + 2 * (size_t)raw_c_rows(J.nr_max) * raw_c_stride(J.nc_max);
+    const size_t vra = ((size_t)J.vr + 3) & ~(size_t)3;
+    const size_t vrp = J.vr <= 32 ? 32 : 64;
+    size_t floats = SMR_TABLE_FLOATS + 256 + 256 + (size_t)((J.taps_h * TW + 3) & ~3) + 3 * TW + 3 * (size_t)J.taps_v * vrp + 9 * vra;
+    size_t bytes = floats * 4 + (size_t)A_WAVES * 2 * J.nc_max * 16 + (size_t)MR * TW * 8;
+    if (J.fast420) bytes += 2 * ((size_t)CH * raw_y_stride(J.nc_max) + 2 * (size_t)RAW_C_ROWS * raw_c_stride(J.nc_max));
     return (bytes + 15) & ~(size_t)15;
 }
 
 bool is_planar_yuv(u32 fmt) { return fmt <= SMR_FRAME_PLANAR_YUVJ420; }
 
-// What wave A covers: planar YUV frames, separable plan, no box pre-reduction, horizontal pass first.
+// What wave A covers: planar YUV frames, separable plan, no box pre-reduction, horizontal pass first, and a vertical
+// window that fits the ring (CH new rows + the window + one output row's advance).
 bool can_fuse_ingest(const smr_frame *f, const smr_resample_plan &plan) {
-    return f && is_planar_yuv(f->format) && f->planes[0] && f->planes[1] && f->planes[2] && plan.kind == 2 && plan.levels[0] == 0 &&
-           plan.levels[1] == 0 && plan.axis[0] == 0;
+    if (!(f && is_planar_yuv(f->format) && f->planes[0] && f->planes[1] && f->planes[2] && plan.kind == 2 && plan.levels[0] == 0 &&
+          plan.levels[1] == 0 && plan.axis[0] == 0))
+        return false;
+    const int taps_v = host_taps(plan.scale[1]);
+    // ring: the chunk being written + the previous chunk + the window of the oldest unresolved row
+    return ingest_vr(plan.scale[1]) <= VR_MAX && 2 * CH + taps_v + (int)ceilf(plan.scale[1]) + 2 <= MR;
 }
 
 int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, IngestJob *out) {
@@ -436,31 +522,46 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     J.dst = view_of(tile);
     J.src_w = (int)f->width; J.src_h = (int)f->height;
     J.full_range = f->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
-    // the staged path reads whole dwords of luma rows: needs the 256 B row pitch of smr_frame_create / a 4 B-aligned pitch
+    // the staged path reads whole dwords of luma and chroma rows: needs 4 B-aligned planes whose pitch covers the last dword
+    auto dword_ok = [](const SurfView &p, u32 w) { return (p.pitch % 4) == 0 && (((uintptr_t)p.ptr) % 4) == 0 && p.pitch >= ((w + 3u) & ~3u); };
     J.fast420 = ((f->format == SMR_FRAME_PLANAR_YUV420 || f->format == SMR_FRAME_PLANAR_YUVJ420) && f->width % 2 == 0 &&
-                 f->height % 2 == 0 && f->width >= 2 && f->height >= 2 && (J.yp.pitch % 4) == 0 && (((uintptr_t)J.yp.ptr) % 4) == 0 &&
-                 J.yp.pitch >= ((f->width + 3u) & ~3u)) ? 1 : 0;
+                 f->height % 2 == 0 && f->width >= 2 && f->height >= 2 && dword_ok(J.yp, f->width) && dword_ok(J.up, f->width / 2) &&
+                 dword_ok(J.vp, f->width / 2)) ? 1 : 0;
     J.ablate = ctx->ablate;
     J.taps_h = wh.taps; J.taps_v = wv.taps;
     J.scale_h = plan.scale[0]; J.off_h = plan.offset[0];
     J.scale_v = plan.scale[1]; J.off_v = plan.offset[1];
     J.wsum_h = wh.wsum; J.w_h = wh.w;
     J.wsum_v = wv.wsum; J.w_v = wv.w;
-    J.tiles_x = ((int)tile->w + TW - 1) / TW; J.tiles_y = ((int)tile->h + TH - 1) / TH;
+    J.strips_x = ((int)tile->w + TW - 1) / TW;
+    J.segs_y = 1; J.seg_h = (int)tile->h;  // launch_ingest splits the rows once it knows how many blocks the launch has
     // +1: the quad path aligns the footprint start down to an odd coordinate
     J.nc_max = (int)ceilf((float)TW * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
-    J.nr_max = (int)ceilf((float)TH * fmaxf(plan.scale[1], 0.0f)) + wv.taps + 3;
     if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
-    if (J.nr_max > J.src_h + 1) J.nr_max = J.src_h + 1;
-    J.nr_max = (J.nr_max + 1) & ~1;  // rows are produced in pairs
+    J.vr = ingest_vr(plan.scale[1]);
+    if (J.vr > (int)tile->h) J.vr = (int)tile->h;
+    if (J.vr > VR_MAX) J.vr = VR_MAX;
+    J.defer8 = (2 * CH + wv.taps + (int)ceilf(8.0f * fmaxf(plan.scale[1], 0.0f)) + 2 <= MR) ? 1 : 0;
     return SMR_OK;
 }
 
-int launch_ingest(smr_ctx *ctx, const std::vector<IngestJob> &jobs) {
+int launch_ingest(smr_ctx *ctx, std::vector<IngestJob> &jobs) {
     static bool attr_set = false;
     if (!attr_set) {
         SMR_HIP(ctx, hipFuncSetAttribute((const void *)k_ingest_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
+    }
+    // Row segments: every block is resident at once (two per CU), so aim at ~2 blocks per CU over the whole launch;
+    // a segment re-converts only the `taps` rows of its vertical halo.
+    int strips = 0;
+    for (const IngestJob &J : jobs) strips += J.strips_x;
+    const int target_blocks = 2 * ctx->cu_count;
+    for (IngestJob &J : jobs) {
+        int segs = strips > 0 ? (target_blocks + strips / 2) / strips : 1;
+        const int max_segs = (J.dst.h + 31) / 32;  // at least 32 output rows per segment
+        segs = segs < 1 ? 1 : (segs > max_segs ? max_segs : segs);
+        J.seg_h = (J.dst.h + segs - 1) / segs;
+        J.segs_y = (J.dst.h + J.seg_h - 1) / J.seg_h;
     }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
     for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_JOBS_PER_LAUNCH) {
@@ -472,8 +573,8 @@ int launch_ingest(smr_ctx *ctx, const std::vector<IngestJob> &jobs) {
         for (size_t j = 0; j < nj; j++) {
             const IngestJob &J = jobs[j0 + j];
             args.jobs[j] = J;
-            gx = J.tiles_x > gx ? J.tiles_x : gx;
-            gy = J.tiles_y > gy ? J.tiles_y : gy;
+            gx = J.strips_x > gx ? J.strips_x : gx;
+            gy = J.segs_y > gy ? J.segs_y : gy;
             size_t b = ingest_lds_bytes(J);
             lds = b > lds ? b : lds;
         }

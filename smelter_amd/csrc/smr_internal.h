@@ -100,6 +100,7 @@ struct smr_ctx {
     };
     std::vector<WeightTable> weight_tables;
     uint64_t weight_clock = 0;
+    int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
 
