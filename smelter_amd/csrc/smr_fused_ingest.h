@@ -110,6 +110,7 @@ struct IngestJob {
     int src_w, src_h;
     int full_range;
     int fast420;          // 4:2:0 with even luma size and dword-aligned planes: LDS-staged 2x2-quad conversion path
+    int nv12;             // `up` is the interleaved UV plane of an NV12 frame (2 bytes per chroma texel), `vp` is unused
     int ablate;           // profiling only (SMR_ABLATE): 1 skip convert, 2 skip H taps, 4 skip V taps, 8 skip staging, 16 dispatch only
     int taps_h, taps_v;
     float scale_h, off_h, scale_v, off_v;  // axis mappings (resampler.rs:36-48): source texels per output texel, crop offset
@@ -240,11 +241,15 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
     // ---- staging geometry (block-uniform) and the software pipeline
     //      The global loads of chunk k+1 are issued before chunk k's arithmetic and land in LDS after it.  One dword of luma,
     //      one of each chroma plane and one vertical weight per thread cover the usual footprints; larger ones
-    //      (ndw > 32, ndc > 16, taps_v * VRp > 512) take the unpipelined path.
-    const int ndw = ((c_hi - cbase) >> 2) + 1;  // luma dwords per row: columns [cbase, c_hi]
-    const int ndc = ((chi - cb) >> 2) + 1;      // chroma dwords per row: columns [cb, chi]
+    //      (ndw > 32, ndc > lanes per chroma row, taps_v * VRp > 512) take the unpipelined path.
+    //      NV12: the interleaved UV rows (2 B per chroma texel) are staged as they are into the U|V region, rows of 2 * cs bytes.
+    const int cm = J.nv12 ? 2 : 1;                        // staged bytes per chroma texel
+    const int csr = cs * cm;                              // staged chroma row stride (bytes)
+    const int csh = J.nv12 ? 5 : 4;                       // chroma staging: 32 (NV12) / 16 lanes per row, 16 / 32 rows >= np + 1
+    const int ndw = ((c_hi - cbase) >> 2) + 1;            // luma dwords per row: columns [cbase, c_hi]
+    const int ndc = (((chi - cb + 1) * cm - 1) >> 2) + 1; // chroma dwords per row: columns [cb, chi]
     const bool stage = J.fast420 && !(J.ablate & 8);
-    const bool piped = ndw <= 32 && ndc <= 16 && wv_sz <= A_THREADS;
+    const bool piped = ndw <= 32 && ndc <= (1 << csh) && wv_sz <= A_THREADS;
     const int vsh = VRp == 32 ? 5 : 6;
     u32 py = 0u, pu = 0u, pv = 0u;
     float pw = 0.0f, pws = 1.0f;
@@ -256,11 +261,11 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
         if (stage) {
             const int rr = wave * 2 + (lane >> 5), row = base + rr, d = lane & 31;  // luma: half a wave per row (128 B)
             if (row >= 0 && row <= e && d < ndw) py = *(const u32 *)(J.yp.ptr + (size_t)row * J.yp.pitch + cbase + 4 * d);
-            const int j = tid >> 4, d2 = tid & 15;                                   // chroma: 16 lanes per row, np + 1 <= 9 rows
+            const int j = tid >> csh, d2 = tid & ((1 << csh) - 1);
             if (j <= np && d2 < ndc) {
                 const int cy = clampi(((base + 1) >> 1) - 1 + j, 0, J.up.h - 1);
-                pu = *(const u32 *)(J.up.ptr + (size_t)cy * J.up.pitch + cb + 4 * d2);
-                pv = *(const u32 *)(J.vp.ptr + (size_t)cy * J.vp.pitch + cb + 4 * d2);
+                pu = *(const u32 *)(J.up.ptr + (size_t)cy * J.up.pitch + cb * cm + 4 * d2);
+                if (!J.nv12) pv = *(const u32 *)(J.vp.ptr + (size_t)cy * J.vp.pitch + cb + 4 * d2);
             }
         }
         const int nv = min(VR, oy1 - y_next);
@@ -274,10 +279,10 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
         if (stage) {
             const int rr = wave * 2 + (lane >> 5), row = base + rr, d = lane & 31;
             if (row >= 0 && row <= e && d < ndw) *(u32 *)(rawY + (size_t)rr * ys + 4 * d) = py;
-            const int j = tid >> 4, d2 = tid & 15;
+            const int j = tid >> csh, d2 = tid & ((1 << csh) - 1);
             if (j <= np && d2 < ndc) {
-                *(u32 *)(rawU + j * cs + 4 * d2) = pu;
-                *(u32 *)(rawV + j * cs + 4 * d2) = pv;
+                *(u32 *)(rawU + j * csr + 4 * d2) = pu;
+                if (!J.nv12) *(u32 *)(rawV + j * cs + 4 * d2) = pv;
             }
         }
         if (tid < wv_sz && (tid & (VRp - 1)) < nv) wvb[tid] = pw;
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
             if (j <= np) {
                 const int cy = clampi(((base + 1) >> 1) - 1 + j, 0, J.up.h - 1);
                 for (int d = tid & 15; d < ndc; d += 16) {
-                    *(u32 *)(rawU + j * cs + 4 * d) = *(const u32 *)(J.up.ptr + (size_t)cy * J.up.pitch + cb + 4 * d);
-                    *(u32 *)(rawV + j * cs + 4 * d) = *(const u32 *)(J.vp.ptr + (size_t)cy * J.vp.pitch + cb + 4 * d);
+                    *(u32 *)(rawU + j * csr + 4 * d) = *(const u32 *)(J.up.ptr + (size_t)cy * J.up.pitch + cb * cm + 4 * d);
+                    if (!J.nv12) *(u32 *)(rawV + j * cs + 4 * d) = *(const u32 *)(J.vp.ptr + (size_t)cy * J.vp.pitch + cb + 4 * d);
                 }
             }
         }
@@ -388,13 +393,15 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
             const int y0 = base + 2 * pr, y1 = y0 + 1;
             if (J.ablate & 1) {
             } else if (J.fast420) {
-                const u8 *ua = rawU + pr * cs - cb, *ub = ua + cs, *va = rawV + pr * cs - cb, *vbp = va + cs;  // index by chroma x
+                // chroma rows indexed by chroma x * cm (NV12: U at even, V at odd bytes of the interleaved row)
+                const u8 *ua = rawU + pr * csr - cb * cm, *ub = ua + csr;
+                const u8 *va = J.nv12 ? ua + 1 : rawV + pr * cs - cb, *vbp = va + csr;
                 const u8 *yr0 = rawY + (size_t)(2 * pr) * ys - cbase, *yr1 = yr0 + ys;                        // index by luma x
                 const bool ok0 = y0 >= 0, ok1 = y1 <= e;
                 const int cw1 = J.up.w - 1;
                 for (int qc = lane; qc < nq; qc += 64) {
                     const int x0 = c_lo + 2 * qc, x1 = x0 + 1;  // x0 odd (or -1), x1 even
-                    const int i0 = max(qx0 - 1 + qc, 0), i1 = min(qx0 + qc, cw1);  // clamp-to-edge chroma taps
+                    const int i0 = max(qx0 - 1 + qc, 0) << (cm - 1), i1 = min(qx0 + qc, cw1) << (cm - 1);  // clamp-to-edge chroma taps
                     const float u00 = s_n255[ua[i0]], u01 = s_n255[ua[i1]], u10 = s_n255[ub[i0]], u11 = s_n255[ub[i1]];
                     const float v00 = s_n255[va[i0]], v01 = s_n255[va[i1]], v10 = s_n255[vbp[i0]], v11 = s_n255[vbp[i1]];
                     // bilinear weights of the chroma tap: odd coordinate -> 1/4, even -> 3/4 (planar_yuv_to_rgba.wgsl:37-39)
@@ -428,8 +435,8 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
                         const int sx = c_lo + col;
                         const float tu = ((float)sx + 0.5f) / (float)sw;
                         const float yy = (float)yrow[sx] / 255.0f;
-                        const float uu = sample_plane_bilinear(J.up, 1, 0, tu, tv);
-                        const float vv = sample_plane_bilinear(J.vp, 1, 0, tu, tv);
+                        const float uu = sample_plane_bilinear(J.up, cm, 0, tu, tv);
+                        const float vv = J.nv12 ? sample_plane_bilinear(J.up, 2, 1, tu, tv) : sample_plane_bilinear(J.vp, 1, 0, tu, tv);
                         const u32 p = yuv_to_rgb_px(yy, uu, vv, J.full_range != 0);
                         S[rr * ncm + col] = make_float4(s_dec[p & 0xff], s_dec[(p >> 8) & 0xff], s_dec[(p >> 16) & 0xff], 1.0f);
                     }
@@ -503,9 +510,10 @@ bool is_planar_yuv(u32 fmt) { return fmt <= SMR_FRAME_PLANAR_YUVJ420; }
 // What wave A covers: planar YUV frames, separable plan, no box pre-reduction, horizontal pass first, and a vertical
 // window that fits the ring (CH new rows + the window + one output row's advance).
 bool can_fuse_ingest(const smr_frame *f, const smr_resample_plan &plan) {
-    if (!(f && is_planar_yuv(f->format) && f->planes[0] && f->planes[1] && f->planes[2] && plan.kind == 2 && plan.levels[0] == 0 &&
-          plan.levels[1] == 0 && plan.axis[0] == 0))
-        return false;
+    if (!f || !f->planes[0] || !f->planes[1]) return false;
+    const bool nv12 = f->format == SMR_FRAME_NV12;
+    if (!nv12 && !(is_planar_yuv(f->format) && f->planes[2])) return false;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0)) return false;
     const int taps_v = host_taps(plan.scale[1]);
     // ring: the chunk being written + the previous chunk + the window of the oldest unresolved row
     return ingest_vr(plan.scale[1]) <= VR_MAX && 2 * CH + taps_v + (int)ceilf(plan.scale[1]) + 2 <= MR;
@@ -518,15 +526,17 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     rc = get_weights(ctx, plan.scale[1], plan.offset[1], (int)tile->h, &wv);
     if (rc != SMR_OK) return rc;
     IngestJob &J = *out;
-    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = view_of(f->planes[2]);
+    J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
+    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = J.nv12 ? J.up : view_of(f->planes[2]);
     J.dst = view_of(tile);
     J.src_w = (int)f->width; J.src_h = (int)f->height;
     J.full_range = f->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
     // the staged path reads whole dwords of luma and chroma rows: needs 4 B-aligned planes whose pitch covers the last dword
-    auto dword_ok = [](const SurfView &p, u32 w) { return (p.pitch % 4) == 0 && (((uintptr_t)p.ptr) % 4) == 0 && p.pitch >= ((w + 3u) & ~3u); };
-    J.fast420 = ((f->format == SMR_FRAME_PLANAR_YUV420 || f->format == SMR_FRAME_PLANAR_YUVJ420) && f->width % 2 == 0 &&
-                 f->height % 2 == 0 && f->width >= 2 && f->height >= 2 && dword_ok(J.yp, f->width) && dword_ok(J.up, f->width / 2) &&
-                 dword_ok(J.vp, f->width / 2)) ? 1 : 0;
+    auto dword_ok = [](const SurfView &p, u32 bytes) { return (p.pitch % 4) == 0 && (((uintptr_t)p.ptr) % 4) == 0 && p.pitch >= ((bytes + 3u) & ~3u); };
+    const bool is420 = f->format == SMR_FRAME_PLANAR_YUV420 || f->format == SMR_FRAME_PLANAR_YUVJ420 || J.nv12;
+    const bool chroma_ok = J.nv12 ? dword_ok(J.up, (f->width / 2) * 2) : (dword_ok(J.up, f->width / 2) && dword_ok(J.vp, f->width / 2));
+    J.fast420 = (is420 && f->width % 2 == 0 && f->height % 2 == 0 && f->width >= 2 && f->height >= 2 && dword_ok(J.yp, f->width) &&
+                 chroma_ok) ? 1 : 0;
     J.ablate = ctx->ablate;
     J.taps_h = wh.taps; J.taps_v = wv.taps;
     J.scale_h = plan.scale[0]; J.off_h = plan.offset[0];

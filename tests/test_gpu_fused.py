@@ -131,6 +131,86 @@ def test_nv12_and_rgba_outputs(ctx, ctx_unfused, hip):
             assert refpipe.max_diff(g, w_) <= 1
 
 
+INPUT_FORMATS = [
+    ("nv12", "FRAME_NV12", orc.YUV420),            # decoder hand-off: Y + interleaved UV (wgpu/texture/nv12.rs)
+    ("yuvj420", "FRAME_PLANAR_YUVJ420", orc.YUVJ420),
+    ("yuv422", "FRAME_PLANAR_YUV422", orc.YUV422),  # staged path is 4:2:0 only: these take wave A's direct-sampling branch
+    ("yuv444", "FRAME_PLANAR_YUV444", orc.YUV444),
+]
+
+
+@pytest.mark.parametrize("name,fmt_name,variant", INPUT_FORMATS, ids=[f[0] for f in INPUT_FORMATS])
+@pytest.mark.parametrize("geom", [(480, 270, 640, 360, 4), (322, 182, 500, 282, 3)], ids=["even", "ragged"])
+def test_fused_ingest_input_formats(ctx, ctx_unfused, hip, name, fmt_name, variant, geom):
+    """Every frame format wave A accepts: fused == pass-per-launch bit for bit, and within 1 LSB of the oracle."""
+    iw, ih, W, H, n = geom
+    fmt = getattr(hip, fmt_name)
+    layouts, res = scenes.cfg2_scene(iw, ih, W, H, n)
+    rng = np.random.default_rng(99)
+    ch, cw = orc.chroma_shape(iw, ih, variant)
+    inputs = []
+    for i in range(n):
+        y, _, _ = scenes.test_input(i, iw, ih, noise_seed=50 + i)
+        u = rng.integers(0, 256, (ch, cw), dtype=np.uint8)
+        v = rng.integers(0, 256, (ch, cw), dtype=np.uint8)
+        inputs.append((y, u, v))
+
+    def frames(c):
+        out = []
+        for y, u, v in inputs:
+            planes = [y, np.stack([u, v], axis=-1)] if name == "nv12" else [y, u, v]
+            out.append(c.frame(fmt, iw, ih, planes))
+        return out
+
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    got = _render(ctx, hip, layouts, frames(ctx), W, H)
+    ctx.sync()
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    assert prof["fused_ingest_resample"][1] == 1 and prof["fused_compose_output"][1] == 1, f"{name} did not take the fused kernels: {prof}"
+    got_unfused = _render(ctx_unfused, hip, layouts, frames(ctx_unfused), W, H)
+    for a, b in zip(got, got_unfused):
+        assert (a == b).all(), f"{name}: fused and unfused paths differ"
+    nodes = [orc.nv12_to_rgba(y, np.stack([u, v], axis=-1), iw, ih) if name == "nv12" else orc.planar_yuv_to_rgba(y, u, v, iw, ih, variant)
+             for y, u, v in inputs]
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+    for g, w_, pl in zip(got, want, "YUV"):
+        assert refpipe.max_diff(g, w_) <= 1, f"{name} plane {pl}"
+        assert refpipe.exact_fraction(g, w_) >= 0.995, f"{name} plane {pl}"
+
+
+def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
+    """The multi-GPU driver with world_size 1 (every input on the root, no exchange): smr_ingest_resample per input into torch
+    tensors wrapped as surfaces + compose from the tiles must equal smr_render_layouts on the raw frames, bit for bit.
+    (world_size > 1 adds only the tile send/recv, covered by tests/test_dist.py over gloo.)"""
+    import torch
+    from smelter_amd import dist as smr_dist
+    torch.cuda.set_device(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    c = hip.Context(0, stream=stream)  # the renderer enqueues on torch's stream, as bench.py does under torchrun
+    iw, ih, W, H, n = 480, 270, 960, 540, 8
+    layouts, res = scenes.cfg3_scene(iw, ih, W, H, n)
+    planes, frames = _inputs(c, hip, n, iw, ih)
+    label_t, _ = _label_surfaces(c, 1)
+    slots = [i for i, r in enumerate(res) if r == (iw, ih)]
+    srcs, k = [], 0
+    for r in res:
+        if r == (iw, ih):
+            srcs.append(frames[k]); k += 1
+        else:
+            srcs.append(label_t)
+    want = _render(c, hip, layouts, srcs, W, H)
+    plan = smr_dist.ShardPlan(n_inputs=n, world=1)
+    sharded = smr_dist.ShardedCompositor(c, hip, plan, 0, layouts, res, slots, label_t, torch, None)
+    out = c.frame(hip.FRAME_PLANAR_YUV420, W, H)
+    sharded.step({i: frames[i] for i in range(n)}, out)
+    c.sync()
+    for a, b in zip(out.download(), want):
+        assert (a == b).all()
+    c.close()
+
+
 def test_missing_input_renders_like_the_reference(ctx, hip):
     # stale / missing input: node texture None -> InputStream size 0x0 -> layout culled (scene/layout.rs:109-115)
     root = S.Tiles(children=[S.InputStream(0), S.InputStream(1)], background_color=(10, 20, 30, 255))
