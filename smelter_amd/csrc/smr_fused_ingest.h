@@ -116,7 +116,7 @@ struct IngestJob {
     float scale_h, off_h, scale_v, off_v;  // axis mappings (resampler.rs:36-48): source texels per output texel, crop offset
     const float *wsum_h; const float *w_h;  // device weight tables: wsum[n], w[taps][n] (tap-major)
     const float *wsum_v; const float *w_v;
-    int strips_x, segs_y, seg_h;  // grid: 64-column strips x row segments of seg_h output rows
+    int strips_x;         // 64-column strips of the tile (launch_ingest splits their rows over the blocks)
     int nc_max;           // LDS capacity: columns of a source strip
     int vr;               // output rows with resident vertical weights per chunk
     int defer8;           // resolve output rows in multiples of 8 (one per wave) while the ring has room for the stragglers
@@ -160,19 +160,20 @@ __device__ __forceinline__ float expand_chroma(float u) {
 constexpr int MAX_JOBS_PER_LAUNCH = 16;
 struct IngestArgs {
     IngestJob jobs[MAX_JOBS_PER_LAUNCH];
+    // Work is measured in "row units": job j owns units [unit_prefix[j], unit_prefix[j+1]) = strips_x * dst.h rows, strip-major.
+    // Block b takes the contiguous range [b * units_per_block, ...): every block of the launch gets the same number of output
+    // rows (two blocks per CU, all resident at once) whatever the number and size of the jobs; a range that crosses a strip
+    // boundary is processed as two pieces.
+    int unit_prefix[MAX_JOBS_PER_LAUNCH + 1];
+    int n_jobs;
+    int units_per_block;
 };
 
-__global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs args, const float *__restrict__ tables) {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const IngestJob &J = args.jobs[blockIdx.z];
-    if ((int)blockIdx.x >= J.strips_x || (int)blockIdx.y >= J.segs_y) return;
-    if (J.ablate & 16) return;  // profiling: pure dispatch cost of this grid
-
+// Output rows [oy0, oy1) of strip `strip` of job J.
+__device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int oy0, int oy1, const float *__restrict__ tables, u8 *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx0 = blockIdx.x * TW;
+    const int tx0 = strip * TW;
     const int tw = min(TW, J.dst.w - tx0);
-    const int oy0 = blockIdx.y * J.seg_h, oy1 = min(oy0 + J.seg_h, J.dst.h);
-    if (oy0 >= oy1) return;
     const int taps_h = J.taps_h, taps_v = J.taps_v;
     const int ncm = J.nc_max;
     const int sw = J.src_w, sh = J.src_h;
@@ -490,6 +491,27 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
     resolve(pend_y, pend_n, pend_vb);  // rows completed by the last chunk
 }
 
+__global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs args, const float *__restrict__ tables) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    if (args.jobs[0].ablate & 16) return;  // profiling: pure dispatch cost of this grid
+    const int total = args.unit_prefix[args.n_jobs];
+    int u = (int)blockIdx.x * args.units_per_block;
+    const int u_end = min(u + args.units_per_block, total);
+    bool first = true;
+    while (u < u_end) {
+        int j = 0;
+        while (j + 1 < args.n_jobs && args.unit_prefix[j + 1] <= u) j++;
+        const IngestJob &J = args.jobs[j];
+        const int local = u - args.unit_prefix[j];
+        const int strip = local / J.dst.h, oy0 = local - strip * J.dst.h;
+        const int oy1 = min(J.dst.h, oy0 + (u_end - u));
+        if (!first) __syncthreads();  // the previous piece's LDS is dead only once every wave has left it
+        ingest_strip(J, strip, oy0, oy1, tables, smem);
+        u += oy1 - oy0;
+        first = false;
+    }
+}
+
 int ingest_vr(float scale_v) {
     // rows that become ready per chunk (<= CH / scale + 1) plus the stragglers deferred from the previous one (<= 7)
     const float s = scale_v > 0.0f ? scale_v : 1.0f;
@@ -544,7 +566,6 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     J.wsum_h = wh.wsum; J.w_h = wh.w;
     J.wsum_v = wv.wsum; J.w_v = wv.w;
     J.strips_x = ((int)tile->w + TW - 1) / TW;
-    J.segs_y = 1; J.seg_h = (int)tile->h;  // launch_ingest splits the rows once it knows how many blocks the launch has
     // +1: the quad path aligns the footprint start down to an odd coordinate
     J.nc_max = (int)ceilf((float)TW * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
     if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
@@ -561,36 +582,38 @@ int launch_ingest(smr_ctx *ctx, std::vector<IngestJob> &jobs) {
         SMR_HIP(ctx, hipFuncSetAttribute((const void *)k_ingest_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    // Row segments: every block is resident at once (two per CU), so aim at ~2 blocks per CU over the whole launch;
-    // a segment re-converts only the `taps` rows of its vertical halo.
-    int strips = 0;
-    for (const IngestJob &J : jobs) strips += J.strips_x;
-    const int target_blocks = 2 * ctx->cu_count;
-    for (IngestJob &J : jobs) {
-        int segs = strips > 0 ? (target_blocks + strips / 2) / strips : 1;
-        const int max_segs = (J.dst.h + 31) / 32;  // at least 32 output rows per segment
-        segs = segs < 1 ? 1 : (segs > max_segs ? max_segs : segs);
-        J.seg_h = (J.dst.h + segs - 1) / segs;
-        J.segs_y = (J.dst.h + J.seg_h - 1) / J.seg_h;
-    }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
     for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_JOBS_PER_LAUNCH) {
         const size_t nj = jobs.size() - j0 < (size_t)MAX_JOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_JOBS_PER_LAUNCH;
         IngestArgs args;
         memset(&args, 0, sizeof(args));
-        int gx = 0, gy = 0;
         size_t lds = 0;
+        int total = 0;
         for (size_t j = 0; j < nj; j++) {
             const IngestJob &J = jobs[j0 + j];
             args.jobs[j] = J;
-            gx = J.strips_x > gx ? J.strips_x : gx;
-            gy = J.segs_y > gy ? J.segs_y : gy;
+            args.unit_prefix[j] = total;
+            total += J.strips_x * J.dst.h;
             size_t b = ingest_lds_bytes(J);
             lds = b > lds ? b : lds;
         }
+        args.unit_prefix[nj] = total;
+        args.n_jobs = (int)nj;
         if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_resample: %zu B of LDS needed", lds);
-        hipLaunchKernelGGL(k_ingest_resample, dim3((unsigned)gx, (unsigned)gy, (unsigned)nj), dim3(A_THREADS), lds, ctx->stream, args,
-                           ctx->d_tables);
+        // every block is resident at once (two per CU at <= 80 KB of LDS): split the launch's output rows evenly over
+        // 2 x CUs blocks, but keep at least 32 rows per block (a piece re-converts the `taps` rows of its vertical halo)
+        // 1/16 of the CUs stay free for the compose kernel of the frame in flight on another stream: measured on MI355X the
+        // ingest kernel alone loses 1.5 % on 240 instead of 256 CUs, the pipelined frame rate gains 3 %
+        // (SMR_INGEST_RESERVE_CUS overrides, profiling only)
+        static const int reserve_env = getenv("SMR_INGEST_RESERVE_CUS") ? atoi(getenv("SMR_INGEST_RESERVE_CUS")) : -1;
+        const int reserve = reserve_env >= 0 && reserve_env < ctx->cu_count ? reserve_env : ctx->cu_count / 16;
+        int blocks = 2 * (ctx->cu_count - reserve);
+        int upb = (total + blocks - 1) / blocks;
+        if (upb < 32) upb = 32;
+        blocks = (total + upb - 1) / upb;
+        args.units_per_block = upb;
+        if (blocks > 0)
+            hipLaunchKernelGGL(k_ingest_resample, dim3((unsigned)blocks), dim3(A_THREADS), lds, ctx->stream, args, ctx->d_tables);
         SMR_HIP(ctx, hipGetLastError());
     }
     return SMR_OK;
