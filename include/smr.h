@@ -151,6 +151,7 @@ typedef struct smr_source {
 SMR_API int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hip_stream, smr_ctx **out);
 SMR_API void smr_ctx_destroy(smr_ctx *ctx);
 SMR_API const char *smr_last_error(const smr_ctx *ctx);
+SMR_API uint32_t smr_ctx_mode(const smr_ctx *ctx);  /* smr_mode the context was created with (RenderingMode, types.rs:8-18) */
 SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — render_loop.rs:177-183 */
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
 SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */
@@ -290,6 +291,47 @@ SMR_API int smr_scene_node_layouts(smr_scene *scene, int node, int64_t pts_ns, c
 SMR_API double smr_cubic_bezier_easing(double progress, double x1, double y1, double x2, double y2);
 SMR_API double smr_bounce_easing(double progress);
 SMR_API int smr_parse_color(const char *text, uint8_t rgba[4]);
+
+/* ---- a14 (+ a2, a4): the renderer ---------------------------------------------------
+ * `Renderer` of smelter-render/src/state.rs:96-252 over the scene engine and the kernels above:
+ *   Renderer::new              -> smr_renderer_create (stream_fallback_timeout: state.rs:43-52, render_loop.rs:29)
+ *   register_input / unregister_input / unregister_output (state.rs:102-121)
+ *   register_renderer(Image)   -> smr_renderer_register_image (bitmap pixels; decoding is the caller's)
+ *   register_renderer(Shader)  -> smr_renderer_register_shader (a built-in kernel id; user WGSL is out of scope)
+ *   update_scene               -> smr_renderer_update_scene(output_id, resolution, OutputFrameFormat, scene JSON) (state.rs:177-189)
+ *   render(FrameSet<InputId>)  -> smr_renderer_render: populate_inputs (stale frames dropped), depth-first walk of every output's
+ *                                 render graph (input refs, images, text, shader and nested layout nodes), read_outputs fused
+ *                                 into the root layout node (state.rs:220-252, render_loop.rs:19-230)
+ * Text nodes: shaping / rasterisation is the caller's (third-party in the reference); after every update_scene the caller
+ * supplies each Text node's glyph run once (smr_renderer_node_info lists them), as text_renderer.rs renders once per update.
+ * Output frames live in HBM, two per output, alternating: a returned frame stays valid until the render after the next. */
+typedef struct smr_renderer smr_renderer;
+typedef struct smr_input_frame {
+    const char *input_id;
+    const smr_frame *frame; /* resident in HBM (smr_frame_upload or wrapped decoder output) */
+    int64_t pts_ns;
+} smr_input_frame;
+typedef struct smr_output_frame {
+    const char *output_id;
+    const smr_frame *frame;
+} smr_output_frame;
+
+SMR_API int smr_renderer_create(smr_ctx *ctx, int64_t stream_fallback_timeout_ns /* < 0: 500 ms */, smr_renderer **out);
+SMR_API void smr_renderer_destroy(smr_renderer *r);
+SMR_API const char *smr_renderer_last_error(const smr_renderer *r);
+SMR_API int smr_renderer_register_input(smr_renderer *r, const char *input_id);
+SMR_API int smr_renderer_unregister_input(smr_renderer *r, const char *input_id);
+SMR_API int smr_renderer_register_image(smr_renderer *r, const char *image_id, const uint8_t *rgba_straight, uint32_t width, uint32_t height);
+SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id, uint32_t builtin_id);
+SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, uint32_t width, uint32_t height, uint32_t output_format,
+                                      const char *scene_json);
+SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_id);
+SMR_API int smr_renderer_node_count(const smr_renderer *r, const char *output_id);
+SMR_API int smr_renderer_node_info(smr_renderer *r, const char *output_id, int node, smr_scene_node *out);
+SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int node, const float bg[4], const smr_glyph *glyphs, uint32_t n,
+                                  const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
+SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs,
+                                smr_output_frame *outputs, uint32_t cap, uint32_t *n_outputs);
 
 SMR_API uint32_t smr_abi_version(void);
 SMR_API uint32_t smr_sizeof_layout(void);

@@ -34,7 +34,11 @@ EXPORTS = [
     "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_blit_glyphs", "smr_builtin_shader",
     "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update", "smr_scene_parse",
     "smr_scene_node_count", "smr_scene_node_info", "smr_scene_node_children", "smr_scene_node_layouts",
-    "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color",
+    "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color", "smr_ctx_mode",
+    "smr_renderer_create", "smr_renderer_destroy", "smr_renderer_last_error", "smr_renderer_register_input",
+    "smr_renderer_unregister_input", "smr_renderer_register_image", "smr_renderer_register_shader", "smr_renderer_update_scene",
+    "smr_renderer_unregister_output", "smr_renderer_node_count", "smr_renderer_node_info", "smr_renderer_set_text",
+    "smr_renderer_render",
     "smr_abi_version", "smr_sizeof_layout",
 ]
 NO_RESOLUTION = 0xFFFFFFFF
@@ -95,6 +99,14 @@ class Source(C.Structure):
 
 class GaussianBlurParams(C.Structure):
     _fields_ = [("sigma", C.c_float)]
+
+
+class InputFrame(C.Structure):
+    _fields_ = [("input_id", C.c_char_p), ("frame", C.POINTER(Frame)), ("pts_ns", C.c_int64)]
+
+
+class OutputFrame(C.Structure):
+    _fields_ = [("output_id", C.c_char_p), ("frame", C.POINTER(Frame))]
 
 
 _lib = None
@@ -164,6 +176,20 @@ def load():
         "smr_cubic_bezier_easing": ([C.c_double] * 5, C.c_double),
         "smr_bounce_easing": ([C.c_double], C.c_double),
         "smr_parse_color": ([C.c_char_p, C.POINTER(C.c_uint8)], I),
+        "smr_ctx_mode": ([P], U),
+        "smr_renderer_create": ([P, C.c_int64, PP], I),
+        "smr_renderer_destroy": ([P], None),
+        "smr_renderer_last_error": ([P], C.c_char_p),
+        "smr_renderer_register_input": ([P, C.c_char_p], I),
+        "smr_renderer_unregister_input": ([P, C.c_char_p], I),
+        "smr_renderer_register_image": ([P, C.c_char_p, P, U, U], I),
+        "smr_renderer_register_shader": ([P, C.c_char_p, U], I),
+        "smr_renderer_update_scene": ([P, C.c_char_p, U, U, U, C.c_char_p], I),
+        "smr_renderer_unregister_output": ([P, C.c_char_p], I),
+        "smr_renderer_node_count": ([P, C.c_char_p], I),
+        "smr_renderer_node_info": ([P, C.c_char_p, I, C.POINTER(SceneNode)], I),
+        "smr_renderer_set_text": ([P, C.c_char_p, I, C.POINTER(F), C.POINTER(Glyph), U, P, U, U], I),
+        "smr_renderer_render": ([P, C.c_int64, C.POINTER(InputFrame), U, C.POINTER(OutputFrame), U, C.POINTER(U)], I),
         "smr_abi_version": ([], U),
         "smr_sizeof_layout": ([], U),
     }

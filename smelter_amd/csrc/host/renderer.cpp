@@ -1,0 +1,452 @@
+// renderer.cpp — the reference's `Renderer` (smelter-render/src/state.rs:96-252) over the scene engine and the smr_* kernels:
+// register inputs / images / built-in shaders, update_scene(output, resolution, format, JSON), render(FrameSet) -> FrameSet.
+// Per frame (InnerRenderer::render, state.rs:220-252): populate_inputs (staleness filter, render_loop.rs:19-42), a depth-first
+// walk of every output's render graph (render_graph.rs, node.rs:22-181) — input refs, images, text, shader nodes, nested
+// layout nodes into RGBA8 node surfaces — and read_outputs (render_loop.rs:59-230) fused into the root layout node's launch.
+// SURVEY.md §8 a14 (+ a2, a4); no GPU code here, only calls into the C ABI of this library.
+#include <cstring>
+#include <map>
+#include <set>
+
+#include "scene.h"
+
+using namespace smr_host;
+
+namespace {
+
+struct ImageRes {
+    smr_surface *surface = nullptr;  // premultiplied RGBA8 node texture at the image's own resolution
+    uint32_t w = 0, h = 0;
+};
+
+struct Source {
+    uint32_t kind = SMR_SOURCE_NONE;
+    const smr_surface *surface = nullptr;
+    const smr_frame *frame = nullptr;
+    uint32_t w = 0, h = 0;
+};
+
+struct Output {
+    Scene scene;
+    uint32_t w = 0, h = 0, format = SMR_FRAME_PLANAR_YUV420;
+    smr_frame frames[2];
+    bool have_frames = false;
+    int flip = 0;
+    std::vector<smr_surface *> node_surface;   // per graph node, (re)allocated on size change (NodeTexture::ensure_size)
+    std::vector<smr_surface *> text_surface;   // per graph node: the rendered glyph run of a Text node (once per scene update)
+    std::vector<smr_surface *> scaled_image;   // per graph node: an Image node whose size differs from the image's
+};
+
+}  // namespace
+
+struct smr_renderer {
+    smr_ctx *ctx = nullptr;
+    int64_t timeout_ns = 500000000;  // stream_fallback_timeout
+    std::set<std::string> inputs;
+    std::map<std::string, ImageRes> images;
+    std::map<std::string, uint32_t> shaders;  // shader_id -> smr_builtin_shader_id
+    std::map<std::string, Output> outputs;
+    std::string err;
+    std::vector<smr_layout> layouts;  // scratch
+};
+
+namespace {
+
+int fail(smr_renderer *r, int code, const std::string &msg) {
+    if (r) r->err = msg;
+    return code;
+}
+int gpu(smr_renderer *r, int rc, const char *what) {
+    if (rc >= 0) return rc;
+    return fail(r, rc, std::string(what) + ": " + smr_last_error(r->ctx));
+}
+
+void free_surfaces(smr_renderer *r, std::vector<smr_surface *> &v) {
+    for (smr_surface *s : v)
+        if (s) smr_surface_destroy(r->ctx, s);
+    v.clear();
+}
+void free_output(smr_renderer *r, Output &o) {
+    free_surfaces(r, o.node_surface);
+    free_surfaces(r, o.text_surface);
+    free_surfaces(r, o.scaled_image);
+    if (o.have_frames) {
+        smr_frame_destroy(r->ctx, &o.frames[0]);
+        smr_frame_destroy(r->ctx, &o.frames[1]);
+        o.have_frames = false;
+    }
+}
+
+// NodeTexture::ensure_size (state/node_texture.rs:22-42)
+int ensure_surface(smr_renderer *r, smr_surface *&slot, uint32_t w, uint32_t h) {
+    smr_surface_info info;
+    if (slot && smr_surface_info_get(slot, &info) == 0 && info.width == w && info.height == h) return 0;
+    if (slot) { smr_surface_destroy(r->ctx, slot); slot = nullptr; }
+    return gpu(r, smr_surface_create(r->ctx, w, h, SMR_PX_RGBA8, &slot), "node surface");
+}
+
+struct FrameSetView {
+    const smr_input_frame *frames;
+    uint32_t n;
+    int64_t pts_ns;
+};
+
+// RenderNode::render (state/node.rs) for one node of one output; returns what its parent samples
+int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Source &out) {
+    const GraphNode &g = o.scene.nodes()[idx];
+    const Stateful &c = *g.component;
+    out = Source();
+    switch (g.kind) {
+    case Kind::InputStream: {
+        // populate_inputs: a registered input with a fresh enough frame, else the node has no texture
+        if (!r->inputs.count(c.ref_id)) return 0;
+        for (uint32_t i = 0; i < fs.n; i++) {
+            const smr_input_frame &f = fs.frames[i];
+            if (!f.input_id || !f.frame || c.ref_id != f.input_id) continue;
+            const int64_t oldest = fs.pts_ns > r->timeout_ns ? fs.pts_ns - r->timeout_ns : 0;  // Duration::saturating_sub
+            if (oldest > f.pts_ns) return 0;
+            out.kind = SMR_SOURCE_FRAME; out.frame = f.frame; out.w = f.frame->width; out.h = f.frame->height;
+            return 0;
+        }
+        return 0;
+    }
+    case Kind::Image: {
+        auto it = r->images.find(c.ref_id);
+        if (it == r->images.end()) return 0;
+        const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+        if (w == it->second.w && h == it->second.h) {
+            out.kind = SMR_SOURCE_SURFACE; out.surface = it->second.surface; out.w = w; out.h = h;
+            return 0;
+        }
+        if (w == 0 || h == 0) return 0;
+        // the image pass draws the asset into the node's own resolution (bitmap_image.rs:65-88): bilinear
+        smr_surface *&dst = o.scaled_image[idx];
+        int rc = ensure_surface(r, dst, w, h);
+        if (rc < 0) return rc;
+        rc = gpu(r, smr_rescale_bilinear(r->ctx, it->second.surface, dst), "image node");
+        if (rc < 0) return rc;
+        out.kind = SMR_SOURCE_SURFACE; out.surface = dst; out.w = w; out.h = h;
+        return 0;
+    }
+    case Kind::Text: {
+        if (o.text_surface[idx]) {
+            out.kind = SMR_SOURCE_SURFACE; out.surface = o.text_surface[idx];
+            out.w = (uint32_t)c.leaf_size.width; out.h = (uint32_t)c.leaf_size.height;
+        }
+        return 0;
+    }
+    default: break;
+    }
+    // nodes with children: render them first (depth first, node.rs:167-181)
+    std::vector<Source> kids(g.children.size());
+    for (size_t k = 0; k < g.children.size(); k++) {
+        int rc = render_node(r, o, g.children[k], fs, kids[k]);
+        if (rc < 0) return rc;
+    }
+    if (g.kind == Kind::Shader) {
+        auto it = r->shaders.find(c.ref_id);
+        if (it == r->shaders.end()) return fail(r, -1, "Shader \"" + c.ref_id + "\" does not exist. You have to register it first before using it in the scene definition.");
+        const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+        if (w == 0 || h == 0) return 0;
+        int rc = ensure_surface(r, o.node_surface[idx], w, h);
+        if (rc < 0) return rc;
+        // shader nodes sample RGBA node textures: raw input frames are converted first (InputTexture::convert_to_node_texture)
+        std::vector<const smr_surface *> srcs;
+        for (size_t k = 0; k < kids.size(); k++) {
+            if (kids[k].kind == SMR_SOURCE_FRAME) {
+                smr_surface *&t = o.node_surface[g.children[k]];
+                rc = ensure_surface(r, t, kids[k].w, kids[k].h);
+                if (rc < 0) return rc;
+                rc = gpu(r, smr_frame_to_rgba(r->ctx, kids[k].frame, t), "input node texture");
+                if (rc < 0) return rc;
+                srcs.push_back(t);
+            } else if (kids[k].kind == SMR_SOURCE_SURFACE) {
+                srcs.push_back(kids[k].surface);
+            }
+        }
+        if (srcs.empty()) return 0;  // nothing to sample: the node stays empty
+        float value = 0.0f;
+        if (const Json *v = c.shader_param.get("value")) value = (float)v->num;  // {"type": "f32", "value": sigma}
+        smr_gaussian_blur_params params{value};
+        // the built-in kernels map texel to texel: a source of another size is first brought to the node's resolution
+        const smr_surface *src0 = srcs[0];
+        smr_surface_info si;
+        smr_surface_info_get(src0, &si);
+        if (si.width != w || si.height != h) {
+            smr_surface *&t = o.scaled_image[idx];
+            rc = ensure_surface(r, t, w, h);
+            if (rc < 0) return rc;
+            rc = gpu(r, smr_rescale_bilinear(r->ctx, src0, t), "shader source");
+            if (rc < 0) return rc;
+            srcs[0] = t;
+        }
+        rc = gpu(r, smr_builtin_shader(r->ctx, it->second, &params, sizeof(params), srcs.data(), (uint32_t)srcs.size(), o.node_surface[idx],
+                                       (float)((double)fs.pts_ns / 1e9)),
+                 "shader node");
+        if (rc < 0) return rc;
+        out.kind = SMR_SOURCE_SURFACE; out.surface = o.node_surface[idx]; out.w = w; out.h = h;
+        return 0;
+    }
+    // layout node (nested): LayoutNode::render into an RGBA8 node surface
+    std::vector<std::optional<Size>> res(kids.size());
+    std::vector<smr_source> srcs(kids.size());
+    for (size_t k = 0; k < kids.size(); k++) {
+        if (kids[k].kind != SMR_SOURCE_NONE) res[k] = Size{(float)kids[k].w, (float)kids[k].h};
+        srcs[k].kind = kids[k].kind; srcs[k].surface = kids[k].surface; srcs[k].frame = kids[k].frame;
+    }
+    uint32_t w = 0, h = 0;
+    std::string err;
+    if (!o.scene.node_layouts(idx, fs.pts_ns, res, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, r->layouts, w, h, err)) return fail(r, -1, err);
+    if (w == 0 || h == 0) return 0;
+    int rc = ensure_surface(r, o.node_surface[idx], w, h);
+    if (rc < 0) return rc;
+    rc = gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h, nullptr,
+                                   o.node_surface[idx]),
+             "layout node");
+    if (rc < 0) return rc;
+    out.kind = SMR_SOURCE_SURFACE; out.surface = o.node_surface[idx]; out.w = w; out.h = h;
+    return 0;
+}
+
+int render_output(smr_renderer *r, Output &o, const FrameSetView &fs, const smr_frame **result) {
+    o.flip ^= 1;
+    smr_frame *target = &o.frames[o.flip];
+    *result = target;
+    if (o.scene.nodes().empty()) return gpu(r, smr_frame_fill_black(r->ctx, target), "empty output");
+    const GraphNode &root = o.scene.nodes()[0];
+    if (root.component->is_layout()) {
+        std::vector<Source> kids(root.children.size());
+        for (size_t k = 0; k < root.children.size(); k++) {
+            int rc = render_node(r, o, root.children[k], fs, kids[k]);
+            if (rc < 0) return rc;
+        }
+        std::vector<std::optional<Size>> res(kids.size());
+        std::vector<smr_source> srcs(kids.size());
+        for (size_t k = 0; k < kids.size(); k++) {
+            if (kids[k].kind != SMR_SOURCE_NONE) res[k] = Size{(float)kids[k].w, (float)kids[k].h};
+            srcs[k].kind = kids[k].kind; srcs[k].surface = kids[k].surface; srcs[k].frame = kids[k].frame;
+        }
+        uint32_t w = 0, h = 0;
+        std::string err;
+        if (!o.scene.node_layouts(0, fs.pts_ns, res, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, r->layouts, w, h, err)) return fail(r, -1, err);
+        if (w == o.w && h == o.h) {
+            // LayoutNode::render + read_outputs in one go: the root's RGBA target never exists
+            return gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h,
+                                             target, nullptr),
+                       "root layout node");
+        }
+        // a root whose own width/height differ from the output resolution: render the node, then convert like any other root
+        if (w == 0 || h == 0) return gpu(r, smr_frame_fill_black(r->ctx, target), "empty output");
+        int rc = ensure_surface(r, o.node_surface[0], w, h);
+        if (rc < 0) return rc;
+        rc = gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h, nullptr,
+                                       o.node_surface[0]),
+                 "root layout node");
+        if (rc < 0) return rc;
+        smr_surface *&t = o.scaled_image[0];
+        rc = ensure_surface(r, t, o.w, o.h);
+        if (rc < 0) return rc;
+        rc = gpu(r, smr_rescale_bilinear(r->ctx, o.node_surface[0], t), "root rescale");
+        if (rc < 0) return rc;
+        return gpu(r, smr_rgba_to_frame(r->ctx, t, target), "output conversion");
+    }
+    Source s;
+    int rc = render_node(r, o, 0, fs, s);
+    if (rc < 0) return rc;
+    if (s.kind == SMR_SOURCE_NONE) return gpu(r, smr_frame_fill_black(r->ctx, target), "empty output");  // render_loop.rs:127-139
+    const smr_surface *rgba = s.surface;
+    if (s.kind == SMR_SOURCE_FRAME) {
+        rc = ensure_surface(r, o.node_surface[0], s.w, s.h);
+        if (rc < 0) return rc;
+        rc = gpu(r, smr_frame_to_rgba(r->ctx, s.frame, o.node_surface[0]), "input node texture");
+        if (rc < 0) return rc;
+        rgba = o.node_surface[0];
+    }
+    if (s.w != o.w || s.h != o.h) {  // the output converters sample the root texture over the whole output (rgba_to_yuv.rs:74-117)
+        smr_surface *&t = o.scaled_image[0];
+        rc = ensure_surface(r, t, o.w, o.h);
+        if (rc < 0) return rc;
+        rc = gpu(r, smr_rescale_bilinear(r->ctx, rgba, t), "root rescale");
+        if (rc < 0) return rc;
+        rgba = t;
+    }
+    return gpu(r, smr_rgba_to_frame(r->ctx, rgba, target), "output conversion");
+}
+
+}  // namespace
+
+extern "C" {
+
+SMR_API int smr_renderer_create(smr_ctx *ctx, int64_t stream_fallback_timeout_ns, smr_renderer **out) {
+    if (!ctx || !out) return -1;
+    smr_renderer *r = new smr_renderer();
+    r->ctx = ctx;
+    if (stream_fallback_timeout_ns >= 0) r->timeout_ns = stream_fallback_timeout_ns;
+    r->shaders["gaussian_blur"] = SMR_SHADER_GAUSSIAN_BLUR;
+    *out = r;
+    return 0;
+}
+
+SMR_API void smr_renderer_destroy(smr_renderer *r) {
+    if (!r) return;
+    for (auto &kv : r->outputs) free_output(r, kv.second);
+    for (auto &kv : r->images)
+        if (kv.second.surface) smr_surface_destroy(r->ctx, kv.second.surface);
+    delete r;
+}
+
+SMR_API const char *smr_renderer_last_error(const smr_renderer *r) { return r ? r->err.c_str() : "null renderer"; }
+
+SMR_API int smr_renderer_register_input(smr_renderer *r, const char *input_id) {
+    if (!r || !input_id) return fail(r, -1, "smr_renderer_register_input: null argument");
+    r->inputs.insert(input_id);
+    return 0;
+}
+SMR_API int smr_renderer_unregister_input(smr_renderer *r, const char *input_id) {
+    if (!r || !input_id) return fail(r, -1, "smr_renderer_unregister_input: null argument");
+    r->inputs.erase(input_id);
+    return 0;
+}
+
+SMR_API int smr_renderer_register_image(smr_renderer *r, const char *image_id, const uint8_t *rgba, uint32_t width, uint32_t height) {
+    if (!r || !image_id || !rgba || !width || !height) return fail(r, -1, "smr_renderer_register_image: null argument");
+    if (r->images.count(image_id)) return fail(r, -1, std::string("Failed to register an image. Image \"") + image_id + "\" is already registered.");
+    // BitmapAsset: straight-alpha pixels uploaded once, premultiplied into the node texture format (bitmap_image.rs:20-88)
+    smr_surface *raw = nullptr, *pm = nullptr;
+    int rc = gpu(r, smr_surface_create(r->ctx, width, height, SMR_PX_RGBA8, &raw), "image upload");
+    if (rc < 0) return rc;
+    rc = gpu(r, smr_surface_upload(r->ctx, raw, rgba, (size_t)width * 4), "image upload");
+    if (rc >= 0) rc = gpu(r, smr_surface_create(r->ctx, width, height, SMR_PX_RGBA8, &pm), "image upload");
+    if (rc >= 0) rc = gpu(r, smr_add_premultiplied_alpha(r->ctx, raw, pm), "image premultiply");
+    if (rc >= 0) rc = gpu(r, smr_sync(r->ctx), "image upload");
+    smr_surface_destroy(r->ctx, raw);
+    if (rc < 0) {
+        if (pm) smr_surface_destroy(r->ctx, pm);
+        return rc;
+    }
+    ImageRes res;
+    res.surface = pm; res.w = width; res.h = height;
+    r->images[image_id] = res;
+    for (auto &kv : r->outputs) kv.second.scene.register_image(image_id, (float)width, (float)height);
+    return 0;
+}
+
+SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id, uint32_t builtin_id) {
+    if (!r || !shader_id) return fail(r, -1, "smr_renderer_register_shader: null argument");
+    if (builtin_id != SMR_SHADER_GAUSSIAN_BLUR) return fail(r, -1, "smr_renderer_register_shader: unknown built-in shader (user WGSL is not supported)");
+    r->shaders[shader_id] = builtin_id;
+    return 0;
+}
+
+SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, uint32_t width, uint32_t height, uint32_t output_format,
+                                      const char *scene_json) {
+    if (!r || !output_id || !scene_json || !width || !height) return fail(r, -1, "smr_renderer_update_scene: null argument");
+    if (output_format != SMR_FRAME_PLANAR_YUV420 && output_format != SMR_FRAME_PLANAR_YUV422 && output_format != SMR_FRAME_PLANAR_YUV444 &&
+        output_format != SMR_FRAME_NV12)
+        return fail(r, -1, "smr_renderer_update_scene: output format must be planar YUV 4:2:0 / 4:2:2 / 4:4:4 or NV12");
+    Output &o = r->outputs[output_id];
+    for (auto &kv : r->images) o.scene.register_image(kv.first, (float)kv.second.w, (float)kv.second.h);
+    std::string err;
+    if (!o.scene.update(scene_json, width, height, err)) {
+        if (!o.have_frames) r->outputs.erase(output_id);  // a failed first update leaves no output behind
+        return fail(r, -1, err);
+    }
+    // shader ids are resolved at update time like ShaderComponent::stateful_component does
+    for (const GraphNode &g : o.scene.nodes())
+        if (g.kind == Kind::Shader && !r->shaders.count(g.component->ref_id))
+            r->err = "Shader \"" + g.component->ref_id + "\" does not exist. You have to register it first before using it in the scene definition.";
+    if (o.have_frames && (o.w != width || o.h != height || o.format != output_format)) {
+        smr_sync(r->ctx);
+        smr_frame_destroy(r->ctx, &o.frames[0]);
+        smr_frame_destroy(r->ctx, &o.frames[1]);
+        o.have_frames = false;
+    }
+    if (!o.have_frames) {
+        int rc = gpu(r, smr_frame_create(r->ctx, output_format, width, height, &o.frames[0]), "output frame");
+        if (rc >= 0) rc = gpu(r, smr_frame_create(r->ctx, output_format, width, height, &o.frames[1]), "output frame");
+        if (rc < 0) return rc;
+        o.have_frames = true;
+    }
+    o.w = width; o.h = height; o.format = output_format;
+    // node indices belong to the new graph: per-node surfaces are re-created on demand, text runs must be supplied again
+    smr_sync(r->ctx);
+    free_surfaces(r, o.node_surface);
+    free_surfaces(r, o.text_surface);
+    free_surfaces(r, o.scaled_image);
+    const size_t n = o.scene.nodes().size();
+    o.node_surface.assign(n, nullptr);
+    o.text_surface.assign(n, nullptr);
+    o.scaled_image.assign(n, nullptr);
+    return 0;
+}
+
+SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_id) {
+    if (!r || !output_id) return fail(r, -1, "smr_renderer_unregister_output: null argument");
+    auto it = r->outputs.find(output_id);
+    if (it == r->outputs.end()) return 0;
+    smr_sync(r->ctx);
+    free_output(r, it->second);
+    r->outputs.erase(it);
+    return 0;
+}
+
+SMR_API int smr_renderer_node_count(const smr_renderer *r, const char *output_id) {
+    if (!r || !output_id) return -1;
+    auto it = r->outputs.find(output_id);
+    return it == r->outputs.end() ? -1 : (int)it->second.scene.nodes().size();
+}
+
+SMR_API int smr_renderer_node_info(smr_renderer *r, const char *output_id, int node, smr_scene_node *out) {
+    if (!r || !output_id || !out) return fail(r, -1, "smr_renderer_node_info: null argument");
+    auto it = r->outputs.find(output_id);
+    if (it == r->outputs.end()) return fail(r, -1, "smr_renderer_node_info: unknown output");
+    const auto &nodes = it->second.scene.nodes();
+    if (node < 0 || node >= (int)nodes.size()) return fail(r, -1, "smr_renderer_node_info: node index out of range");
+    const GraphNode &g = nodes[node];
+    const Stateful &c = *g.component;
+    memset(out, 0, sizeof(*out));
+    out->kind = g.kind == Kind::InputStream ? SMR_NODE_INPUT_STREAM : g.kind == Kind::Text ? SMR_NODE_TEXT : g.kind == Kind::Image ? SMR_NODE_IMAGE
+              : g.kind == Kind::Shader ? SMR_NODE_SHADER : SMR_NODE_LAYOUT;
+    out->parent = g.parent;
+    out->n_children = (uint32_t)g.children.size();
+    const Size sz = g.has_forced_size ? g.forced_size : c.leaf_size;
+    out->width = (uint32_t)sz.width; out->height = (uint32_t)sz.height;
+    out->ref_id = c.ref_id.c_str(); out->id = c.id.c_str();
+    out->payload = c.kind == Kind::Text ? c.text.c_str() : "";
+    return 0;
+}
+
+SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int node, const float bg[4], const smr_glyph *glyphs, uint32_t n,
+                                  const uint8_t *atlas, uint32_t atlas_w, uint32_t atlas_h) {
+    if (!r || !output_id || !bg) return fail(r, -1, "smr_renderer_set_text: null argument");
+    auto it = r->outputs.find(output_id);
+    if (it == r->outputs.end()) return fail(r, -1, "smr_renderer_set_text: unknown output");
+    Output &o = it->second;
+    if (node < 0 || node >= (int)o.scene.nodes().size() || o.scene.nodes()[node].kind != Kind::Text)
+        return fail(r, -1, "smr_renderer_set_text: not a text node");
+    const Stateful &c = *o.scene.nodes()[node].component;
+    const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+    if (!w || !h) return 0;
+    int rc = ensure_surface(r, o.text_surface[node], w, h);
+    if (rc < 0) return rc;
+    // TextRendererNode::render (text_renderer.rs:72-167): clear to the background colour, blit the glyph run — once per update
+    return gpu(r, smr_blit_glyphs(r->ctx, o.text_surface[node], bg, glyphs, n, atlas, atlas_w, atlas_h), "text node");
+}
+
+SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs, smr_output_frame *outputs,
+                                uint32_t cap, uint32_t *n_outputs) {
+    if (!r || (n_inputs && !inputs) || !n_outputs) return fail(r, -1, "smr_renderer_render: null argument");
+    FrameSetView fs{inputs, n_inputs, pts_ns};
+    uint32_t k = 0;
+    for (auto &kv : r->outputs) {
+        const smr_frame *frame = nullptr;
+        int rc = render_output(r, kv.second, fs, &frame);
+        if (rc < 0) return rc;
+        if (k < cap && outputs) { outputs[k].output_id = kv.first.c_str(); outputs[k].frame = frame; }
+        k++;
+    }
+    *n_outputs = k;
+    return 0;
+}
+
+}  // extern "C"

@@ -107,6 +107,7 @@ static double srgb_to_linear_f64(double c) {
 extern "C" {
 
 uint32_t smr_abi_version(void) { return 1; }
+uint32_t smr_ctx_mode(const smr_ctx *ctx) { return ctx ? ctx->mode : 0u; }
 uint32_t smr_sizeof_layout(void) { return (uint32_t)sizeof(smr_layout); }
 
 int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hip_stream, smr_ctx **out) {

@@ -1,8 +1,8 @@
 // smr_fused_ingest.h — wave A of the hot path: k_ingest_resample (included by smr_fused.hip only).
 //
-// One launch covers every scaled planar-YUV input of the frame (blockIdx.z = job).  A 512-thread workgroup owns a
-// 64-column strip of the dst-sized RGBA8 tile surface over a segment of its rows and streams the matching source rows
-// through LDS in chunks of 16 (one row pair per wave):
+// One launch covers every scaled planar-YUV / NV12 input of the frame: the launch's output rows (all jobs, strip-major) are
+// split evenly over the blocks.  A 512-thread workgroup owns a 64-column strip of a dst-sized RGBA8 tile surface over a
+// range of its rows and streams the matching source rows through LDS in chunks of 16 (one row pair per wave):
 //   * stage   — the chunk's raw Y/U/V footprint (aligned dwords) into LDS;
 //   * convert — per wave: YUV -> RGBA8 bytes -> sRGB-decoded linear f32 (2x2 quads sharing one chroma neighbourhood for
 //               4:2:0) into a wave-private LDS strip, then the horizontal Lanczos of exactly those two rows into a ring of
