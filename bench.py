@@ -154,33 +154,39 @@ def main():
     my_inputs = plan.inputs_of(rank)
     ring = make_inputs(ctx, hip, RING, my_inputs)
     n_lanes = max(1, args.inflight) if world == 1 else 1
-    # two output frames per lane: a lane's frames are stream-ordered, lanes never share an output frame
-    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2 * n_lanes)] if rank == 0 else []
+    # (single GPU: every renderer owns two alternating output frames; sharded path: the root's two)
+    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2)] if rank == 0 and world > 1 else []
 
     def out_for(step):
-        return outs[(step % n_lanes) + n_lanes * ((step // n_lanes) % 2)]
+        return outs[step % 2]
     input_source_slot = [i for i, r in enumerate(res) if r == (IN_W, IN_H)]  # source index of input k
 
     lanes = [ctx]
     if world == 1:
-        def sources_for(step):
-            row = ring[step % RING]
-            srcs, k = [], 0
-            for r in res:
-                if r == (IN_W, IN_H):
-                    srcs.append(row[k]); k += 1
-                else:
-                    srcs.append(label)
-            return srcs
-        src_cache = [sources_for(s) for s in range(RING)]
-        # frames in flight: consecutive frames go to separate renderer contexts (own HIP stream, own tile / parameter scratch),
-        # so the latency-bound tail of one frame's compose kernel overlaps the next frame's ingest kernel.  Frames are
-        # independent (inputs read-only, distinct output frames), exactly like two outputs of the reference's pipeline.
+        # The whole per-frame path of the reference's Renderer::render (state.rs:220-252) is inside a step: frame set ->
+        # populate_inputs -> layout maths at this pts (scene engine) -> parameter pack -> ingest + compose kernels -> output frame.
+        # Frames in flight: consecutive frames go to separate renderers (own context / HIP stream / scratch / output frames), so
+        # the latency-bound tail of one frame's compose kernel overlaps the next frame's ingest kernel.  Frames are independent
+        # (inputs read-only), exactly like separate outputs of the reference's pipeline.
+        from smelter_amd import _ffi, synth
+        from smelter_amd.renderer import Renderer
         lanes += [hip.Context(local_rank) for _ in range(n_lanes - 1)]
+        atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
+        renderers, frame_sets = [], []
+        for c in lanes:
+            r = Renderer(c, stream_fallback_timeout_s=3600.0)  # the synthetic ring carries no timestamps
+            for i in range(N_IN):
+                r.register_input(f"input_{i}")
+            for node in r.update_scene("out", OUT_W, OUT_H, scene_json()):
+                if node.kind == _ffi.NODE_TEXT:
+                    r.set_text("out", node.index, glyphs, atlas)
+            renderers.append(r)
+            frame_sets.append([r.make_frame_set({f"input_{i}": row[i] for i in range(N_IN)}) for row in ring])
+        FRAME_NS = 1_000_000_000 // 60
 
         def step_fn(step, lane=None):
-            c = lanes[step % n_lanes] if lane is None else lane
-            c.render_layouts(layouts, src_cache[step % RING], OUT_W, OUT_H, out=out_for(step) if lane is None else outs[0], packed=packed)
+            k = step % n_lanes if lane is None else 0
+            renderers[k].render_packed(step * FRAME_NS, frame_sets[k][step % RING])
     else:
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
 
@@ -219,6 +225,8 @@ def main():
                                    "+ text label per tile, GpuOptimized (linear-light Lanczos3 + blend)",
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
                        "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
+                       "per_frame_host_work": "smr_renderer_render: frame set -> layout maths at pts (C++ scene engine) -> parameter pack -> 2 kernels"
+                       if world == 1 else "pre-flattened layout list (scene engine, once) -> ingest per shard -> gather -> compose",
                        "parallelism": "single GPU" if world == 1 else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
             "frame": {"algorithmic_bytes": ALGO_BYTES_PER_FRAME, "achieved_GBps": round(ALGO_BYTES_PER_FRAME * fps / 1e9, 2),
                       "frac_of_hbm_peak": round(ALGO_BYTES_PER_FRAME * fps / 1e9 / HBM_PEAK_GBPS, 5)},
@@ -269,6 +277,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if world == 1:
+        for r in renderers:
+            r.close()
     for c in lanes[1:]:
         c.close()
     ctx.close()
