@@ -255,9 +255,21 @@ def main():
         if dom is not None:
             b = kernel_bytes.get(dom, ALGO_BYTES_PER_FRAME)
             ach = b / (stages[dom]["avg_us"] * 1e-6) / 1e9
-            result["roofline"] = {"bound": "hbm", "kernel": {"fused_ingest_resample": "k_ingest_resample", "fused_compose_output": "k_compose_output"}.get(dom, dom),
+            kname = {"fused_ingest_resample": "k_ingest_resample", "fused_compose_output": "k_compose_output"}.get(dom, dom)
+            # HBM bytes per launch from the PMC passes of tools/prof.sh on this same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+            # separate --pmc runs): counters cannot be read from inside the process, so the committed summary is quoted
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            if os.path.exists(tpath):
+                t = json.load(open(tpath)).get(kname)
+                if t:
+                    traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            result["roofline"] = {"bound": "hbm", "kernel": kname,
                                   "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-                                  "bytes_per_launch": b, "avg_launch_us": stages[dom]["avg_us"], "traffic": None}
+                                  "bytes_per_launch": b, "avg_launch_us": stages[dom]["avg_us"], "traffic": traffic,
+                                  "traffic_source": traffic_src,
+                                  "limiter": "vector ALU + LDS pipe (exact f32 colour conversion, 10+10-tap Lanczos, sRGB tables), not HBM: "
+                                             "see DESIGN.md section 3"}
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM
         lat = []

@@ -495,7 +495,12 @@ __global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs 
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     if (args.jobs[0].ablate & 16) return;  // profiling: pure dispatch cost of this grid
     const int total = args.unit_prefix[args.n_jobs];
-    int u = (int)blockIdx.x * args.units_per_block;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Virtual id v puts ids that share an
+    // XCD next to each other in the unit space, so neighbouring strips (which share source cache lines) — with 8 equal jobs a
+    // whole input — go through one L2 and every line is fetched from memory once instead of once per XCD.
+    const int per_xcd = (int)gridDim.x >> 3;  // the grid is a multiple of 8
+    const int v = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    int u = v * args.units_per_block;
     const int u_end = min(u + args.units_per_block, total);
     bool first = true;
     while (u < u_end) {
@@ -610,7 +615,7 @@ int launch_ingest(smr_ctx *ctx, std::vector<IngestJob> &jobs) {
         int blocks = 2 * (ctx->cu_count - reserve);
         int upb = (total + blocks - 1) / blocks;
         if (upb < 32) upb = 32;
-        blocks = (total + upb - 1) / upb;
+        blocks = ((total + upb - 1) / upb + 7) & ~7;  // whole rounds over the 8 XCDs (surplus blocks find no units and leave)
         args.units_per_block = upb;
         if (blocks > 0)
             hipLaunchKernelGGL(k_ingest_resample, dim3((unsigned)blocks), dim3(A_THREADS), lds, ctx->stream, args, ctx->d_tables);

@@ -41,3 +41,29 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             for c, v in sorted(cs.items()):
                 n = cnt[(k, c)]
                 print("     %-28s per-dispatch avg %16.1f   (dispatches %d)" % (c, v / max(n, 1), n))
+
+# ---- HBM traffic per launch for bench.py's roofline.traffic (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are KB
+#      at the L2's memory side, collected in separate --pmc passes; on gfx950 FETCH_SIZE reports half of the bytes read -> x2.
+import json
+
+traffic = {}
+for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True) if os.path.isdir(d) else []:
+        acc, cnt = defaultdict(float), defaultdict(int)
+        for row in csv.DictReader(open(f)):
+            c = row.get("Counter_Name")
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                k = short(row.get("Kernel_Name", ""))
+                acc[(k, c)] += float(row.get("Counter_Value", 0) or 0)
+                cnt[(k, c)] += 1
+        for (k, c), v in acc.items():
+            traffic.setdefault(k, {})[c] = v / cnt[(k, c)]
+res = {}
+for k, t in traffic.items():
+    if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+        res[k] = {"fetch_kb_raw": round(t["FETCH_SIZE"], 1), "write_kb": round(t["WRITE_SIZE"], 1),
+                  "hbm_bytes_per_launch": int(t["FETCH_SIZE"] * 1024 * 2 + t["WRITE_SIZE"] * 1024),
+                  "correction": "FETCH_SIZE x2 (gfx950), WRITE_SIZE as reported"}
+if res:
+    json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    print("== traffic:", json.dumps(res))
