@@ -187,8 +187,9 @@ def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
     import torch
     from smelter_amd import dist as smr_dist
     torch.cuda.set_device(0)
-    stream = torch.cuda.current_stream().cuda_stream
-    c = hip.Context(0, stream=stream)  # the renderer enqueues on torch's stream, as bench.py does under torchrun
+    side = torch.cuda.Stream()  # the renderer enqueues on torch's (non-default) current stream, as bench.py does under torchrun
+    torch.cuda.set_stream(side)
+    c = hip.Context(0, stream=side.cuda_stream)
     iw, ih, W, H, n = 480, 270, 960, 540, 8
     layouts, res = scenes.cfg3_scene(iw, ih, W, H, n)
     planes, frames = _inputs(c, hip, n, iw, ih)
@@ -209,6 +210,7 @@ def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
     for a, b in zip(out.download(), want):
         assert (a == b).all()
     c.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())
 
 
 def test_missing_input_renders_like_the_reference(ctx, hip):
