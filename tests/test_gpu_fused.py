@@ -213,6 +213,44 @@ def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
     torch.cuda.set_stream(torch.cuda.default_stream())
 
 
+def test_long_layout_lists_and_odd_output_sizes(ctx, ctx_unfused, hip):
+    """More layouts than the fused compose kernel keeps in LDS (48) and an output width that is not a multiple of 4: the library
+    must fall back to the general kernels on its own and still match the pass-per-launch path and the oracle."""
+    iw, ih = 160, 90
+    for (W, H, n) in [(1280, 720, 12), (642, 362, 3)]:
+        layouts, res = scenes.cfg3_scene(iw, ih, W, H, n)
+        assert n < 12 or 48 < len(layouts) <= 100  # (beyond max_layouts_count = 100 the reference drops layouts, params.rs:176-182)
+        planes, _ = _inputs(ctx, hip, n, iw, ih)
+        _, label_host = _label_surfaces(ctx, 1)
+
+        def sources_for(c):
+            srcs, k = [], 0
+            lt = c.surface_from(label_host)
+            for r in res:
+                if r == (iw, ih):
+                    srcs.append(c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[k]))); k += 1
+                else:
+                    srcs.append(lt)
+            return srcs
+
+        if W % 4 == 0:
+            got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
+            ref = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
+            for a, b in zip(got, ref):
+                assert (a == b).all()
+        rgba = ctx.surface(W, H)
+        ctx.render_layouts(layouts, sources_for(ctx), W, H, out_rgba=rgba)
+        nodes, k = [], 0
+        for r in res:
+            if r == (iw, ih):
+                nodes.append(orc.planar_yuv_to_rgba(*planes[k], iw, ih)); k += 1
+            else:
+                nodes.append(label_host)
+        want = refpipe.layout_node_render(layouts, nodes, W, H)
+        g = rgba.download()
+        assert refpipe.max_diff(g, want) <= 1 and refpipe.exact_fraction(g, want) >= 0.995
+
+
 def test_missing_input_renders_like_the_reference(ctx, hip):
     # stale / missing input: node texture None -> InputStream size 0x0 -> layout culled (scene/layout.rs:109-115)
     root = S.Tiles(children=[S.InputStream(0), S.InputStream(1)], background_color=(10, 20, 30, 255))
