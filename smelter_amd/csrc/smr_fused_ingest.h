@@ -331,6 +331,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
             if (lane >= tw || (J.ablate & 4)) {
             } else if (fv >= 0 && fv + taps_v - 1 <= sh - 1 && s0 + taps_v <= MR) {
                 const uint2 *pm = M + (size_t)s0 * TW + lane;  // the window is contiguous in the ring
+#pragma unroll 2
                 for (int t = 0; t < taps_v; t++) {
                     const float wgt = wv[t * VRp];
                     const float4 m = half4_to_float4(pm[(size_t)t * TW]);
@@ -458,6 +459,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
                 } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
                     // interior: no edge clamp, consecutive texels
                     const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
+#pragma unroll 2
                     for (int t = 0; t < taps_h; t++) {
                         const float wgt = wcol[t * TW];
                         const float4 ta = pa[t], tb = pb[t];
@@ -491,7 +493,9 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
     resolve(pend_y, pend_n, pend_vb);  // rows completed by the last chunk
 }
 
-__global__ __launch_bounds__(A_THREADS) void k_ingest_resample(const IngestArgs args, const float *__restrict__ tables) {
+// (second bound = waves per SIMD: two 8-wave workgroups per CU need 4, i.e. at most 128 VGPRs — without it a small change in
+//  the tap loops' unrolling silently halves the occupancy)
+__global__ __launch_bounds__(A_THREADS, 4) void k_ingest_resample(const IngestArgs args, const float *__restrict__ tables) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     if (args.jobs[0].ablate & 16) return;  // profiling: pure dispatch cost of this grid
     const int total = args.unit_prefix[args.n_jobs];
