@@ -116,7 +116,8 @@ struct IngestJob {
     float scale_h, off_h, scale_v, off_v;  // axis mappings (resampler.rs:36-48): source texels per output texel, crop offset
     const float *wsum_h; const float *w_h;  // device weight tables: wsum[n], w[taps][n] (tap-major)
     const float *wsum_v; const float *w_v;
-    int strips_x;         // 64-column strips of the tile (launch_ingest splits their rows over the blocks)
+    int tw;               // strip width in columns: 64, or 32 when that is what keeps two workgroups per CU (LDS)
+    int strips_x;         // strips of the tile (launch_ingest splits their rows over the blocks)
     int nc_max;           // LDS capacity: columns of a source strip
     int vr;               // output rows with resident vertical weights per chunk
     int defer8;           // resolve output rows in multiples of 8 (one per wave) while the ring has room for the stragglers
@@ -169,11 +170,14 @@ struct IngestArgs {
     int units_per_block;
 };
 
-// Output rows [oy0, oy1) of strip `strip` of job J.
+// Output rows [oy0, oy1) of strip `strip` of job J.  TWT = strip width in columns: 64 (one lane per column, two source rows per
+// lane in the horizontal pass, one output row per wave in the vertical pass) or 32 (the two half-waves take one source row /
+// one output row each) — the narrow strip halves the LDS footprint of the source strips and of the ring at large scale factors.
+template <int TWT>
 __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int oy0, int oy1, const float *__restrict__ tables, u8 *smem) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tx0 = strip * TW;
-    const int tw = min(TW, J.dst.w - tx0);
+    const int tx0 = strip * TWT;
+    const int tw = min(TWT, J.dst.w - tx0);
     const int taps_h = J.taps_h, taps_v = J.taps_v;
     const int ncm = J.nc_max;
     const int sw = J.src_w, sh = J.src_h;
@@ -183,19 +187,19 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
     float *s_tab = (float *)smem;                          // SMR_TABLE_FLOATS: dec | thr | enc
     float *s_n255 = s_tab + SMR_TABLE_FLOATS;              // 256: u8 / 255
     float *s_ylut = s_n255 + 256;                          // 256: luma u8 -> range-expanded y
-    float *s_wh = s_ylut + 256;                            // [taps_h][TW]
-    float *s_wsh = s_wh + ((taps_h * TW + 3) & ~3);        // [TW]   wsum
-    float *s_rsh = s_wsh + TW;                             // [TW]   1 / wsum
-    int *s_fh = (int *)(s_rsh + TW);                       // [TW]
-    float *s_wv = (float *)(s_fh + TW);                    // [3][taps_v][VRp]  (tap-major like the global table; three chunks deep)
+    float *s_wh = s_ylut + 256;                            // [taps_h][TWT]
+    float *s_wsh = s_wh + ((taps_h * TWT + 3) & ~3);        // [TWT]  wsum
+    float *s_rsh = s_wsh + TWT;                             // [TWT]  1 / wsum
+    int *s_fh = (int *)(s_rsh + TWT);                       // [TW]
+    float *s_wv = (float *)(s_fh + TWT);                    // [3][taps_v][VRp]  (tap-major like the global table; three chunks deep)
     const int VRp = VR <= 32 ? 32 : 64;
     const int wv_sz = taps_v * VRp;
     int *s_fv = (int *)(s_wv + 3 * wv_sz);                 // [3][VRa]
     float *s_wsv = (float *)(s_fv + 3 * VRa);              // [3][VRa]
     float *s_rsv = s_wsv + 3 * VRa;                        // [3][VRa]
     float4 *S_all = (float4 *)(s_rsv + 3 * VRa);           // [A_WAVES][2][nc_max] linear RGBA, wave-private strips
-    uint2 *M = (uint2 *)(S_all + (size_t)A_WAVES * 2 * ncm);  // [MR][TW] half4 ring, row r lives in slot (r - R_lo) & (MR - 1)
-    u8 *raw0 = (u8 *)(M + (size_t)MR * TW);                // [2]{ Y [CH][ys], U [RAW_C_ROWS][cs], V [RAW_C_ROWS][cs] }  (fast420 only)
+    uint2 *M = (uint2 *)(S_all + (size_t)A_WAVES * 2 * ncm);  // [MR][TWT] half4 ring, row r lives in slot (r - R_lo) & (MR - 1)
+    u8 *raw0 = (u8 *)(M + (size_t)MR * TWT);                // [2]{ Y [CH][ys], U [RAW_C_ROWS][cs], V [RAW_C_ROWS][cs] }  (fast420 only)
     const int ys = raw_y_stride(ncm), cs = raw_c_stride(ncm);
     const int raw_sz = CH * ys + 2 * RAW_C_ROWS * cs;
 
@@ -226,8 +230,8 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
         s_ylut[tid] = J.full_range ? v : clampf((v - (16.0f / 255.0f)) / 0.85882352941f, 0.0f, 1.0f);
     }
     // weight tables are stored tap-major in global memory (w[t * n + i]): a strip's slice of every tap is contiguous
-    for (int i = tid; i < taps_h * TW; i += A_THREADS) {
-        const int t = i >> 6, x = i & 63;
+    for (int i = tid; i < taps_h * TWT; i += A_THREADS) {
+        const int t = i / TWT, x = i % TWT;
         s_wh[i] = x < tw ? J.w_h[(size_t)t * J.dst.w + tx0 + x] : 0.0f;
     }
     if (tid < tw) {
@@ -316,40 +320,45 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
         }
     };
 
-    // resolve: vertical Lanczos (pass 2) over the ring + sRGB encode + store of output rows [yr, yr + n); weights in buffer b
+    // resolve: vertical Lanczos (pass 2) over the ring + sRGB encode + store of output rows [yr, yr + n); weights in buffer b.
+    // A wave takes 64 / TWT output rows per step (lane = column, upper half-wave = the next row when TWT == 32).
+    constexpr int RPW = 64 / TWT;
+    const int col = lane & (TWT - 1), sub = lane / TWT;
     auto resolve = [&](int yr, int n, int b) {
         if (J.ablate & 128) return;
         const float *wvb = s_wv + b * wv_sz;
         const int *fvb = s_fv + b * VRa;
         const float *wsvb = s_wsv + b * VRa, *rsvb = s_rsv + b * VRa;
-        for (int j = wave; j < n; j += A_WAVES) {
+        for (int j0 = wave * RPW; j0 < n; j0 += A_WAVES * RPW) {
+            const bool live = j0 + sub < n && col < tw;
+            const int j = j0 + sub < n ? j0 + sub : j0;  // dead lanes shadow a valid row
             const int y = yr + j;
             const int fv = fvb[j];
             float sx_ = 0.f, sy_ = 0.f, sz_ = 0.f;
             const float *wv = wvb + j;  // tap t at wv[t * VRp]
             const int s0 = (fv - R_lo) & (MR - 1);
-            if (lane >= tw || (J.ablate & 4)) {
+            if (!live || (J.ablate & 4)) {
             } else if (fv >= 0 && fv + taps_v - 1 <= sh - 1 && s0 + taps_v <= MR) {
-                const uint2 *pm = M + (size_t)s0 * TW + lane;  // the window is contiguous in the ring
+                const uint2 *pm = M + (size_t)s0 * TWT + col;  // the window is contiguous in the ring
 #pragma unroll 2
                 for (int t = 0; t < taps_v; t++) {
                     const float wgt = wv[t * VRp];
-                    const float4 m = half4_to_float4(pm[(size_t)t * TW]);
+                    const float4 m = half4_to_float4(pm[(size_t)t * TWT]);
                     sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
                 }
             } else {
                 for (int t = 0; t < taps_v; t++) {
                     const float wgt = wv[t * VRp];
                     const int r = (clampi(fv + t, 0, sh - 1) - R_lo) & (MR - 1);
-                    const float4 m = half4_to_float4(M[(size_t)r * TW + lane]);
+                    const float4 m = half4_to_float4(M[(size_t)r * TWT + col]);
                     sx_ = __builtin_fmaf(m.x, wgt, sx_); sy_ = __builtin_fmaf(m.y, wgt, sy_); sz_ = __builtin_fmaf(m.z, wgt, sz_);
                 }
             }
-            if (lane < tw) {
+            if (live) {
                 const float ws = wsvb[j], rs = rsvb[j];
                 const u32 r8 = srgb_encode8(div_cr(sx_, ws, rs), s_thr), g8 = srgb_encode8(div_cr(sy_, ws, rs), s_thr),
                           b8 = srgb_encode8(div_cr(sz_, ws, rs), s_thr);
-                *(u32 *)(J.dst.ptr + (size_t)y * J.dst.pitch + (size_t)(tx0 + lane) * 4) = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+                *(u32 *)(J.dst.ptr + (size_t)y * J.dst.pitch + (size_t)(tx0 + col) * 4) = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
             }
         }
     };
@@ -450,38 +459,70 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- horizontal Lanczos of the two rows into the f16 ring (pass 1 of the separable plan).
             //      All four channels ride in packed FMAs; alpha comes out as (sum w)/(sum w) == 1 exactly.
-            if (lane < tw) {
-                const int fh = s_fh[lane];
-                const float wsh = s_wsh[lane], rsh = s_rsh[lane];
-                float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float *wcol = s_wh + lane;
-                if (J.ablate & 2) {
-                } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
-                    // interior: no edge clamp, consecutive texels
-                    const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
+            if constexpr (TWT == 64) {
+                if (lane < tw) {  // one lane per column, both rows
+                    const int fh = s_fh[lane];
+                    const float wsh = s_wsh[lane], rsh = s_rsh[lane];
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float *wcol = s_wh + lane;
+                    if (J.ablate & 2) {
+                    } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
+                        // interior: no edge clamp, consecutive texels
+                        const float4 *pa = S + (fh - c_lo), *pb = pa + ncm;
 #pragma unroll 2
-                    for (int t = 0; t < taps_h; t++) {
-                        const float wgt = wcol[t * TW];
-                        const float4 ta = pa[t], tb = pb[t];
-                        a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
-                        a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
-                        b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
-                        b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                        for (int t = 0; t < taps_h; t++) {
+                            const float wgt = wcol[t * TWT];
+                            const float4 ta = pa[t], tb = pb[t];
+                            a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                            a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                            b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
+                            b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                        }
+                    } else {
+                        const float4 *Sa = S - c_lo, *Sb = S + ncm - c_lo;
+                        for (int t = 0; t < taps_h; t++) {
+                            const float wgt = wcol[t * TWT];
+                            const int s = clampi(fh + t, 0, sw - 1);
+                            const float4 ta = Sa[s], tb = Sb[s];
+                            a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                            a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                            b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
+                            b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
+                        }
                     }
-                } else {
-                    const float4 *Sa = S - c_lo, *Sb = S + ncm - c_lo;
-                    for (int t = 0; t < taps_h; t++) {
-                        const float wgt = wcol[t * TW];
-                        const int s = clampi(fh + t, 0, sw - 1);
-                        const float4 ta = Sa[s], tb = Sb[s];
-                        a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
-                        a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
-                        b.x = __builtin_fmaf(tb.x, wgt, b.x); b.y = __builtin_fmaf(tb.y, wgt, b.y);
-                        b.z = __builtin_fmaf(tb.z, wgt, b.z); b.w = __builtin_fmaf(tb.w, wgt, b.w);
-                    }
+                    if (y0 >= 0) M[(size_t)((y0 - R_lo) & (MR - 1)) * TWT + lane] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
+                    if (y1 <= e) M[(size_t)((y1 - R_lo) & (MR - 1)) * TWT + lane] = float4_to_half4(div_cr(b.x, wsh, rsh), div_cr(b.y, wsh, rsh), div_cr(b.z, wsh, rsh), div_cr(b.w, wsh, rsh));
                 }
-                if (y0 >= 0) M[(size_t)((y0 - R_lo) & (MR - 1)) * TW + lane] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
-                if (y1 <= e) M[(size_t)((y1 - R_lo) & (MR - 1)) * TW + lane] = float4_to_half4(div_cr(b.x, wsh, rsh), div_cr(b.y, wsh, rsh), div_cr(b.z, wsh, rsh), div_cr(b.w, wsh, rsh));
+            } else {
+                // 32-column strip: the lower half-wave filters row y0, the upper half-wave row y1
+                const int yrow = sub ? y1 : y0;
+                if (col < tw && (sub ? y1 <= e : y0 >= 0)) {
+                    const int fh = s_fh[col];
+                    const float wsh = s_wsh[col], rsh = s_rsh[col];
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const float *wcol = s_wh + col;
+                    const float4 *Srow = S + sub * ncm;
+                    if (J.ablate & 2) {
+                    } else if (fh >= 0 && fh + taps_h - 1 <= sw - 1) {
+                        const float4 *pa = Srow + (fh - c_lo);
+#pragma unroll 2
+                        for (int t = 0; t < taps_h; t++) {
+                            const float wgt = wcol[t * TWT];
+                            const float4 ta = pa[t];
+                            a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                            a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                        }
+                    } else {
+                        const float4 *Sa = Srow - c_lo;
+                        for (int t = 0; t < taps_h; t++) {
+                            const float wgt = wcol[t * TWT];
+                            const float4 ta = Sa[clampi(fh + t, 0, sw - 1)];
+                            a.x = __builtin_fmaf(ta.x, wgt, a.x); a.y = __builtin_fmaf(ta.y, wgt, a.y);
+                            a.z = __builtin_fmaf(ta.z, wgt, a.z); a.w = __builtin_fmaf(ta.w, wgt, a.w);
+                        }
+                    }
+                    M[(size_t)((yrow - R_lo) & (MR - 1)) * TWT + col] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
+                }
             }
         }
         // ---- (d) this wave's share of the rows the previous chunk completed
@@ -515,7 +556,8 @@ __global__ __launch_bounds__(A_THREADS, 4) void k_ingest_resample(const IngestAr
         const int strip = local / J.dst.h, oy0 = local - strip * J.dst.h;
         const int oy1 = min(J.dst.h, oy0 + (u_end - u));
         if (!first) __syncthreads();  // the previous piece's LDS is dead only once every wave has left it
-        ingest_strip(J, strip, oy0, oy1, tables, smem);
+        if (J.tw == 32) ingest_strip<32>(J, strip, oy0, oy1, tables, smem);
+        else ingest_strip<64>(J, strip, oy0, oy1, tables, smem);
         u += oy1 - oy0;
         first = false;
     }
@@ -530,8 +572,9 @@ int ingest_vr(float scale_v) {
 size_t ingest_lds_bytes(const IngestJob &J) {
     const size_t vra = ((size_t)J.vr + 3) & ~(size_t)3;
     const size_t vrp = J.vr <= 32 ? 32 : 64;
-    size_t floats = SMR_TABLE_FLOATS + 256 + 256 + (size_t)((J.taps_h * TW + 3) & ~3) + 3 * TW + 3 * (size_t)J.taps_v * vrp + 9 * vra;
-    size_t bytes = floats * 4 + (size_t)A_WAVES * 2 * J.nc_max * 16 + (size_t)MR * TW * 8;
+    const size_t tw = (size_t)J.tw;
+    size_t floats = SMR_TABLE_FLOATS + 256 + 256 + (((size_t)J.taps_h * tw + 3) & ~(size_t)3) + 3 * tw + 3 * (size_t)J.taps_v * vrp + 9 * vra;
+    size_t bytes = floats * 4 + (size_t)A_WAVES * 2 * J.nc_max * 16 + (size_t)MR * tw * 8;
     if (J.fast420) bytes += 2 * ((size_t)CH * raw_y_stride(J.nc_max) + 2 * (size_t)RAW_C_ROWS * raw_c_stride(J.nc_max));
     return (bytes + 15) & ~(size_t)15;
 }
@@ -574,13 +617,32 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
     J.scale_v = plan.scale[1]; J.off_v = plan.offset[1];
     J.wsum_h = wh.wsum; J.w_h = wh.w;
     J.wsum_v = wv.wsum; J.w_v = wv.w;
-    J.strips_x = ((int)tile->w + TW - 1) / TW;
-    // +1: the quad path aligns the footprint start down to an odd coordinate
-    J.nc_max = (int)ceilf((float)TW * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
-    if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
+    // strip width: 64 columns unless only the 32-column variant fits two workgroups per CU (LDS <= 80 KB each) — the source
+    // strips grow with the scale factor
     J.vr = ingest_vr(plan.scale[1]);
     if (J.vr > (int)tile->h) J.vr = (int)tile->h;
     if (J.vr > VR_MAX) J.vr = VR_MAX;
+    for (int tw : {64, 32}) {
+        J.tw = tw;
+        // +1: the quad path aligns the footprint start down to an odd coordinate
+        J.nc_max = (int)ceilf((float)tw * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
+        if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
+        if (ingest_lds_bytes(J) <= 80 * 1024) break;
+    }
+    if (ingest_lds_bytes(J) > 80 * 1024) {  // neither fits twice: the wide strip has the smaller halo
+        J.tw = 64;
+        J.nc_max = (int)ceilf(64.0f * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
+        if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
+    }
+    if (const char *force = getenv("SMR_INGEST_TW")) {  // tests / profiling: pin the strip width
+        const int tw = atoi(force);
+        if (tw == 32 || tw == 64) {
+            J.tw = tw;
+            J.nc_max = (int)ceilf((float)tw * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
+            if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
+        }
+    }
+    J.strips_x = ((int)tile->w + J.tw - 1) / J.tw;
     J.defer8 = (2 * CH + wv.taps + (int)ceilf(8.0f * fmaxf(plan.scale[1], 0.0f)) + 2 <= MR) ? 1 : 0;
     return SMR_OK;
 }

@@ -131,6 +131,32 @@ def test_nv12_and_rgba_outputs(ctx, ctx_unfused, hip):
             assert refpipe.max_diff(g, w_) <= 1
 
 
+@pytest.mark.parametrize("name,mk,iw,ih,W,H", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+def test_narrow_strip_variant_of_the_ingest_kernel(ctx, ctx_unfused, hip, monkeypatch, name, mk, iw, ih, W, H):
+    """The ingest kernel picks 32-column strips when 64-column ones no longer fit two workgroups per CU (large scale factors);
+    pinned here on every geometry: still bit-identical to the pass-per-launch path."""
+    monkeypatch.setenv("SMR_INGEST_TW", "32")
+    layouts, res = mk()
+    n_in = sum(1 for r in res if r == (iw, ih))
+    planes, _ = _inputs(ctx, hip, n_in, iw, ih)
+    _, label_host = _label_surfaces(ctx, 1)
+
+    def sources_for(c):
+        srcs, k = [], 0
+        lt = c.surface_from(label_host)
+        for r in res:
+            if r == (iw, ih):
+                srcs.append(c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[k]))); k += 1
+            else:
+                srcs.append(lt)
+        return srcs
+
+    got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
+    ref = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
+    for a, b in zip(got, ref):
+        assert (a == b).all(), name
+
+
 INPUT_FORMATS = [
     ("nv12", "FRAME_NV12", orc.YUV420),            # decoder hand-off: Y + interleaved UV (wgpu/texture/nv12.rs)
     ("yuvj420", "FRAME_PLANAR_YUVJ420", orc.YUVJ420),
