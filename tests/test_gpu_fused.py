@@ -157,6 +157,47 @@ def test_narrow_strip_variant_of_the_ingest_kernel(ctx, ctx_unfused, hip, monkey
         assert (a == b).all(), name
 
 
+@pytest.mark.parametrize("seed", range(72))
+def test_random_geometries_fused_equals_unfused(ctx, ctx_unfused, hip, seed):
+    """Random input sizes (even and odd), output sizes, fit / fill (cropping) rescalers, positions and strip widths: the fused
+    kernels must reproduce the pass-per-launch path bit for bit — footprints, crop offsets, edge clamps, ragged last strips."""
+    import os
+    rng = np.random.default_rng(1000 + seed)
+    iw, ih = int(rng.integers(8, 700)), int(rng.integers(8, 500))
+    ih = int(np.clip(ih, iw // 3, iw * 3))  # (a `fill` of an extreme aspect ratio asks for a tile beyond the maximum node size)
+    if seed % 3:
+        iw, ih = iw & ~1, ih & ~1  # the staged 4:2:0 path needs even sizes; odd ones take the direct-sampling branch
+    iw, ih = max(iw, 2), max(ih, 2)
+    W, H = int(rng.integers(8, 300)) * 4, int(rng.integers(8, 250)) * 2
+    n = int(rng.integers(1, 4))
+    kids = []
+    for i in range(n):
+        w, h = float(rng.integers(4, W)), float(rng.integers(4, H))
+        kids.append({"type": "rescaler", "mode": str(rng.choice(["fit", "fill"])), "width": w, "height": h,
+                     "top": float(rng.integers(0, max(1, H - int(h)))), "left": float(rng.integers(0, max(1, W - int(w)))),
+                     "horizontal_align": str(rng.choice(["left", "center", "right"])), "vertical_align": str(rng.choice(["top", "center", "bottom"])),
+                     "child": {"type": "input_stream", "input_id": f"in{i}"}})
+    scene = {"type": "view", "background_color": "#102030FF", "children": kids}
+    from smelter_amd.scene import Scene
+    sc = Scene()
+    sc.update(scene, W, H)
+    layouts = sc.layouts(0, 0, [(iw, ih)] * n)
+    planes = [scenes.random_yuv420(iw, ih, 77 + seed * 10 + i) for i in range(n)]
+    planes = [(y, u[: ih // 2, : iw // 2], v[: ih // 2, : iw // 2]) for y, u, v in planes]
+
+    def frames(c):
+        return [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes]
+
+    os.environ["SMR_INGEST_TW"] = "32" if seed % 2 else "64"
+    try:
+        got = _render(ctx, hip, layouts, frames(ctx), W, H)
+    finally:
+        del os.environ["SMR_INGEST_TW"]
+    ref = _render(ctx_unfused, hip, layouts, frames(ctx_unfused), W, H)
+    for a, b in zip(got, ref):
+        assert (a == b).all(), (seed, iw, ih, W, H, scene)
+
+
 INPUT_FORMATS = [
     ("nv12", "FRAME_NV12", orc.YUV420),            # decoder hand-off: Y + interleaved UV (wgpu/texture/nv12.rs)
     ("yuvj420", "FRAME_PLANAR_YUVJ420", orc.YUVJ420),
