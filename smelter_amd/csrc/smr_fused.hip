@@ -148,9 +148,13 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
 
     // ---- parameters -> device (one pinned staging slot, one copy)
+    const u32 b_tiles_x = (out_w + B_TILE_W - 1) / B_TILE_W, b_tiles_y = (out_h + B_TILE_H - 1) / B_TILE_H;
+    const u32 b_tiles = b_tiles_x * b_tiles_y;
+    const size_t order_bytes = sizeof(ComposeOrder) + (size_t)((b_tiles + 31) / 32) * 4;
     PackedLayouts packed;
-    int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, 0, &packed);
+    int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes, &packed);
     if (rc != SMR_OK) return rc;
+    const u32 n_first = compose_order(packed, (int)b_tiles_x, (int)b_tiles_y, (ComposeOrder *)packed.extra_host);
     rc = smr_pack_commit(ctx, &packed);
     if (rc != SMR_OK) return rc;
 
@@ -167,14 +171,18 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                           (out->format == SMR_FRAME_NV12 || out->planes[2]);
     if (fuse_out) {
         StageScope scope(ctx, SMR_STAGE_FUSED_COMPOSE);
-        dim3 grid((out_w + B_TILE_W - 1) / B_TILE_W, (out_h + B_TILE_H - 1) / B_TILE_H, 1);
+        // 1-D grid: the tiles the host expects to need the (latency-bound) general path go first, then every tile in order
+        dim3 grid(n_first + b_tiles, 1, 1);
+        const ComposeOrder *order = (const ComposeOrder *)packed.extra_dev;
         SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
         if (out->format == SMR_FRAME_NV12) {
             hipLaunchKernelGGL(k_compose_output<1>, grid, dim3(256), 0, ctx->stream, yp, up, up, (int)out_w, (int)out_h, packed.layouts,
-                               packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables);
+                               packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables, order,
+                               (int)b_tiles_x);
         } else {
             hipLaunchKernelGGL(k_compose_output<0>, grid, dim3(256), 0, ctx->stream, yp, up, view_of(out->planes[2]), (int)out_w, (int)out_h,
-                               packed.layouts, packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables);
+                               packed.layouts, packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables,
+                               order, (int)b_tiles_x);
         }
         SMR_HIP(ctx, hipGetLastError());
         return smr_pack_done(ctx, &packed);

@@ -23,6 +23,88 @@ constexpr int B_MAX_LAYOUTS = 48;             // LDS-resident layout list (large
 constexpr int B_MAX_MASKS = 96;
 static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS copies move 16 B words");
 
+// Launch order of the tiles (rides behind the layout list in the parameter slot).  The few tiles that take the general path
+// are latency-bound (one wave per SIMD, ~25 us each); started last they are the tail of the kernel, started first they
+// overlap the copy tiles.  The host predicts them from the layout geometry — only the order depends on the prediction,
+// every workgroup still classifies its tile itself.
+constexpr u32 B_MAX_FIRST = 1024;
+struct ComposeOrder {
+    u32 n_first;             // workgroups [0, n_first) take first[]; workgroup n_first + t takes tile t unless it is in `taken`
+    u16 first[B_MAX_FIRST];  // linear tile indices
+    u32 taken[1];            // bitmap over all tiles (really (tiles + 31) / 32 words)
+};
+
+// Host: tiles likely to need the general path.  A layer that can never be a tile's copy layer (translucent colour, texture
+// that is not an aligned opaque blit, rotated quad) marks its whole pixel box; a copy-capable layer marks the corner squares
+// of its rounded rect and of its masks, and the bands along its edges where border / blur / fractional coordinates keep the
+// fragment from being the base value.
+inline u32 compose_order(const PackedLayouts &p, int tiles_x, int tiles_y, ComposeOrder *out) {
+    const int tiles = tiles_x * tiles_y, words = (tiles + 31) / 32;
+    out->n_first = 0;
+    for (int i = 0; i < words; i++) out->taken[i] = 0u;
+    if (tiles > 65535) return 0;
+    auto mark = [&](float x0, float y0, float x1, float y1) {  // pixel-space box, clipped to the tile grid
+        int tx0 = (int)floorf(x0 / (float)B_TILE_W), tx1 = (int)floorf(x1 / (float)B_TILE_W);
+        int ty0 = (int)floorf(y0 / (float)B_TILE_H), ty1 = (int)floorf(y1 / (float)B_TILE_H);
+        tx0 = tx0 < 0 ? 0 : tx0; ty0 = ty0 < 0 ? 0 : ty0;
+        tx1 = tx1 >= tiles_x ? tiles_x - 1 : tx1; ty1 = ty1 >= tiles_y ? tiles_y - 1 : ty1;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const int t = ty * tiles_x + tx;
+                out->taken[t >> 5] |= 1u << (t & 31);
+            }
+    };
+    auto corners = [&](float left, float top, float w, float h, float c, const DevLayout &L) {
+        if (!(c > 0.0f)) return;
+        const float bx0 = (float)L.bx0, by0 = (float)L.by0, bx1 = (float)L.bx1 - 1.0f, by1 = (float)L.by1 - 1.0f;  // only where L draws
+        const float xs[2][2] = {{left, left + c}, {left + w - c, left + w}}, ys[2][2] = {{top, top + c}, {top + h - c, top + h}};
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 2; b++) {
+                const float x0 = fmaxf(xs[a][0], bx0), x1 = fminf(xs[a][1], bx1), y0 = fmaxf(ys[b][0], by0), y1 = fminf(ys[b][1], by1);
+                if (x0 <= x1 && y0 <= y1) mark(x0, y0, x1, y1);
+            }
+    };
+    for (int i = 0; i < p.n; i++) {
+        const DevLayout &L = p.host_layouts[i];
+        if (L.bx1 <= L.bx0 || L.by1 <= L.by0) continue;
+        const bool copy_capable = (L.flags & DL_UNROTATED) && (L.type == 0 ? ((L.flags & DL_ALIGNED) && L.src_kind == 2) : (L.flags & DL_COLOR_OPAQUE) != 0);
+        if (!copy_capable) {
+            mark((float)L.bx0, (float)L.by0, (float)L.bx1 - 1.0f, (float)L.by1 - 1.0f);
+            continue;
+        }
+        corners(L.left, L.top, L.width, L.height, L.corner, L);
+        for (u32 m = 0; m < L.masks_len; m++) {
+            const DevMask &K = p.host_masks[L.masks_off + m];
+            corners(K.left, K.top, K.width, K.height, K.corner, L);
+            // a mask edge that cuts through the layer leaves a band of partially covered / uncovered pixels
+            if (K.left > L.left || K.top > L.top || K.left + K.width < L.left + L.width || K.top + K.height < L.top + L.height)
+                mark((float)L.bx0, (float)L.by0, (float)L.bx1 - 1.0f, (float)L.by1 - 1.0f);
+        }
+        if (L.inset != 0.5f) {  // border, blur or fractional coordinates: bands along the four edges
+            const float d = ceilf(L.inset);
+            const float x0 = (float)L.bx0, y0 = (float)L.by0, x1 = (float)L.bx1 - 1.0f, y1 = (float)L.by1 - 1.0f;
+            mark(x0, y0, x1, fminf(y0 + d, y1)); mark(x0, fmaxf(y1 - d, y0), x1, y1);
+            mark(x0, y0, fminf(x0 + d, x1), y1); mark(fmaxf(x1 - d, x0), y0, x1, y1);
+        }
+    }
+    u32 nf = 0;
+    for (int w = 0; w < words && nf <= B_MAX_FIRST; w++) {
+        u32 bits = out->taken[w];
+        while (bits) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            if (nf < B_MAX_FIRST) out->first[nf] = (u16)(w * 32 + b);
+            nf++;
+        }
+    }
+    if (nf > B_MAX_FIRST) {  // too many to matter: plain order
+        for (int i = 0; i < words; i++) out->taken[i] = 0u;
+        nf = 0;
+    }
+    out->n_first = nf;
+    return nf;
+}
+
 __device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int *s_start, const DevLayout *__restrict__ layouts,
                                                  const DevMask *__restrict__ masks, int n, int x0, int y0, int x1, int y1, int tid,
                                                  int nthreads) {
@@ -102,7 +184,8 @@ __device__ __forceinline__ u32 compose_px(u32 a, const DevLayout &L, const DevMa
 template <int NV>
 __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
                                                         const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
-                                                        int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables) {
+                                                        int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
+                                                        const ComposeOrder *__restrict__ order, int tiles_x) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;
     __shared__ float s_tab[SMR_TABLE_FLOATS];
@@ -112,6 +195,10 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
     __shared__ __attribute__((aligned(16))) DevMask s_mask[B_MAX_MASKS];
     const int tid = threadIdx.x;
+    // which tile: the host's "general path first" list, then every tile not in it, in row-major order
+    int tile = (int)blockIdx.x - (int)order->n_first;
+    if (tile < 0) tile = order->first[blockIdx.x];
+    else if ((order->taken[tile >> 5] >> (tile & 31)) & 1u) return;
     {
         const uint4 *gl = (const uint4 *)layouts_g;
         uint4 *ll = (uint4 *)s_lay;
@@ -125,7 +212,8 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     const int srgb = srgb_and_ablate & 1;
     const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
     if (ablate & 1) return;
-    const int tx0 = blockIdx.x * B_TILE_W, ty0 = blockIdx.y * B_TILE_H;
+    const int tile_y = tile / tiles_x;
+    const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H;
     if (tid == 0) s_general = 0;
     classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + B_TILE_H, H), tid, 256);
     const int start = s_start;

@@ -197,6 +197,7 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
     out->layouts = (const DevLayout *)slot.dev;
     out->masks = (const DevMask *)((u8 *)slot.dev + lay_bytes);
     out->host_layouts = hl;
+    out->host_masks = hm;
     out->n = (int)n;
     out->n_masks = (int)mo;
     out->slot = &slot;

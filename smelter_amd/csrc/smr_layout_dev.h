@@ -61,6 +61,7 @@ struct PackedLayouts {
     const DevLayout *layouts = nullptr;  // device
     const DevMask *masks = nullptr;      // device
     DevLayout *host_layouts = nullptr;   // pinned host copy (valid until the slot is reused)
+    DevMask *host_masks = nullptr;
     int n = 0;
     int n_masks = 0;
     LayoutSlot *slot = nullptr;
