@@ -320,6 +320,35 @@ def main():
             result["pcie_inclusive"] = {"frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3),
                                         "host_bytes_per_frame": moved, "GBps": round(moved / dt / 1e9, 2),
                                         "note": "pageable host buffers, blocking copies, 1 frame in flight"}
+            # the same with pinned host buffers and stream-ordered copies (smr_host_alloc / smr_frame_*_async), two frames in
+            # flight on two renderers: frame k+1's upload overlaps frame k's kernels and read-back
+            k_lanes = min(2, len(lanes))
+            pin_in = [[lanes[k].frame(hip.FRAME_PLANAR_YUV420, IN_W, IN_H) for _ in range(N_IN)] for k in range(k_lanes)]
+            pin_host = [[f.pinned_planes() for f in pin_in[k]] for k in range(k_lanes)]
+            for k in range(k_lanes):
+                for i in range(N_IN):
+                    for dst, src in zip(pin_host[k][i], host_planes[i]):
+                        dst[...] = src
+            pin_sets = [renderers[k].make_frame_set({f"input_{i}": pin_in[k][i] for i in range(N_IN)}) for k in range(k_lanes)]
+            out_host = [None] * k_lanes
+            t1 = time.perf_counter()
+            reps = 200
+            for s in range(reps):
+                k = s % k_lanes
+                lanes[k].sync()  # the lane's previous frame (its host buffers are free again)
+                for i in range(N_IN):
+                    pin_in[k][i].upload_async(pin_host[k][i])
+                renderers[k].render_packed(s * FRAME_NS, pin_sets[k])
+                of = BorrowedFrame(lanes[k], renderers[k]._outs[0].frame.contents)
+                if out_host[k] is None:
+                    out_host[k] = of.pinned_planes()
+                of.download_async(out_host[k])
+            for k in range(k_lanes):
+                lanes[k].sync()
+            dt = (time.perf_counter() - t1) / reps
+            result["pcie_inclusive_pinned"] = {"frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3),
+                                               "GBps": round(moved / dt / 1e9, 2),
+                                               "note": f"pinned host buffers, stream-ordered copies, {k_lanes} frames in flight"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(layouts, res)
 

@@ -179,6 +179,13 @@ SMR_API int smr_frame_create(smr_ctx *ctx, uint32_t format, uint32_t w, uint32_t
 SMR_API void smr_frame_destroy(smr_ctx *ctx, smr_frame *f);
 SMR_API int smr_frame_upload(smr_ctx *ctx, const smr_frame *f, const void *const host_planes[3]);
 SMR_API int smr_frame_download(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]);
+/* Pinned host memory and stream-ordered copies (no staging, no implicit synchronisation): what replaces the reference's
+ * queue.write_texture staging (input_texture.rs:69-201) and the padded read-back + repack (output_texture.rs:68-113) for hosts
+ * that can keep frames in buffers from smr_host_alloc.  Host buffers must stay untouched until smr_sync has returned. */
+SMR_API int smr_host_alloc(smr_ctx *ctx, size_t bytes, void **out);
+SMR_API void smr_host_free(smr_ctx *ctx, void *p);
+SMR_API int smr_frame_upload_async(smr_ctx *ctx, const smr_frame *f, const void *const host_planes[3]);
+SMR_API int smr_frame_download_async(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]);
 
 /* ---- a3: InputTexture::convert_to_node_texture (input_texture.rs:203-219) ---------
  * wgpu/format/{planar_yuv,nv12,interleaved_uyvy,interleaved_yuyv,bgra,argb}_to_rgba.{rs,wgsl};

@@ -28,6 +28,7 @@ EXPORTS = [
     "smr_surface_create", "smr_surface_wrap", "smr_surface_destroy", "smr_surface_info_get", "smr_surface_upload",
     "smr_surface_download", "smr_surface_clear",
     "smr_frame_create", "smr_frame_destroy", "smr_frame_upload", "smr_frame_download",
+    "smr_host_alloc", "smr_host_free", "smr_frame_upload_async", "smr_frame_download_async",
     "smr_frame_to_rgba", "smr_add_premultiplied_alpha", "smr_remove_premultiplied_alpha",
     "smr_rgba_to_frame", "smr_frame_fill_black",
     "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear",
@@ -147,6 +148,10 @@ def load():
         "smr_frame_destroy": ([P, C.POINTER(Frame)], None),
         "smr_frame_upload": ([P, C.POINTER(Frame), PP], I),
         "smr_frame_download": ([P, C.POINTER(Frame), PP], I),
+        "smr_host_alloc": ([P, C.c_size_t, PP], I),
+        "smr_host_free": ([P, P], None),
+        "smr_frame_upload_async": ([P, C.POINTER(Frame), PP], I),
+        "smr_frame_download_async": ([P, C.POINTER(Frame), PP], I),
         "smr_frame_to_rgba": ([P, C.POINTER(Frame), P], I),
         "smr_add_premultiplied_alpha": ([P, P, P], I),
         "smr_remove_premultiplied_alpha": ([P, P, P], I),

@@ -406,6 +406,40 @@ int smr_frame_upload(smr_ctx *ctx, const smr_frame *f, const void *const host_pl
     return SMR_OK;
 }
 
+// Pinned host memory + stream-ordered copies: the zero-staging variant of InputTexture::upload / download_buffer for hosts that
+// can place decoder output / encoder input in buffers from smr_host_alloc.  The copies are enqueued on the ctx stream and
+// return at once; the host buffers must stay untouched until smr_sync (or a later blocking call) has returned.
+int smr_host_alloc(smr_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out || !bytes) return SMR_ERR_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return smr_fail(ctx, SMR_ERR_OOM, "smr_host_alloc: %zu B of pinned memory", bytes);
+    return SMR_OK;
+}
+void smr_host_free(smr_ctx *ctx, void *p) {
+    (void)ctx;
+    if (p) (void)hipHostFree(p);
+}
+static int frame_copy_async(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3], bool to_device, const char *what) {
+    if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
+    u32 pw[3], ph[3], pf[3];
+    int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);
+    for (int i = 0; i < n; i++) {
+        if (!f->planes[i] || !host_planes[i]) return smr_fail(ctx, SMR_ERR_INVALID, "%s: missing plane %d", what, i);
+        if (pw[i] == 0 || ph[i] == 0) continue;
+        const smr_surface *s = f->planes[i];
+        size_t row = (size_t)pw[i] * bytes_per_px(pf[i]);
+        if (to_device) SMR_HIP(ctx, hipMemcpy2DAsync(s->ptr, s->pitch, host_planes[i], row, row, ph[i], hipMemcpyHostToDevice, ctx->stream));
+        else SMR_HIP(ctx, hipMemcpy2DAsync(host_planes[i], row, s->ptr, s->pitch, row, ph[i], hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return SMR_OK;
+}
+int smr_frame_upload_async(smr_ctx *ctx, const smr_frame *f, const void *const host_planes[3]) {
+    return frame_copy_async(ctx, f, (void *const *)host_planes, true, "smr_frame_upload_async");
+}
+int smr_frame_download_async(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]) {
+    return frame_copy_async(ctx, f, host_planes, false, "smr_frame_download_async");
+}
+
 int smr_frame_download(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]) {
     if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
     u32 pw[3], ph[3], pf[3];

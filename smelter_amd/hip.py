@@ -98,6 +98,19 @@ class DeviceFrame:
         self.ctx._check(self.ctx.lib.smr_frame_download(self.ctx.handle, C.byref(self.c), ptrs))
         return outs
 
+    def pinned_planes(self) -> List[np.ndarray]:
+        """Host plane buffers in pinned memory (smr_host_alloc), shaped like this frame's planes; freed with the context."""
+        return [self.ctx.host_array(s) for s in self.plane_shapes()]
+
+    def upload_async(self, pinned: Sequence[np.ndarray]):
+        """Stream-ordered copy from pinned host planes: returns at once, the buffers must stay untouched until ctx.sync()."""
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in pinned] + [None] * (3 - len(pinned)))
+        self.ctx._check(self.ctx.lib.smr_frame_upload_async(self.ctx.handle, C.byref(self.c), ptrs))
+
+    def download_async(self, pinned: Sequence[np.ndarray]):
+        ptrs = (C.c_void_p * 3)(*[p.ctypes.data for p in pinned] + [None] * (3 - len(pinned)))
+        self.ctx._check(self.ctx.lib.smr_frame_download_async(self.ctx.handle, C.byref(self.c), ptrs))
+
     def destroy(self):
         self.ctx.lib.smr_frame_destroy(self.ctx.handle, C.byref(self.c))
 
@@ -134,6 +147,7 @@ class Context:
         self.handle = h
         self.mode = mode
         self.device = device
+        self._pinned = []
 
     # -- plumbing
     def _check(self, rc: int) -> int:
@@ -143,8 +157,19 @@ class Context:
 
     def close(self):
         if self.handle:
+            for p in self._pinned:
+                self.lib.smr_host_free(self.handle, p)
+            self._pinned = []
             self.lib.smr_ctx_destroy(self.handle)
             self.handle = None
+
+    def host_array(self, shape) -> np.ndarray:
+        """uint8 array in pinned host memory (smr_host_alloc); lives until close()."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        self._check(self.lib.smr_host_alloc(self.handle, max(n, 1), C.byref(p)))
+        self._pinned.append(p)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n, 1),))[:n].reshape(shape)
 
     def sync(self):
         self._check(self.lib.smr_sync(self.handle))

@@ -195,6 +195,23 @@ def test_non_layout_root_and_empty_output(ctx, hip, renderer):
     assert set(renderer.render(0.0, frames)) == {"direct"}
 
 
+def test_pinned_async_transfers_round_trip(ctx, hip):
+    """smr_host_alloc + smr_frame_upload_async / _download_async: stream-ordered, byte-exact, every plane shape."""
+    rng = np.random.default_rng(5)
+    for fmt, w, h in [(hip.FRAME_PLANAR_YUV420, 322, 182), (hip.FRAME_NV12, 640, 360), (hip.FRAME_PLANAR_YUV444, 65, 33)]:
+        f = ctx.frame(fmt, w, h)
+        src, dst = f.pinned_planes(), f.pinned_planes()
+        for p in src:
+            p[...] = rng.integers(0, 256, p.shape, dtype=np.uint8)
+        f.upload_async(src)
+        f.download_async(dst)
+        ctx.sync()
+        for a, b in zip(src, dst):
+            assert (a == b).all()
+        for a, b in zip(f.download(), src):
+            assert (a == b).all()
+
+
 def test_scene_errors_surface_through_the_renderer(renderer):
     from smelter_amd.scene import SceneError
     with pytest.raises(SceneError) as e:
