@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-frames", type=int, default=500)
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight on one GPU (renderer contexts / HIP streams)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (ingest per shard, gather, compose) with the ranks given")
     ap.add_argument("--transfers", action="store_true", help="also time host buffers in -> host buffers out (PCIe inclusive, informational)")
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3],
                     help="BASELINE.json configs[] index: 2 = the metric's 8x1080p -> 4K (default, the judged line); "
@@ -159,7 +160,8 @@ def main():
     # Multi-GPU: the renderer enqueues on the same (non-default) torch stream the RCCL send/recv calls are issued under, so a
     # tile is sent only after the ingest kernel that writes it and composed only after it has arrived.  (The default stream's
     # handle is 0, which smr_ctx_create reads as "create your own stream" — hence an explicit side stream.)
-    side = torch.cuda.Stream() if world > 1 else None
+    single = world == 1 and not args.force_sharded  # --force-sharded: the N > 1 code path with world_size 1 (no exchange), for tests
+    side = torch.cuda.Stream() if not single else None
     if side is not None:
         torch.cuda.set_stream(side)
     ctx = hip.Context(local_rank, stream=side.cuda_stream if side is not None else None)
@@ -170,16 +172,16 @@ def main():
     plan = smr_dist.ShardPlan(n_inputs=N_IN, world=world)
     my_inputs = plan.inputs_of(rank)
     ring = make_inputs(ctx, hip, RING, my_inputs)
-    n_lanes = max(1, args.inflight) if world == 1 else 1
+    n_lanes = max(1, args.inflight) if single else 1
     # (single GPU: every renderer owns two alternating output frames; sharded path: the root's two)
-    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2)] if rank == 0 and world > 1 else []
+    outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2)] if rank == 0 and not single else []
 
     def out_for(step):
         return outs[step % 2]
     input_source_slot = [i for i, r in enumerate(res) if r == (IN_W, IN_H)]  # source index of input k
 
     lanes = [ctx]
-    if world == 1:
+    if single:
         # The whole per-frame path of the reference's Renderer::render (state.rs:220-252) is inside a step: frame set ->
         # populate_inputs -> layout maths at this pts (scene engine) -> parameter pack -> ingest + compose kernels -> output frame.
         # Frames in flight: consecutive frames go to separate renderers (own context / HIP stream / scratch / output frames), so
@@ -245,15 +247,15 @@ def main():
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
                        "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
                        "per_frame_host_work": "smr_renderer_render: frame set -> layout maths at pts (C++ scene engine) -> parameter pack -> 2 kernels"
-                       if world == 1 else "pre-flattened layout list (scene engine, once) -> ingest per shard -> gather -> compose",
-                       "parallelism": "single GPU" if world == 1 else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
+                       if single else "pre-flattened layout list (scene engine, once) -> ingest per shard -> gather -> compose",
+                       "parallelism": "single GPU" if single else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
             "frame": {"algorithmic_bytes": ALGO_BYTES_PER_FRAME, "achieved_GBps": round(ALGO_BYTES_PER_FRAME * fps / 1e9, 2),
                       "frac_of_hbm_peak": round(ALGO_BYTES_PER_FRAME * fps / 1e9 / HBM_PEAK_GBPS, 5)},
         }
 
     # ---- per-kernel timing with HIP events on the ctx stream (outside the timed region: per-launch events
     #      serialise the pipeline), then the dominant kernel's roofline entry
-    if world == 1:
+    if single:
         ctx.profile_reset()
         ctx.profile_enable(True)
         for s in range(min(args.steps, 200)):
@@ -351,13 +353,41 @@ def main():
                                                "note": f"pinned host buffers, stream-ordered copies, {k_lanes} frames in flight"}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(layouts, res)
+    else:
+        # N > 1: every rank runs a few more steps with per-launch HIP events on; rank 0 reports the kernels of the root
+        # (its own shard's ingest + the compose of the gathered tiles) and the dominant one's roofline entry
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for s in range(40):
+            step_fn(s)
+        barrier()
+        prof = ctx.profile_read()
+        ctx.profile_enable(False)
+        if rank == 0:
+            stages = {k: {"avg_us": round(1000.0 * ms / n, 3), "launches": n} for k, (ms, n) in prof.items() if n}
+            tile_px = {}
+            for L in layouts:
+                if L.type == 0 and res[L.source_index] == (IN_W, IN_H):
+                    tile_px[L.source_index] = max(int(np.floor(L.width + 0.5)), 1) * max(int(np.floor(L.height + 0.5)), 1) * 4
+            tile_bytes = sum(tile_px.values())
+            local_tiles = sum(tile_px[input_source_slot[i]] for i in my_inputs if input_source_slot[i] in tile_px)
+            kernel_bytes = {"fused_ingest_resample": len(my_inputs) * yuv420_bytes(IN_W, IN_H) + local_tiles,
+                            "fused_compose_output": tile_bytes + yuv420_bytes(OUT_W, OUT_H)}
+            dom = max((k for k in stages if k in kernel_bytes), key=lambda k: stages[k]["avg_us"], default=None)
+            if dom is not None:
+                ach = kernel_bytes[dom] / (stages[dom]["avg_us"] * 1e-6) / 1e9
+                result["roofline"] = {"bound": "hbm", "kernel": {"fused_ingest_resample": "k_ingest_resample", "fused_compose_output": "k_compose_output"}[dom],
+                                      "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                                      "bytes_per_launch": kernel_bytes[dom], "avg_launch_us": stages[dom]["avg_us"], "traffic": None,
+                                      "rank": 0}
+            result["kernels"] = stages
 
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if world == 1:
+    if single:
         for r in renderers:
             r.close()
     for c in lanes[1:]:

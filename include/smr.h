@@ -137,7 +137,13 @@ typedef struct smr_glyph {
 } smr_glyph;
 
 /* Source of a texture layout for the fused render entry point. */
-typedef enum smr_source_kind { SMR_SOURCE_NONE = 0, SMR_SOURCE_SURFACE = 1, SMR_SOURCE_FRAME = 2 } smr_source_kind;
+typedef enum smr_source_kind {
+    SMR_SOURCE_NONE = 0,
+    SMR_SOURCE_SURFACE = 1,
+    SMR_SOURCE_FRAME = 2,
+    SMR_SOURCE_OPAQUE_SURFACE = 3 /* an RGBA8 surface the caller knows to be alpha == 255 everywhere (e.g. a tile produced by
+                                     smr_ingest_resample on another GPU): lets the compositor treat it as a base layer */
+} smr_source_kind;
 typedef struct smr_source {
     uint32_t kind;
     const smr_surface *surface; /* RGBA8 node surface (text, image, shader output, ...) */
@@ -233,6 +239,9 @@ SMR_API int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint32_t
  * (input_texture.rs:203-219) + ResampledChild::render (resampler.rs:305-378) in one step, frame -> dst-sized
  * RGBA8 tile.  Returns the plan kind (0 = direct: dst untouched) or a negative status. */
 SMR_API int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const float crop[4], smr_surface *dst);
+/* All inputs of a shard in one launch: crops = n x {top, left, width, height}; kinds[i] (optional) = plan kind of input i. */
+SMR_API int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, const float *crops, smr_surface *const *dst, uint32_t n,
+                                      int *kinds);
 
 /* ---- a12: text node blit (transformations/text_renderer.rs:72-167) ----------------- */
 SMR_API int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const smr_glyph *glyphs, uint32_t n,

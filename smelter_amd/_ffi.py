@@ -18,7 +18,7 @@ PX_RGBA8, PX_RGBA16F, PX_R8, PX_RG8 = 0, 1, 2, 3
  FRAME_NV12, FRAME_BGRA, FRAME_ARGB, FRAME_RGBA) = range(10)
 MAX_MASKS = 20
 NO_SOURCE = 0xFFFFFFFF
-SOURCE_NONE, SOURCE_SURFACE, SOURCE_FRAME = 0, 1, 2
+SOURCE_NONE, SOURCE_SURFACE, SOURCE_FRAME, SOURCE_OPAQUE_SURFACE = 0, 1, 2, 3
 SHADER_GAUSSIAN_BLUR = 0
 
 # every symbol include/smr.h declares (checked by tests/test_abi.py without a GPU)
@@ -32,7 +32,7 @@ EXPORTS = [
     "smr_frame_to_rgba", "smr_add_premultiplied_alpha", "smr_remove_premultiplied_alpha",
     "smr_rgba_to_frame", "smr_frame_fill_black",
     "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear",
-    "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_blit_glyphs", "smr_builtin_shader",
+    "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_ingest_resample_batch", "smr_blit_glyphs", "smr_builtin_shader",
     "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update", "smr_scene_parse",
     "smr_scene_node_count", "smr_scene_node_info", "smr_scene_node_children", "smr_scene_node_layouts",
     "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color", "smr_ctx_mode",
@@ -165,6 +165,7 @@ def load():
         "smr_apply_layouts": ([P, P, C.POINTER(Layout), U, PP, U], I),
         "smr_render_layouts": ([P, C.POINTER(Layout), U, C.POINTER(Source), U, U, U, C.POINTER(Frame), P], I),
         "smr_ingest_resample": ([P, C.POINTER(Frame), C.POINTER(F), P], I),
+        "smr_ingest_resample_batch": ([P, C.POINTER(C.POINTER(Frame)), C.POINTER(F), PP, U, C.POINTER(I)], I),
         "smr_blit_glyphs": ([P, P, C.POINTER(F), C.POINTER(Glyph), U, P, U, U], I),
         "smr_builtin_shader": ([P, U, P, C.c_size_t, PP, U, P, F], I),
         "smr_scene_create": ([PP], I),

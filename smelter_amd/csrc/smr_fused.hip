@@ -68,10 +68,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<u8> node_ready(n_sources + 1, 0);
     for (u32 i = 0; i < n_sources; i++) {
         const smr_source &s = sources[i];
-        if (s.kind == SMR_SOURCE_SURFACE && s.surface) {
+        if ((s.kind == SMR_SOURCE_SURFACE || s.kind == SMR_SOURCE_OPAQUE_SURFACE) && s.surface) {
             if (s.surface->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: source %u is not RGBA8", i);
             views[i] = view_of(s.surface);
-            kinds[i] = 1;
+            kinds[i] = s.kind == SMR_SOURCE_OPAQUE_SURFACE ? 2 : 1;
             src_w[i] = (int)s.surface->w;
             src_h[i] = (int)s.surface->h;
             node_ready[i] = 1;
@@ -79,7 +79,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             kinds[i] = frame_is_opaque(s.frame->format) ? 2 : 1;  // view filled lazily by ensure_node
             src_w[i] = (int)s.frame->width;
             src_h[i] = (int)s.frame->height;
-        } else if (s.kind != SMR_SOURCE_NONE && s.kind > SMR_SOURCE_FRAME) {
+        } else if (s.kind != SMR_SOURCE_NONE && s.kind > SMR_SOURCE_OPAQUE_SURFACE) {
             return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: bad source kind %u", s.kind);
         }
     }
@@ -221,4 +221,36 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
     int rc = smr_frame_to_rgba(ctx, in, node);
     if (rc != SMR_OK) return rc;
     return smr_resample(ctx, node, crop, dst);
+}
+
+// The same for all inputs of a shard at once: every fusable input rides in one launch of wave A (its rows are balanced over
+// the blocks together), the others go one by one.  kinds[i] receives the plan kind of input i (0 = direct: dst untouched).
+extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, const float *crops, smr_surface *const *dst, uint32_t n,
+                                         int *kinds) {
+    if (!ctx || (n && (!in || !crops || !dst))) return SMR_ERR_INVALID;
+    if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
+    std::vector<IngestJob> jobs;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!in[i] || !dst[i] || dst[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: bad input %u", i);
+        const float *crop = crops + 4 * i;
+        smr_resample_plan plan;
+        int kind = smr_resample_plan_make(in[i]->width, in[i]->height, crop, dst[i]->w, dst[i]->h, &plan);
+        if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample_batch: degenerate plan for input %u", i);
+        if (kinds) kinds[i] = kind;
+        if (kind == 0) continue;
+        if (!fused_disabled(ctx) && can_fuse_ingest(in[i], plan)) {
+            IngestJob J;
+            int rc = make_ingest_job(ctx, in[i], plan, dst[i], &J);
+            if (rc != SMR_OK) return rc;
+            jobs.push_back(J);
+        } else {
+            int rc = smr_ingest_resample(ctx, in[i], crop, dst[i]);
+            if (rc < 0) return rc;
+        }
+    }
+    if (!jobs.empty()) {
+        int rc = launch_ingest(ctx, jobs);
+        if (rc != SMR_OK) return rc;
+    }
+    return SMR_OK;
 }

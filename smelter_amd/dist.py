@@ -93,6 +93,10 @@ class ShardedCompositor:
             self.tiles[k] = t
             if ctx is not None:
                 self.tile_surfaces[k] = ctx.wrap(t.data_ptr(), pitch_of(dw), dw, dh)
+                # tiles come out of the resampler with alpha == 255 (planar YUV / NV12 inputs): the compositor may use them
+                # as base layers (SMR_SOURCE_OPAQUE_SURFACE) exactly as it does with the raw frames on a single GPU
+                self.tile_surfaces[k].opaque = True
+        self.batched = ingest_fn is None and ctx is not None  # default device path: all local inputs in one launch
         self.ingest_fn = ingest_fn or self._ingest
         self.compose_fn = compose_fn or self._compose
         if rank == plan.root:
@@ -119,8 +123,14 @@ class ShardedCompositor:
         self.ctx.render_layouts(self.root_layouts, srcs, out.w, out.h, out=out, packed=self.root_packed)
 
     def step(self, frames_row: Dict[int, object], out):
-        for k in self.plan.inputs_of(self.rank):
-            if k in self.tile_geom:
+        mine = [k for k in self.plan.inputs_of(self.rank) if k in self.tile_geom]
+        if self.batched:
+            kinds = self.ctx.ingest_resample_batch([frames_row[k] for k in mine], [self.tile_geom[k][2] for k in mine],
+                                                   [self.tile_surfaces[k] for k in mine])
+            if any(kd == 0 for kd in kinds):
+                raise RuntimeError("sharded path expects scaled inputs (direct 1:1 inputs need no resample shard)")
+        else:
+            for k in mine:
                 self.ingest_fn(k, frames_row[k], self.tiles[k])
         gather_tiles(self.dist, self.plan, self.rank, self.tiles)
         if self.rank == self.plan.root:

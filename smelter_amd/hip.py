@@ -281,11 +281,21 @@ class Context:
                 srcs[i].kind = _ffi.SOURCE_FRAME
                 srcs[i].frame = C.pointer(s.c)
             else:
-                srcs[i].kind = _ffi.SOURCE_SURFACE
+                srcs[i].kind = _ffi.SOURCE_OPAQUE_SURFACE if getattr(s, "opaque", False) else _ffi.SOURCE_SURFACE
                 srcs[i].surface = s.handle
         self._check(self.lib.smr_render_layouts(self.handle, arr, n, srcs, len(sources), out_w, out_h,
                                                 C.byref(out.c) if out is not None else None,
                                                 out_rgba.handle if out_rgba is not None else None))
+
+    def ingest_resample_batch(self, frames: Sequence[DeviceFrame], crops, dsts: Sequence[Surface]) -> List[int]:
+        """All inputs of a shard in one launch of the ingest kernel; returns the plan kind per input (0 = direct)."""
+        n = len(frames)
+        fp = (C.POINTER(_ffi.Frame) * max(n, 1))(*[C.pointer(f.c) for f in frames])
+        cr = (C.c_float * max(4 * n, 1))(*[float(x) for c in crops for x in c])
+        dp = (C.c_void_p * max(n, 1))(*[d.handle for d in dsts])
+        kinds = (C.c_int * max(n, 1))()
+        self._check(self.lib.smr_ingest_resample_batch(self.handle, fp, cr, dp, n, kinds))
+        return list(kinds[:n])
 
     def ingest_resample(self, frame: DeviceFrame, crop, dst: Surface) -> int:
         c = (C.c_float * 4)(*[float(x) for x in crop])
