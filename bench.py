@@ -210,9 +210,12 @@ def main():
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
 
         def step_fn(step):
-            sharded.step(ring[step % RING], out_for(step) if rank == 0 else None)
+            # frame k's tiles travel over xGMI while frame k-1 is composed (two tile sets, two output frames)
+            sharded.step_pipelined(ring[step % RING], out_for(step) if rank == 0 else None)
 
     def barrier():
+        if not single:
+            sharded.flush()  # the frame still in flight
         if world > 1:
             dist.barrier()
         for c in lanes:

@@ -43,10 +43,24 @@ def pitch_of(width_px: int) -> int:
     return (width_px * 4 + 255) & ~255
 
 
+def post_gather(dist, plan: ShardPlan, rank: int, tiles: Dict[int, "object"]):
+    """Posts one exchange step without waiting: non-root ranks send their tiles to the root, the root receives every remote
+    tile.  `tiles[i]` is the tile tensor of input i: filled on owner(i), receive buffer on the root.  Returns the work handles;
+    `w.wait()` orders the current stream after completion."""
+    ops = []
+    if rank == plan.root:
+        for i in plan.remote_inputs():
+            if i in tiles:
+                ops.append(dist.P2POp(dist.irecv, tiles[i], plan.owner(i), tag=i))
+    else:
+        for i in plan.inputs_of(rank):
+            if i in tiles:
+                ops.append(dist.P2POp(dist.isend, tiles[i], plan.root, tag=i))
+    return dist.batch_isend_irecv(ops) if ops else []
+
+
 def gather_tiles(dist, plan: ShardPlan, rank: int, tiles: Dict[int, "object"]):
-    """One exchange step.  `tiles[i]` is the tile tensor of input i: filled on owner(i), receive buffer on the root.
-    Non-root ranks send their tiles to the root; the root receives every remote tile. Returns the list of work handles
-    (already waited on: the current stream is ordered after completion)."""
+    """One exchange step, posted and waited on (see post_gather)."""
     ops = []
     if rank == plan.root:
         for i in plan.remote_inputs():
@@ -83,19 +97,25 @@ class ShardedCompositor:
                 k = self.input_of_slot[L.source_index]
                 self.tile_geom[k] = (max(rust_round(L.width), 1), max(rust_round(L.height), 1), tuple(L.crop))
         needed = plan.inputs_of(rank) if rank != plan.root else list(range(plan.n_inputs))
-        self.tiles = {}
-        self.tile_surfaces = {}
-        for k in needed:
-            if k not in self.tile_geom:
-                continue
-            dw, dh, _ = self.tile_geom[k]
-            t = torch.zeros((dh, pitch_of(dw)), dtype=torch.uint8, device=device)
-            self.tiles[k] = t
-            if ctx is not None:
-                self.tile_surfaces[k] = ctx.wrap(t.data_ptr(), pitch_of(dw), dw, dh)
-                # tiles come out of the resampler with alpha == 255 (planar YUV / NV12 inputs): the compositor may use them
-                # as base layers (SMR_SOURCE_OPAQUE_SURFACE) exactly as it does with the raw frames on a single GPU
-                self.tile_surfaces[k].opaque = True
+        # two sets of tiles: frame k+1 is resampled / received into one set while frame k's is still being sent / composed
+        self.tile_sets = [{}, {}]
+        self.surface_sets = [{}, {}]
+        for par in range(2):
+            for k in needed:
+                if k not in self.tile_geom:
+                    continue
+                dw, dh, _ = self.tile_geom[k]
+                t = torch.zeros((dh, pitch_of(dw)), dtype=torch.uint8, device=device)
+                self.tile_sets[par][k] = t
+                if ctx is not None:
+                    s = ctx.wrap(t.data_ptr(), pitch_of(dw), dw, dh)
+                    # tiles come out of the resampler with alpha == 255 (planar YUV / NV12 inputs): the compositor may use them
+                    # as base layers (SMR_SOURCE_OPAQUE_SURFACE) exactly as it does with the raw frames on a single GPU
+                    s.opaque = True
+                    self.surface_sets[par][k] = s
+        self.tiles, self.tile_surfaces = self.tile_sets[0], self.surface_sets[0]  # the set of the frame being worked on
+        self.frame_no = 0
+        self.pending = None  # (works, parity, out) of the frame whose exchange is in flight
         self.batched = ingest_fn is None and ctx is not None  # default device path: all local inputs in one launch
         self.ingest_fn = ingest_fn or self._ingest
         self.compose_fn = compose_fn or self._compose
@@ -122,7 +142,7 @@ class ShardedCompositor:
             srcs.append(self.tile_surfaces[self.input_of_slot[slot]] if slot in self.input_of_slot else self.label)
         self.ctx.render_layouts(self.root_layouts, srcs, out.w, out.h, out=out, packed=self.root_packed)
 
-    def step(self, frames_row: Dict[int, object], out):
+    def _ingest_local(self, frames_row):
         mine = [k for k in self.plan.inputs_of(self.rank) if k in self.tile_geom]
         if self.batched:
             kinds = self.ctx.ingest_resample_batch([frames_row[k] for k in mine], [self.tile_geom[k][2] for k in mine],
@@ -132,6 +152,39 @@ class ShardedCompositor:
         else:
             for k in mine:
                 self.ingest_fn(k, frames_row[k], self.tiles[k])
+
+    def step(self, frames_row: Dict[int, object], out):
+        """One frame, start to finish: resample the local inputs, exchange, compose on the root."""
+        self.flush()
+        self._ingest_local(frames_row)
         gather_tiles(self.dist, self.plan, self.rank, self.tiles)
         if self.rank == self.plan.root:
             self.compose_fn(self.tiles, out)
+
+    def step_pipelined(self, frames_row: Dict[int, object], out):
+        """One frame per call, one frame of latency: frame k is resampled and its exchange posted, then frame k-1 (whose tiles
+        have been travelling meanwhile) is composed — the xGMI transfer of one frame overlaps the kernels of its neighbours.
+        The two tile sets alternate; call flush() after the last frame."""
+        par = self.frame_no & 1
+        self.tiles, self.tile_surfaces = self.tile_sets[par], self.surface_sets[par]
+        self._ingest_local(frames_row)
+        works = post_gather(self.dist, self.plan, self.rank, self.tiles)
+        prev, self.pending = self.pending, (works, par, out)
+        self.frame_no += 1
+        self._finish(prev)
+
+    def _finish(self, pending):
+        if pending is None:
+            return
+        works, par, out = pending
+        for w in works:
+            w.wait()  # the current stream now waits for this frame's sends / receives
+        if self.rank == self.plan.root:
+            self.tiles, self.tile_surfaces = self.tile_sets[par], self.surface_sets[par]
+            self.compose_fn(self.tiles, out)
+            nxt = self.frame_no & 1
+            self.tiles, self.tile_surfaces = self.tile_sets[nxt], self.surface_sets[nxt]
+
+    def flush(self):
+        prev, self.pending = self.pending, None
+        self._finish(prev)

@@ -36,19 +36,28 @@ def _worker(rank, world, port, n_inputs, q):
         slots = [i for i, r in enumerate(res) if r == (480, 270)]
         plan = smr_dist.ShardPlan(n_inputs=n_inputs, world=world)
         seen = {}
+        composed = []
 
         def ingest(k, frame, tile):
-            assert plan.owner(k) == rank and frame == f"frame{k}"
-            tile.copy_(torch.from_numpy(_tile_pattern(k, tile.shape[0], tile.shape[1])))
+            assert plan.owner(k) == rank and frame[0] == f"frame{k}"
+            tile.copy_(torch.from_numpy(_tile_pattern(k + 7 * frame[1], tile.shape[0], tile.shape[1])))
 
-        def compose(tiles, out):
+        def compose(tiles, out):  # `out` carries the frame number the root believes it is composing
+            composed.append(out)
             for k, t in tiles.items():
-                seen[k] = bool((t.numpy() == _tile_pattern(k, t.shape[0], t.shape[1])).all())
+                ok = bool((t.numpy() == _tile_pattern(k + 7 * out, t.shape[0], t.shape[1])).all())
+                seen[k] = seen.get(k, True) and ok
 
         comp = smr_dist.ShardedCompositor(None, None, plan, rank, layouts, res, slots, "label", torch, dist, ingest_fn=ingest,
                                           compose_fn=compose, device="cpu")
         for step in range(3):
-            comp.step({k: f"frame{k}" for k in plan.inputs_of(rank)}, None)
+            comp.step({k: (f"frame{k}", step) for k in plan.inputs_of(rank)}, step)
+        # pipelined: frame k's exchange overlaps frame k-1's compose; every frame must still be composed from its own tiles
+        for step in range(3, 9):
+            comp.step_pipelined({k: (f"frame{k}", step) for k in plan.inputs_of(rank)}, step)
+        comp.flush()
+        if rank == 0:
+            assert composed == list(range(9)), composed
         if rank == 0:
             # root-side layouts sample whole tiles 1:1
             geom_ok = all(L.crop == (0.0, 0.0, float(comp.tile_geom[comp.input_of_slot[L.source_index]][0]),

@@ -276,6 +276,19 @@ def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
     c.sync()
     for a, b in zip(out.download(), want):
         assert (a == b).all()
+    # pipelined mode: frame k is resampled while frame k-1 is composed; two tile sets, one output frame per frame in flight
+    _, frames_b = _inputs(c, hip, n, iw, ih, seed=4321)
+    srcs_b = [frames_b[slots.index(i)] if i in slots else label_t for i in range(len(res))]
+    want_b = _render(c, hip, layouts, srcs_b, W, H)
+    outs = [c.frame(hip.FRAME_PLANAR_YUV420, W, H) for _ in range(3)]
+    rows = [{i: frames[i] for i in range(n)}, {i: frames_b[i] for i in range(n)}, {i: frames[i] for i in range(n)}]
+    for k in range(3):
+        sharded.step_pipelined(rows[k], outs[k])
+    sharded.flush()
+    c.sync()
+    for k, w_ in enumerate([want, want_b, want]):
+        for a, b in zip(outs[k].download(), w_):
+            assert (a == b).all(), k
     c.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
 
