@@ -5,7 +5,23 @@ import collections, math, sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bench
-from test_solid_region import solid_params, half_int
+import numpy as np
+
+F = np.float32
+
+
+def half_int(v):
+    v = F(v)
+    return bool(v * F(2) == np.floor(v * F(2)) and abs(v) < F(32768))
+
+
+def solid_params(left, top, width, height, radii, need):
+    """(inset, corner) as smr_pack_layouts computes them (smr_layout.hip)."""
+    exact = all(half_int(x) for x in (left, top, width, height, need, *radii))
+    slack = F(0) if exact else F(0.015625)
+    inset = F(need) + slack
+    rmax = max(F(r) for r in radii)
+    return inset, (rmax + slack if rmax + slack > inset else F(0))
 
 L, res = bench.build_scene()
 W, H, TW, TH = 3840, 2160, 128, 16
