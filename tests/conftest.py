@@ -12,6 +12,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Every test session starts from built artefacts (HIP library + CPU oracle); a no-op when they are up to date."""
+    import __graft_entry__ as ge
+    ge.build()
+
+
 @pytest.fixture(scope="session")
 def orc():
     from oracle import oracle
