@@ -326,6 +326,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
     const int col = lane & (TWT - 1), sub = lane / TWT;
     auto resolve = [&](int yr, int n, int b) {
         if (J.ablate & 128) return;
+        __builtin_amdgcn_s_setprio(2);
         const float *wvb = s_wv + b * wv_sz;
         const int *fvb = s_fv + b * VRa;
         const float *wsvb = s_wsv + b * VRa, *rsvb = s_rsv + b * VRa;
@@ -361,6 +362,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
                 *(u32 *)(J.dst.ptr + (size_t)y * J.dst.pitch + (size_t)(tx0 + col) * 4) = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
 
     // One barrier per chunk.  Phase k (between barriers k and k+1): every wave converts + filters its row pair of chunk k into
@@ -459,6 +461,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // ---- horizontal Lanczos of the two rows into the f16 ring (pass 1 of the separable plan).
             //      All four channels ride in packed FMAs; alpha comes out as (sum w)/(sum w) == 1 exactly.
+            __builtin_amdgcn_s_setprio(3);  // the LDS-bound loop issues ahead of the other waves' vector work
             if constexpr (TWT == 64) {
                 if (lane < tw) {  // one lane per column, both rows
                     const int fh = s_fh[lane];
@@ -524,6 +527,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
                     M[(size_t)((yrow - R_lo) & (MR - 1)) * TWT + col] = float4_to_half4(div_cr(a.x, wsh, rsh), div_cr(a.y, wsh, rsh), div_cr(a.z, wsh, rsh), div_cr(a.w, wsh, rsh));
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         // ---- (d) this wave's share of the rows the previous chunk completed
         if (!(wave & 1)) resolve(pend_y, pend_n, pend_vb);
