@@ -404,6 +404,7 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
         const int pr = wave;
         if (pr < np) {
             const int y0 = base + 2 * pr, y1 = y0 + 1;
+            __builtin_amdgcn_s_setprio(1);
             if (J.ablate & 1) {
             } else if (J.fast420) {
                 // chroma rows indexed by chroma x * cm (NV12: U at even, V at odd bytes of the interleaved row)
