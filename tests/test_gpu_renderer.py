@@ -195,6 +195,29 @@ def test_non_layout_root_and_empty_output(ctx, hip, renderer):
     assert set(renderer.render(0.0, frames)) == {"direct"}
 
 
+def test_cpu_optimized_mode_renderer(hip):
+    """RenderingMode::CpuOptimized (types.rs:8-18): plain unorm node textures, no resampler (bilinear layout sampling only),
+    colours converted without the sRGB decode — end to end through the renderer, against the oracle in the same mode."""
+    from smelter_amd.renderer import Renderer
+    c = hip.Context(0, mode=hip.MODE_CPU_OPTIMIZED)
+    r = Renderer(c)
+    iw, ih, W, H, n = 320, 180, 640, 360, 4
+    planes, frames = _frames(c, hip, n, iw, ih)
+    for k in frames:
+        r.register_input(k)
+    r.update_scene("out", W, H, scenes.cfg2_scene_json(n))
+    got = r.render(0.0, frames)["out"].download()
+    from oracle import scene as S
+    root = S.Tiles(children=[S.InputStream(i) for i in range(n)], background_color=(0, 0, 0, 255))
+    layouts = S.scene_layouts(root, W, H, [(iw, ih)] * n, srgb=False)
+    nodes = [orc.planar_yuv_to_rgba(*planes[k], iw, ih) for k in range(n)]
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H, srgb=False)
+    for g, w_ in zip(got, want):
+        assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.99
+    r.close()
+    c.close()
+
+
 def test_pinned_async_transfers_round_trip(ctx, hip):
     """smr_host_alloc + smr_frame_upload_async / _download_async: stream-ordered, byte-exact, every plane shape."""
     rng = np.random.default_rng(5)
