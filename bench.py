@@ -234,6 +234,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    serial_fps = None
+    if single and n_lanes > 1:
+        # the same K steps on ONE renderer (frames strictly one after the other on one stream), reported beside `value`
+        t1 = time.perf_counter()
+        for s in range(args.steps):
+            step_fn(s, ctx)
+        barrier()
+        serial_fps = args.steps / (time.perf_counter() - t1)
 
     result = None
     if rank == 0:
@@ -249,6 +257,7 @@ def main():
                                     3: "configs[3] on ONE GPU: 8x4K YUV420 inputs tiled -> 3840x2160 YUV420, same scene as configs[2]"}[args.config],
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
                        "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
+                       "frames_per_s_one_in_flight": round(serial_fps, 2) if serial_fps else None,
                        "per_frame_host_work": "smr_renderer_render: frame set -> layout maths at pts (C++ scene engine) -> parameter pack -> 2 kernels"
                        if single else "pre-flattened layout list (scene engine, once) -> ingest per shard -> gather -> compose",
                        "parallelism": "single GPU" if single else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
