@@ -67,3 +67,25 @@ def test_plan_make_is_host_only_and_matches_oracle(lib):
             assert tuple(p.scale)[:n] == o.scale[:n] and tuple(p.offset)[:n] == o.offset[:n]
             if kind == 2:
                 assert (p.mid_w, p.mid_h) == o.mid
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "render_scene")
+    libdir = os.path.join(ROOT, "smelter_amd")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "render_scene.c"),
+           "-o", exe, "-L", libdir, "-l:libsmr_hip.so", f"-Wl,-rpath,{libdir}", "-lm"]
+    subprocess.run(cmd, check=True, capture_output=True)
+    return exe
+
+
+def test_header_is_plain_c_and_the_example_links(lib, tmp_path):
+    """include/smr.h compiles as C11 (-Wall -Wextra -Werror) and examples/render_scene.c links against the library; with no
+    GPU in the container the program stops at smr_ctx_create — loudly, exit code 2."""
+    import subprocess
+    import torch
+    exe = _build_c_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu test")
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2 and "no HIP device" in p.stderr

@@ -243,3 +243,16 @@ def test_scene_errors_surface_through_the_renderer(renderer):
     with pytest.raises(SceneError) as e:
         renderer.update_scene("out", 64, 64, {"type": "image", "image_id": "missing"})
     assert "does not exist" in str(e.value)
+
+
+def test_c_example_runs(tmp_path):
+    """examples/render_scene.c: the renderer driven from plain C."""
+    import subprocess
+    from tests.test_abi import _build_c_example
+    exe = _build_c_example(tmp_path)
+    out = tmp_path / "out.yuv"
+    p = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert "rendered 1280x720 from 4 inputs" in p.stdout
+    data = np.fromfile(out, np.uint8)
+    assert data.size == 1280 * 720 * 3 // 2 and data[: 1280 * 720].std() > 10
