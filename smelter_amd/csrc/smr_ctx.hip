@@ -49,15 +49,29 @@ void *smr_scratch(smr_ctx *ctx, int slot, size_t bytes) {
     return s.ptr;
 }
 
+static int surface_create_with(smr_ctx *ctx, u32 w, u32 h, u32 format, size_t headroom, smr_surface **out);
+
 smr_surface *smr_cached_surface(smr_ctx *ctx, size_t slot, u32 w, u32 h, u32 fmt) {
     if (slot >= ctx->surf_cache.size()) ctx->surf_cache.resize(slot + 1, nullptr);
     smr_surface *&s = ctx->surf_cache[slot];
     if (s && s->w == w && s->h == h && s->fmt == fmt) return s;
+    // NodeTexture::ensure_size re-creates the texture on every size change; an animated layout changes the size of its
+    // resample target every frame, and hipFree / hipMalloc synchronise the device — so a scratch surface is re-described in
+    // place while the new size fits its allocation (work on the stream is ordered, the previous frame is done with it by then)
+    const u32 bpp = bytes_per_px(fmt);
+    const size_t pitch = ((size_t)w * bpp + 255) & ~(size_t)255;
+    if (s && bpp && w && h && w <= 7682 * 2 && h <= 4320 * 2 && pitch * h <= s->capacity) {
+        s->w = w; s->h = h; s->fmt = fmt; s->pitch = pitch;
+        return s;
+    }
+    // a slot that outgrew its allocation once takes 25 % headroom, so a layout that keeps growing through a transition does
+    // not reallocate on every frame
+    const size_t headroom = s ? (pitch * h) / 4 : 0;
     if (s) {
         smr_surface_destroy(ctx, s);
         s = nullptr;
     }
-    if (smr_surface_create(ctx, w, h, fmt, &s) != SMR_OK) return nullptr;
+    if (surface_create_with(ctx, w, h, fmt, headroom, &s) != SMR_OK) return nullptr;
     return s;
 }
 
@@ -246,6 +260,10 @@ int smr_profile_reset(smr_ctx *ctx) {
 
 // ---------------------------------------------------------------------------- surfaces
 int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, smr_surface **out) {
+    return surface_create_with(ctx, w, h, format, 0, out);
+}
+
+static int surface_create_with(smr_ctx *ctx, u32 w, u32 h, u32 format, size_t headroom, smr_surface **out) {
     if (!ctx || !out) return SMR_ERR_INVALID;
     *out = nullptr;
     u32 bpp = bytes_per_px(format);
@@ -260,7 +278,8 @@ int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, sm
     s->fmt = format;
     s->pitch = ((size_t)w * bpp + 255) & ~(size_t)255;
     s->owned = true;
-    hipError_t e = hipMalloc(&s->ptr, s->pitch * h);
+    s->capacity = s->pitch * h + headroom;
+    hipError_t e = hipMalloc(&s->ptr, s->capacity);
     if (e != hipSuccess) {
         delete s;
         return smr_check_hip(ctx, e, "hipMalloc(surface)");

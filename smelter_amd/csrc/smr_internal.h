@@ -37,6 +37,7 @@ struct smr_surface {
     size_t pitch = 0;
     u32 w = 0, h = 0, fmt = 0;
     bool owned = false;
+    size_t capacity = 0;  // bytes behind ptr when owned (cached scratch surfaces are re-described in place while they fit)
 };
 
 // Device-side view of a surface.

@@ -172,6 +172,35 @@ def test_transition_animates_between_updates(ctx, hip, renderer):
     assert not (a[0] == mid[0]).all()
 
 
+def test_resample_targets_are_reused_across_sizes(ctx, hip, renderer):
+    """The resample target of an animated rescaler changes size on every frame; the scratch surface behind it is re-described
+    in place while it fits its allocation and regrown otherwise.  Shrinking, growing past the first allocation and coming back
+    all give the frame a fresh renderer gives for the same static scene."""
+    from smelter_amd.renderer import Renderer
+    iw, ih, W, H = 320, 180, 640, 360
+    _, frames = _frames(ctx, hip, 1, iw, ih)
+    renderer.register_input("in0")
+
+    def scene(width):
+        return {"type": "view", "background_color": "#102030FF", "children": [
+            {"type": "rescaler", "width": width, "height": round(width * 9 / 16), "top": 8, "left": 8,
+             "child": {"type": "input_stream", "input_id": "in0"}}]}
+
+    for width in (400, 250, 96, 97, 401, 520, 600, 130, 600, 17):
+        renderer.update_scene("out", W, H, scene(width))
+        got = renderer.render(0.0, frames)["out"].download()
+        ctx2 = hip.Context(0)                  # scratch surfaces are cached per context: a new one has nothing cached
+        _, frames2 = _frames(ctx2, hip, 1, iw, ih)
+        fresh = Renderer(ctx2)
+        fresh.register_input("in0")
+        fresh.update_scene("o", W, H, scene(width))
+        want = fresh.render(0.0, frames2)["o"].download()
+        fresh.close()
+        ctx2.close()
+        for g, w_ in zip(got, want):
+            assert (g == w_).all(), width
+
+
 def test_non_layout_root_and_empty_output(ctx, hip, renderer):
     iw, ih = 320, 180
     planes, frames = _frames(ctx, hip, 1, iw, ih)
