@@ -41,10 +41,16 @@ ALGO_BYTES_PER_FRAME = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT
 
 LABEL_W, LABEL_H = 176, 32
 PLAIN_TILES = False  # --config 1: Tiles of bare input streams (rescale + blend only)
+ANIMATED = False     # --config 4: animated Tiles grid + one gaussian-blur layer (smelter_amd/synth.py:animated_grid_scene)
+LAYER_W, LAYER_H, LAYER_SIGMA = 960, 540, 3.0
+UPDATE_EVERY = 45    # --config 4: a scene update (tiles swap places, 500 ms transition) every 45 frames = 0.75 s at 60 fps
 
 
-def scene_json():
+def scene_json(rotate=0):
     """configs[2] as the scene JSON the reference's API takes (smelter-api/src/video/component.rs)."""
+    if ANIMATED:
+        from smelter_amd import synth
+        return synth.animated_grid_scene(N_IN, rotate, LAYER_W, LAYER_H, 500, LAYER_SIGMA)
     if PLAIN_TILES:
         return {"type": "tiles", "background_color": "#000000FF", "children": [{"type": "input_stream", "input_id": f"input_{i}"} for i in range(N_IN)]}
     kids = []
@@ -65,7 +71,14 @@ def build_scene():
     sc = Scene()
     nodes = sc.update(scene_json(), OUT_W, OUT_H)
     res = [(IN_W, IN_H) if nodes[k].kind == _ffi.NODE_INPUT_STREAM else (nodes[k].width, nodes[k].height) for k in nodes[0].children]
+    global INNER_LAYOUTS
+    if ANIMATED:  # the layout node under the blur shader: View{Rescaler{input_0}} at the layer's size
+        shader = list(nodes[0].children)[-1]
+        INNER_LAYOUTS = sc.layouts(list(nodes[shader].children)[0], 0, [(IN_W, IN_H)])
     return sc.layouts(0, 0, res), res
+
+
+INNER_LAYOUTS = None
 
 
 def make_inputs(ctx, hip, frame_sets, input_ids):
@@ -107,12 +120,15 @@ def cpu_baseline(layouts, res):
             y, u, v = planes[k]
             k += 1
             nodes.append(orc.planar_yuv_to_rgba(y, u, v, IN_W, IN_H, omp=True))
+        elif ANIMATED:  # the blur layer: its own layout node, then the shader
+            inner = refpipe.layout_node_render(INNER_LAYOUTS, [nodes[0]], LAYER_W, LAYER_H, omp=True)
+            nodes.append(orc.gaussian_blur(inner, LAYER_SIGMA))
         else:
             nodes.append(label)
     refpipe.render_yuv420(layouts, nodes, OUT_W, OUT_H, omp=True)
     dt = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "1 composited frame of the same workload (8x1080p YUV420 -> 4K YUV420, all passes), "
+            "sample": f"1 composited frame of the same workload ({N_IN}x{IN_W}x{IN_H} YUV420 -> {OUT_W}x{OUT_H} YUV420, all passes), "
                       f"oracle/smr_oracle.c -O2 + OpenMP on {cores} threads, {dt:.2f} s"}
 
 
@@ -126,16 +142,24 @@ def main():
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight on one GPU (renderer contexts / HIP streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (ingest per shard, gather, compose) with the ranks given")
     ap.add_argument("--transfers", action="store_true", help="also time host buffers in -> host buffers out (PCIe inclusive, informational)")
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3],
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4],
                     help="BASELINE.json configs[] index: 2 = the metric's 8x1080p -> 4K (default, the judged line); "
-                         "1 = 4x1080p -> 1080p tiles, 3 = 8x4K -> 4K on one GPU (informational)")
+                         "1 = 4x1080p -> 1080p tiles, 3 = 8x4K -> 4K on one GPU, 4 = 16x1080p animated grid + blur layer "
+                         "-> 4K on one GPU (informational)")
     args = ap.parse_args()
-    global IN_W, IN_H, OUT_W, OUT_H, N_IN, ALGO_BYTES_PER_FRAME, PLAIN_TILES
+    global IN_W, IN_H, OUT_W, OUT_H, N_IN, ALGO_BYTES_PER_FRAME, PLAIN_TILES, ANIMATED
     if args.config == 1:
         IN_W, IN_H, OUT_W, OUT_H, N_IN, PLAIN_TILES = 1920, 1080, 1920, 1080, 4, True
     elif args.config == 3:
         IN_W, IN_H, OUT_W, OUT_H, N_IN = 3840, 2160, 3840, 2160, 8
+    elif args.config == 4:
+        N_IN, ANIMATED = 16, True
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded:
+            raise SystemExit("--config 4 (scene updates + transitions every frame) runs through the renderer on one GPU; "
+                             "the sharded driver takes a static layout list")
     ALGO_BYTES_PER_FRAME = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H)
+    if ANIMATED:
+        ALGO_BYTES_PER_FRAME += 2 * LAYER_W * LAYER_H * 4  # the blur layer written and read once
 
     import torch
     import torch.distributed as dist
@@ -196,6 +220,8 @@ def main():
             r = Renderer(c, stream_fallback_timeout_s=3600.0)  # the synthetic ring carries no timestamps
             for i in range(N_IN):
                 r.register_input(f"input_{i}")
+            if ANIMATED:
+                r.register_shader("soften")
             for node in r.update_scene("out", OUT_W, OUT_H, scene_json()):
                 if node.kind == _ffi.NODE_TEXT:
                     r.set_text("out", node.index, glyphs, atlas)
@@ -203,9 +229,19 @@ def main():
             frame_sets.append([r.make_frame_set({f"input_{i}": row[i] for i in range(N_IN)}) for row in ring])
         FRAME_NS = 1_000_000_000 // 60
 
+        tick = [0]  # frames rendered so far: presentation timestamps never go backwards (the warm-up, timed, serial and
+        #             profiling loops all restart `step` at 0; transitions are defined on a monotonic pts)
+
         def step_fn(step, lane=None):
             k = step % n_lanes if lane is None else 0
-            renderers[k].render_packed(step * FRAME_NS, frame_sets[k][step % RING])
+            t = tick[0]
+            tick[0] += 1
+            if ANIMATED and t % UPDATE_EVERY < (n_lanes if lane is None else 1):
+                # update_scene (the cold path of the reference, instance.rs:295-332) is part of this workload: the grid's
+                # children swap places and animate for 500 ms of every 750 ms.  Every renderer in flight gets the update
+                # before the first frame it renders after it.
+                renderers[k].update_scene("out", OUT_W, OUT_H, scene_json(t // UPDATE_EVERY))
+            renderers[k].render_packed(t * FRAME_NS, frame_sets[k][step % RING])
     else:
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
 
@@ -254,7 +290,9 @@ def main():
             "config": {"workload": {1: "configs[1]: 4x1080p YUV420 inputs -> 1920x1080 YUV420, Tiles, rescale + blend only, GpuOptimized",
                                     2: "configs[2]: 8x1080p YUV420 inputs tiled -> 3840x2160 YUV420, Tiles + Rescaler(border_radius 24) "
                                        "+ text label per tile, GpuOptimized (linear-light Lanczos3 + blend)",
-                                    3: "configs[3] on ONE GPU: 8x4K YUV420 inputs tiled -> 3840x2160 YUV420, same scene as configs[2]"}[args.config],
+                                    3: "configs[3] on ONE GPU: 8x4K YUV420 inputs tiled -> 3840x2160 YUV420, same scene as configs[2]",
+                                    4: "configs[4] on ONE GPU: 16x1080p YUV420 inputs in an animated Tiles grid (scene update every 45 frames, "
+                                       "500 ms cubic-bezier transitions) + one 960x540 layer through the gaussian-blur shader -> 3840x2160 YUV420"}[args.config],
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
                        "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
                        "frames_per_s_one_in_flight": round(serial_fps, 2) if serial_fps else None,

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmr_hip.so")
+LIB_PATH = os.environ.get("SMR_LIB") or os.path.join(_HERE, "libsmr_hip.so")  # SMR_LIB: A/B builds (tools/variant.sh)
 
 SMR_OK, SMR_ERR_INVALID, SMR_ERR_OOM, SMR_ERR_INTERNAL = 0, -1, -2, -3
 MODE_GPU_OPTIMIZED, MODE_CPU_OPTIMIZED = 0, 1

@@ -93,10 +93,15 @@ StageScope::StageScope(smr_ctx *c, int s) : ctx(c), stage(s) {
     if (a) (void)hipEventRecord(a, ctx->stream);
 }
 
+static void drain_profile(smr_ctx *ctx);
+
 StageScope::~StageScope() {
     if (!ctx->profiling || !a || !b) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->pending.push_back({a, b, stage});
+    // the runtime's pool of timestamp signals is finite: a few thousand recorded-but-unread events stall hipEventRecord for good
+    // (seen with ~2 400 outstanding), so the pairs are read back and recycled in batches
+    if (ctx->pending.size() >= 256) drain_profile(ctx);
 }
 
 static void drain_profile(smr_ctx *ctx) {

@@ -172,7 +172,10 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
             };
             D.solid_px = enc(L.color[0]) | (enc(L.color[1]) << 8) | (enc(L.color[2]) << 16) | (255u << 24);
         }
-        if (!(qw > 0.0f) || !(qh > 0.0f) || L.type > 2) {
+        const bool finite = std::isfinite(qleft) && std::isfinite(qtop) && std::isfinite(qw) && std::isfinite(qh) && std::isfinite(D.cs) &&
+                            std::isfinite(D.sn);
+        if (!(qw > 0.0f) || !(qh > 0.0f) || L.type > 2 || !finite) {
+            // (a quad with a NaN / infinite corner rasterises to nothing; it must not reach the float -> int conversions below)
             D.bx0 = D.by0 = 0; D.bx1 = D.by1 = -1;  // never binned
         } else if (D.flags & DL_UNROTATED) {
             // pixel x is covered iff qleft <= x + .5 < qleft + qw (layout_covers), i.e. qleft - .5 <= x < qleft + qw - .5.

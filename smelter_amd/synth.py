@@ -93,3 +93,21 @@ def label_glyphs(text: str, scale: int = 3):
         glyphs.append(Glyph(x, 5, gw, gh, ci * gw, 0, (1.0, 1.0, 1.0, 1.0)))
         x += gw + scale
     return atlas, glyphs
+
+
+def animated_grid_scene(n: int = 16, rotate: int = 0, layer_w: int = 960, layer_h: int = 540, transition_ms: int = 500,
+                        sigma: float = 3.0) -> dict:
+    """BASELINE.json configs[4] as scene JSON: `n` input streams in a Tiles grid whose children swap places between
+    scene updates (`rotate` shifts the child order; Tiles animates children matched by id, tiles_component/interpolation.rs:17-64)
+    with a 500 ms cubic-bezier transition, plus one layer that goes through the built-in gaussian-blur shader (a Shader node
+    with its own layout sub-tree) and sits on top of the grid with rounded corners."""
+    order = [(i + rotate) % n for i in range(n)]
+    grid = {"type": "tiles", "id": "grid", "background_color": "#101018FF",
+            "transition": {"duration_ms": transition_ms, "easing_function": {"function_name": "cubic_bezier", "points": [0.65, 0.0, 0.35, 1.0]}},
+            "children": [{"type": "input_stream", "id": f"tile_{i}", "input_id": f"input_{i}"} for i in order]}
+    layer = {"type": "view", "width": layer_w, "height": layer_h, "top": round(layer_h / 8), "left": round(layer_w / 8), "border_radius": 16,
+             "children": [{"type": "shader", "shader_id": "soften", "resolution": {"width": layer_w, "height": layer_h},
+                           "shader_param": {"type": "f32", "value": sigma},
+                           "children": [{"type": "view", "width": layer_w, "height": layer_h,
+                                         "children": [{"type": "rescaler", "child": {"type": "input_stream", "input_id": "input_0"}}]}]}]}
+    return {"type": "view", "children": [grid, layer]}

@@ -343,6 +343,30 @@ def test_missing_input_renders_like_the_reference(ctx, hip):
         assert refpipe.max_diff(g, w_) <= 1
 
 
+def test_non_finite_layouts_draw_nothing(ctx, ctx_unfused, hip):
+    """A quad with a NaN or infinite corner rasterises to nothing on the reference's GPU (a transition evaluated outside its
+    contract can produce one: transition.rs:88-101 divides by 1 - state_offset).  Such layouts must neither draw nor reach the
+    float -> int conversions of the tile binning (which once cost a 2^31-iteration host loop per frame)."""
+    import time
+    from dataclasses import replace
+    layouts = [orc.Layout(0.0, 0.0, 640.0, 360.0, 1, color=orc.color_to_shader((10, 20, 30, 255))),
+               orc.Layout(10.0, 20.0, 100.0, 60.0, 1, color=orc.color_to_shader((200, 40, 40, 255)), border_radius=(8.0, 8.0, 8.0, 8.0)),
+               orc.Layout(100.5, 200.25, 80.0, 80.0, 1, color=orc.color_to_shader((40, 200, 40, 255)))]
+    nan, inf = float("nan"), float("inf")
+    bad = [replace(layouts[1], left=nan), replace(layouts[1], top=inf), replace(layouts[2], width=nan), replace(layouts[2], left=-inf),
+           replace(layouts[1], rotation_degrees=nan), replace(layouts[2], left=nan, top=nan, width=nan, height=nan)]
+    for c in (ctx, ctx_unfused):
+        want = _render(c, hip, [layouts[0]], [], 640, 360)
+        both = _render(c, hip, layouts, [], 640, 360)
+        assert not (both[0] == want[0]).all()
+        for b in bad:
+            t0 = time.perf_counter()
+            got = _render(c, hip, [layouts[0], b], [], 640, 360)
+            assert time.perf_counter() - t0 < 0.5
+            for g, w_ in zip(got, want):
+                assert (g == w_).all()
+
+
 def test_empty_scene_is_transparent_black(ctx, hip):
     out = ctx.frame(hip.FRAME_PLANAR_YUV420, 64, 36)
     ctx.render_layouts([], [], 64, 36, out=out)

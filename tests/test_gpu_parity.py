@@ -206,6 +206,36 @@ def test_single_passes_and_downsample(ctx, hip):
     assert np.abs(mid.download().view(np.int16).astype(np.int32) - want_mid.view(np.int16).astype(np.int32)).max() <= 2
 
 
+@pytest.mark.parametrize("dw,dh", [(1, 1), (2, 1), (4, 2), (7, 5), (16, 9)])
+def test_large_box_reductions_keep_the_reference_sum_order(ctx, hip, dw, dh):
+    """A 1080p child laid out into a few pixels reduces by up to 512 x 512 before the Lanczos passes (predecimate_levels,
+    resampler.rs:60-66).  The one-wave-per-pixel box kernel fetches in parallel but adds in the reference's order: the reduced
+    surface equals the oracle's sequential sum bit for bit (f16 patterns), and the whole resample stays within 1 LSB — in
+    milliseconds, not tens of them."""
+    import time
+    sw, sh = 1920, 1080
+    y, u, v = scenes.test_input(5, sw, sh, noise_seed=3)
+    src = orc.planar_yuv_to_rgba(y, u, v, sw, sh)
+    s = ctx.surface_from(src)
+    plan = orc.resample_plan(sw, sh, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+    fx, fy = 1 << plan.levels[0], 1 << plan.levels[1]
+    assert fx * fy >= 256
+    red = ctx.surface((sw + fx - 1) // fx, (sh + fy - 1) // fy, hip.PX_RGBA16F)
+    ctx.downsample(s, fx, fy, red)
+    want_red = orc.downsample(src, orc.PX_RGBA8_SRGB, fx, fy)
+    assert (red.download().view(np.int16) == want_red.view(np.int16)).all()
+    d = ctx.surface(dw, dh)
+    ctx.resample(s, (0.0, 0.0, float(sw), float(sh)), d)
+    ctx.sync()
+    t0 = time.perf_counter()
+    kind = ctx.resample(s, (0.0, 0.0, float(sw), float(sh)), d)
+    ctx.sync()
+    assert time.perf_counter() - t0 < 0.01
+    okind, want = orc.resample(src, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+    assert kind == okind
+    assert np.abs(d.download().astype(np.int32) - want.astype(np.int32)).max() <= 1
+
+
 @pytest.mark.parametrize("srgb", [True, False])
 def test_rescale_bilinear(ctx, ctx_cpu, hip, srgb):
     c = ctx if srgb else ctx_cpu

@@ -172,6 +172,46 @@ def test_transition_animates_between_updates(ctx, hip, renderer):
     assert not (a[0] == mid[0]).all()
 
 
+def test_animated_grid_with_blur_layer_matches_the_oracle_mid_transition(ctx, hip, renderer):
+    """BASELINE configs[4] at a quarter of its size: 16 inputs in a Tiles grid that is half way through a transition (tiles at
+    fractional positions: bilinear-sampled, not copy tiles) plus a layer through the gaussian-blur shader.  The frame is compared
+    with the oracle's pass sequence run on the layout lists the scene engine produces for the same pts."""
+    from smelter_amd import synth
+    from smelter_amd.scene import Scene
+    iw, ih, W, H, n, lw, lh = 480, 270, 960, 540, 16, 240, 136
+    planes, frames = _frames(ctx, hip, n, iw, ih)
+    frames = {f"input_{i}": frames[f"in{i}"] for i in range(n)}
+    for k in frames:
+        renderer.register_input(k)
+    renderer.register_shader("soften")
+    sc = Scene()
+    res = [(iw, ih)] * n + [(lw, lh)]
+    renderer.update_scene("out", W, H, synth.animated_grid_scene(n, 0, lw, lh))
+    sc.update(synth.animated_grid_scene(n, 0, lw, lh), W, H)
+    first = renderer.render(0.0, frames, {k: 0.0 for k in frames})["out"].download()
+    sc.layouts(0, 0, res)                               # the same first frame at pts 0 for the bare engine
+    renderer.update_scene("out", W, H, synth.animated_grid_scene(n, 3, lw, lh))
+    sc.update(synth.animated_grid_scene(n, 3, lw, lh), W, H)
+    t = 0.2                                             # 40 % of the 500 ms transition
+    got = renderer.render(t, frames, {k: t for k in frames})["out"].download()
+    assert not (got[0] == first[0]).all()
+    # the oracle on the engine's layout lists: inner node (View{Rescaler{input_0}}) -> blur -> root
+    nodes = sc.nodes()
+    root_kids = list(nodes[0].children)
+    shader = root_kids[-1]
+    inner = list(nodes[shader].children)[0]
+    rgba = [orc.planar_yuv_to_rgba(*p, iw, ih) for p in planes]
+    inner_px = refpipe.layout_node_render(sc.layouts(inner, int(t * 1e9), [(iw, ih)]), [rgba[0]], lw, lh)
+    layer = orc.gaussian_blur(inner_px, 3.0)
+    root_layouts = sc.layouts(0, int(t * 1e9), res)
+    moving = [L for L in root_layouts if L.type == 0 and (L.left != round(L.left) or L.top != round(L.top))]
+    assert len(moving) >= 8                              # really mid-flight
+    order = [(i + 3) % n for i in range(n)]              # child k of the grid shows input order[k]
+    want, _ = refpipe.render_yuv420(root_layouts, [rgba[i] for i in order] + [layer], W, H)
+    for g, w_ in zip(got, want):
+        assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.99
+
+
 def test_resample_targets_are_reused_across_sizes(ctx, hip, renderer):
     """The resample target of an animated rescaler changes size on every frame; the scratch surface behind it is re-described
     in place while it fits its allocation and regrown otherwise.  Shrinking, growing past the first allocation and coming back
