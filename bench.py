@@ -331,7 +331,7 @@ def main():
             # separate --pmc runs): counters cannot be read from inside the process, so the committed summary is quoted
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and args.config == 2:  # the committed counter passes are of the default workload
                 t = json.load(open(tpath)).get(kname)
                 if t:
                     traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
