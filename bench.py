@@ -154,9 +154,6 @@ def main():
         IN_W, IN_H, OUT_W, OUT_H, N_IN = 3840, 2160, 3840, 2160, 8
     elif args.config == 4:
         N_IN, ANIMATED = 16, True
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded:
-            raise SystemExit("--config 4 (scene updates + transitions every frame) runs through the renderer on one GPU; "
-                             "the sharded driver takes a static layout list")
     ALGO_BYTES_PER_FRAME = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H)
     if ANIMATED:
         ALGO_BYTES_PER_FRAME += 2 * LAYER_W * LAYER_H * 4  # the blur layer written and read once
@@ -243,9 +240,34 @@ def main():
                 renderers[k].update_scene("out", OUT_W, OUT_H, scene_json(t // UPDATE_EVERY))
             renderers[k].render_packed(t * FRAME_NS, frame_sets[k][step % RING])
     else:
+        FRAME_NS = 1_000_000_000 // 60
+        tick = [0]
+        if ANIMATED:
+            # every rank evaluates the same scene at the same pts (C++ scene engine, host only): no geometry travels.  Child k of
+            # the grid shows input (k + rotate) % N after an update, so the source slot -> input map changes with it.  The blur
+            # layer (input 0 lives on the root) is rendered on the root: its layout node, then the shader, one surface per parity.
+            from smelter_amd.scene import Scene
+            engine = Scene()
+            engine.update(scene_json(0), OUT_W, OUT_H)
+            inner_s = [ctx.surface(LAYER_W, LAYER_H) for _ in range(2)] if rank == 0 else None
+            layer_s = [ctx.surface(LAYER_W, LAYER_H) for _ in range(2)] if rank == 0 else None
+            label = layer_s[0] if rank == 0 else None
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
 
         def step_fn(step):
+            t = tick[0]
+            tick[0] += 1
+            if ANIMATED:
+                rot = t // UPDATE_EVERY
+                if t % UPDATE_EVERY == 0 and t:
+                    engine.update(scene_json(rot), OUT_W, OUT_H)
+                slots = [(i - rot) % N_IN for i in range(N_IN)]  # input i is child (i - rotate) % N of the grid
+                sharded.set_layouts(engine.layouts(0, t * FRAME_NS, res), slots)
+                if rank == 0:
+                    par = t & 1
+                    ctx.render_layouts(INNER_LAYOUTS, [ring[step % RING][0]], LAYER_W, LAYER_H, out_rgba=inner_s[par])
+                    ctx.gaussian_blur(inner_s[par], LAYER_SIGMA, dst=layer_s[par])
+                    sharded.label = layer_s[par]
             # frame k's tiles travel over xGMI while frame k-1 is composed (two tile sets, two output frames)
             sharded.step_pipelined(ring[step % RING], out_for(step) if rank == 0 else None)
 
@@ -297,7 +319,8 @@ def main():
                        "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
                        "frames_per_s_one_in_flight": round(serial_fps, 2) if serial_fps else None,
                        "per_frame_host_work": "smr_renderer_render: frame set -> layout maths at pts (C++ scene engine) -> parameter pack -> 2 kernels"
-                       if single else "pre-flattened layout list (scene engine, once) -> ingest per shard -> gather -> compose",
+                       if single else ("layout maths at pts on every rank (C++ scene engine) -> ingest per shard -> gather -> blur layer + compose on the root"
+                                       if ANIMATED else "pre-flattened layout list (scene engine, once) -> ingest per shard -> gather -> compose"),
                        "parallelism": "single GPU" if single else f"inputs sharded over {world} GPUs, RCCL gather to rank 0"},
             "frame": {"algorithmic_bytes": ALGO_BYTES_PER_FRAME, "achieved_GBps": round(ALGO_BYTES_PER_FRAME * fps / 1e9, 2),
                       "frac_of_hbm_peak": round(ALGO_BYTES_PER_FRAME * fps / 1e9 / HBM_PEAK_GBPS, 5)},

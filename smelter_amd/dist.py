@@ -81,6 +81,8 @@ def gather_tiles(dist, plan: ShardPlan, rank: int, tiles: Dict[int, "object"]):
 class ShardedCompositor:
     """Per-frame driver of the sharded path for one output scene."""
 
+    _FRAME_STATE = ("root_layouts", "root_packed", "label", "slot_of_input", "input_of_slot")  # what a frame in flight keeps
+
     def __init__(self, ctx, hip, plan: ShardPlan, rank: int, layouts, res, input_source_slot: Sequence[int], label_surface,
                  torch, dist, ingest_fn: Optional[Callable] = None, compose_fn: Optional[Callable] = None, device=None):
         self.ctx, self.hip, self.plan, self.rank, self.dist, self.torch = ctx, hip, plan, rank, dist, torch
@@ -119,15 +121,40 @@ class ShardedCompositor:
         self.batched = ingest_fn is None and ctx is not None  # default device path: all local inputs in one launch
         self.ingest_fn = ingest_fn or self._ingest
         self.compose_fn = compose_fn or self._compose
+        self.root_layouts, self.root_packed = None, None
         if rank == plan.root:
-            # root-side layout list: inputs are replaced by their (already resampled) tiles, crop = whole tile
-            self.root_layouts = []
-            for L in self.layouts:
-                if L.type == 0 and L.source_index in self.input_of_slot:
-                    dw, dh, _ = self.tile_geom[self.input_of_slot[L.source_index]]
-                    L = replace(L, crop=(0.0, 0.0, float(dw), float(dh)))
-                self.root_layouts.append(L)
-            self.root_packed = hip.pack_layouts(self.root_layouts) if hip is not None else None
+            self._rewrite_for_root(pack=True)
+
+    def _rewrite_for_root(self, pack: bool):
+        # root-side layout list: inputs are replaced by their (already resampled) tiles, crop = whole tile
+        self.root_layouts = []
+        for L in self.layouts:
+            if L.type == 0 and L.source_index in self.input_of_slot:
+                dw, dh, _ = self.tile_geom[self.input_of_slot[L.source_index]]
+                L = replace(L, crop=(0.0, 0.0, float(dw), float(dh)))
+            self.root_layouts.append(L)
+        self.root_packed = self.hip.pack_layouts(self.root_layouts) if (pack and self.hip is not None) else None
+
+    def set_layouts(self, layouts, input_source_slot: Optional[Sequence[int]] = None):
+        """The layout list of the next frame of an animated scene (every rank evaluates the same scene at the same pts, so all
+        ranks call this with the same list and no geometry travels).  Layouts may move, rotate, change masks or order; the size
+        of the tile each input is resampled to must stay what the tile buffers were allocated for — true for Tiles / absolute
+        position transitions, which move children without resizing them (tiles_component/interpolation.rs:17-64)."""
+        layouts = list(layouts)
+        if input_source_slot is not None:  # a scene update re-ordered the children: source slot s now shows another input
+            self.slot_of_input = list(input_source_slot)
+            self.input_of_slot = {s: k for k, s in enumerate(self.slot_of_input)}
+        for L in layouts:
+            if L.type == 0 and L.source_index in self.input_of_slot:
+                k = self.input_of_slot[L.source_index]
+                geom = (max(rust_round(L.width), 1), max(rust_round(L.height), 1), tuple(L.crop))
+                if k not in self.tile_geom or self.tile_geom[k][:2] != geom[:2]:
+                    raise ValueError(f"input {k}: tile size changed from {self.tile_geom.get(k, (None,))[:2]} to {geom[:2]}; "
+                                     "build a new ShardedCompositor for a scene that resizes its inputs")
+                self.tile_geom[k] = geom
+        self.layouts = layouts
+        if self.rank == self.plan.root:
+            self._rewrite_for_root(pack=False)  # packed per frame by render_layouts
 
     # -- default device implementations
     def _ingest(self, k, frame, tile_tensor):
@@ -169,19 +196,24 @@ class ShardedCompositor:
         self.tiles, self.tile_surfaces = self.tile_sets[par], self.surface_sets[par]
         self._ingest_local(frames_row)
         works = post_gather(self.dist, self.plan, self.rank, self.tiles)
-        prev, self.pending = self.pending, (works, par, out)
+        prev, self.pending = self.pending, (works, par, out, {name: getattr(self, name) for name in self._FRAME_STATE})
         self.frame_no += 1
         self._finish(prev)
 
     def _finish(self, pending):
         if pending is None:
             return
-        works, par, out = pending
+        works, par, out, state = pending
         for w in works:
             w.wait()  # the current stream now waits for this frame's sends / receives
         if self.rank == self.plan.root:
+            # the frame is composed with the tile set, the layout list, the slot -> input map and the non-input surface (`label`)
+            # it was prepared with (set_layouts / a new label may have moved on to the next frame)
+            now = {name: getattr(self, name) for name in self._FRAME_STATE}
             self.tiles, self.tile_surfaces = self.tile_sets[par], self.surface_sets[par]
+            self.__dict__.update(state)
             self.compose_fn(self.tiles, out)
+            self.__dict__.update(now)
             nxt = self.frame_no & 1
             self.tiles, self.tile_surfaces = self.tile_sets[nxt], self.surface_sets[nxt]
 

@@ -58,6 +58,27 @@ def _worker(rank, world, port, n_inputs, q):
         comp.flush()
         if rank == 0:
             assert composed == list(range(9)), composed
+        # animated scene: every rank sets the frame's layout list before the frame; the root must compose frame k with the list
+        # (and the non-input surface) of frame k although frame k + 1's were set before frame k's exchange completed
+        from dataclasses import replace
+        moved = {}
+        first_tex = next(i for i, L in enumerate(layouts) if L.type == 0 and L.source_index in comp.input_of_slot)
+        comp.compose_fn = lambda tiles, out: (compose(tiles, out), moved.__setitem__(out, (comp.root_layouts[first_tex].left, comp.label)))
+        for step in range(9, 15):
+            comp.set_layouts([replace(L, left=L.left + 0.25 * step) if L.type == 0 else L for L in layouts])
+            comp.label = f"layer{step}"
+            comp.step_pipelined({k: (f"frame{k}", step) for k in plan.inputs_of(rank)}, step)
+        comp.flush()
+        if rank == 0:
+            assert composed == list(range(15)), composed
+            base = layouts[first_tex].left
+            assert moved == {s: (base + 0.25 * s, f"layer{s}") for s in range(9, 15)}, moved
+        try:
+            comp.set_layouts([replace(L, width=L.width * 2) if L.type == 0 else L for L in layouts])
+            resized_ok = False
+        except ValueError:
+            resized_ok = True
+        assert resized_ok
         if rank == 0:
             # root-side layouts sample whole tiles 1:1
             geom_ok = all(L.crop == (0.0, 0.0, float(comp.tile_geom[comp.input_of_slot[L.source_index]][0]),

@@ -289,6 +289,21 @@ def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
     for k, w_ in enumerate([want, want_b, want]):
         for a, b in zip(outs[k].download(), w_):
             assert (a == b).all(), k
+    # animated scene: a new layout list per frame (tiles move by fractions of a pixel, their sizes stay), set before the frame
+    # whose exchange then overlaps the previous frame's compose — each frame must come out with its own list
+    from dataclasses import replace
+    moved = [[replace(L, left=L.left + 0.37 * (j + 1), top=L.top + 1.5 * j) if L.type == 0 and L.source_index in slots else L
+              for L in layouts] for j in range(3)]
+    wants = [_render(c, hip, moved[j], srcs_b if j == 1 else srcs, W, H) for j in range(3)]
+    for j in range(3):
+        sharded.set_layouts(moved[j])
+        sharded.step_pipelined(rows[j], outs[j])
+    sharded.flush()
+    c.sync()
+    for j in range(3):
+        for a, b in zip(outs[j].download(), wants[j]):
+            assert (a == b).all(), j
+    assert not (wants[0][0] == want[0]).all()
     c.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
 
