@@ -222,10 +222,13 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         if (!((s_touch[i >> 5] >> (i & 31)) & 1u) || i < start) continue;
         const DevLayout &L = layouts[i];
         const bool copy_layer = i == start && (L.type != 0 || (L.flags & DL_ALIGNED));
-        if (!copy_layer) s_general = 1;
+        const bool sample_layer = i == start && L.type == 0 && !(L.flags & DL_ALIGNED);  // opaque texture, solid over the tile, not a 1:1 blit
+        if (sample_layer) atomicOr(&s_general, 2);
+        else if (!copy_layer) atomicOr(&s_general, 1);
     }
     __syncthreads();
-    const bool general = s_general != 0;
+    const bool general = (s_general & 1) != 0;
+    const bool sampled = s_general == 2;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)
     if (ablate & 2) return;
     if ((ablate & 16) && general) return;   // profiling: copy tiles only
     if ((ablate & 32) && !general) return;  // profiling: general tiles only
@@ -303,6 +306,20 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         const uint4 t0 = *(const uint4 *)&s_px[ly0 * B_TILE_W + lx0], t1 = *(const uint4 *)&s_px[(ly0 + 1) * B_TILE_W + lx0];
         acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
         acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+    } else if (sampled) {
+        // ---- sampled tiles: the whole tile lies in the solid region of one opaque texture layer that is not a texel-aligned
+        //      blit (a video tile at a fractional position or another scale — every tile of a grid in mid-transition) and
+        //      nothing above touches it.  Per pixel this is exactly what the general path does for such a layer (coverage is
+        //      certain, the fragment is the sample, blended over the cleared target), without the per-pixel start search, the
+        //      LDS-resident running colour and the one-pixel-at-a-time sweeps: the eight pixels of a thread's 4x2 block are
+        //      independent, so their texel fetches overlap.
+        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
+        __syncthreads();
+        if (px0 >= W || py0 >= H) return;
+        const float *dec = s_tab, *thr = s_tab + 256;
+        const DevLayout L = load_uniform(&layouts[start]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(0u, L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
     } else {
         if (px0 >= W || py0 >= H) return;  // W % 4 == 0, H % 2 == 0: a block is entirely inside or outside
         if (start >= 0) {
