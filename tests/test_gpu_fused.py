@@ -390,6 +390,30 @@ def test_empty_scene_is_transparent_black(ctx, hip):
     assert (y == 16).all() and (u == 128).all() and (v == 128).all()
 
 
+@pytest.mark.parametrize("name,mk,iw,ih,W,H,n", [
+    ("configs1", lambda: scenes.cfg2_scene(1920, 1080, 1920, 1080, 4), 1920, 1080, 1920, 1080, 4),   # 2x, 13 taps, 32-column strips
+    ("configs3_one_gpu", lambda: scenes.cfg3_scene(3840, 2160, 3840, 2160, 8), 3840, 2160, 3840, 2160, 8),  # 3x, 19 taps
+], ids=["configs1", "configs3_one_gpu"])
+def test_other_baseline_configs_at_full_size_match_the_oracle(ctx, hip, name, mk, iw, ih, W, H, n):
+    """BASELINE.json configs[1] and configs[3] (on one GPU) at their full sizes against the oracle's pass sequence."""
+    layouts, res = mk()
+    planes, frames = _inputs(ctx, hip, n, iw, ih)
+    label_t, label_host = _label_surfaces(ctx, 1)
+    srcs, nodes, k = [], [], 0
+    for r in res:
+        if r == (iw, ih):
+            srcs.append(frames[k])
+            nodes.append(orc.planar_yuv_to_rgba(*planes[k], iw, ih, omp=True))
+            k += 1
+        else:
+            srcs.append(label_t)
+            nodes.append(label_host)
+    got = _render(ctx, hip, layouts, srcs, W, H)
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H, omp=True)
+    for g, w_ in zip(got, want):
+        assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.995
+
+
 # ---- BASELINE.json full sizes: properties that do not need the oracle at 4K ----------------------
 def test_full_size_properties(ctx, ctx_unfused, hip):
     iw, ih, W, H, n = 1920, 1080, 3840, 2160, 8
@@ -435,3 +459,13 @@ def test_full_size_properties(ctx, ctx_unfused, hip):
     want, _ = refpipe.render_yuv420(sub_layouts, nodes, 2560, 720, omp=True)
     for g, w_ in zip(sub, want):
         assert refpipe.max_diff(g, w_) <= 1
+    # and the whole frame of the benchmark workload against the oracle's pass sequence (OpenMP build: about a second)
+    nodes_full, k = [], 0
+    for r in res:
+        if r == (iw, ih):
+            nodes_full.append(orc.planar_yuv_to_rgba(*planes[k], iw, ih, omp=True)); k += 1
+        else:
+            nodes_full.append(label_host)
+    want_full, _ = refpipe.render_yuv420(layouts, nodes_full, W, H, omp=True)
+    for g, w_ in zip(a, want_full):
+        assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.995
