@@ -116,7 +116,7 @@ class DeviceFrame:
 
 
 def pack_layouts(layouts) -> "C.Array":
-    """Accepts oracle-style Layout dataclasses (duck-typed) and fills smr_layout[]."""
+    """Accepts Layout records (smelter_amd.scene.Layout or any object with the same fields) and fills smr_layout[]."""
     arr = (_ffi.Layout * max(len(layouts), 1))()
     for i, L in enumerate(layouts):
         s = arr[i]
