@@ -219,16 +219,17 @@ def main():
     if single:
         # The whole per-frame path of the reference's Renderer::render (state.rs:220-252) is inside a step: frame set ->
         # populate_inputs -> layout maths at this pts (scene engine) -> parameter pack -> ingest + compose kernels -> output frame.
-        # Frames in flight: consecutive frames go to separate renderers (own context / HIP stream / scratch / output frames), so
-        # the latency-bound tail of one frame's compose kernel overlaps the next frame's ingest kernel.  Frames are independent
-        # (inputs read-only), exactly like separate outputs of the reference's pipeline.
+        # Frames in flight: ONE renderer with `--inflight` lanes (smr_renderer_add_lane: extra contexts = HIP streams + scratch +
+        # output frames).  Consecutive frames rotate through the lanes, so the latency-bound tail of one frame's compose kernel
+        # overlaps the next frame's ingest kernel; the scene is one state (one update_scene call, one pts sequence).  The
+        # strictly serial rate, the per-kernel timing and the latency come from a second, single-lane renderer.
         from smelter_amd import _ffi, synth
         from smelter_amd.renderer import Renderer
         lanes += [hip.Context(local_rank) for _ in range(n_lanes - 1)]
         atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
-        renderers, frame_sets = [], []
-        for c in lanes:
-            r = Renderer(c, stream_fallback_timeout_s=3600.0)  # the synthetic ring carries no timestamps
+
+        def make_renderer(c, extra=()):
+            r = Renderer(c, stream_fallback_timeout_s=3600.0, lanes=extra)  # the synthetic ring carries no timestamps
             for i in range(N_IN):
                 r.register_input(f"input_{i}")
             if ANIMATED:
@@ -236,23 +237,24 @@ def main():
             for node in r.update_scene("out", OUT_W, OUT_H, scene_json()):
                 if node.kind == _ffi.NODE_TEXT:
                     r.set_text("out", node.index, glyphs, atlas)
-            renderers.append(r)
-            frame_sets.append([r.make_frame_set({f"input_{i}": row[i] for i in range(N_IN)}) for row in ring])
+            return r
+        r_pipe, r_one = make_renderer(lanes[0], lanes[1:]), make_renderer(lanes[0])
+        renderers = [r_pipe, r_one]
+        frame_set_ring = [r_one.make_frame_set({f"input_{i}": row[i] for i in range(N_IN)}) for row in ring]
         FRAME_NS = 1_000_000_000 // 60
 
-        tick = [0]  # frames rendered so far: presentation timestamps never go backwards (the warm-up, timed, serial and
-        #             profiling loops all restart `step` at 0; transitions are defined on a monotonic pts)
+        tick = {id(r_pipe): 0, id(r_one): 0}  # frames rendered so far per renderer: presentation timestamps never go backwards
+        #   (the warm-up, timed, serial and profiling loops all restart `step` at 0; transitions are defined on a monotonic pts)
 
         def step_fn(step, lane=None):
-            k = step % n_lanes if lane is None else 0
-            t = tick[0]
-            tick[0] += 1
-            if ANIMATED and t % UPDATE_EVERY < (n_lanes if lane is None else 1):
+            r = r_pipe if lane is None else r_one
+            t = tick[id(r)]
+            tick[id(r)] += 1
+            if ANIMATED and t % UPDATE_EVERY == 0 and t:
                 # update_scene (the cold path of the reference, instance.rs:295-332) is part of this workload: the grid's
-                # children swap places and animate for 500 ms of every 750 ms.  Every renderer in flight gets the update
-                # before the first frame it renders after it.
-                renderers[k].update_scene("out", OUT_W, OUT_H, scene_json(t // UPDATE_EVERY))
-            renderers[k].render_packed(t * FRAME_NS, frame_sets[k][step % RING])
+                # children swap places and animate for 500 ms of every 750 ms
+                r.update_scene("out", OUT_W, OUT_H, scene_json(t // UPDATE_EVERY))
+            r.render_packed(t * FRAME_NS, frame_set_ring[step % RING])
     else:
         FRAME_NS = 1_000_000_000 // 60
         tick = [0]
@@ -395,7 +397,7 @@ def main():
         for s in range(min(args.latency_frames, 300)):
             t1 = time.perf_counter()
             step_fn(s, ctx)
-            of = BorrowedFrame(ctx, renderers[0]._outs[0].frame.contents)
+            of = r_one.output(0)
             if host_out is None:
                 host_out = of.pinned_planes()
             of.download_async(host_out)
@@ -432,10 +434,10 @@ def main():
             for s in range(reps):
                 for i in range(N_IN):
                     row0[i].upload(host_planes[i])
-                n_out = renderers[0].render_packed(s * FRAME_NS, frame_sets[0][0])
+                n_out = r_one.render_packed((tick[id(r_one)] + s) * FRAME_NS, frame_set_ring[0])
                 assert n_out == 1
                 from smelter_amd.renderer import BorrowedFrame
-                BorrowedFrame(ctx, renderers[0]._outs[0].frame.contents).download()
+                r_one.output(0).download()
             dt = (time.perf_counter() - t1) / reps
             moved = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H)
             result["pcie_inclusive"] = {"frames_per_s": round(1.0 / dt, 1), "ms_per_frame": round(dt * 1e3, 3),
@@ -450,7 +452,9 @@ def main():
                 for i in range(N_IN):
                     for dst, src in zip(pin_host[k][i], host_planes[i]):
                         dst[...] = src
-            pin_sets = [renderers[k].make_frame_set({f"input_{i}": pin_in[k][i] for i in range(N_IN)}) for k in range(k_lanes)]
+            rt = [make_renderer(lanes[k]) for k in range(k_lanes)]  # one single-lane renderer per frame in flight (uploads ride on its stream)
+            renderers += rt
+            pin_sets = [rt[k].make_frame_set({f"input_{i}": pin_in[k][i] for i in range(N_IN)}) for k in range(k_lanes)]
             out_host = [None] * k_lanes
             t1 = time.perf_counter()
             reps = 200
@@ -459,8 +463,8 @@ def main():
                 lanes[k].sync()  # the lane's previous frame (its host buffers are free again)
                 for i in range(N_IN):
                     pin_in[k][i].upload_async(pin_host[k][i])
-                renderers[k].render_packed(s * FRAME_NS, pin_sets[k])
-                of = BorrowedFrame(lanes[k], renderers[k]._outs[0].frame.contents)
+                rt[k].render_packed(s * FRAME_NS, pin_sets[k])
+                of = rt[k].output(0)
                 if out_host[k] is None:
                     out_host[k] = of.pinned_planes()
                 of.download_async(out_host[k])

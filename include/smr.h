@@ -329,7 +329,8 @@ typedef struct smr_input_frame {
 } smr_input_frame;
 typedef struct smr_output_frame {
     const char *output_id;
-    const smr_frame *frame;
+    const smr_frame *frame; /* owned by the renderer; valid until the lane that rendered it has rendered two more frames */
+    smr_ctx *ctx;           /* the context (stream) the frame's GPU work was issued on: sync / download through this one */
 } smr_output_frame;
 
 SMR_API int smr_renderer_create(smr_ctx *ctx, int64_t stream_fallback_timeout_ns /* < 0: 500 ms */, smr_renderer **out);
@@ -348,6 +349,13 @@ SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int no
                                   const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
 SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs,
                                 smr_output_frame *outputs, uint32_t cap, uint32_t *n_outputs);
+/* Frames in flight.  The reference submits one frame at a time (one wgpu queue); here a renderer may own several lanes — extra
+ * contexts on the same device (own HIP stream, own scratch).  Consecutive smr_renderer_render calls rotate through the lanes, so
+ * the latency-bound tail of one frame overlaps the next frame's kernels, while the scene stays ONE state: one update_scene call,
+ * one pts sequence, transitions identical to the single-lane renderer.  Each lane keeps its own pair of output frames and node
+ * surfaces; smr_output_frame.ctx says which context produced a frame.  smr_renderer_sync waits for every lane. */
+SMR_API int smr_renderer_add_lane(smr_renderer *r, smr_ctx *ctx);
+SMR_API int smr_renderer_sync(smr_renderer *r);
 
 SMR_API uint32_t smr_abi_version(void);
 SMR_API uint32_t smr_sizeof_layout(void);

@@ -39,7 +39,7 @@ EXPORTS = [
     "smr_renderer_create", "smr_renderer_destroy", "smr_renderer_last_error", "smr_renderer_register_input",
     "smr_renderer_unregister_input", "smr_renderer_register_image", "smr_renderer_register_shader", "smr_renderer_update_scene",
     "smr_renderer_unregister_output", "smr_renderer_node_count", "smr_renderer_node_info", "smr_renderer_set_text",
-    "smr_renderer_render",
+    "smr_renderer_render", "smr_renderer_add_lane", "smr_renderer_sync",
     "smr_abi_version", "smr_sizeof_layout",
 ]
 NO_RESOLUTION = 0xFFFFFFFF
@@ -107,7 +107,7 @@ class InputFrame(C.Structure):
 
 
 class OutputFrame(C.Structure):
-    _fields_ = [("output_id", C.c_char_p), ("frame", C.POINTER(Frame))]
+    _fields_ = [("output_id", C.c_char_p), ("frame", C.POINTER(Frame)), ("ctx", C.c_void_p)]
 
 
 _lib = None
@@ -196,6 +196,8 @@ def load():
         "smr_renderer_node_info": ([P, C.c_char_p, I, C.POINTER(SceneNode)], I),
         "smr_renderer_set_text": ([P, C.c_char_p, I, C.POINTER(F), C.POINTER(Glyph), U, P, U, U], I),
         "smr_renderer_render": ([P, C.c_int64, C.POINTER(InputFrame), U, C.POINTER(OutputFrame), U, C.POINTER(U)], I),
+        "smr_renderer_add_lane": ([P, P], I),
+        "smr_renderer_sync": ([P], I),
         "smr_abi_version": ([], U),
         "smr_sizeof_layout": ([], U),
     }

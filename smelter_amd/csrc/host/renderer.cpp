@@ -5,6 +5,7 @@
 // layout nodes into RGBA8 node surfaces — and read_outputs (render_loop.rs:59-230) fused into the root layout node's launch.
 // SURVEY.md §8 a14 (+ a2, a4); no GPU code here, only calls into the C ABI of this library.
 #include <cstring>
+#include <deque>
 #include <map>
 #include <set>
 
@@ -26,21 +27,31 @@ struct Source {
     uint32_t w = 0, h = 0;
 };
 
-struct Output {
-    Scene scene;
-    uint32_t w = 0, h = 0, format = SMR_FRAME_PLANAR_YUV420;
+// What one frame in flight owns of an output: its two alternating output frames and the per-node intermediate surfaces.
+// (One lane = the reference's renderer; with more lanes consecutive frames are enqueued on different contexts / HIP streams
+// and overlap on the device, while the scene — and with it every transition — stays one state advanced by one pts sequence.)
+struct OutputLane {
     smr_frame frames[2];
     bool have_frames = false;
     int flip = 0;
     std::vector<smr_surface *> node_surface;   // per graph node, (re)allocated on size change (NodeTexture::ensure_size)
-    std::vector<smr_surface *> text_surface;   // per graph node: the rendered glyph run of a Text node (once per scene update)
     std::vector<smr_surface *> scaled_image;   // per graph node: an Image node whose size differs from the image's
+};
+
+struct Output {
+    Scene scene;
+    uint32_t w = 0, h = 0, format = SMR_FRAME_PLANAR_YUV420;
+    std::deque<OutputLane> lanes;              // one per renderer lane, grown on demand (a deque: callers hold pointers to `frames`)
+    OutputLane *l = nullptr;                   // the lane of the frame being rendered
+    std::vector<smr_surface *> text_surface;   // per graph node: the rendered glyph run of a Text node (once per scene update; read-only per frame)
 };
 
 }  // namespace
 
 struct smr_renderer {
-    smr_ctx *ctx = nullptr;
+    smr_ctx *ctx = nullptr;           // the context GPU work is issued on: lane_ctx[0] outside smr_renderer_render, the frame's lane inside
+    std::vector<smr_ctx *> lane_ctx;  // [0] = the context given to smr_renderer_create, then smr_renderer_add_lane's
+    uint64_t frame_no = 0;
     int64_t timeout_ns = 500000000;  // stream_fallback_timeout
     std::set<std::string> inputs;
     std::map<std::string, ImageRes> images;
@@ -66,15 +77,45 @@ void free_surfaces(smr_renderer *r, std::vector<smr_surface *> &v) {
         if (s) smr_surface_destroy(r->ctx, s);
     v.clear();
 }
-void free_output(smr_renderer *r, Output &o) {
-    free_surfaces(r, o.node_surface);
-    free_surfaces(r, o.text_surface);
-    free_surfaces(r, o.scaled_image);
-    if (o.have_frames) {
-        smr_frame_destroy(r->ctx, &o.frames[0]);
-        smr_frame_destroy(r->ctx, &o.frames[1]);
-        o.have_frames = false;
+void sync_lanes(smr_renderer *r) {
+    for (smr_ctx *c : r->lane_ctx) smr_sync(c);
+}
+void free_lane_frames(smr_renderer *r, OutputLane &l) {
+    if (!l.have_frames) return;
+    smr_frame_destroy(r->ctx, &l.frames[0]);
+    smr_frame_destroy(r->ctx, &l.frames[1]);
+    l.have_frames = false;
+}
+// per-node surfaces belong to one render graph: dropped (and re-created on demand) when the graph changes
+void free_node_surfaces(smr_renderer *r, Output &o) {
+    const size_t n = o.scene.nodes().size();
+    for (OutputLane &l : o.lanes) {
+        free_surfaces(r, l.node_surface);
+        free_surfaces(r, l.scaled_image);
+        l.node_surface.assign(n, nullptr);
+        l.scaled_image.assign(n, nullptr);
     }
+    free_surfaces(r, o.text_surface);
+    o.text_surface.assign(n, nullptr);
+}
+void free_output(smr_renderer *r, Output &o) {
+    free_node_surfaces(r, o);
+    for (OutputLane &l : o.lanes) free_lane_frames(r, l);
+}
+// the lane's share of an output, created the first time the lane renders it
+int enter_lane(smr_renderer *r, Output &o, size_t lane) {
+    if (o.lanes.size() <= lane) o.lanes.resize(lane + 1);
+    OutputLane &l = o.lanes[lane];
+    o.l = &l;
+    const size_t n = o.scene.nodes().size();
+    if (l.node_surface.size() != n) { l.node_surface.assign(n, nullptr); l.scaled_image.assign(n, nullptr); }
+    if (!l.have_frames) {
+        int rc = gpu(r, smr_frame_create(r->ctx, o.format, o.w, o.h, &l.frames[0]), "output frame");
+        if (rc >= 0) rc = gpu(r, smr_frame_create(r->ctx, o.format, o.w, o.h, &l.frames[1]), "output frame");
+        if (rc < 0) return rc;
+        l.have_frames = true;
+    }
+    return 0;
 }
 
 // NodeTexture::ensure_size (state/node_texture.rs:22-42)
@@ -120,7 +161,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
         }
         if (w == 0 || h == 0) return 0;
         // the image pass draws the asset into the node's own resolution (bitmap_image.rs:65-88): bilinear
-        smr_surface *&dst = o.scaled_image[idx];
+        smr_surface *&dst = o.l->scaled_image[idx];
         int rc = ensure_surface(r, dst, w, h);
         if (rc < 0) return rc;
         rc = gpu(r, smr_rescale_bilinear(r->ctx, it->second.surface, dst), "image node");
@@ -148,13 +189,13 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
         if (it == r->shaders.end()) return fail(r, -1, "Shader \"" + c.ref_id + "\" does not exist. You have to register it first before using it in the scene definition.");
         const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
         if (w == 0 || h == 0) return 0;
-        int rc = ensure_surface(r, o.node_surface[idx], w, h);
+        int rc = ensure_surface(r, o.l->node_surface[idx], w, h);
         if (rc < 0) return rc;
         // shader nodes sample RGBA node textures: raw input frames are converted first (InputTexture::convert_to_node_texture)
         std::vector<const smr_surface *> srcs;
         for (size_t k = 0; k < kids.size(); k++) {
             if (kids[k].kind == SMR_SOURCE_FRAME) {
-                smr_surface *&t = o.node_surface[g.children[k]];
+                smr_surface *&t = o.l->node_surface[g.children[k]];
                 rc = ensure_surface(r, t, kids[k].w, kids[k].h);
                 if (rc < 0) return rc;
                 rc = gpu(r, smr_frame_to_rgba(r->ctx, kids[k].frame, t), "input node texture");
@@ -173,18 +214,18 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
         smr_surface_info si;
         smr_surface_info_get(src0, &si);
         if (si.width != w || si.height != h) {
-            smr_surface *&t = o.scaled_image[idx];
+            smr_surface *&t = o.l->scaled_image[idx];
             rc = ensure_surface(r, t, w, h);
             if (rc < 0) return rc;
             rc = gpu(r, smr_rescale_bilinear(r->ctx, src0, t), "shader source");
             if (rc < 0) return rc;
             srcs[0] = t;
         }
-        rc = gpu(r, smr_builtin_shader(r->ctx, it->second, &params, sizeof(params), srcs.data(), (uint32_t)srcs.size(), o.node_surface[idx],
+        rc = gpu(r, smr_builtin_shader(r->ctx, it->second, &params, sizeof(params), srcs.data(), (uint32_t)srcs.size(), o.l->node_surface[idx],
                                        (float)((double)fs.pts_ns / 1e9)),
                  "shader node");
         if (rc < 0) return rc;
-        out.kind = SMR_SOURCE_SURFACE; out.surface = o.node_surface[idx]; out.w = w; out.h = h;
+        out.kind = SMR_SOURCE_SURFACE; out.surface = o.l->node_surface[idx]; out.w = w; out.h = h;
         return 0;
     }
     // layout node (nested): LayoutNode::render into an RGBA8 node surface
@@ -198,19 +239,19 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
     std::string err;
     if (!o.scene.node_layouts(idx, fs.pts_ns, res, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, r->layouts, w, h, err)) return fail(r, -1, err);
     if (w == 0 || h == 0) return 0;
-    int rc = ensure_surface(r, o.node_surface[idx], w, h);
+    int rc = ensure_surface(r, o.l->node_surface[idx], w, h);
     if (rc < 0) return rc;
     rc = gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h, nullptr,
-                                   o.node_surface[idx]),
+                                   o.l->node_surface[idx]),
              "layout node");
     if (rc < 0) return rc;
-    out.kind = SMR_SOURCE_SURFACE; out.surface = o.node_surface[idx]; out.w = w; out.h = h;
+    out.kind = SMR_SOURCE_SURFACE; out.surface = o.l->node_surface[idx]; out.w = w; out.h = h;
     return 0;
 }
 
 int render_output(smr_renderer *r, Output &o, const FrameSetView &fs, const smr_frame **result) {
-    o.flip ^= 1;
-    smr_frame *target = &o.frames[o.flip];
+    o.l->flip ^= 1;
+    smr_frame *target = &o.l->frames[o.l->flip];
     *result = target;
     if (o.scene.nodes().empty()) return gpu(r, smr_frame_fill_black(r->ctx, target), "empty output");
     const GraphNode &root = o.scene.nodes()[0];
@@ -237,16 +278,16 @@ int render_output(smr_renderer *r, Output &o, const FrameSetView &fs, const smr_
         }
         // a root whose own width/height differ from the output resolution: render the node, then convert like any other root
         if (w == 0 || h == 0) return gpu(r, smr_frame_fill_black(r->ctx, target), "empty output");
-        int rc = ensure_surface(r, o.node_surface[0], w, h);
+        int rc = ensure_surface(r, o.l->node_surface[0], w, h);
         if (rc < 0) return rc;
         rc = gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h, nullptr,
-                                       o.node_surface[0]),
+                                       o.l->node_surface[0]),
                  "root layout node");
         if (rc < 0) return rc;
-        smr_surface *&t = o.scaled_image[0];
+        smr_surface *&t = o.l->scaled_image[0];
         rc = ensure_surface(r, t, o.w, o.h);
         if (rc < 0) return rc;
-        rc = gpu(r, smr_rescale_bilinear(r->ctx, o.node_surface[0], t), "root rescale");
+        rc = gpu(r, smr_rescale_bilinear(r->ctx, o.l->node_surface[0], t), "root rescale");
         if (rc < 0) return rc;
         return gpu(r, smr_rgba_to_frame(r->ctx, t, target), "output conversion");
     }
@@ -256,14 +297,14 @@ int render_output(smr_renderer *r, Output &o, const FrameSetView &fs, const smr_
     if (s.kind == SMR_SOURCE_NONE) return gpu(r, smr_frame_fill_black(r->ctx, target), "empty output");  // render_loop.rs:127-139
     const smr_surface *rgba = s.surface;
     if (s.kind == SMR_SOURCE_FRAME) {
-        rc = ensure_surface(r, o.node_surface[0], s.w, s.h);
+        rc = ensure_surface(r, o.l->node_surface[0], s.w, s.h);
         if (rc < 0) return rc;
-        rc = gpu(r, smr_frame_to_rgba(r->ctx, s.frame, o.node_surface[0]), "input node texture");
+        rc = gpu(r, smr_frame_to_rgba(r->ctx, s.frame, o.l->node_surface[0]), "input node texture");
         if (rc < 0) return rc;
-        rgba = o.node_surface[0];
+        rgba = o.l->node_surface[0];
     }
     if (s.w != o.w || s.h != o.h) {  // the output converters sample the root texture over the whole output (rgba_to_yuv.rs:74-117)
-        smr_surface *&t = o.scaled_image[0];
+        smr_surface *&t = o.l->scaled_image[0];
         rc = ensure_surface(r, t, o.w, o.h);
         if (rc < 0) return rc;
         rc = gpu(r, smr_rescale_bilinear(r->ctx, rgba, t), "root rescale");
@@ -281,6 +322,7 @@ SMR_API int smr_renderer_create(smr_ctx *ctx, int64_t stream_fallback_timeout_ns
     if (!ctx || !out) return -1;
     smr_renderer *r = new smr_renderer();
     r->ctx = ctx;
+    r->lane_ctx.push_back(ctx);
     if (stream_fallback_timeout_ns >= 0) r->timeout_ns = stream_fallback_timeout_ns;
     r->shaders["gaussian_blur"] = SMR_SHADER_GAUSSIAN_BLUR;
     *out = r;
@@ -289,6 +331,7 @@ SMR_API int smr_renderer_create(smr_ctx *ctx, int64_t stream_fallback_timeout_ns
 
 SMR_API void smr_renderer_destroy(smr_renderer *r) {
     if (!r) return;
+    sync_lanes(r);
     for (auto &kv : r->outputs) free_output(r, kv.second);
     for (auto &kv : r->images)
         if (kv.second.surface) smr_surface_destroy(r->ctx, kv.second.surface);
@@ -348,43 +391,28 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
     for (auto &kv : r->images) o.scene.register_image(kv.first, (float)kv.second.w, (float)kv.second.h);
     std::string err;
     if (!o.scene.update(scene_json, width, height, err)) {
-        if (!o.have_frames) r->outputs.erase(output_id);  // a failed first update leaves no output behind
+        if (o.w == 0) r->outputs.erase(output_id);  // a failed first update leaves no output behind
         return fail(r, -1, err);
     }
     // shader ids are resolved at update time like ShaderComponent::stateful_component does
     for (const GraphNode &g : o.scene.nodes())
         if (g.kind == Kind::Shader && !r->shaders.count(g.component->ref_id))
             r->err = "Shader \"" + g.component->ref_id + "\" does not exist. You have to register it first before using it in the scene definition.";
-    if (o.have_frames && (o.w != width || o.h != height || o.format != output_format)) {
-        smr_sync(r->ctx);
-        smr_frame_destroy(r->ctx, &o.frames[0]);
-        smr_frame_destroy(r->ctx, &o.frames[1]);
-        o.have_frames = false;
-    }
-    if (!o.have_frames) {
-        int rc = gpu(r, smr_frame_create(r->ctx, output_format, width, height, &o.frames[0]), "output frame");
-        if (rc >= 0) rc = gpu(r, smr_frame_create(r->ctx, output_format, width, height, &o.frames[1]), "output frame");
-        if (rc < 0) return rc;
-        o.have_frames = true;
-    }
+    // frames in flight read the surfaces dropped below
+    sync_lanes(r);
+    if (o.w != width || o.h != height || o.format != output_format)
+        for (OutputLane &l : o.lanes) free_lane_frames(r, l);  // re-created at the new geometry when the lane next renders
     o.w = width; o.h = height; o.format = output_format;
     // node indices belong to the new graph: per-node surfaces are re-created on demand, text runs must be supplied again
-    smr_sync(r->ctx);
-    free_surfaces(r, o.node_surface);
-    free_surfaces(r, o.text_surface);
-    free_surfaces(r, o.scaled_image);
-    const size_t n = o.scene.nodes().size();
-    o.node_surface.assign(n, nullptr);
-    o.text_surface.assign(n, nullptr);
-    o.scaled_image.assign(n, nullptr);
-    return 0;
+    free_node_surfaces(r, o);
+    return enter_lane(r, o, 0);  // the output's first frames exist after a successful update, as before
 }
 
 SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_id) {
     if (!r || !output_id) return fail(r, -1, "smr_renderer_unregister_output: null argument");
     auto it = r->outputs.find(output_id);
     if (it == r->outputs.end()) return 0;
-    smr_sync(r->ctx);
+    sync_lanes(r);
     free_output(r, it->second);
     r->outputs.erase(it);
     return 0;
@@ -430,23 +458,54 @@ SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int no
     int rc = ensure_surface(r, o.text_surface[node], w, h);
     if (rc < 0) return rc;
     // TextRendererNode::render (text_renderer.rs:72-167): clear to the background colour, blit the glyph run — once per update
-    return gpu(r, smr_blit_glyphs(r->ctx, o.text_surface[node], bg, glyphs, n, atlas, atlas_w, atlas_h), "text node");
+    rc = gpu(r, smr_blit_glyphs(r->ctx, o.text_surface[node], bg, glyphs, n, atlas, atlas_w, atlas_h), "text node");
+    // every lane's stream reads the run from its next frame on
+    if (rc >= 0 && r->lane_ctx.size() > 1) rc = gpu(r, smr_sync(r->ctx), "text node");
+    return rc;
 }
 
 SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs, smr_output_frame *outputs,
                                 uint32_t cap, uint32_t *n_outputs) {
     if (!r || (n_inputs && !inputs) || !n_outputs) return fail(r, -1, "smr_renderer_render: null argument");
     FrameSetView fs{inputs, n_inputs, pts_ns};
+    // consecutive frames rotate through the lanes: this frame's GPU work goes to its lane's context (stream, scratch) and
+    // into the lane's own output frames and node surfaces; the scene state is shared and advances with pts as ever
+    const size_t lane = (size_t)(r->frame_no++ % r->lane_ctx.size());
+    smr_ctx *base = r->ctx;
+    r->ctx = r->lane_ctx[lane];
     uint32_t k = 0;
+    int rc = 0;
     for (auto &kv : r->outputs) {
         const smr_frame *frame = nullptr;
-        int rc = render_output(r, kv.second, fs, &frame);
-        if (rc < 0) return rc;
-        if (k < cap && outputs) { outputs[k].output_id = kv.first.c_str(); outputs[k].frame = frame; }
+        rc = enter_lane(r, kv.second, lane);
+        if (rc >= 0) rc = render_output(r, kv.second, fs, &frame);
+        if (rc < 0) break;
+        if (k < cap && outputs) { outputs[k].output_id = kv.first.c_str(); outputs[k].frame = frame; outputs[k].ctx = r->ctx; }
         k++;
     }
+    r->ctx = base;
+    if (rc < 0) return rc;
     *n_outputs = k;
     return 0;
+}
+
+SMR_API int smr_renderer_add_lane(smr_renderer *r, smr_ctx *ctx) {
+    if (!r || !ctx) return fail(r, -1, "smr_renderer_add_lane: null argument");
+    for (smr_ctx *c : r->lane_ctx)
+        if (c == ctx) return fail(r, -1, "smr_renderer_add_lane: this context is a lane already");
+    if (smr_ctx_mode(ctx) != smr_ctx_mode(r->ctx)) return fail(r, -1, "smr_renderer_add_lane: the lane's context has another rendering mode");
+    r->lane_ctx.push_back(ctx);
+    return 0;
+}
+
+SMR_API int smr_renderer_sync(smr_renderer *r) {
+    if (!r) return -1;
+    int rc = 0;
+    for (smr_ctx *c : r->lane_ctx) {
+        const int e = smr_sync(c);
+        if (e < 0 && rc >= 0) rc = gpu(r, e, "sync");
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -29,13 +29,27 @@ class BorrowedFrame(DeviceFrame):
 
 
 class Renderer:
-    def __init__(self, ctx: Context, stream_fallback_timeout_s: float = 0.5):
+    def __init__(self, ctx: Context, stream_fallback_timeout_s: float = 0.5, lanes: Sequence[Context] = ()):
+        """`lanes`: extra contexts on the same device — consecutive frames rotate through `ctx` and these, so up to
+        1 + len(lanes) frames are in flight on the GPU while the scene stays one state (smr_renderer_add_lane)."""
         self.ctx, self.lib = ctx, ctx.lib
         h = C.c_void_p()
         if self.lib.smr_renderer_create(ctx.handle, int(stream_fallback_timeout_s * 1e9), C.byref(h)) != 0:
             raise RuntimeError("smr_renderer_create failed")
         self._h = h
         self._outs = (_ffi.OutputFrame * 16)()
+        self._ctx_of = {ctx.handle.value: ctx}
+        for c in lanes:
+            self._check(self.lib.smr_renderer_add_lane(self._h, c.handle))
+            self._ctx_of[c.handle.value] = c
+
+    def sync(self):
+        """Waits for the frames in flight on every lane."""
+        self._check(self.lib.smr_renderer_sync(self._h))
+
+    def output(self, i: int = 0) -> "BorrowedFrame":
+        """Output `i` of the last render call, bound to the context (lane) that produced it."""
+        return BorrowedFrame(self._ctx_of[self._outs[i].ctx], self._outs[i].frame.contents)
 
     def close(self):
         if self._h:
@@ -119,4 +133,4 @@ class Renderer:
     def render(self, pts_s: float, frames: Dict[str, DeviceFrame], frame_pts_s: Optional[Dict[str, float]] = None) -> Dict[str, BorrowedFrame]:
         packed = self.make_frame_set(frames, pts_s, frame_pts_s)
         n = self.render_packed(int(pts_s * 1e9), packed)
-        return {self._outs[i].output_id.decode(): BorrowedFrame(self.ctx, self._outs[i].frame.contents) for i in range(min(n, 16))}
+        return {self._outs[i].output_id.decode(): self.output(i) for i in range(min(n, 16))}

@@ -212,6 +212,44 @@ def test_animated_grid_with_blur_layer_matches_the_oracle_mid_transition(ctx, hi
         assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.99
 
 
+def test_frames_in_flight_share_one_scene_state(ctx, hip, renderer):
+    """A renderer with three lanes (smr_renderer_add_lane) against the plain one-lane renderer on the same call sequence —
+    scene updates with transitions, a text run, a shader node: every frame comes out bit-identical, whichever lane rendered it,
+    and a frame stays valid while the other lanes render."""
+    from smelter_amd import synth
+    from smelter_amd.renderer import Renderer
+    iw, ih, W, H, n, lw, lh = 320, 180, 640, 360, 6, 160, 90
+    _, frames = _frames(ctx, hip, n, iw, ih)
+    frames = {f"input_{i}": frames[f"in{i}"] for i in range(n)}
+    extra = [hip.Context(0), hip.Context(0)]
+    piped = Renderer(ctx, lanes=extra)
+    for r in (renderer, piped):
+        for k in frames:
+            r.register_input(k)
+        r.register_shader("soften")
+    held = []
+    for step in range(14):
+        if step % 5 == 0:
+            for r in (renderer, piped):
+                r.update_scene("out", W, H, synth.animated_grid_scene(n, step // 5, lw, lh, transition_ms=100))
+        t = step / 60
+        pts = {k: t for k in frames}
+        want = renderer.render(t, frames, pts)["out"].download()
+        got_frame = piped.render(t, frames, pts)["out"]
+        held.append((got_frame, want))
+        if len(held) == 3:  # read a frame back two render calls later: its lane has not been reused yet
+            f, w_ = held.pop(0)
+            for a, b in zip(f.download(), w_):
+                assert (a == b).all(), step
+    piped.sync()
+    for f, w_ in held:
+        for a, b in zip(f.download(), w_):
+            assert (a == b).all()
+    piped.close()
+    for c in extra:
+        c.close()
+
+
 def test_resample_targets_are_reused_across_sizes(ctx, hip, renderer):
     """The resample target of an animated rescaler changes size on every frame; the scratch surface behind it is re-described
     in place while it fits its allocation and regrown otherwise.  Shrinking, growing past the first allocation and coming back
