@@ -229,7 +229,14 @@ def test_frames_in_flight_share_one_scene_state(ctx, hip, renderer):
         r.register_shader("soften")
     held = []
     for step in range(14):
-        if step % 5 == 0:
+        if step == 10:
+            # a scene with text runs: the glyph surfaces are rendered once (on the first lane's stream) and read by every lane
+            for r in (renderer, piped):
+                for i in range(n):
+                    r.register_input(f"in{i}")
+                _set_labels(r, "out", r.update_scene("out", W, H, scenes.cfg3_scene_json(n)))
+            frames = {**frames, **{f"in{i}": frames[f"input_{i}"] for i in range(n)}}
+        elif step % 5 == 0:
             for r in (renderer, piped):
                 r.update_scene("out", W, H, synth.animated_grid_scene(n, step // 5, lw, lh, transition_ms=100))
         t = step / 60
