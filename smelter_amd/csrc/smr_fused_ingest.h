@@ -413,6 +413,9 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
                 const u8 *yr0 = rawY + (size_t)(2 * pr) * ys - cbase, *yr1 = yr0 + ys;                        // index by luma x
                 const bool ok0 = y0 >= 0, ok1 = y1 <= e;
                 const int cw1 = J.up.w - 1;
+                // (the range of the frame is decided once per row pair, not per pixel: two copies of the loop)
+                auto quads = [&](auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;
                 for (int qc = lane; qc < nq; qc += 64) {
                     const int x0 = c_lo + 2 * qc, x1 = x0 + 1;  // x0 odd (or -1), x1 even
                     const int i0 = max(qx0 - 1 + qc, 0) << (cm - 1), i1 = min(qx0 + qc, cw1) << (cm - 1);  // clamp-to-edge chroma taps
@@ -428,16 +431,19 @@ __device__ __forceinline__ void ingest_strip(const IngestJob &J, int strip, int 
                         const float vt = v00 * gx + v01 * fx, vbt = v10 * gx + v11 * fx;
                         if (ok0) {
                             const float uu = ut * 0.75f + ubt * 0.25f, vv = vt * 0.75f + vbt * 0.25f;
-                            const float ue = J.full_range ? uu : expand_chroma(uu), ve = J.full_range ? vv : expand_chroma(vv);
+                            const float ue = FULL ? uu : expand_chroma(uu), ve = FULL ? vv : expand_chroma(vv);
                             S[sx - c_lo] = yuv_expanded_to_linear(s_ylut[yr0[sx]], ue, ve, s_dec);
                         }
                         if (ok1) {
                             const float uu = ut * 0.25f + ubt * 0.75f, vv = vt * 0.25f + vbt * 0.75f;
-                            const float ue = J.full_range ? uu : expand_chroma(uu), ve = J.full_range ? vv : expand_chroma(vv);
+                            const float ue = FULL ? uu : expand_chroma(uu), ve = FULL ? vv : expand_chroma(vv);
                             S[ncm + sx - c_lo] = yuv_expanded_to_linear(s_ylut[yr1[sx]], ue, ve, s_dec);
                         }
                     }
                 }
+                };
+                if (J.full_range) quads(std::true_type{});
+                else quads(std::false_type{});
             } else {
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
