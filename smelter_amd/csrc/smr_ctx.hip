@@ -6,6 +6,7 @@
 #include "smr_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 
 int smr_fail(smr_ctx *ctx, int code, const char *fmt, ...) {
     if (ctx) {
@@ -151,7 +152,8 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         }
         ctx->own_stream = true;
     }
-    static float tables[SMR_TABLE_FLOATS];
+    // (a local buffer: two threads creating contexts at once must not share a half-built table)
+    float tables[SMR_TABLE_FLOATS];
     memset(tables, 0, sizeof(tables));
     for (int i = 0; i < 256; i++) tables[i] = (float)srgb_to_linear_f64((double)i / 255.0);
     float *thr = tables + 256;
@@ -172,13 +174,33 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
             memcpy(&lo, &lo_bits, 4);
             memcpy(&hi, &hi_bits, 4);
             int cl = code_of(lo), chh = code_of(hi);
-            if (chh - cl > 1) return SMR_ERR_INTERNAL;  // the one-step fix-up in srgb_encode8 would not suffice
+            if (chh - cl > 1) {  // the one-step fix-up in srgb_encode8 would not suffice
+                smr_ctx_destroy(ctx);
+                return SMR_ERR_INTERNAL;
+            }
             enc[idx] = (u8)cl;
         }
     }
     memcpy(ctx->h_tables, tables, sizeof(tables));
+    // decode table as an f16 pair per entry (hi, lo = t - hi): the A operand of the matrix-core resampler (smr_ingest_mfma.h)
+    u32 lut16[256];
+    for (int i = 0; i < 256; i++) {
+        const _Float16 hi = (_Float16)tables[i];
+        const _Float16 lo = (_Float16)(tables[i] - (float)hi);
+        u16 hb, lb;
+        memcpy(&hb, &hi, 2);
+        memcpy(&lb, &lo, 2);
+        lut16[i] = (u32)hb | ((u32)lb << 16);
+    }
+    if (const char *e = getenv("SMR_INGEST_IMPL")) {  // tools / A-B runs: "valu" or "mfma"; smr_ctx_set_ingest_impl overrides
+        if (!strcmp(e, "valu")) ctx->ingest_impl = SMR_INGEST_VALU_F32;
+        else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
+    }
+    if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_lut16, sizeof(lut16)) != hipSuccess ||
+        hipMemcpy(ctx->d_lut16, lut16, sizeof(lut16), hipMemcpyHostToDevice) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         smr_ctx_destroy(ctx);
         return SMR_ERR_INTERNAL;
@@ -199,6 +221,9 @@ void smr_ctx_destroy(smr_ctx *ctx) {
         if (s) smr_surface_destroy(ctx, s);
     for (auto &t : ctx->weight_tables)
         if (t.dev) (void)hipFree(t.dev);
+    for (auto &t : ctx->mfma_tables)
+        if (t.dev) (void)hipFree(t.dev);
+    if (ctx->d_lut16) (void)hipFree(ctx->d_lut16);
     for (auto &l : ctx->layout_ring) {
         if (l.host) (void)hipHostFree(l.host);
         if (l.dev) (void)hipFree(l.dev);
@@ -209,6 +234,13 @@ void smr_ctx_destroy(smr_ctx *ctx) {
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int smr_ctx_set_ingest_impl(smr_ctx *ctx, uint32_t impl) {
+    if (!ctx) return SMR_ERR_INVALID;
+    if (impl > SMR_INGEST_MFMA_F16) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_ingest_impl: unknown implementation %u", impl);
+    ctx->ingest_impl = impl;
+    return SMR_OK;
 }
 
 const char *smr_last_error(const smr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }

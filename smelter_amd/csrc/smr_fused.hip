@@ -21,6 +21,7 @@
 // general kernels of smr_convert / smr_resample / smr_layout per layout — never to the CPU.
 #include "smr_fused_compose.h"
 #include "smr_fused_ingest.h"
+#include "smr_ingest_mfma.h"
 
 #include <cstdlib>
 
@@ -32,6 +33,8 @@ bool fused_disabled(smr_ctx *ctx) {
         ctx->fused_disabled = (e && e[0] && e[0] != '0') ? 1 : 0;
         const char *a = getenv("SMR_ABLATE");
         ctx->ablate = a ? atoi(a) : 0;
+        const char *t = getenv("SMR_INGEST_TW");
+        ctx->force_tw = t ? atoi(t) : 0;
     }
     return ctx->fused_disabled == 1;
 }
@@ -98,6 +101,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- resample_scaled_children (layout.rs:238-278): per texture layout decide direct / general / fused
     std::vector<smr_layout> eff(layouts, layouts + n);
     std::vector<IngestJob> jobs;
+    std::vector<MJob> mjobs;
+    ctx->weight_call++;
     u32 next_view = n_sources;
     for (u32 li = 0; li < n; li++) {
         smr_layout &L = eff[li];
@@ -116,7 +121,15 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 if (dw > 16384 || dh > 16384) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: layout %u is too large", li);
                 smr_surface *tile = smr_cached_surface(ctx, SLOT_TILE0 + li, dw, dh, SMR_PX_RGBA8);
                 if (!tile) return SMR_ERR_OOM;
-                if (fused && is_frame && can_fuse_ingest(sources[si].frame, plan)) {
+                bool on_mfma = false;
+                if (fused && is_frame && can_fuse_mfma(ctx, sources[si].frame, plan, tile)) {
+                    MJob J;
+                    int rc = make_mfma_job(ctx, sources[si].frame, plan, tile, &J, &on_mfma);
+                    if (rc != SMR_OK) return rc;
+                    if (on_mfma) mjobs.push_back(J);
+                }
+                if (on_mfma) {
+                } else if (fused && is_frame && can_fuse_ingest(sources[si].frame, plan)) {
                     IngestJob J;
                     int rc = make_ingest_job(ctx, sources[si].frame, plan, tile, &J);
                     if (rc != SMR_OK) return rc;
@@ -159,6 +172,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (rc != SMR_OK) return rc;
 
     // ---- wave A (job descriptors ride in the kernel arguments)
+    if (!mjobs.empty()) {
+        rc = launch_mfma(ctx, mjobs);
+        if (rc != SMR_OK) return rc;
+    }
     if (!jobs.empty()) {
         rc = launch_ingest(ctx, jobs);
         if (rc != SMR_OK) return rc;
@@ -209,6 +226,17 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
     int kind = smr_resample_plan_make(in->width, in->height, crop, dst->w, dst->h, &plan);
     if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample: degenerate plan");
     if (kind == 0) return 0;
+    ctx->weight_call++;
+    if (!fused_disabled(ctx) && can_fuse_mfma(ctx, in, plan, dst)) {
+        std::vector<MJob> mjobs(1);
+        bool fits = false;
+        int rc = make_mfma_job(ctx, in, plan, dst, &mjobs[0], &fits);
+        if (rc != SMR_OK) return rc;
+        if (fits) {
+            rc = launch_mfma(ctx, mjobs);
+            return rc == SMR_OK ? kind : rc;
+        }
+    }
     if (!fused_disabled(ctx) && can_fuse_ingest(in, plan)) {
         std::vector<IngestJob> jobs(1);
         int rc = make_ingest_job(ctx, in, plan, dst, &jobs[0]);
@@ -230,6 +258,8 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
     if (!ctx || (n && (!in || !crops || !dst))) return SMR_ERR_INVALID;
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
     std::vector<IngestJob> jobs;
+    std::vector<MJob> mjobs;
+    const uint64_t call = ++ctx->weight_call;
     for (uint32_t i = 0; i < n; i++) {
         if (!in[i] || !dst[i] || dst[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: bad input %u", i);
         const float *crop = crops + 4 * i;
@@ -238,7 +268,15 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample_batch: degenerate plan for input %u", i);
         if (kinds) kinds[i] = kind;
         if (kind == 0) continue;
-        if (!fused_disabled(ctx) && can_fuse_ingest(in[i], plan)) {
+        bool on_mfma = false;
+        if (!fused_disabled(ctx) && can_fuse_mfma(ctx, in[i], plan, dst[i])) {
+            MJob J;
+            int rc = make_mfma_job(ctx, in[i], plan, dst[i], &J, &on_mfma);
+            if (rc != SMR_OK) return rc;
+            if (on_mfma) mjobs.push_back(J);
+        }
+        if (on_mfma) {
+        } else if (!fused_disabled(ctx) && can_fuse_ingest(in[i], plan)) {
             IngestJob J;
             int rc = make_ingest_job(ctx, in[i], plan, dst[i], &J);
             if (rc != SMR_OK) return rc;
@@ -246,7 +284,12 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         } else {
             int rc = smr_ingest_resample(ctx, in[i], crop, dst[i]);
             if (rc < 0) return rc;
+            ctx->weight_call = call;  // (the single-input entry point opened a call of its own; pending jobs stay protected)
         }
+    }
+    if (!mjobs.empty()) {
+        int rc = launch_mfma(ctx, mjobs);
+        if (rc != SMR_OK) return rc;
     }
     if (!jobs.empty()) {
         int rc = launch_ingest(ctx, jobs);

@@ -60,12 +60,15 @@ int get_weights(smr_ctx *ctx, float scale, float offset, int n, WeightPtrs *out)
         if (t.dev && t.n == n && t.scale == scale && t.offset == offset) { hit = &t; break; }
     }
     if (!hit) {
-        if (ctx->weight_tables.size() < 64) {
+        // Jobs are collected first and launched afterwards: a table this call (ctx->weight_call) already handed to a pending job
+        // is never a victim — rebuilding it in place or freeing it would give that job wrong weights or a dangling pointer.
+        // The cache grows instead (bounded by 2 x max_layouts distinct tables per call).
+        if (ctx->weight_tables.size() >= 64)
+            for (auto &t : ctx->weight_tables)
+                if (t.last_call != ctx->weight_call && (!victim || t.last_use < victim->last_use)) victim = &t;
+        if (!victim) {
             ctx->weight_tables.emplace_back();
             victim = &ctx->weight_tables.back();
-        } else {
-            for (auto &t : ctx->weight_tables)
-                if (!victim || t.last_use < victim->last_use) victim = &t;
         }
         const size_t need = (size_t)n * (2 + taps) * 4;
         if (victim->bytes < need) {
@@ -88,6 +91,7 @@ int get_weights(smr_ctx *ctx, float scale, float offset, int n, WeightPtrs *out)
         hit = victim;
     }
     hit->last_use = ctx->weight_clock;
+    hit->last_call = ctx->weight_call;
     out->first = (const int *)hit->dev;
     out->wsum = (const float *)hit->dev + n;
     out->w = (const float *)hit->dev + 2 * (size_t)n;
@@ -645,8 +649,8 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
         J.nc_max = (int)ceilf(64.0f * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
         if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
     }
-    if (const char *force = getenv("SMR_INGEST_TW")) {  // tests / profiling: pin the strip width
-        const int tw = atoi(force);
+    {  // tests / profiling: SMR_INGEST_TW pins the strip width (read once per ctx, smr_fused.hip:fused_disabled)
+        const int tw = ctx->force_tw;
         if (tw == 32 || tw == 64) {
             J.tw = tw;
             J.nc_max = (int)ceilf((float)tw * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
@@ -659,10 +663,9 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
 }
 
 int launch_ingest(smr_ctx *ctx, std::vector<IngestJob> &jobs) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->valu_attr_set) {  // per device, hence per ctx
         SMR_HIP(ctx, hipFuncSetAttribute((const void *)k_ingest_resample, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        ctx->valu_attr_set = true;
     }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
     for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_JOBS_PER_LAUNCH) {
@@ -687,8 +690,7 @@ int launch_ingest(smr_ctx *ctx, std::vector<IngestJob> &jobs) {
         // 1/16 of the CUs stay free for the compose kernel of the frame in flight on another stream: measured on MI355X the
         // ingest kernel alone loses 1.5 % on 240 instead of 256 CUs, the pipelined frame rate gains 3 %
         // (SMR_INGEST_RESERVE_CUS overrides, profiling only)
-        static const int reserve_env = getenv("SMR_INGEST_RESERVE_CUS") ? atoi(getenv("SMR_INGEST_RESERVE_CUS")) : -1;
-        const int reserve = reserve_env >= 0 && reserve_env < ctx->cu_count ? reserve_env : ctx->cu_count / 16;
+        const int reserve = ctx->ingest_reserve_cus >= 0 && ctx->ingest_reserve_cus < ctx->cu_count ? ctx->ingest_reserve_cus : ctx->cu_count / 16;
         int blocks = 2 * (ctx->cu_count - reserve);
         int upb = (total + blocks - 1) / blocks;
         if (upb < 32) upb = 32;

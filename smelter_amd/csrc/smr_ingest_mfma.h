@@ -1,0 +1,571 @@
+// smr_ingest_mfma.h — wave A of the hot path on the matrix cores: k_ingest_mfma (included by smr_fused.hip only).
+//
+// Same job as k_ingest_resample (smr_fused_ingest.h): planar 4:2:0 frame -> dst-sized sRGB RGBA8 tile, i.e. the reference's
+// planar_yuv_to_rgba pass (wgpu/format/planar_yuv_to_rgba.wgsl:35-58) followed by the two Lanczos3 passes of
+// transformations/layout/resample.wgsl:31-87 with their Rgba16Float intermediate (layout/resampler.rs:25-28) — but the two
+// separable filter passes are recast as banded GEMMs on v_mfma_f32_16x16x32_f16:
+//
+//   pass 1   H[r][x]  = sum_k  T[r][k]  * Wh[k][x]      M = 16 source rows (one chunk), N = 16 output columns, K = source columns
+//   pass 2   O[x][y]  = sum_r  H[x][r]  * Wv[r][y]      M = 16 output columns, N = 16 output rows,            K = source rows
+//
+// * T = the node texture's sRGB-decoded linear value per texel, kept as an f16 pair (hi, lo = t - hi) interleaved along K, so the
+//   product is exact to ~2^-22 although the matrix cores take f16 (one f16 alone costs ~1 % of the output bytes one LSB,
+//   tools/mfma_precision_sim.py); the weights are f16, normalised and quantised with error feedback so that every output's
+//   weights sum to 1 (flat areas stay exact).  The reference's own quantisation points are kept: u8 node texture, f16 (RTNE)
+//   between the passes, u8 sRGB tile.  Deviation from the oracle: <= 1 LSB, > 99.9 % of the bytes identical (tests/).
+// * Clamp-to-edge is folded into the weight band (taps that clamp onto the same texel are summed), out-of-band entries are 0.
+// * A 256-thread workgroup owns a 64-column strip of the tile (one 16-column N tile per wave) over a range of 16-row output
+//   tiles and streams the source rows through LDS in chunks of 16:
+//     stage    raw Y/U/V dwords of the chunk (prefetched into registers one chunk ahead)
+//     convert  4x2 pixel blocks per lane: chroma by v_dot4_u32_u8 (9/3/3/1 bilinear in 1/16 units, exact), BT.709 matrix with
+//              folded constants (one FMA per term), u8 quantisation, (hi, lo) LUT lookup, 16-byte stores into T
+//     pass 1   per wave: 3 channels x KH k-steps of MFMA, result -> f16 -> ring of rows Mh (LDS, [8-row granule][column])
+//     pass 2   for every 16-row output tile whose window is now complete: 3 x KV MFMAs, sRGB encode, 16-byte stores
+//   The ring columns of a wave are written and read by that wave only, so a chunk costs two barriers.
+#pragma once
+
+#include "smr_convert_dev.h"
+#include "smr_resample_dev.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int M_WAVES = 4;
+constexpr int M_THREADS = M_WAVES * 64;
+constexpr int M_SW = 16 * M_WAVES;  // strip width: one 16-column N tile per wave
+constexpr int M_CH = 16;            // source rows per chunk = M of pass 1
+constexpr int M_KH_MAX = 6;         // k-steps of 32 (16 texels as hi/lo pairs) in pass 1
+constexpr int M_KV_MAX = 4;         // k-steps of 32 rows in pass 2
+constexpr int M_NG_MAX = 64;        // 4-texel column groups of a strip's source footprint (one luma row = one wave-wide load)
+constexpr int M_WSPAN = 136;        // >= 32 * M_KV_MAX, >= 16 * M_KH_MAX
+
+// ------------------------------------------------------------------ weight bands in MFMA B-operand layout (device cache)
+// Per tile of 16 outputs: meta = (base, last) — base = first source texel of the K window (pass 1: multiple of 4; pass 2:
+// = 1 mod 8), last = last texel with a non-zero weight — and K fragments of 64 lanes x 8 f16:
+//   lane l holds W[k = 32 j + 8 (l >> 4) + e][n = l & 15], e = 0..7;  pass 1: texel = base + (k >> 1) (hi and lo share a weight).
+__host__ __device__ inline int mfma_window_base(int lo, int axis) { return axis == 0 ? (lo & ~3) : (((lo - 1) & ~7) + 1); }
+
+__global__ __launch_bounds__(64) void k_build_mfma_weights(float scale, float offset, int taps, int n_dst, int n_src, int axis, int K,
+                                                           int2 *__restrict__ meta, uint4 *__restrict__ frag) {
+    __shared__ float s_w[16][M_WSPAN];
+    __shared__ _Float16 s_q[16][M_WSPAN];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const int o0 = 16 * t, o1 = min(o0 + 15, n_dst - 1);
+    const int lo = clampi(lanczos_first(o0, scale, offset), 0, n_src - 1);
+    const int hi = clampi(lanczos_first(o1, scale, offset) + taps - 1, 0, n_src - 1);
+    const int base = mfma_window_base(lo, axis);
+    const int span = axis == 0 ? 16 * K : 32 * K;
+    if (lane == 0) meta[t] = make_int2(base, hi);
+    for (int i = lane; i < 16 * M_WSPAN; i += 64) {
+        (&s_w[0][0])[i] = 0.0f;
+        (&s_q[0][0])[i] = (_Float16)0.0f;
+    }
+    __syncthreads();
+    if (lane < 16 && o0 + lane < n_dst) {
+        float w[MAX_TAPS];
+        float ws;
+        const int first = lanczos_weights(o0 + lane, scale, offset, taps, w, &ws);
+        for (int i = 0; i < taps; i++) {
+            const int idx = clampi(first + i, 0, n_src - 1) - base;
+            if (idx >= 0 && idx < span) s_w[lane][idx] += w[i] / ws;
+        }
+        // f16 with error feedback: the rounding residual of the whole row goes to the tap that can absorb it best
+        float sum = 0.0f;
+        for (int i = 0; i < span; i++) {
+            const _Float16 q = (_Float16)s_w[lane][i];
+            s_q[lane][i] = q;
+            sum += (float)q;
+        }
+        const float r = 1.0f - sum;
+        int best = -1;
+        float best_err = 1e30f;
+        for (int i = 0; i < span; i++) {
+            if (s_w[lane][i] == 0.0f) continue;
+            const float c = (float)s_q[lane][i] + r;
+            const float err = fabsf((float)(_Float16)c - c);
+            if (err < best_err) { best_err = err; best = i; }
+        }
+        if (best >= 0) s_q[lane][best] = (_Float16)((float)s_q[lane][best] + r);
+    }
+    __syncthreads();
+    for (int j = 0; j < K; j++) {
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int kk = 32 * j + 8 * (lane >> 4) + e;
+            v[e] = s_q[lane & 15][axis == 0 ? (kk >> 1) : kk];
+        }
+        frag[((size_t)t * K + j) * 64 + lane] = __builtin_bit_cast(uint4, v);
+    }
+}
+
+struct MfmaBand {
+    const int2 *meta;
+    const uint4 *frag;
+    int K;        // k-steps
+    int n_tiles;
+    int max_span; // max over tiles of (last - base + 1)
+};
+
+// host twin of the tile geometry (same f32 sequence as the device: lanczos_first is __host__ __device__)
+void mfma_band_geometry(float scale, float offset, int n_dst, int n_src, int axis, int *K, int *max_span) {
+    const int taps = host_taps(scale);
+    const int n_tiles = (n_dst + 15) / 16;
+    int span = 1;
+    for (int t = 0; t < n_tiles; t++) {
+        const int o0 = 16 * t, o1 = o0 + 15 < n_dst - 1 ? o0 + 15 : n_dst - 1;
+        int lo = lanczos_first(o0, scale, offset), hi = lanczos_first(o1, scale, offset) + taps - 1;
+        lo = lo < 0 ? 0 : (lo > n_src - 1 ? n_src - 1 : lo);
+        hi = hi < 0 ? 0 : (hi > n_src - 1 ? n_src - 1 : hi);
+        const int s = hi - mfma_window_base(lo, axis) + 1;
+        span = s > span ? s : span;
+    }
+    *max_span = span;
+    *K = axis == 0 ? (2 * span + 31) / 32 : (span + 31) / 32;
+}
+
+int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis, MfmaBand *out) {
+    int K, span;
+    mfma_band_geometry(scale, offset, n_dst, n_src, axis, &K, &span);
+    const int n_tiles = (n_dst + 15) / 16;
+    smr_ctx::MfmaTable *hit = nullptr, *victim = nullptr;
+    for (auto &t : ctx->mfma_tables)
+        if (t.dev && t.n_dst == n_dst && t.n_src == n_src && t.axis == axis && t.scale == scale && t.offset == offset) { hit = &t; break; }
+    if (!hit) {
+        // never evict a table the current call already handed to a job that is not launched yet
+        for (auto &t : ctx->mfma_tables)
+            if (t.last_call != ctx->weight_call && (!victim || t.last_use < victim->last_use)) victim = &t;
+        if (!victim || ctx->mfma_tables.size() < 64) {
+            ctx->mfma_tables.emplace_back();
+            victim = &ctx->mfma_tables.back();
+        }
+        const size_t meta_bytes = ((size_t)n_tiles * sizeof(int2) + 15) & ~(size_t)15;
+        const size_t need = meta_bytes + (size_t)n_tiles * K * 64 * sizeof(uint4);
+        if (victim->bytes < need) {
+            if (victim->dev) {
+                SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a queued kernel may still read it
+                (void)hipFree(victim->dev);
+                victim->dev = nullptr;
+                victim->bytes = 0;
+            }
+            const size_t want = (need + 4095) & ~(size_t)4095;
+            SMR_HIP(ctx, hipMalloc(&victim->dev, want));
+            victim->bytes = want;
+        }
+        victim->scale = scale; victim->offset = offset; victim->n_dst = n_dst; victim->n_src = n_src; victim->axis = axis;
+        victim->K = K; victim->max_span = span; victim->meta_bytes = meta_bytes;
+        hipLaunchKernelGGL(k_build_mfma_weights, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, scale, offset, host_taps(scale), n_dst, n_src,
+                           axis, K, (int2 *)victim->dev, (uint4 *)((u8 *)victim->dev + meta_bytes));
+        SMR_HIP(ctx, hipGetLastError());
+        hit = victim;
+    }
+    hit->last_use = ++ctx->weight_clock;
+    hit->last_call = ctx->weight_call;
+    out->meta = (const int2 *)hit->dev;
+    out->frag = (const uint4 *)((const u8 *)hit->dev + hit->meta_bytes);
+    out->K = hit->K;
+    out->n_tiles = n_tiles;
+    out->max_span = hit->max_span;
+    return SMR_OK;
+}
+
+// ------------------------------------------------------------------ kernel
+struct MJob {
+    SurfView yp, up, vp;  // planar 4:2:0 source planes (chroma views carry the chroma size)
+    SurfView dst;         // RGBA8 tile, dst-sized
+    int src_w, src_h;
+    // Y'CbCr -> 255 * R'G'B' + 0.5 with the range expansion and the clamps of planar_yuv_to_rgba.wgsl:45-57 folded in:
+    // luma in u8 units clamped to [ylo, yhi], chroma in 1/16 u8 units clamped to [clo, chi]
+    float ky, krv, kgu, kgv, kbu, cr, cg, cb;
+    float ylo, yhi;
+    int clo, chi;
+    const int2 *h_meta; const uint4 *h_frag;
+    const int2 *v_meta; const uint4 *v_frag;
+    int KH, KV, n_htiles, n_vtiles, strips_x;
+    int ts;   // T row stride in dwords (= 8 mod 16: conflict-free ds_read_b128 of the A operand)
+    int ngm;  // column groups (4 texels) the LDS is sized for
+    int RG;   // ring depth in 8-row granules (even)
+};
+
+constexpr int MAX_MJOBS_PER_LAUNCH = 12;
+struct MArgs {
+    MJob jobs[MAX_MJOBS_PER_LAUNCH];
+    int unit_prefix[MAX_MJOBS_PER_LAUNCH + 1];  // units = strips_x * n_vtiles per job (strip-major)
+    int n_jobs;
+    int units_per_block;
+};
+
+constexpr int M_OFF_THR = 1024;                                  // after the (hi | lo << 16) decode LUT
+constexpr int M_OFF_T = M_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
+static_assert(M_OFF_T % 16 == 0, "T must start on a 16-byte boundary");
+__host__ __device__ inline int m_ncd(int ngm) { return ((2 * (ngm - 1) + 3) >> 2) + 2; }  // staged chroma dwords per row
+__host__ __device__ inline size_t m_lds_bytes(int ts, int ngm, int RG) {
+    return (size_t)M_OFF_T + (size_t)3 * M_CH * ts * 4 + (size_t)3 * RG * M_SW * 16 + (size_t)M_CH * 4 * ngm + (size_t)2 * 9 * 4 * m_ncd(ngm);
+}
+
+__device__ __forceinline__ u32 m_lut_px(const u32 *__restrict__ lut, float x255) {
+    // floor(clamp(r, 0, 1) * 255 + 0.5) of the reference's unorm store; x255 already carries the + 0.5
+    const u32 code = (u32)__builtin_amdgcn_fmed3f(x255, 0.5f, 255.5f);
+    return lut[code];
+}
+
+// one 4x2 pixel block: luma dwords ya / yb (rows 2p, 2p + 1 of the chunk), chroma neighbourhoods (4 bytes: columns 2q-1 .. 2q+2) of
+// chroma rows p and p + 1 for both planes -> (hi, lo) linear texels, 3 channels x 2 rows x 16 bytes into T
+__device__ __forceinline__ void m_convert_block(const MJob &J, const u32 *__restrict__ lut, u32 ya, u32 yb, u32 ua, u32 ub, u32 va, u32 vb,
+                                                u32 *__restrict__ Trow_a /* T + (2p) * ts + 4g, channel stride 16 * ts */, int ts) {
+    const u32 pu0 = __builtin_amdgcn_perm(ub, ua, 0x05040100u), pu1 = __builtin_amdgcn_perm(ub, ua, 0x06050201u), pu2 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    const u32 pv0 = __builtin_amdgcn_perm(vb, va, 0x05040100u), pv1 = __builtin_amdgcn_perm(vb, va, 0x06050201u), pv2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    // bilinear chroma tap at the luma texcoord (planar_yuv_to_rgba.wgsl:37-39): weights (1/4, 3/4) per axis, in 1/16 units
+    constexpr u32 WA13 = 0x03010903u, WA31 = 0x01030309u;  // odd luma row: 3/4 of chroma row p;  columns (1/4, 3/4) | (3/4, 1/4)
+    constexpr u32 WB13 = 0x09030301u, WB31 = 0x03090103u;  // even luma row: 3/4 of chroma row p + 1
+    const u32 pus[4] = {pu0, pu1, pu1, pu2}, pvs[4] = {pv0, pv1, pv1, pv2};
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const u32 yy = row ? yb : ya;
+        uint4 o[3];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const u32 wgt = row ? ((i & 1) ? WB31 : WB13) : ((i & 1) ? WA31 : WA13);
+            const int u16 = (int)__builtin_amdgcn_udot4(pus[i], wgt, 0u, false), v16 = (int)__builtin_amdgcn_udot4(pvs[i], wgt, 0u, false);
+            const float uf = (float)min(max(u16, J.clo), J.chi), vf = (float)min(max(v16, J.clo), J.chi);
+            const float yf = __builtin_amdgcn_fmed3f((float)((yy >> (8 * i)) & 0xffu), J.ylo, J.yhi);
+            const float r = __builtin_fmaf(yf, J.ky, __builtin_fmaf(vf, J.krv, J.cr));
+            const float g = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kgu, __builtin_fmaf(vf, J.kgv, J.cg)));
+            const float b = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kbu, J.cb));
+            const u32 tr = m_lut_px(lut, r), tg = m_lut_px(lut, g), tb = m_lut_px(lut, b);
+            if (i == 0) { o[0].x = tr; o[1].x = tg; o[2].x = tb; }
+            if (i == 1) { o[0].y = tr; o[1].y = tg; o[2].y = tb; }
+            if (i == 2) { o[0].z = tr; o[1].z = tg; o[2].z = tb; }
+            if (i == 3) { o[0].w = tr; o[1].w = tg; o[2].w = tb; }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) *(uint4 *)(Trow_a + (size_t)(c * M_CH + row) * ts) = o[c];
+    }
+}
+
+// Output tiles [vt0, vt1] (16 rows each) of strip `strip` of job J.
+__device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, int vt1, u8 *smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, lq = lane >> 4;
+    const u32 *s_lut = (const u32 *)smem;
+    const float *s_thr = (const float *)(smem + M_OFF_THR);
+    u32 *T = (u32 *)(smem + M_OFF_T);
+    const int ts = J.ts, RG = J.RG;
+    uint4 *Mh = (uint4 *)(T + 3 * M_CH * ts);
+    u8 *rawY = (u8 *)(Mh + 3 * RG * M_SW);
+    const int ys = 4 * J.ngm, cs = 4 * m_ncd(J.ngm);
+    u8 *rawU = rawY + M_CH * ys, *rawV = rawU + 9 * cs;
+    const int sw = J.src_w, sh = J.src_h, cw = J.up.w, chh = J.up.h;
+
+    // ---- strip geometry
+    const int nt0 = strip * M_WAVES, ntn = min(M_WAVES, J.n_htiles - nt0);
+    const int cbase = J.h_meta[nt0].x & ~7;  // luma column of T column 0 (chroma staging wants it = 0 mod 8)
+    const int ngroups = min((J.h_meta[nt0 + ntn - 1].x + 16 * J.KH - cbase + 3) >> 2, J.ngm);
+    const int ncd = m_ncd(ngroups);
+    const bool wave_on = wave < ntn;
+    const int my_tile = nt0 + (wave_on ? wave : 0);
+    const int colw = J.h_meta[my_tile].x - cbase;  // T column (dword) of this wave's K window
+    uint4 bh[M_KH_MAX];
+#pragma unroll
+    for (int j = 0; j < M_KH_MAX; j++)
+        if (j < J.KH) bh[j] = J.h_frag[((size_t)my_tile * J.KH + j) * 64 + lane];
+    const int R_lo = J.v_meta[vt0].x, R_hi = J.v_meta[vt1].y;
+    const int tx0 = strip * M_SW + 16 * wave;
+
+    // ---- staging: luma = one row per wave and step (64 lanes x 4 B), chroma = 18 (plane, row) tasks of <= 64 dwords
+    u32 py[4], pc[5];
+    const int sw4 = (sw + 3) & ~3;
+    auto issue = [&](int base) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = wave + 4 * k;
+            const int srow = clampi(base + row, 0, sh - 1), col = cbase + 4 * lane;
+            if (lane < ngroups && col < sw4) py[k] = *(const u32 *)(J.yp.ptr + (size_t)srow * J.yp.pitch + col);
+        }
+        const int i0 = (base - 1) >> 1;  // chroma row of the chunk's first row pair
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int rt = wave + 4 * k;
+            if (rt < 18 && lane < ncd) {
+                const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
+                const int crow = clampi(i0 + r, 0, chh - 1);
+                const int col0 = (cbase >> 1) - 4 + 4 * lane;
+                const int col0c = clampi(col0, 0, (cw - 1) & ~3);
+                const SurfView &P = plane ? J.vp : J.up;
+                pc[k] = *(const u32 *)(P.ptr + (size_t)crow * P.pitch + col0c);
+            }
+        }
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int row = wave + 4 * k;
+            if (lane < ngroups && cbase + 4 * lane < sw4) *(u32 *)(rawY + row * ys + 4 * lane) = py[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int rt = wave + 4 * k;
+            if (rt < 18 && lane < ncd) {
+                const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
+                const int col0 = (cbase >> 1) - 4 + 4 * lane;
+                u32 v = pc[k];
+                if (col0 < 0 || col0 + 3 > cw - 1) {  // clamp-to-edge columns
+                    const int col0c = clampi(col0, 0, (cw - 1) & ~3);
+                    u32 o = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) o |= ((v >> (8 * (clampi(col0 + b, 0, cw - 1) - col0c))) & 0xffu) << (8 * b);
+                    v = o;
+                }
+                *(u32 *)((plane ? rawV : rawU) + r * cs + 4 * lane) = v;
+            }
+        }
+    };
+
+    // convert tasks of this thread: (row pair p, column group g) for id = tid and id = tid + M_THREADS (8 * ngroups <= 512)
+    const int cp0 = tid / ngroups, cg0 = tid - cp0 * ngroups;
+    const int cp1 = (tid + M_THREADS) / ngroups, cg1 = tid + M_THREADS - cp1 * ngroups;
+
+    int vt = vt0;
+    int cg = 0;  // ring granule of the chunk being written
+    issue(R_lo);
+    for (int base = R_lo; base <= R_hi; base += M_CH) {
+        land();
+        __syncthreads();
+        if (base + M_CH <= R_hi) issue(base + M_CH);
+
+        // ---- convert: 8 row pairs x ngroups column groups
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+            const int p = it ? cp1 : cp0, g = it ? cg1 : cg0;
+            if (p >= 8) break;
+            const u32 *ry = (const u32 *)(rawY + (2 * p) * ys) + g;
+            const int bi = 2 * g + 3;
+            const u32 *ru = (const u32 *)(rawU + p * cs) + (bi >> 2), *rv = (const u32 *)(rawV + p * cs) + (bi >> 2);
+            const u32 shb = (u32)(bi & 3);
+            const u32 ua = __builtin_amdgcn_alignbyte(ru[1], ru[0], shb), ub = __builtin_amdgcn_alignbyte(ru[(cs >> 2) + 1], ru[cs >> 2], shb);
+            const u32 va = __builtin_amdgcn_alignbyte(rv[1], rv[0], shb), vb = __builtin_amdgcn_alignbyte(rv[(cs >> 2) + 1], rv[cs >> 2], shb);
+            m_convert_block(J, s_lut, ry[0], ry[ys >> 2], ua, ub, va, vb, T + (size_t)(2 * p) * ts + 4 * g, ts);
+        }
+        __syncthreads();
+
+        if (wave_on) {
+            // ---- pass 1: rows of the chunk x this wave's 16 output columns
+            f32x4 acc[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const u32 *Ta = T + (size_t)l16 * ts + colw + 4 * lq;
+#pragma unroll
+            for (int j = 0; j < M_KH_MAX; j++) {
+                if (j < J.KH) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const uint4 a = *(const uint4 *)(Ta + (size_t)c * M_CH * ts + 16 * j);
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bh[j]), acc[c], 0, 0, 0);
+                    }
+                }
+            }
+            // lane holds rows 4 lq .. 4 lq + 3 of column l16: one half granule of the ring
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const __half2 h0 = __floats2half2_rn(acc[c][0], acc[c][1]), h1 = __floats2half2_rn(acc[c][2], acc[c][3]);
+                uint2 raw;
+                raw.x = *(const u32 *)&h0;
+                raw.y = *(const u32 *)&h1;
+                *(uint2 *)((u8 *)(Mh + (size_t)(c * RG + cg + (lq >> 1)) * M_SW + 16 * wave + l16) + 8 * (lq & 1)) = raw;
+            }
+        }
+        // ---- pass 2: every output tile whose window ends inside this chunk
+        const int e = base + M_CH - 1;
+        while (vt <= vt1) {
+            const int2 vm = J.v_meta[vt];
+            if (vm.y > e) break;
+            if (wave_on) {
+                const int g0 = ((vm.x - R_lo) >> 3) % RG;
+                f32x4 acc[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < M_KV_MAX; j++) {
+                    if (j < J.KV) {
+                        const uint4 bv = J.v_frag[((size_t)vt * J.KV + j) * 64 + lane];
+                        int rg = g0 + 4 * j + lq;
+                        rg -= rg >= RG ? RG : 0;
+                        rg -= rg >= RG ? RG : 0;
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const uint4 a = Mh[(size_t)(c * RG + rg) * M_SW + 16 * wave + l16];
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bv), acc[c], 0, 0, 0);
+                        }
+                    }
+                }
+                // lane holds columns tx0 + 4 lq .. + 3 of output row 16 vt + l16
+                const int y = 16 * vt + l16, x = tx0 + 4 * lq;
+                if (y < J.dst.h && x < J.dst.w) {
+                    u32 px[4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
+                    u8 *o = J.dst.ptr + (size_t)y * J.dst.pitch + (size_t)x * 4;
+                    if (x + 3 < J.dst.w) {
+                        *(uint4 *)o = make_uint4(px[0], px[1], px[2], px[3]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            if (x + i < J.dst.w) ((u32 *)o)[i] = px[i];
+                    }
+                }
+            }
+            vt++;
+        }
+        cg += 2;
+        cg -= cg >= RG ? RG : 0;
+    }
+}
+
+__global__ __launch_bounds__(M_THREADS, 2) void k_ingest_mfma(const MArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const int tid = threadIdx.x;
+    // tables: (hi | lo << 16) decode LUT, encode thresholds + estimate table
+    ((u32 *)smem)[tid] = lut[tid];
+    for (int i = tid; i < SMR_TABLE_FLOATS - 256; i += M_THREADS) ((float *)(smem + M_OFF_THR))[i] = tables[256 + i];
+    const int total = args.unit_prefix[args.n_jobs];
+    // XCD-aware order (as k_ingest_resample): ids that share an XCD are neighbours in the unit space
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int v = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    int u = v * args.units_per_block;
+    const int u_end = min(u + args.units_per_block, total);
+    bool first = true;
+    while (u < u_end) {
+        int j = 0;
+        while (j + 1 < args.n_jobs && args.unit_prefix[j + 1] <= u) j++;
+        const MJob &J = args.jobs[j];
+        const int local = u - args.unit_prefix[j];
+        const int strip = local / J.n_vtiles, vt0 = local - strip * J.n_vtiles;
+        const int vt1 = min(J.n_vtiles, vt0 + (u_end - u)) - 1;
+        if (!first) __syncthreads();
+        {
+            // the ring must hold finite values wherever a zero weight meets it
+            uint4 *Mh = (uint4 *)(smem + M_OFF_T + (size_t)3 * M_CH * J.ts * 4);
+            for (int i = tid; i < 3 * J.RG * M_SW; i += M_THREADS) Mh[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        mfma_piece(J, strip, vt0, vt1, smem);
+        u += vt1 - vt0 + 1;
+        first = false;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+bool mfma_plane_ok(const SurfView &p, u32 bytes) { return (p.pitch % 4) == 0 && (((uintptr_t)p.ptr) % 4) == 0 && p.pitch >= ((bytes + 3u) & ~3u); }
+
+// What k_ingest_mfma covers: planar 4:2:0 (limited or full range) with even luma size and dword-aligned planes, separable
+// plan, horizontal pass first, no box pre-reduction, 16-byte aligned tile rows, footprints that fit the LDS.
+bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32) return false;
+    if (!f || !f->planes[0] || !f->planes[1] || !f->planes[2]) return false;
+    if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420) return false;
+    if (f->width % 2 || f->height % 2 || f->width < 8 || f->height < 2) return false;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0)) return false;
+    if (!mfma_plane_ok(view_of(f->planes[0]), f->width) || !mfma_plane_ok(view_of(f->planes[1]), f->width / 2) ||
+        !mfma_plane_ok(view_of(f->planes[2]), f->width / 2))
+        return false;
+    if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
+    int KH, KV, sh_, sv_;
+    mfma_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 0, &KH, &sh_);
+    mfma_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 1, &KV, &sv_);
+    if (KH > M_KH_MAX || KV > M_KV_MAX) return false;
+    return true;
+}
+
+int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, MJob *out, bool *fits) {
+    MfmaBand bh, bv;
+    int rc = get_mfma_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 0, &bh);
+    if (rc != SMR_OK) return rc;
+    rc = get_mfma_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 1, &bv);
+    if (rc != SMR_OK) return rc;
+    MJob &J = *out;
+    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = view_of(f->planes[2]);
+    J.dst = view_of(tile);
+    J.src_w = (int)f->width; J.src_h = (int)f->height;
+    // planar_yuv_to_rgba.wgsl:45-57 with every constant folded; chroma arrives in 1/16 u8 units (16 * 255 * u)
+    const bool full = f->format == SMR_FRAME_PLANAR_YUVJ420;
+    const double ys = full ? 1.0 : 255.0 / 219.0, y0 = full ? 0.0 : 16.0;          // 255 * ye = ys * (Y - y0)
+    const double cs = full ? 1.0 / 16.0 : 255.0 / (16.0 * 224.0);                  // 255 * ue = cs * (U16 - 16 * c0)
+    const double c0 = full ? 0.0 : 16.0 * 16.0, half = full ? 16.0 * 127.5 : 16.0 * 112.0;  // 255 * (ue - 0.5) = cs * (U16 - c0 - half)
+    J.ky = (float)ys;
+    J.krv = (float)(1.5748 * cs); J.kgu = (float)(-0.1873 * cs); J.kgv = (float)(-0.4681 * cs); J.kbu = (float)(1.8556 * cs);
+    J.cr = (float)(0.5 - ys * y0 - 1.5748 * cs * (c0 + half));
+    J.cg = (float)(0.5 - ys * y0 + (0.1873 + 0.4681) * cs * (c0 + half));
+    J.cb = (float)(0.5 - ys * y0 - 1.8556 * cs * (c0 + half));
+    J.ylo = full ? 0.0f : 16.0f; J.yhi = full ? 255.0f : 235.0f;
+    J.clo = full ? 0 : 256; J.chi = full ? 4080 : 3840;
+    J.h_meta = bh.meta; J.h_frag = bh.frag; J.KH = bh.K; J.n_htiles = bh.n_tiles;
+    J.v_meta = bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_tiles;
+    J.strips_x = (bh.n_tiles + M_WAVES - 1) / M_WAVES;
+    // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
+    const int taps_h = host_taps(plan.scale[0]);
+    int ngm = 1;
+    for (int s = 0; s < J.strips_x; s++) {
+        const int t0 = s * M_WAVES, t1 = (t0 + M_WAVES < bh.n_tiles ? t0 + M_WAVES : bh.n_tiles) - 1;
+        auto a0 = [&](int t) {
+            int lo = lanczos_first(16 * t, plan.scale[0], plan.offset[0]);
+            lo = lo < 0 ? 0 : (lo > J.src_w - 1 ? J.src_w - 1 : lo);
+            return mfma_window_base(lo, 0);
+        };
+        const int g = (a0(t1) + 16 * J.KH - (a0(t0) & ~7) + 3) >> 2;
+        ngm = g > ngm ? g : ngm;
+    }
+    (void)taps_h;
+    J.ngm = ngm;
+    J.ts = ((4 * ngm + 7) & ~15) + 8;  // >= 4 * ngm and = 8 mod 16
+    if (J.ts < 4 * ngm) J.ts += 16;
+    // ring: the widest window plus the chunk that may land before the window's tile is resolved
+    int rg = (bv.max_span + M_CH - 1 + 7) / 8;
+    rg += rg & 1;
+    J.RG = rg;
+    *fits = ngm <= M_NG_MAX && m_lds_bytes(J.ts, J.ngm, J.RG) <= 160 * 1024;
+    return SMR_OK;
+}
+
+int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
+    if (!ctx->mfma_attr_set) {
+        SMR_HIP(ctx, hipFuncSetAttribute((const void *)k_ingest_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->mfma_attr_set = true;
+    }
+    StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_MJOBS_PER_LAUNCH) {
+        const size_t nj = jobs.size() - j0 < (size_t)MAX_MJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_MJOBS_PER_LAUNCH;
+        MArgs args;
+        memset(&args, 0, sizeof(args));
+        size_t lds = 0;
+        int total = 0;
+        for (size_t j = 0; j < nj; j++) {
+            const MJob &J = jobs[j0 + j];
+            args.jobs[j] = J;
+            args.unit_prefix[j] = total;
+            total += J.strips_x * J.n_vtiles;
+            const size_t b = m_lds_bytes(J.ts, J.ngm, J.RG);
+            lds = b > lds ? b : lds;
+        }
+        args.unit_prefix[nj] = total;
+        args.n_jobs = (int)nj;
+        // as many workgroups as fit at once (LDS-bound), minus the share left to the other stream's compose kernel
+        const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+        const int reserve = ctx->ingest_reserve_cus >= 0 && ctx->ingest_reserve_cus < ctx->cu_count ? ctx->ingest_reserve_cus : ctx->cu_count / 16;
+        int blocks = (per_cu > 4 ? 4 : per_cu) * (ctx->cu_count - reserve);
+        int upb = (total + blocks - 1) / blocks;
+        if (upb < 2) upb = 2;  // a piece re-converts the rows of its vertical halo
+        blocks = ((total + upb - 1) / upb + 7) & ~7;
+        args.units_per_block = upb;
+        if (blocks > 0)
+            hipLaunchKernelGGL(k_ingest_mfma, dim3((unsigned)blocks), dim3(M_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16);
+        SMR_HIP(ctx, hipGetLastError());
+    }
+    return SMR_OK;
+}
+
+}  // namespace

@@ -97,13 +97,29 @@ struct smr_ctx {
         int n = 0, taps = 0;
         void *dev = nullptr;  // int first[n]; float wsum[n]; float w[n * taps]
         size_t bytes = 0;
-        uint64_t last_use = 0;
+        uint64_t last_use = 0, last_call = 0;
     };
     std::vector<WeightTable> weight_tables;
     uint64_t weight_clock = 0;
+    uint64_t weight_call = 0;  // id of the public call building jobs: tables it already handed out are never evicted
+    // Lanczos weight bands in MFMA B-operand layout (smr_ingest_mfma.h), keyed by (axis, scale, offset, n_dst, n_src)
+    struct MfmaTable {
+        float scale = 0.f, offset = 0.f;
+        int n_dst = 0, n_src = 0, axis = 0, K = 0, max_span = 0;
+        void *dev = nullptr;  // int2 meta[n_tiles] (padded to 16 B); uint4 frag[n_tiles][K][64]
+        size_t bytes = 0, meta_bytes = 0;
+        uint64_t last_use = 0, last_call = 0;
+    };
+    std::vector<MfmaTable> mfma_tables;
+    u32 *d_lut16 = nullptr;      // 256 x (f16 hi | f16 lo << 16) of the sRGB decode table
+    u32 ingest_impl = 0;         // smr_ingest_impl
+    bool mfma_attr_set = false;  // hipFuncSetAttribute is per device: kept per ctx, not per process
+    bool valu_attr_set = false;
+    int ingest_reserve_cus = -1; // SMR_INGEST_RESERVE_CUS (profiling), read once per ctx
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
+    int force_tw = 0;         // SMR_INGEST_TW (tests / profiling): strip width of k_ingest_resample, 0 = automatic
 
     bool srgb() const { return mode == SMR_MODE_GPU_OPTIMIZED; }
 };

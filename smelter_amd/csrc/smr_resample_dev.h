@@ -9,18 +9,19 @@ constexpr int MAX_TAPS = 32;  // taps = ceil(6 * max(scale,1)) + 1 <= 25 once th
 
 #ifdef __HIPCC__
 
-__device__ __forceinline__ int lanczos_taps(float scale) {
-    float kernel_scale = scale > 1.0f ? scale : 1.0f;
-    int taps = (int)ceilf(2.0f * (3.0f * kernel_scale)) + 1;
-    return taps > MAX_TAPS ? MAX_TAPS : taps;
-}
-
-// first source texel of output coordinate `out_coord` (resample.wgsl:47-49) — the same f32 sequence as lanczos_weights
-__device__ __forceinline__ int lanczos_first(int out_coord, float scale, float offset) {
+// first source texel of output coordinate `out_coord` (resample.wgsl:47-49) — the same f32 sequence as lanczos_weights;
+// host + device: the host sizes the fused kernels' footprints with it
+__host__ __device__ __forceinline__ int lanczos_first(int out_coord, float scale, float offset) {
     float kernel_scale = scale > 1.0f ? scale : 1.0f;
     float support = 3.0f * kernel_scale;
     float center = offset + ((float)out_coord + 0.5f) * scale - 0.5f;
     return (int)ceilf(center - support);
+}
+
+__device__ __forceinline__ int lanczos_taps(float scale) {
+    float kernel_scale = scale > 1.0f ? scale : 1.0f;
+    int taps = (int)ceilf(2.0f * (3.0f * kernel_scale)) + 1;
+    return taps > MAX_TAPS ? MAX_TAPS : taps;
 }
 
 // Weights of output coordinate `out_coord`: w[0..taps), returns first source index; *wsum = sum of weights.

@@ -137,6 +137,9 @@ def pack_layouts(layouts) -> "C.Array":
     return arr
 
 
+INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16 = 0, 1, 2
+
+
 class Context:
     def __init__(self, device: int = 0, mode: int = MODE_GPU_OPTIMIZED, max_layouts: int = 100, stream: Optional[int] = None):
         self.lib = _ffi.load()
@@ -173,6 +176,10 @@ class Context:
 
     def sync(self):
         self._check(self.lib.smr_sync(self.handle))
+
+    def set_ingest_impl(self, impl: int):
+        """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (smr_ctx_set_ingest_impl)."""
+        self._check(self.lib.smr_ctx_set_ingest_impl(self.handle, impl))
 
     def timer_start(self):
         self._check(self.lib.smr_timer_start(self.handle))
