@@ -190,6 +190,7 @@ struct MJob {
     int ts;   // T row stride in dwords (= 8 mod 16: conflict-free ds_read_b128 of the A operand)
     int ngm;  // column groups (4 texels) the LDS is sized for
     int RG;   // ring depth in 8-row granules (even)
+    int ablate;  // profiling only (SMR_ABLATE): 1 skip convert, 2 skip pass 1, 4 skip pass 2, 8 skip encode + store, 16 skip staging, 32 dispatch only
 };
 
 constexpr int MAX_MJOBS_PER_LAUNCH = 12;
@@ -204,8 +205,10 @@ constexpr int M_OFF_THR = 1024;                                  // after the (h
 constexpr int M_OFF_T = M_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
 static_assert(M_OFF_T % 16 == 0, "T must start on a 16-byte boundary");
 __host__ __device__ inline int m_ncd(int ngm) { return ((2 * (ngm - 1) + 3) >> 2) + 2; }  // staged chroma dwords per row
+constexpr int M_PIECE_TILES = 256;  // output tiles of one piece (their window table sits in LDS)
 __host__ __device__ inline size_t m_lds_bytes(int ts, int ngm, int RG) {
-    return (size_t)M_OFF_T + (size_t)3 * M_CH * ts * 4 + (size_t)3 * RG * M_SW * 16 + (size_t)M_CH * 4 * ngm + (size_t)2 * 9 * 4 * m_ncd(ngm);
+    return (size_t)M_OFF_T + (size_t)3 * M_CH * ts * 4 + (size_t)3 * RG * M_SW * 16 + (size_t)M_CH * 4 * ngm + (size_t)2 * 9 * 4 * m_ncd(ngm) +
+           (size_t)M_PIECE_TILES * 8;
 }
 
 __device__ __forceinline__ u32 m_lut_px(const u32 *__restrict__ lut, float x255) {
@@ -216,7 +219,11 @@ __device__ __forceinline__ u32 m_lut_px(const u32 *__restrict__ lut, float x255)
 
 // one 4x2 pixel block: luma dwords ya / yb (rows 2p, 2p + 1 of the chunk), chroma neighbourhoods (4 bytes: columns 2q-1 .. 2q+2) of
 // chroma rows p and p + 1 for both planes -> (hi, lo) linear texels, 3 channels x 2 rows x 16 bytes into T
-__device__ __forceinline__ void m_convert_block(const MJob &J, const u32 *__restrict__ lut, u32 ya, u32 yb, u32 ua, u32 ub, u32 va, u32 vb,
+struct MConv {  // the job's colour constants, read once per piece (scalar registers)
+    float ky, krv, kgu, kgv, kbu, cr, cg, cb, ylo, yhi, clo, chi;
+};
+
+__device__ __forceinline__ void m_convert_block(const MConv &J, const u32 *__restrict__ lut, u32 ya, u32 yb, u32 ua, u32 ub, u32 va, u32 vb,
                                                 u32 *__restrict__ Trow_a /* T + (2p) * ts + 4g, channel stride 16 * ts */, int ts) {
     const u32 pu0 = __builtin_amdgcn_perm(ub, ua, 0x05040100u), pu1 = __builtin_amdgcn_perm(ub, ua, 0x06050201u), pu2 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
     const u32 pv0 = __builtin_amdgcn_perm(vb, va, 0x05040100u), pv1 = __builtin_amdgcn_perm(vb, va, 0x06050201u), pv2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
@@ -232,7 +239,7 @@ __device__ __forceinline__ void m_convert_block(const MJob &J, const u32 *__rest
         for (int i = 0; i < 4; i++) {
             const u32 wgt = row ? ((i & 1) ? WB31 : WB13) : ((i & 1) ? WA31 : WA13);
             const int u16 = (int)__builtin_amdgcn_udot4(pus[i], wgt, 0u, false), v16 = (int)__builtin_amdgcn_udot4(pvs[i], wgt, 0u, false);
-            const float uf = (float)min(max(u16, J.clo), J.chi), vf = (float)min(max(v16, J.clo), J.chi);
+            const float uf = __builtin_amdgcn_fmed3f((float)u16, J.clo, J.chi), vf = __builtin_amdgcn_fmed3f((float)v16, J.clo, J.chi);
             const float yf = __builtin_amdgcn_fmed3f((float)((yy >> (8 * i)) & 0xffu), J.ylo, J.yhi);
             const float r = __builtin_fmaf(yf, J.ky, __builtin_fmaf(vf, J.krv, J.cr));
             const float g = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kgu, __builtin_fmaf(vf, J.kgv, J.cg)));
@@ -248,10 +255,24 @@ __device__ __forceinline__ void m_convert_block(const MJob &J, const u32 *__rest
     }
 }
 
-// Output tiles [vt0, vt1] (16 rows each) of strip `strip` of job J.
+// Output tiles [vt0, vt1] (16 rows each) of strip `strip` of job J.  KH_T / KV_T: the k-step counts when the whole launch shares
+// them (0 = read them from the job: loops unrolled to the maximum and predicated); ABL: profiling build with the SMR_ABLATE switches.
+template <int KH_T, int KV_T, bool ABL>
 __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, int vt1, u8 *smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: keeps per-wave addressing on the scalar unit)
     const int l16 = lane & 15, lq = lane >> 4;
+    // job fields used inside the chunk loop, read once (the descriptor lives in the kernel-argument segment: every later access
+    // would be a scalar load sharing a counter with the LDS traffic)
+    const MConv K = {J.ky, J.krv, J.kgu, J.kgv, J.kbu, J.cr, J.cg, J.cb, J.ylo, J.yhi, (float)J.clo, (float)J.chi};
+    const u8 *const y_ptr = J.yp.ptr, *const u_ptr = J.up.ptr, *const v_ptr = J.vp.ptr;
+    const u32 y_pitch = J.yp.pitch, u_pitch = J.up.pitch, v_pitch = J.vp.pitch;
+    u8 *const d_ptr = J.dst.ptr;
+    const u32 d_pitch = J.dst.pitch;
+    const int d_w = J.dst.w, d_h = J.dst.h;
+    const int KH = KH_T ? KH_T : J.KH, KV = KV_T ? KV_T : J.KV, ablate = ABL ? J.ablate : 0;
+    constexpr int KH_N = KH_T ? KH_T : M_KH_MAX, KV_N = KV_T ? KV_T : M_KV_MAX;
+    const uint4 *const v_frag = J.v_frag;
     const u32 *s_lut = (const u32 *)smem;
     const float *s_thr = (const float *)(smem + M_OFF_THR);
     u32 *T = (u32 *)(smem + M_OFF_T);
@@ -260,21 +281,23 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
     u8 *rawY = (u8 *)(Mh + 3 * RG * M_SW);
     const int ys = 4 * J.ngm, cs = 4 * m_ncd(J.ngm);
     u8 *rawU = rawY + M_CH * ys, *rawV = rawU + 9 * cs;
+    int2 *s_vmeta = (int2 *)(rawV + 9 * cs);  // (window base, last row) of the piece's output tiles
     const int sw = J.src_w, sh = J.src_h, cw = J.up.w, chh = J.up.h;
 
     // ---- strip geometry
     const int nt0 = strip * M_WAVES, ntn = min(M_WAVES, J.n_htiles - nt0);
     const int cbase = J.h_meta[nt0].x & ~7;  // luma column of T column 0 (chroma staging wants it = 0 mod 8)
-    const int ngroups = min((J.h_meta[nt0 + ntn - 1].x + 16 * J.KH - cbase + 3) >> 2, J.ngm);
+    const int ngroups = min((J.h_meta[nt0 + ntn - 1].x + 16 * KH - cbase + 3) >> 2, J.ngm);
     const int ncd = m_ncd(ngroups);
     const bool wave_on = wave < ntn;
     const int my_tile = nt0 + (wave_on ? wave : 0);
     const int colw = J.h_meta[my_tile].x - cbase;  // T column (dword) of this wave's K window
-    uint4 bh[M_KH_MAX];
+    uint4 bh[KH_N];
 #pragma unroll
-    for (int j = 0; j < M_KH_MAX; j++)
-        if (j < J.KH) bh[j] = J.h_frag[((size_t)my_tile * J.KH + j) * 64 + lane];
+    for (int j = 0; j < KH_N; j++)
+        if (j < KH) bh[j] = J.h_frag[((size_t)my_tile * KH + j) * 64 + lane];
     const int R_lo = J.v_meta[vt0].x, R_hi = J.v_meta[vt1].y;
+    if (vt0 + tid <= vt1) s_vmeta[tid] = J.v_meta[vt0 + tid];  // (visible after the first barrier of the chunk loop)
     const int tx0 = strip * M_SW + 16 * wave;
 
     // ---- staging: luma = one row per wave and step (64 lanes x 4 B), chroma = 18 (plane, row) tasks of <= 64 dwords
@@ -285,7 +308,7 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
         for (int k = 0; k < 4; k++) {
             const int row = wave + 4 * k;
             const int srow = clampi(base + row, 0, sh - 1), col = cbase + 4 * lane;
-            if (lane < ngroups && col < sw4) py[k] = *(const u32 *)(J.yp.ptr + (size_t)srow * J.yp.pitch + col);
+            if (lane < ngroups && col < sw4) py[k] = *(const u32 *)(y_ptr + (size_t)srow * y_pitch + col);
         }
         const int i0 = (base - 1) >> 1;  // chroma row of the chunk's first row pair
 #pragma unroll
@@ -296,8 +319,7 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
                 const int crow = clampi(i0 + r, 0, chh - 1);
                 const int col0 = (cbase >> 1) - 4 + 4 * lane;
                 const int col0c = clampi(col0, 0, (cw - 1) & ~3);
-                const SurfView &P = plane ? J.vp : J.up;
-                pc[k] = *(const u32 *)(P.ptr + (size_t)crow * P.pitch + col0c);
+                pc[k] = *(const u32 *)((plane ? v_ptr : u_ptr) + (size_t)crow * (plane ? v_pitch : u_pitch) + col0c);
             }
         }
     };
@@ -332,36 +354,49 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
 
     int vt = vt0;
     int cg = 0;  // ring granule of the chunk being written
-    issue(R_lo);
-    for (int base = R_lo; base <= R_hi; base += M_CH) {
+    // pass-2 weights of the next output tile, fetched a chunk ahead (they depend on the tile row only)
+    uint4 bv[KV_N];
+    int bv_vt = -1;
+    auto fetch_bv = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < KV_N; j++)
+            if (j < KV) bv[j] = v_frag[((size_t)t * KV + j) * 64 + lane];
+        bv_vt = t;
+    };
+    if (!(ablate & 16)) {
+        issue(R_lo);
         land();
-        __syncthreads();
-        if (base + M_CH <= R_hi) issue(base + M_CH);
+    }
+    for (int base = R_lo; base <= R_hi; base += M_CH) {
+        __syncthreads();  // raw footprint of this chunk landed; T is free (every wave is past pass 1 of the previous chunk)
+        const bool more = base + M_CH <= R_hi;
+        if (more && !(ablate & 16)) issue(base + M_CH);
+        if (vt <= vt1 && bv_vt != vt) fetch_bv(vt);
 
         // ---- convert: 8 row pairs x ngroups column groups
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const int p = it ? cp1 : cp0, g = it ? cg1 : cg0;
-            if (p >= 8) break;
+            if (p >= 8 || (ablate & 1)) break;
             const u32 *ry = (const u32 *)(rawY + (2 * p) * ys) + g;
             const int bi = 2 * g + 3;
             const u32 *ru = (const u32 *)(rawU + p * cs) + (bi >> 2), *rv = (const u32 *)(rawV + p * cs) + (bi >> 2);
             const u32 shb = (u32)(bi & 3);
             const u32 ua = __builtin_amdgcn_alignbyte(ru[1], ru[0], shb), ub = __builtin_amdgcn_alignbyte(ru[(cs >> 2) + 1], ru[cs >> 2], shb);
             const u32 va = __builtin_amdgcn_alignbyte(rv[1], rv[0], shb), vb = __builtin_amdgcn_alignbyte(rv[(cs >> 2) + 1], rv[cs >> 2], shb);
-            m_convert_block(J, s_lut, ry[0], ry[ys >> 2], ua, ub, va, vb, T + (size_t)(2 * p) * ts + 4 * g, ts);
+            m_convert_block(K, s_lut, ry[0], ry[ys >> 2], ua, ub, va, vb, T + (size_t)(2 * p) * ts + 4 * g, ts);
         }
-        __syncthreads();
+        __syncthreads();  // T complete; the raw footprint is dead
 
-        if (wave_on) {
+        if (wave_on && !(ablate & 2)) {
             // ---- pass 1: rows of the chunk x this wave's 16 output columns
             f32x4 acc[3];
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             const u32 *Ta = T + (size_t)l16 * ts + colw + 4 * lq;
 #pragma unroll
-            for (int j = 0; j < M_KH_MAX; j++) {
-                if (j < J.KH) {
+            for (int j = 0; j < KH_N; j++) {
+                if (j < KH) {
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
                         const uint4 a = *(const uint4 *)(Ta + (size_t)c * M_CH * ts + 16 * j);
@@ -379,44 +414,48 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
                 *(uint2 *)((u8 *)(Mh + (size_t)(c * RG + cg + (lq >> 1)) * M_SW + 16 * wave + l16) + 8 * (lq & 1)) = raw;
             }
         }
+        // the next chunk's raw footprint reaches LDS here: its loads were issued before the convert, and the stores of the
+        // epilogue below are not yet in the memory queue the wait has to drain
+        if (more && !(ablate & 16)) land();
+
         // ---- pass 2: every output tile whose window ends inside this chunk
         const int e = base + M_CH - 1;
         while (vt <= vt1) {
-            const int2 vm = J.v_meta[vt];
+            const int2 vm = s_vmeta[vt - vt0];
             if (vm.y > e) break;
-            if (wave_on) {
+            if (wave_on && !(ablate & 4)) {
+                if (bv_vt != vt) fetch_bv(vt);
                 const int g0 = ((vm.x - R_lo) >> 3) % RG;
                 f32x4 acc[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < M_KV_MAX; j++) {
-                    if (j < J.KV) {
-                        const uint4 bv = J.v_frag[((size_t)vt * J.KV + j) * 64 + lane];
+                for (int j = 0; j < KV_N; j++) {
+                    if (j < KV) {
                         int rg = g0 + 4 * j + lq;
                         rg -= rg >= RG ? RG : 0;
                         rg -= rg >= RG ? RG : 0;
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
                             const uint4 a = Mh[(size_t)(c * RG + rg) * M_SW + 16 * wave + l16];
-                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bv), acc[c], 0, 0, 0);
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bv[j]), acc[c], 0, 0, 0);
                         }
                     }
                 }
                 // lane holds columns tx0 + 4 lq .. + 3 of output row 16 vt + l16
                 const int y = 16 * vt + l16, x = tx0 + 4 * lq;
-                if (y < J.dst.h && x < J.dst.w) {
+                if (y < d_h && x < d_w && !(ablate & 8)) {
                     u32 px[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++)
                         px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
-                    u8 *o = J.dst.ptr + (size_t)y * J.dst.pitch + (size_t)x * 4;
-                    if (x + 3 < J.dst.w) {
+                    u8 *o = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
+                    if (x + 3 < d_w) {
                         *(uint4 *)o = make_uint4(px[0], px[1], px[2], px[3]);
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; i++)
-                            if (x + i < J.dst.w) ((u32 *)o)[i] = px[i];
+                            if (x + i < d_w) ((u32 *)o)[i] = px[i];
                     }
                 }
             }
@@ -427,9 +466,11 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
     }
 }
 
+template <int KH_T, int KV_T, bool ABL>
 __global__ __launch_bounds__(M_THREADS, 2) void k_ingest_mfma(const MArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int tid = threadIdx.x;
+    if (ABL && (args.jobs[0].ablate & 32)) return;
     // tables: (hi | lo << 16) decode LUT, encode thresholds + estimate table
     ((u32 *)smem)[tid] = lut[tid];
     for (int i = tid; i < SMR_TABLE_FLOATS - 256; i += M_THREADS) ((float *)(smem + M_OFF_THR))[i] = tables[256 + i];
@@ -446,14 +487,14 @@ __global__ __launch_bounds__(M_THREADS, 2) void k_ingest_mfma(const MArgs args, 
         const MJob &J = args.jobs[j];
         const int local = u - args.unit_prefix[j];
         const int strip = local / J.n_vtiles, vt0 = local - strip * J.n_vtiles;
-        const int vt1 = min(J.n_vtiles, vt0 + (u_end - u)) - 1;
+        const int vt1 = min(min(J.n_vtiles, vt0 + (u_end - u)), vt0 + M_PIECE_TILES) - 1;
         if (!first) __syncthreads();
         {
             // the ring must hold finite values wherever a zero weight meets it
             uint4 *Mh = (uint4 *)(smem + M_OFF_T + (size_t)3 * M_CH * J.ts * 4);
             for (int i = tid; i < 3 * J.RG * M_SW; i += M_THREADS) Mh[i] = make_uint4(0u, 0u, 0u, 0u);
         }
-        mfma_piece(J, strip, vt0, vt1, smem);
+        mfma_piece<KH_T, KV_T, ABL>(J, strip, vt0, vt1, smem);
         u += vt1 - vt0 + 1;
         first = false;
     }
@@ -506,6 +547,7 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.h_meta = bh.meta; J.h_frag = bh.frag; J.KH = bh.K; J.n_htiles = bh.n_tiles;
     J.v_meta = bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_tiles;
     J.strips_x = (bh.n_tiles + M_WAVES - 1) / M_WAVES;
+    J.ablate = ctx->ablate;
     // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
     const int taps_h = host_taps(plan.scale[0]);
     int ngm = 1;
@@ -531,9 +573,13 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     return SMR_OK;
 }
 
+// the scale range of the benchmark scenes (1.5x .. 2x: 3 k-steps per pass-1 tile, 2 per pass-2 tile) gets its own build
+typedef void (*MfmaKernel)(const MArgs, const float *, const u32 *);
+constexpr MfmaKernel M_KERNELS[3] = {k_ingest_mfma<0, 0, false>, k_ingest_mfma<3, 2, false>, k_ingest_mfma<0, 0, true>};
+
 int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
-    if (!ctx->mfma_attr_set) {
-        SMR_HIP(ctx, hipFuncSetAttribute((const void *)k_ingest_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (!ctx->mfma_attr_set) {  // per device, hence per ctx
+        for (MfmaKernel k : M_KERNELS) SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->mfma_attr_set = true;
     }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
@@ -561,8 +607,10 @@ int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
         if (upb < 2) upb = 2;  // a piece re-converts the rows of its vertical halo
         blocks = ((total + upb - 1) / upb + 7) & ~7;
         args.units_per_block = upb;
-        if (blocks > 0)
-            hipLaunchKernelGGL(k_ingest_mfma, dim3((unsigned)blocks), dim3(M_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16);
+        bool all32 = true;
+        for (size_t j = 0; j < nj; j++) all32 = all32 && args.jobs[j].KH == 3 && args.jobs[j].KV == 2;
+        const MfmaKernel kern = ctx->ablate ? M_KERNELS[2] : (all32 ? M_KERNELS[1] : M_KERNELS[0]);
+        if (blocks > 0) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(M_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16);
         SMR_HIP(ctx, hipGetLastError());
     }
     return SMR_OK;
