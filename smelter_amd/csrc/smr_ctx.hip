@@ -197,6 +197,8 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
     }
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
+    if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
+    ctx->debug_ingest = getenv("SMR_DEBUG_INGEST") != nullptr;
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&ctx->d_lut16, sizeof(lut16)) != hipSuccess ||

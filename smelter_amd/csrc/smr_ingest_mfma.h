@@ -35,9 +35,13 @@ namespace {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int M_WAVES = 4;
+constexpr int M_NT = 4;             // 16-column N tiles per strip = filter waves of a workgroup
+#ifndef SMR_MFMA_CONV_WAVES
+#define SMR_MFMA_CONV_WAVES 4
+#endif
+constexpr int M_WAVES = M_NT + SMR_MFMA_CONV_WAVES;  // + convert waves (4 or 8)
 constexpr int M_THREADS = M_WAVES * 64;
-constexpr int M_SW = 16 * M_WAVES;  // strip width: one 16-column N tile per wave
+constexpr int M_SW = 16 * M_NT;     // strip width
 constexpr int M_CH = 16;            // source rows per chunk = M of pass 1
 constexpr int M_KH_MAX = 6;         // k-steps of 32 (16 texels as hi/lo pairs) in pass 1
 constexpr int M_KV_MAX = 4;         // k-steps of 32 rows in pass 2
@@ -179,7 +183,7 @@ struct MJob {
     SurfView yp, up, vp;  // planar 4:2:0 source planes (chroma views carry the chroma size)
     SurfView dst;         // RGBA8 tile, dst-sized
     int src_w, src_h;
-    // Y'CbCr -> 255 * R'G'B' + 0.5 with the range expansion and the clamps of planar_yuv_to_rgba.wgsl:45-57 folded in:
+    // Y'CbCr -> 255 * R'G'B' with the range expansion and the clamps of planar_yuv_to_rgba.wgsl:45-57 folded in:
     // luma in u8 units clamped to [ylo, yhi], chroma in 1/16 u8 units clamped to [clo, chi]
     float ky, krv, kgu, kgv, kbu, cr, cg, cb;
     float ylo, yhi;
@@ -205,11 +209,7 @@ constexpr int M_OFF_THR = 1024;                                  // after the (h
 constexpr int M_OFF_T = M_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
 static_assert(M_OFF_T % 16 == 0, "T must start on a 16-byte boundary");
 __host__ __device__ inline int m_ncd(int ngm) { return ((2 * (ngm - 1) + 3) >> 2) + 2; }  // staged chroma dwords per row
-constexpr int M_PIECE_TILES = 256;  // output tiles of one piece (their window table sits in LDS)
-__host__ __device__ inline size_t m_lds_bytes(int ts, int ngm, int RG) {
-    return (size_t)M_OFF_T + (size_t)3 * M_CH * ts * 4 + (size_t)3 * RG * M_SW * 16 + (size_t)M_CH * 4 * ngm + (size_t)2 * 9 * 4 * m_ncd(ngm) +
-           (size_t)M_PIECE_TILES * 8;
-}
+constexpr int M_PIECE_TILES = 64;   // output tiles of one piece (their window table sits in LDS)
 
 __device__ __forceinline__ u32 m_lut_px(const u32 *__restrict__ lut, float x255) {
     // floor(clamp(r, 0, 1) * 255 + 0.5) of the reference's unorm store; x255 already carries the + 0.5
@@ -217,78 +217,244 @@ __device__ __forceinline__ u32 m_lut_px(const u32 *__restrict__ lut, float x255)
     return lut[code];
 }
 
-// one 4x2 pixel block: luma dwords ya / yb (rows 2p, 2p + 1 of the chunk), chroma neighbourhoods (4 bytes: columns 2q-1 .. 2q+2) of
-// chroma rows p and p + 1 for both planes -> (hi, lo) linear texels, 3 channels x 2 rows x 16 bytes into T
 struct MConv {  // the job's colour constants, read once per piece (scalar registers)
     float ky, krv, kgu, kgv, kbu, cr, cg, cb, ylo, yhi, clo, chi;
 };
 
-__device__ __forceinline__ void m_convert_block(const MConv &J, const u32 *__restrict__ lut, u32 ya, u32 yb, u32 ua, u32 ub, u32 va, u32 vb,
-                                                u32 *__restrict__ Trow_a /* T + (2p) * ts + 4g, channel stride 16 * ts */, int ts) {
+// One 4x1 pixel block: luma dword yy, chroma neighbourhoods (4 bytes: columns 2q-1 .. 2q+2) of chroma rows p (ua, va) and p + 1
+// (ub, vb), w13 / w31 = the row's bilinear weight vectors -> (hi, lo) linear texels, 3 channels x 16 bytes into T.
+template <int ABL>
+__device__ __forceinline__ void m_convert_block(const MConv &J, const u32 *__restrict__ lut, u32 yy, u32 ua, u32 ub, u32 va, u32 vb, u32 w13, u32 w31,
+                                                u32 *__restrict__ Trow /* T + row * ts + 4g, channel stride 16 * ts */, int ts) {
     const u32 pu0 = __builtin_amdgcn_perm(ub, ua, 0x05040100u), pu1 = __builtin_amdgcn_perm(ub, ua, 0x06050201u), pu2 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
     const u32 pv0 = __builtin_amdgcn_perm(vb, va, 0x05040100u), pv1 = __builtin_amdgcn_perm(vb, va, 0x06050201u), pv2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-    // bilinear chroma tap at the luma texcoord (planar_yuv_to_rgba.wgsl:37-39): weights (1/4, 3/4) per axis, in 1/16 units
-    constexpr u32 WA13 = 0x03010903u, WA31 = 0x01030309u;  // odd luma row: 3/4 of chroma row p;  columns (1/4, 3/4) | (3/4, 1/4)
-    constexpr u32 WB13 = 0x09030301u, WB31 = 0x03090103u;  // even luma row: 3/4 of chroma row p + 1
     const u32 pus[4] = {pu0, pu1, pu1, pu2}, pvs[4] = {pv0, pv1, pv1, pv2};
+    uint4 o[3];
 #pragma unroll
-    for (int row = 0; row < 2; row++) {
-        const u32 yy = row ? yb : ya;
-        uint4 o[3];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const u32 wgt = row ? ((i & 1) ? WB31 : WB13) : ((i & 1) ? WA31 : WA13);
-            const int u16 = (int)__builtin_amdgcn_udot4(pus[i], wgt, 0u, false), v16 = (int)__builtin_amdgcn_udot4(pvs[i], wgt, 0u, false);
-            const float uf = __builtin_amdgcn_fmed3f((float)u16, J.clo, J.chi), vf = __builtin_amdgcn_fmed3f((float)v16, J.clo, J.chi);
-            const float yf = __builtin_amdgcn_fmed3f((float)((yy >> (8 * i)) & 0xffu), J.ylo, J.yhi);
-            const float r = __builtin_fmaf(yf, J.ky, __builtin_fmaf(vf, J.krv, J.cr));
-            const float g = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kgu, __builtin_fmaf(vf, J.kgv, J.cg)));
-            const float b = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kbu, J.cb));
-            const u32 tr = m_lut_px(lut, r), tg = m_lut_px(lut, g), tb = m_lut_px(lut, b);
-            if (i == 0) { o[0].x = tr; o[1].x = tg; o[2].x = tb; }
-            if (i == 1) { o[0].y = tr; o[1].y = tg; o[2].y = tb; }
-            if (i == 2) { o[0].z = tr; o[1].z = tg; o[2].z = tb; }
-            if (i == 3) { o[0].w = tr; o[1].w = tg; o[2].w = tb; }
+    for (int i = 0; i < 4; i++) {
+        const u32 wgt = (i & 1) ? w31 : w13;
+        const int u16 = (int)__builtin_amdgcn_udot4(pus[i], wgt, 0u, false), v16 = (int)__builtin_amdgcn_udot4(pvs[i], wgt, 0u, false);
+        const float uf = __builtin_amdgcn_fmed3f((float)u16, J.clo, J.chi), vf = __builtin_amdgcn_fmed3f((float)v16, J.clo, J.chi);
+        const float yf = __builtin_amdgcn_fmed3f((float)((yy >> (8 * i)) & 0xffu), J.ylo, J.yhi);
+        const float r = __builtin_fmaf(yf, J.ky, __builtin_fmaf(vf, J.krv, J.cr));
+        const float g = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kgu, __builtin_fmaf(vf, J.kgv, J.cg)));
+        const float b = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kbu, J.cb));
+        // u8 quantisation of the node texture: one saturating convert per channel into a byte of `code` (round-to-nearest-even;
+        // the reference's floor(x + 0.5) differs on exact .5 ties only), then byte k << 2 = the LUT offset
+        u32 code = __builtin_amdgcn_cvt_pk_u8_f32(r, 0, 0u);
+        code = __builtin_amdgcn_cvt_pk_u8_f32(g, 1, code);
+        code = __builtin_amdgcn_cvt_pk_u8_f32(b, 2, code);
+        u32 tr, tg, tb;
+        if (ABL & 256) {  // profiling: no LUT gathers
+            tr = code & 0xffu; tg = (code >> 8) & 0xffu; tb = (code >> 16) & 0xffu;
+        } else {
+            // LDS offset of entry = byte k << 2 in one SDWA shift (the LUT sits at LDS offset 0: the kernel has no static LDS,
+            // launch_mfma checks it)
+            u32 ar, ag, ab;
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(ar) : "v"(2u), "v"(code));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ag) : "v"(2u), "v"(code));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(ab) : "v"(2u), "v"(code));
+            typedef __attribute__((address_space(3))) const u32 lds_u32;
+            tr = *(lds_u32 *)(uintptr_t)ar;
+            tg = *(lds_u32 *)(uintptr_t)ag;
+            tb = *(lds_u32 *)(uintptr_t)ab;
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) *(uint4 *)(Trow_a + (size_t)(c * M_CH + row) * ts) = o[c];
+        if (i == 0) { o[0].x = tr; o[1].x = tg; o[2].x = tb; }
+        if (i == 1) { o[0].y = tr; o[1].y = tg; o[2].y = tb; }
+        if (i == 2) { o[0].z = tr; o[1].z = tg; o[2].z = tb; }
+        if (i == 3) { o[0].w = tr; o[1].w = tg; o[2].w = tb; }
     }
+    if (ABL & 512) {  // profiling: one dword instead of 48 bytes
+        *Trow = o[0].x ^ o[0].y ^ o[0].z ^ o[0].w ^ o[1].x ^ o[1].y ^ o[1].z ^ o[1].w ^ o[2].x ^ o[2].y ^ o[2].z ^ o[2].w;
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) *(uint4 *)(Trow + (size_t)c * M_CH * ts) = o[c];
+}
+
+// LDS carve (bytes): decode LUT | encode tables | T[2] | ring | raw[2] | tile windows of the piece
+struct MLds {
+    int t, t_bytes, ring, raw, raw_bytes, vmeta, total;
+};
+__host__ __device__ inline MLds m_lds(int ts, int ngm, int RG) {
+    MLds L;
+    L.t = M_OFF_T;
+    L.t_bytes = 3 * M_CH * ts * 4;
+    L.ring = L.t + 2 * L.t_bytes;
+    L.raw = L.ring + 3 * RG * M_SW * 16;
+    L.raw_bytes = M_CH * 4 * ngm + 2 * 9 * 4 * m_ncd(ngm);
+    L.vmeta = L.raw + 2 * L.raw_bytes;
+    L.total = L.vmeta + M_PIECE_TILES * 8;
+    return L;
 }
 
 // Output tiles [vt0, vt1] (16 rows each) of strip `strip` of job J.  KH_T / KV_T: the k-step counts when the whole launch shares
-// them (0 = read them from the job: loops unrolled to the maximum and predicated); ABL: profiling build with the SMR_ABLATE switches.
-template <int KH_T, int KV_T, bool ABL>
-__device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, int vt1, u8 *smem) {
+// them (0 = read them from the job: loops unrolled to the maximum and predicated); ABL: profiling build with phases compiled out.
+//
+// Every workgroup of a launch is resident at once, so the launch lasts as long as one workgroup's instruction streams.  The
+// waves are therefore specialised and run as a two-stage pipeline, one barrier per chunk of 16 source rows:
+//   convert waves (4)   chunk k:     land the raw footprint of chunk k + 1, issue the loads of chunk k + 2, convert chunk k
+//                                    (one 4x1 block per lane and step) into T[k & 1]            — vector ALU + LDS gathers
+//   filter waves (4)    chunk k - 1: pass 1 from T[(k - 1) & 1] into the ring columns of the wave's own N tile, then pass 2 +
+//                                    sRGB encode + store of every output tile whose window is complete   — MFMA + LDS reads
+// A ring column is written and read by one wave only; T and the raw footprint are double-buffered across the barrier.
+template <int KH_T, int KV_T, int ABL>
+__device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, int vt1, u8 *smem, unsigned long long *dbg) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: keeps per-wave addressing on the scalar unit)
-    const int l16 = lane & 15, lq = lane >> 4;
-    // job fields used inside the chunk loop, read once (the descriptor lives in the kernel-argument segment: every later access
-    // would be a scalar load sharing a counter with the LDS traffic)
-    const MConv K = {J.ky, J.krv, J.kgu, J.kgv, J.kbu, J.cr, J.cg, J.cb, J.ylo, J.yhi, (float)J.clo, (float)J.chi};
-    const u8 *const y_ptr = J.yp.ptr, *const u_ptr = J.up.ptr, *const v_ptr = J.vp.ptr;
-    const u32 y_pitch = J.yp.pitch, u_pitch = J.up.pitch, v_pitch = J.vp.pitch;
-    u8 *const d_ptr = J.dst.ptr;
-    const u32 d_pitch = J.dst.pitch;
-    const int d_w = J.dst.w, d_h = J.dst.h;
-    const int KH = KH_T ? KH_T : J.KH, KV = KV_T ? KV_T : J.KV, ablate = ABL ? J.ablate : 0;
+    const bool is_conv = wave >= M_NT;
+    constexpr int ablate = ABL;  // compile-time switch set (profiling builds only)
+    // profiling build (ABL & 64): shader cycles per phase, wave 0 (filter) -> dbg[0..7], wave M_NT (convert) -> dbg[8..15]
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+    const bool timing = (ablate & 64) && dbg && (wave == 0 || wave == M_NT);
+    auto mark = [&](int ph) {
+        if (timing) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): charge LDS latency to the phase that issued it
+            const unsigned long long now = __builtin_readcyclecounter();
+            tph[ph] += now - tlast;
+            tlast = now;
+        }
+    };
+    const int KH = KH_T ? KH_T : J.KH, KV = KV_T ? KV_T : J.KV;
     constexpr int KH_N = KH_T ? KH_T : M_KH_MAX, KV_N = KV_T ? KV_T : M_KV_MAX;
-    const uint4 *const v_frag = J.v_frag;
+    const int ts = J.ts, RG = J.RG;
+    const MLds L = m_lds(ts, J.ngm, RG);
     const u32 *s_lut = (const u32 *)smem;
     const float *s_thr = (const float *)(smem + M_OFF_THR);
-    u32 *T = (u32 *)(smem + M_OFF_T);
-    const int ts = J.ts, RG = J.RG;
-    uint4 *Mh = (uint4 *)(T + 3 * M_CH * ts);
-    u8 *rawY = (u8 *)(Mh + 3 * RG * M_SW);
+    u32 *T = (u32 *)(smem + L.t);
+    uint4 *Mh = (uint4 *)(smem + L.ring);
+    int2 *s_vmeta = (int2 *)(smem + L.vmeta);  // (window base, last row) of the piece's output tiles
     const int ys = 4 * J.ngm, cs = 4 * m_ncd(J.ngm);
-    u8 *rawU = rawY + M_CH * ys, *rawV = rawU + 9 * cs;
-    int2 *s_vmeta = (int2 *)(rawV + 9 * cs);  // (window base, last row) of the piece's output tiles
-    const int sw = J.src_w, sh = J.src_h, cw = J.up.w, chh = J.up.h;
 
     // ---- strip geometry
-    const int nt0 = strip * M_WAVES, ntn = min(M_WAVES, J.n_htiles - nt0);
+    const int nt0 = strip * M_NT, ntn = min(M_NT, J.n_htiles - nt0);
     const int cbase = J.h_meta[nt0].x & ~7;  // luma column of T column 0 (chroma staging wants it = 0 mod 8)
-    const int ngroups = min((J.h_meta[nt0 + ntn - 1].x + 16 * KH - cbase + 3) >> 2, J.ngm);
-    const int ncd = m_ncd(ngroups);
+    // columns converted per chunk: up to the last texel that carries a weight.  A K window may run past them — into the row
+    // padding, the next row, the other T buffer or the ring: all finite, all under zero weights.
+    const int ngroups = min((J.h_meta[nt0 + ntn - 1].y - cbase + 4) >> 2, J.ngm);
+    const int R_lo = J.v_meta[vt0].x, R_hi = J.v_meta[vt1].y;
+    const int n_chunks = (R_hi - R_lo) / M_CH + 1;
+    if (vt0 + tid <= vt1) s_vmeta[tid] = J.v_meta[vt0 + tid];
+    __syncthreads();  // tables, zeroed ring / T padding and the tile windows are in place
+
+    if (is_conv) {
+        // ================================================================== convert waves
+        const int cwave = wave - M_NT, ctid = tid - M_NT * 64;
+        constexpr int CW = M_WAVES - M_NT, CT = CW * 64;
+        const MConv K = {J.ky, J.krv, J.kgu, J.kgv, J.kbu, J.cr, J.cg, J.cb, J.ylo, J.yhi, (float)J.clo, (float)J.chi};
+        const u8 *const y_ptr = J.yp.ptr, *const u_ptr = J.up.ptr, *const v_ptr = J.vp.ptr;
+        const u32 y_pitch = J.yp.pitch, u_pitch = J.up.pitch, v_pitch = J.vp.pitch;
+        const int sw = J.src_w, sh = J.src_h, cw = J.up.w, chh = J.up.h;
+        const int ncd = m_ncd(ngroups);
+        // staging: luma = one row per wave and step (64 lanes x 4 B), chroma = 18 (plane, row) tasks of <= 64 dwords.
+        // Every lane always loads (dead lanes re-read the last live dword: same cache line, no extra traffic).
+        constexpr int NY = M_CH / CW, NC = (18 + CW - 1) / CW;
+        u32 py[NY], pc[NC];
+        const int sw4 = (sw + 3) & ~3;
+        const bool y_live = lane < ngroups && cbase + 4 * lane < sw4;
+        const bool c_live = lane < ncd;
+        const int c_col0 = (cbase >> 1) - 4 + 4 * lane;                 // first chroma column of this lane's staged dword
+        const int c_col0c = clampi(c_col0, 0, (cw - 1) & ~3);           // ... of the dword actually loaded (clamp-to-edge)
+        const bool c_edge = c_live && (c_col0 < 0 || c_col0 + 3 > cw - 1);
+        // (uniform row base in scalar registers + a 32-bit lane offset: the loads need no vector address arithmetic)
+        const u32 y_off = (u32)min(cbase + 4 * lane, sw4 - 4), c_off = (u32)c_col0c;
+        auto issue = [&](int base) {
+            if (ablate & 1024) base = R_lo;  // profiling: always the same rows (cache / TLB hits)
+#pragma unroll
+            for (int k = 0; k < NY; k++) {
+                const u8 *rowp = y_ptr + (size_t)clampi(base + cwave + CW * k, 0, sh - 1) * y_pitch;
+                py[k] = *(const u32 *)(rowp + y_off);
+            }
+            const int i0 = (base - 1) >> 1;  // chroma row of the chunk's first row pair
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                const int rt = min(cwave + CW * k, 17);  // (plane, row) task, uniform per wave; tasks past the 18th repeat the last one
+                const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
+                const u8 *rowp = (plane ? v_ptr : u_ptr) + (size_t)clampi(i0 + r, 0, chh - 1) * (plane ? v_pitch : u_pitch);
+                pc[k] = *(const u32 *)(rowp + c_off);
+            }
+        };
+        auto land = [&](u8 *raw) {
+            u8 *rawY = raw, *rawU = rawY + M_CH * ys, *rawV = rawU + 9 * cs;
+            if (y_live) {
+#pragma unroll
+                for (int k = 0; k < NY; k++) *(u32 *)(rawY + (cwave + CW * k) * ys + 4 * lane) = (ablate & 128) ? 0x80808080u : py[k];
+            }
+            if (c_edge) {
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    u32 o = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; b++) o |= ((pc[k] >> (8 * (clampi(c_col0 + b, 0, cw - 1) - c_col0c))) & 0xffu) << (8 * b);
+                    pc[k] = o;
+                }
+            }
+            if (c_live) {
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    const int rt = cwave + CW * k;
+                    if (rt < 18) {
+                        const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
+                        *(u32 *)((plane ? rawV : rawU) + r * cs + 4 * lane) = (ablate & 128) ? 0x80808080u : pc[k];
+                    }
+                }
+            }
+        };
+        // convert tasks of this thread: (chunk row, column group g) for id = ctid + k * CT, 16 * ngroups <= 1024 of them.
+        // Row 0 of a chunk is an odd luma row: 3/4 of chroma row p = row / 2 (weights A); odd chunk rows take 3/4 of row p + 1 (B).
+        constexpr u32 WA13 = 0x03010903u, WA31 = 0x01030309u, WB13 = 0x09030301u, WB31 = 0x03090103u;
+        constexpr int NCV = 1024 / CT;
+        int crow[NCV], cgrp[NCV];
+#pragma unroll
+        for (int k = 0; k < NCV; k++) {
+            crow[k] = (ctid + k * CT) / ngroups;
+            cgrp[k] = ctid + k * CT - crow[k] * ngroups;
+        }
+        u8 *const raw0 = smem + L.raw;
+        if (!(ablate & 16)) {
+            issue(R_lo);
+            land(raw0);
+            if (n_chunks > 1) issue(R_lo + M_CH);
+        }
+        __syncthreads();  // (pairs with the filter waves' prologue barrier) chunk 0's footprint is visible to every convert wave
+        if (timing) tlast = __builtin_readcyclecounter();
+        for (int k = 0; k <= n_chunks; k++) {
+            mark(0);
+            if (k < n_chunks) {
+                // the one wait for memory of the chunk: the footprint of chunk k + 1, issued a whole chunk ago
+                __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+                mark(1);
+                if (k + 1 < n_chunks && !(ablate & 16)) land(raw0 + ((k + 1) & 1) * L.raw_bytes);
+                mark(2);
+                if (k + 2 < n_chunks && !(ablate & 48)) issue(R_lo + (k + 2) * M_CH);
+                mark(3);
+                const u8 *rawY = raw0 + (k & 1) * L.raw_bytes, *rawU = rawY + M_CH * ys, *rawV = rawU + 9 * cs;
+                u32 *Tk = T + (size_t)(k & 1) * (L.t_bytes >> 2);
+#pragma unroll
+                for (int it = 0; it < NCV; it++) {
+                    const int row = crow[it], g = cgrp[it];
+                    if (row >= M_CH || (ablate & 1)) break;
+                    const int p = row >> 1;
+                    const u32 yy = *((const u32 *)(rawY + row * ys) + g);
+                    const int bi = 2 * g + 3;
+                    const u32 *ru = (const u32 *)(rawU + p * cs) + (bi >> 2), *rv = (const u32 *)(rawV + p * cs) + (bi >> 2);
+                    const u32 shb = (u32)(bi & 3);
+                    const u32 ua = __builtin_amdgcn_alignbyte(ru[1], ru[0], shb), ub = __builtin_amdgcn_alignbyte(ru[(cs >> 2) + 1], ru[cs >> 2], shb);
+                    const u32 va = __builtin_amdgcn_alignbyte(rv[1], rv[0], shb), vb = __builtin_amdgcn_alignbyte(rv[(cs >> 2) + 1], rv[cs >> 2], shb);
+                    m_convert_block<ABL>(K, s_lut, yy, ua, ub, va, vb, (row & 1) ? WB13 : WA13, (row & 1) ? WB31 : WA31, Tk + (size_t)row * ts + 4 * g, ts);
+                    mark(4 + (it > 0));
+                }
+            }
+            mark(6);
+            __syncthreads();  // T[k & 1] and the raw footprint of chunk k + 1 are complete
+        }
+        if (timing && lane == 0)
+            for (int i = 0; i < 8; i++) atomicAdd(dbg + 8 + i, tph[i]);
+        return;
+    }
+
+    // ====================================================================== filter waves: N tile `wave` of the strip
+    const int l16 = lane & 15, lq = lane >> 4;
     const bool wave_on = wave < ntn;
     const int my_tile = nt0 + (wave_on ? wave : 0);
     const int colw = J.h_meta[my_tile].x - cbase;  // T column (dword) of this wave's K window
@@ -296,183 +462,121 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
 #pragma unroll
     for (int j = 0; j < KH_N; j++)
         if (j < KH) bh[j] = J.h_frag[((size_t)my_tile * KH + j) * 64 + lane];
-    const int R_lo = J.v_meta[vt0].x, R_hi = J.v_meta[vt1].y;
-    if (vt0 + tid <= vt1) s_vmeta[tid] = J.v_meta[vt0 + tid];  // (visible after the first barrier of the chunk loop)
+    u8 *const d_ptr = J.dst.ptr;
+    const u32 d_pitch = J.dst.pitch;
+    const int d_w = J.dst.w, d_h = J.dst.h;
+    const uint4 *const v_frag = J.v_frag;
     const int tx0 = strip * M_SW + 16 * wave;
-
-    // ---- staging: luma = one row per wave and step (64 lanes x 4 B), chroma = 18 (plane, row) tasks of <= 64 dwords
-    u32 py[4], pc[5];
-    const int sw4 = (sw + 3) & ~3;
-    auto issue = [&](int base) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int row = wave + 4 * k;
-            const int srow = clampi(base + row, 0, sh - 1), col = cbase + 4 * lane;
-            if (lane < ngroups && col < sw4) py[k] = *(const u32 *)(y_ptr + (size_t)srow * y_pitch + col);
-        }
-        const int i0 = (base - 1) >> 1;  // chroma row of the chunk's first row pair
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int rt = wave + 4 * k;
-            if (rt < 18 && lane < ncd) {
-                const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
-                const int crow = clampi(i0 + r, 0, chh - 1);
-                const int col0 = (cbase >> 1) - 4 + 4 * lane;
-                const int col0c = clampi(col0, 0, (cw - 1) & ~3);
-                pc[k] = *(const u32 *)((plane ? v_ptr : u_ptr) + (size_t)crow * (plane ? v_pitch : u_pitch) + col0c);
-            }
-        }
-    };
-    auto land = [&]() {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int row = wave + 4 * k;
-            if (lane < ngroups && cbase + 4 * lane < sw4) *(u32 *)(rawY + row * ys + 4 * lane) = py[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const int rt = wave + 4 * k;
-            if (rt < 18 && lane < ncd) {
-                const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
-                const int col0 = (cbase >> 1) - 4 + 4 * lane;
-                u32 v = pc[k];
-                if (col0 < 0 || col0 + 3 > cw - 1) {  // clamp-to-edge columns
-                    const int col0c = clampi(col0, 0, (cw - 1) & ~3);
-                    u32 o = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; b++) o |= ((v >> (8 * (clampi(col0 + b, 0, cw - 1) - col0c))) & 0xffu) << (8 * b);
-                    v = o;
-                }
-                *(u32 *)((plane ? rawV : rawU) + r * cs + 4 * lane) = v;
-            }
-        }
-    };
-
-    // convert tasks of this thread: (row pair p, column group g) for id = tid and id = tid + M_THREADS (8 * ngroups <= 512)
-    const int cp0 = tid / ngroups, cg0 = tid - cp0 * ngroups;
-    const int cp1 = (tid + M_THREADS) / ngroups, cg1 = tid + M_THREADS - cp1 * ngroups;
-
     int vt = vt0;
     int cg = 0;  // ring granule of the chunk being written
     // pass-2 weights of the next output tile, fetched a chunk ahead (they depend on the tile row only)
     uint4 bv[KV_N];
-    int bv_vt = -1;
     auto fetch_bv = [&](int t) {
 #pragma unroll
         for (int j = 0; j < KV_N; j++)
             if (j < KV) bv[j] = v_frag[((size_t)t * KV + j) * 64 + lane];
-        bv_vt = t;
     };
-    if (!(ablate & 16)) {
-        issue(R_lo);
-        land();
-    }
-    for (int base = R_lo; base <= R_hi; base += M_CH) {
-        __syncthreads();  // raw footprint of this chunk landed; T is free (every wave is past pass 1 of the previous chunk)
-        const bool more = base + M_CH <= R_hi;
-        if (more && !(ablate & 16)) issue(base + M_CH);
-        if (vt <= vt1 && bv_vt != vt) fetch_bv(vt);
-
-        // ---- convert: 8 row pairs x ngroups column groups
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-            const int p = it ? cp1 : cp0, g = it ? cg1 : cg0;
-            if (p >= 8 || (ablate & 1)) break;
-            const u32 *ry = (const u32 *)(rawY + (2 * p) * ys) + g;
-            const int bi = 2 * g + 3;
-            const u32 *ru = (const u32 *)(rawU + p * cs) + (bi >> 2), *rv = (const u32 *)(rawV + p * cs) + (bi >> 2);
-            const u32 shb = (u32)(bi & 3);
-            const u32 ua = __builtin_amdgcn_alignbyte(ru[1], ru[0], shb), ub = __builtin_amdgcn_alignbyte(ru[(cs >> 2) + 1], ru[cs >> 2], shb);
-            const u32 va = __builtin_amdgcn_alignbyte(rv[1], rv[0], shb), vb = __builtin_amdgcn_alignbyte(rv[(cs >> 2) + 1], rv[cs >> 2], shb);
-            m_convert_block(K, s_lut, ry[0], ry[ys >> 2], ua, ub, va, vb, T + (size_t)(2 * p) * ts + 4 * g, ts);
-        }
-        __syncthreads();  // T complete; the raw footprint is dead
-
-        if (wave_on && !(ablate & 2)) {
-            // ---- pass 1: rows of the chunk x this wave's 16 output columns
-            f32x4 acc[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const u32 *Ta = T + (size_t)l16 * ts + colw + 4 * lq;
-#pragma unroll
-            for (int j = 0; j < KH_N; j++) {
-                if (j < KH) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const uint4 a = *(const uint4 *)(Ta + (size_t)c * M_CH * ts + 16 * j);
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bh[j]), acc[c], 0, 0, 0);
-                    }
-                }
-            }
-            // lane holds rows 4 lq .. 4 lq + 3 of column l16: one half granule of the ring
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const __half2 h0 = __floats2half2_rn(acc[c][0], acc[c][1]), h1 = __floats2half2_rn(acc[c][2], acc[c][3]);
-                uint2 raw;
-                raw.x = *(const u32 *)&h0;
-                raw.y = *(const u32 *)&h1;
-                *(uint2 *)((u8 *)(Mh + (size_t)(c * RG + cg + (lq >> 1)) * M_SW + 16 * wave + l16) + 8 * (lq & 1)) = raw;
-            }
-        }
-        // the next chunk's raw footprint reaches LDS here: its loads were issued before the convert, and the stores of the
-        // epilogue below are not yet in the memory queue the wait has to drain
-        if (more && !(ablate & 16)) land();
-
-        // ---- pass 2: every output tile whose window ends inside this chunk
-        const int e = base + M_CH - 1;
-        while (vt <= vt1) {
-            const int2 vm = s_vmeta[vt - vt0];
-            if (vm.y > e) break;
-            if (wave_on && !(ablate & 4)) {
-                if (bv_vt != vt) fetch_bv(vt);
-                const int g0 = ((vm.x - R_lo) >> 3) % RG;
+    fetch_bv(vt0);
+    __syncthreads();  // (pairs with the convert waves' prologue barrier)
+    if (timing) tlast = __builtin_readcyclecounter();
+    for (int k = 0; k <= n_chunks; k++) {
+        mark(0);
+        if (k >= 1 && wave_on) {
+            const int base = R_lo + (k - 1) * M_CH;
+            if (!(ablate & 2)) {
+                // ---- pass 1 of chunk k - 1: its 16 rows x this wave's 16 output columns, three channels
                 f32x4 acc[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const u32 *Ta = T + (size_t)((k - 1) & 1) * (L.t_bytes >> 2) + (size_t)l16 * ts + colw + 4 * lq;
 #pragma unroll
-                for (int j = 0; j < KV_N; j++) {
-                    if (j < KV) {
-                        int rg = g0 + 4 * j + lq;
-                        rg -= rg >= RG ? RG : 0;
-                        rg -= rg >= RG ? RG : 0;
+                for (int j = 0; j < KH_N; j++) {
+                    if (j < KH) {
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
-                            const uint4 a = Mh[(size_t)(c * RG + rg) * M_SW + 16 * wave + l16];
-                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bv[j]), acc[c], 0, 0, 0);
+                            const uint4 a = *(const uint4 *)(Ta + (size_t)c * M_CH * ts + 16 * j);
+                            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bh[j]), acc[c], 0, 0, 0);
                         }
                     }
                 }
-                // lane holds columns tx0 + 4 lq .. + 3 of output row 16 vt + l16
-                const int y = 16 * vt + l16, x = tx0 + 4 * lq;
-                if (y < d_h && x < d_w && !(ablate & 8)) {
-                    u32 px[4];
+                mark(1);
+                // lane holds rows 4 lq .. 4 lq + 3 of column l16: one half granule of the ring
+                int rgw = cg + (lq >> 1);
+                rgw -= rgw >= RG ? RG : 0;
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
-                    u8 *o = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
-                    if (x + 3 < d_w) {
-                        *(uint4 *)o = make_uint4(px[0], px[1], px[2], px[3]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; i++)
-                            if (x + i < d_w) ((u32 *)o)[i] = px[i];
-                    }
+                for (int c = 0; c < 3; c++) {
+                    const __half2 h0 = __floats2half2_rn(acc[c][0], acc[c][1]), h1 = __floats2half2_rn(acc[c][2], acc[c][3]);
+                    *(uint2 *)((u8 *)(Mh + (size_t)(c * RG + rgw) * M_SW + 16 * wave + l16) + 8 * (lq & 1)) = make_uint2(*(const u32 *)&h0, *(const u32 *)&h1);
                 }
             }
-            vt++;
+            mark(2);
+            cg += 2;
+            cg -= cg >= RG ? RG : 0;
+            // ---- pass 2 + encode + store of every output tile whose window ends inside chunk k - 1
+            const int e = base + M_CH - 1;
+            while (vt <= vt1) {
+                const int2 vm = s_vmeta[vt - vt0];
+                if (vm.y > e) break;
+                if (!(ablate & 4)) {
+                    const int g0 = ((vm.x - R_lo) >> 3) % RG;
+                    f32x4 acc[3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < KV_N; j++) {
+                        if (j < KV) {
+                            int rg = g0 + 4 * j + lq;
+                            rg -= rg >= RG ? RG : 0;
+                            rg -= rg >= RG ? RG : 0;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) {
+                                const uint4 a = Mh[(size_t)(c * RG + rg) * M_SW + 16 * wave + l16];
+                                acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bv[j]), acc[c], 0, 0, 0);
+                            }
+                        }
+                    }
+                    // the next tile's weights, before the stores below enter the memory queue: on gfx950 a wait for a load drains
+                    // the stores issued before it too (one counter)
+                    mark(3);
+                    fetch_bv(min(vt + 1, vt1));
+                    // lane holds columns tx0 + 4 lq .. + 3 of output row 16 vt + l16
+                    const int y = 16 * vt + l16, x = tx0 + 4 * lq;
+                    if (ablate & 8) {  // profiling: no encode, one dword store keeps the MFMAs alive
+                        if (y < d_h && x < d_w) *(float *)(d_ptr + (size_t)y * d_pitch + (size_t)x * 4) = acc[0][0] + acc[1][1] + acc[2][2] + acc[0][3];
+                    } else if (y < d_h && x < d_w) {
+                        u32 px[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++)
+                            px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
+                        u8 *o = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
+                        if (x + 3 < d_w) {
+                            *(uint4 *)o = make_uint4(px[0], px[1], px[2], px[3]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; i++)
+                                if (x + i < d_w) ((u32 *)o)[i] = px[i];
+                        }
+                    }
+                    mark(4);
+                }
+                vt++;
+            }
         }
-        cg += 2;
-        cg -= cg >= RG ? RG : 0;
+        mark(5);
+        __syncthreads();  // T[k & 1] (chunk k) is complete; this wave is done with T[(k - 1) & 1]
     }
+    if (timing && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(dbg + i, tph[i]);
 }
 
-template <int KH_T, int KV_T, bool ABL>
-__global__ __launch_bounds__(M_THREADS, 2) void k_ingest_mfma(const MArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
+template <int KH_T, int KV_T, int ABL>
+__global__ __launch_bounds__(M_THREADS, M_WAVES / 2) void k_ingest_mfma(const MArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut,
+                                                              unsigned long long *dbg) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int tid = threadIdx.x;
-    if (ABL && (args.jobs[0].ablate & 32)) return;
+    if (ABL & 32) return;
     // tables: (hi | lo << 16) decode LUT, encode thresholds + estimate table
-    ((u32 *)smem)[tid] = lut[tid];
+    if (tid < 256) ((u32 *)smem)[tid] = lut[tid];
     for (int i = tid; i < SMR_TABLE_FLOATS - 256; i += M_THREADS) ((float *)(smem + M_OFF_THR))[i] = tables[256 + i];
     const int total = args.unit_prefix[args.n_jobs];
     // XCD-aware order (as k_ingest_resample): ids that share an XCD are neighbours in the unit space
@@ -490,11 +594,12 @@ __global__ __launch_bounds__(M_THREADS, 2) void k_ingest_mfma(const MArgs args, 
         const int vt1 = min(min(J.n_vtiles, vt0 + (u_end - u)), vt0 + M_PIECE_TILES) - 1;
         if (!first) __syncthreads();
         {
-            // the ring must hold finite values wherever a zero weight meets it
-            uint4 *Mh = (uint4 *)(smem + M_OFF_T + (size_t)3 * M_CH * J.ts * 4);
-            for (int i = tid; i < 3 * J.RG * M_SW; i += M_THREADS) Mh[i] = make_uint4(0u, 0u, 0u, 0u);
+            // T (row padding included) and the ring must hold finite values wherever a zero weight meets them
+            const MLds L = m_lds(J.ts, J.ngm, J.RG);
+            u32 *z = (u32 *)(smem + L.t);
+            for (int i = tid; i < (L.raw - L.t) / 4; i += M_THREADS) z[i] = 0u;
         }
-        mfma_piece<KH_T, KV_T, ABL>(J, strip, vt0, vt1, smem);
+        mfma_piece<KH_T, KV_T, ABL>(J, strip, vt0, vt1, smem, dbg);
         u += vt1 - vt0 + 1;
         first = false;
     }
@@ -539,47 +644,63 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     const double c0 = full ? 0.0 : 16.0 * 16.0, half = full ? 16.0 * 127.5 : 16.0 * 112.0;  // 255 * (ue - 0.5) = cs * (U16 - c0 - half)
     J.ky = (float)ys;
     J.krv = (float)(1.5748 * cs); J.kgu = (float)(-0.1873 * cs); J.kgv = (float)(-0.4681 * cs); J.kbu = (float)(1.8556 * cs);
-    J.cr = (float)(0.5 - ys * y0 - 1.5748 * cs * (c0 + half));
-    J.cg = (float)(0.5 - ys * y0 + (0.1873 + 0.4681) * cs * (c0 + half));
-    J.cb = (float)(0.5 - ys * y0 - 1.8556 * cs * (c0 + half));
+    J.cr = (float)(-ys * y0 - 1.5748 * cs * (c0 + half));
+    J.cg = (float)(-ys * y0 + (0.1873 + 0.4681) * cs * (c0 + half));
+    J.cb = (float)(-ys * y0 - 1.8556 * cs * (c0 + half));
     J.ylo = full ? 0.0f : 16.0f; J.yhi = full ? 255.0f : 235.0f;
     J.clo = full ? 0 : 256; J.chi = full ? 4080 : 3840;
     J.h_meta = bh.meta; J.h_frag = bh.frag; J.KH = bh.K; J.n_htiles = bh.n_tiles;
     J.v_meta = bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_tiles;
-    J.strips_x = (bh.n_tiles + M_WAVES - 1) / M_WAVES;
+    J.strips_x = (bh.n_tiles + M_NT - 1) / M_NT;
     J.ablate = ctx->ablate;
     // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
     const int taps_h = host_taps(plan.scale[0]);
     int ngm = 1;
     for (int s = 0; s < J.strips_x; s++) {
-        const int t0 = s * M_WAVES, t1 = (t0 + M_WAVES < bh.n_tiles ? t0 + M_WAVES : bh.n_tiles) - 1;
-        auto a0 = [&](int t) {
-            int lo = lanczos_first(16 * t, plan.scale[0], plan.offset[0]);
-            lo = lo < 0 ? 0 : (lo > J.src_w - 1 ? J.src_w - 1 : lo);
-            return mfma_window_base(lo, 0);
-        };
-        const int g = (a0(t1) + 16 * J.KH - (a0(t0) & ~7) + 3) >> 2;
+        const int t0 = s * M_NT, t1 = (t0 + M_NT < bh.n_tiles ? t0 + M_NT : bh.n_tiles) - 1;
+        int lo = lanczos_first(16 * t0, plan.scale[0], plan.offset[0]);
+        lo = lo < 0 ? 0 : (lo > J.src_w - 1 ? J.src_w - 1 : lo);
+        const int o1 = 16 * t1 + 15 < (int)tile->w - 1 ? 16 * t1 + 15 : (int)tile->w - 1;
+        int hi = lanczos_first(o1, plan.scale[0], plan.offset[0]) + taps_h - 1;
+        hi = hi < 0 ? 0 : (hi > J.src_w - 1 ? J.src_w - 1 : hi);
+        const int g = (hi - (mfma_window_base(lo, 0) & ~7) + 4) >> 2;
         ngm = g > ngm ? g : ngm;
     }
-    (void)taps_h;
     J.ngm = ngm;
     J.ts = ((4 * ngm + 7) & ~15) + 8;  // >= 4 * ngm and = 8 mod 16
     if (J.ts < 4 * ngm) J.ts += 16;
     // ring: the widest window plus the chunk that may land before the window's tile is resolved
     int rg = (bv.max_span + M_CH - 1 + 7) / 8;
-    rg += rg & 1;
-    J.RG = rg;
-    *fits = ngm <= M_NG_MAX && m_lds_bytes(J.ts, J.ngm, J.RG) <= 160 * 1024;
+    J.RG = rg < 2 ? 2 : rg;
+    *fits = ngm <= M_NG_MAX && (size_t)m_lds(J.ts, J.ngm, J.RG).total <= 160 * 1024;
     return SMR_OK;
 }
 
 // the scale range of the benchmark scenes (1.5x .. 2x: 3 k-steps per pass-1 tile, 2 per pass-2 tile) gets its own build
-typedef void (*MfmaKernel)(const MArgs, const float *, const u32 *);
-constexpr MfmaKernel M_KERNELS[3] = {k_ingest_mfma<0, 0, false>, k_ingest_mfma<3, 2, false>, k_ingest_mfma<0, 0, true>};
+typedef void (*MfmaKernel)(const MArgs, const float *, const u32 *, unsigned long long *);
+#ifdef SMR_ABLATION_BUILDS  // tools/ablate_mfma.sh: the (3,2) build with phases compiled out (1 convert, 2 pass 1, 4 pass 2, 16 staging, 64 phase timers)
+constexpr int M_ABL[] = {0, 0, 1, 2, 4, 5, 6, 7, 16, 23, 64, 128, 262, 518, 774, 1024, 1088, 3, 9, 13, 8, 256, 512, 768, 39};
+constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>,  k_ingest_mfma<3, 2, 0>,  k_ingest_mfma<3, 2, 1>,  k_ingest_mfma<3, 2, 2>,
+                                    k_ingest_mfma<3, 2, 4>,  k_ingest_mfma<3, 2, 5>,  k_ingest_mfma<3, 2, 6>,  k_ingest_mfma<3, 2, 7>,
+                                    k_ingest_mfma<3, 2, 16>, k_ingest_mfma<3, 2, 23>, k_ingest_mfma<3, 2, 64>, k_ingest_mfma<3, 2, 128>,
+                                    k_ingest_mfma<3, 2, 262>, k_ingest_mfma<3, 2, 518>, k_ingest_mfma<3, 2, 774>,
+                                    k_ingest_mfma<3, 2, 1024>, k_ingest_mfma<3, 2, 1088>, k_ingest_mfma<3, 2, 3>, k_ingest_mfma<3, 2, 9>, k_ingest_mfma<3, 2, 13>,
+                                    k_ingest_mfma<3, 2, 8>, k_ingest_mfma<3, 2, 256>, k_ingest_mfma<3, 2, 512>, k_ingest_mfma<3, 2, 768>, k_ingest_mfma<3, 2, 39>};
+#else
+constexpr int M_ABL[] = {0, 0};
+constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>, k_ingest_mfma<3, 2, 0>};
+#endif
+constexpr int M_NKERNELS = (int)(sizeof(M_KERNELS) / sizeof(M_KERNELS[0]));
 
 int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
     if (!ctx->mfma_attr_set) {  // per device, hence per ctx
-        for (MfmaKernel k : M_KERNELS) SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (MfmaKernel k : M_KERNELS) {
+            SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipFuncAttributes fa;
+            SMR_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)k));
+            // the convert waves address the decode LUT by its LDS offset 0: holds while the kernel declares no static LDS
+            if (fa.sharedSizeBytes != 0) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_mfma: %zu B of static LDS in front of the dynamic segment", (size_t)fa.sharedSizeBytes);
+        }
         ctx->mfma_attr_set = true;
     }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
@@ -594,23 +715,51 @@ int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
             args.jobs[j] = J;
             args.unit_prefix[j] = total;
             total += J.strips_x * J.n_vtiles;
-            const size_t b = m_lds_bytes(J.ts, J.ngm, J.RG);
+            const size_t b = (size_t)m_lds(J.ts, J.ngm, J.RG).total;
             lds = b > lds ? b : lds;
         }
         args.unit_prefix[nj] = total;
         args.n_jobs = (int)nj;
-        // as many workgroups as fit at once (LDS-bound), minus the share left to the other stream's compose kernel
-        const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+        bool all32 = true;
+        for (size_t j = 0; j < nj; j++) all32 = all32 && args.jobs[j].KH == 3 && args.jobs[j].KV == 2;
+        int ki = all32 ? 1 : 0;
+        for (int i = 2; i < M_NKERNELS; i++)
+            if (all32 && ctx->ablate == M_ABL[i]) ki = i;
+        const MfmaKernel kern = M_KERNELS[ki];
+        // as many workgroups as are resident at once (LDS and registers), minus the share left to the other stream's compose kernel
+        int per_cu = 0;
+        for (auto &o : ctx->mfma_occupancy)
+            if (o.kernel == ki && o.lds == lds) per_cu = o.per_cu;
+        if (!per_cu) {
+            SMR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, M_THREADS, lds));
+            if (per_cu < 1) per_cu = 1;
+            ctx->mfma_occupancy.push_back({ki, lds, per_cu});
+        }
         const int reserve = ctx->ingest_reserve_cus >= 0 && ctx->ingest_reserve_cus < ctx->cu_count ? ctx->ingest_reserve_cus : ctx->cu_count / 16;
-        int blocks = (per_cu > 4 ? 4 : per_cu) * (ctx->cu_count - reserve);
+        const int wg_cap = ctx->ingest_wg_per_cu > 0 ? ctx->ingest_wg_per_cu : 4;
+        int blocks = (per_cu > wg_cap ? wg_cap : per_cu) * (ctx->cu_count - reserve);
         int upb = (total + blocks - 1) / blocks;
         if (upb < 2) upb = 2;  // a piece re-converts the rows of its vertical halo
         blocks = ((total + upb - 1) / upb + 7) & ~7;
         args.units_per_block = upb;
-        bool all32 = true;
-        for (size_t j = 0; j < nj; j++) all32 = all32 && args.jobs[j].KH == 3 && args.jobs[j].KV == 2;
-        const MfmaKernel kern = ctx->ablate ? M_KERNELS[2] : (all32 ? M_KERNELS[1] : M_KERNELS[0]);
-        if (blocks > 0) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(M_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16);
+        if (ctx->debug_ingest)
+            fprintf(stderr, "k_ingest_mfma: %zu jobs, lds %zu B (%d/CU), blocks %d x %d tiles, job0: KH %d KV %d ts %d ngm %d RG %d strips %d vtiles %d\n", nj, lds,
+                    per_cu, blocks, upb, args.jobs[0].KH, args.jobs[0].KV, args.jobs[0].ts, args.jobs[0].ngm, args.jobs[0].RG, args.jobs[0].strips_x,
+                    args.jobs[0].n_vtiles);
+        unsigned long long *dbg = nullptr;
+        if (M_ABL[ki] & 64) {  // profiling: per-phase cycle sums of wave 0 of every block, printed after the launch
+            dbg = (unsigned long long *)smr_scratch(ctx, 7, 128);
+            if (dbg) SMR_HIP(ctx, hipMemsetAsync(dbg, 0, 128, ctx->stream));
+        }
+        if (blocks > 0) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(M_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16, dbg);
+        if (dbg) {
+            unsigned long long h[16];
+            SMR_HIP(ctx, hipMemcpyAsync(h, dbg, 128, hipMemcpyDeviceToHost, ctx->stream));
+            SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const double b = 1e3 * blocks;
+            fprintf(stderr, "k_ingest_mfma kcycles per block: filter: barrier %.1f pass1-mfma %.1f ring-write %.1f pass2-mfma %.1f encode+store %.1f tail %.1f | convert: barrier %.1f vmwait %.1f land %.1f issue %.1f task0 %.1f task1+ %.1f tail %.1f\n",
+                    h[0] / b, h[1] / b, h[2] / b, h[3] / b, h[4] / b, h[5] / b, h[8] / b, h[9] / b, h[10] / b, h[11] / b, h[12] / b, h[13] / b, h[14] / b);
+        }
         SMR_HIP(ctx, hipGetLastError());
     }
     return SMR_OK;

@@ -111,11 +111,15 @@ struct smr_ctx {
         uint64_t last_use = 0, last_call = 0;
     };
     std::vector<MfmaTable> mfma_tables;
+    struct MfmaOccupancy { int kernel; size_t lds; int per_cu; };
+    std::vector<MfmaOccupancy> mfma_occupancy;  // resident k_ingest_mfma workgroups per CU, per (kernel build, LDS bytes)
     u32 *d_lut16 = nullptr;      // 256 x (f16 hi | f16 lo << 16) of the sRGB decode table
     u32 ingest_impl = 0;         // smr_ingest_impl
     bool mfma_attr_set = false;  // hipFuncSetAttribute is per device: kept per ctx, not per process
     bool valu_attr_set = false;
     int ingest_reserve_cus = -1; // SMR_INGEST_RESERVE_CUS (profiling), read once per ctx
+    int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (profiling): cap on resident k_ingest_mfma workgroups per CU, 0 = as many as fit
+    bool debug_ingest = false;   // SMR_DEBUG_INGEST: print the launch geometry
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
