@@ -37,9 +37,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int M_NT = 4;             // 16-column N tiles per strip = filter waves of a workgroup
 #ifndef SMR_MFMA_CONV_WAVES
-#define SMR_MFMA_CONV_WAVES 4
+#define SMR_MFMA_CONV_WAVES 8
 #endif
-constexpr int M_WAVES = M_NT + SMR_MFMA_CONV_WAVES;  // + convert waves (4 or 8)
+constexpr int M_WAVES = M_NT + SMR_MFMA_CONV_WAVES;  // + convert waves (8: one 4x1 block per lane and chunk; 4 measured 10 % slower)
 constexpr int M_THREADS = M_WAVES * 64;
 constexpr int M_SW = 16 * M_NT;     // strip width
 constexpr int M_CH = 16;            // source rows per chunk = M of pass 1
@@ -183,7 +183,7 @@ struct MJob {
     SurfView yp, up, vp;  // planar 4:2:0 source planes (chroma views carry the chroma size)
     SurfView dst;         // RGBA8 tile, dst-sized
     int src_w, src_h;
-    // Y'CbCr -> 255 * R'G'B' with the range expansion and the clamps of planar_yuv_to_rgba.wgsl:45-57 folded in:
+    // Y'CbCr -> 255 * R'G'B' + 1280.5 with the range expansion and the clamps of planar_yuv_to_rgba.wgsl:45-57 folded in:
     // luma in u8 units clamped to [ylo, yhi], chroma in 1/16 u8 units clamped to [clo, chi]
     float ky, krv, kgu, kgv, kbu, cr, cg, cb;
     float ylo, yhi;
@@ -205,17 +205,12 @@ struct MArgs {
     int units_per_block;
 };
 
-constexpr int M_OFF_THR = 1024;                                  // after the (hi | lo << 16) decode LUT
+constexpr int M_LUT_ENTRIES = 768;  // decode LUT indexed by the unclamped code + 256: entries below 256 / above 511 repeat the ends
+constexpr int M_OFF_THR = M_LUT_ENTRIES * 4;
 constexpr int M_OFF_T = M_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
-static_assert(M_OFF_T % 16 == 0, "T must start on a 16-byte boundary");
+static_assert(M_OFF_THR % 16 == 0 && M_OFF_T % 16 == 0, "T must start on a 16-byte boundary");
 __host__ __device__ inline int m_ncd(int ngm) { return ((2 * (ngm - 1) + 3) >> 2) + 2; }  // staged chroma dwords per row
 constexpr int M_PIECE_TILES = 64;   // output tiles of one piece (their window table sits in LDS)
-
-__device__ __forceinline__ u32 m_lut_px(const u32 *__restrict__ lut, float x255) {
-    // floor(clamp(r, 0, 1) * 255 + 0.5) of the reference's unorm store; x255 already carries the + 0.5
-    const u32 code = (u32)__builtin_amdgcn_fmed3f(x255, 0.5f, 255.5f);
-    return lut[code];
-}
 
 struct MConv {  // the job's colour constants, read once per piece (scalar registers)
     float ky, krv, kgu, kgv, kbu, cr, cg, cb, ylo, yhi, clo, chi;
@@ -239,25 +234,18 @@ __device__ __forceinline__ void m_convert_block(const MConv &J, const u32 *__res
         const float r = __builtin_fmaf(yf, J.ky, __builtin_fmaf(vf, J.krv, J.cr));
         const float g = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kgu, __builtin_fmaf(vf, J.kgv, J.cg)));
         const float b = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kbu, J.cb));
-        // u8 quantisation of the node texture: one saturating convert per channel into a byte of `code` (round-to-nearest-even;
-        // the reference's floor(x + 0.5) differs on exact .5 ties only), then byte k << 2 = the LUT offset
-        u32 code = __builtin_amdgcn_cvt_pk_u8_f32(r, 0, 0u);
-        code = __builtin_amdgcn_cvt_pk_u8_f32(g, 1, code);
-        code = __builtin_amdgcn_cvt_pk_u8_f32(b, 2, code);
+        // u8 quantisation of the node texture + decode in one lookup: the constants carry + 1280.5, so r = 1024 + 256 + floor(255 R' + 0.5)
+        // + fraction with a fixed exponent — the code sits in mantissa bits [22:13], its LDS offset is (bits >> 11) & 0xffc, and the
+        // clamp to [0, 255] is folded into the table (768 entries: the matrix cannot leave [-237, 492]).  Two full-rate integer
+        // ops per channel instead of clamp + convert + shift.
         u32 tr, tg, tb;
         if (ABL & 256) {  // profiling: no LUT gathers
-            tr = code & 0xffu; tg = (code >> 8) & 0xffu; tb = (code >> 16) & 0xffu;
+            tr = __float_as_uint(r) >> 13; tg = __float_as_uint(g) >> 13; tb = __float_as_uint(b) >> 13;
         } else {
-            // LDS offset of entry = byte k << 2 in one SDWA shift (the LUT sits at LDS offset 0: the kernel has no static LDS,
-            // launch_mfma checks it)
-            u32 ar, ag, ab;
-            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(ar) : "v"(2u), "v"(code));
-            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ag) : "v"(2u), "v"(code));
-            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(ab) : "v"(2u), "v"(code));
-            typedef __attribute__((address_space(3))) const u32 lds_u32;
-            tr = *(lds_u32 *)(uintptr_t)ar;
-            tg = *(lds_u32 *)(uintptr_t)ag;
-            tb = *(lds_u32 *)(uintptr_t)ab;
+            typedef __attribute__((address_space(3))) const u32 lds_u32;  // (the LUT sits at LDS offset 0: launch_mfma checks it)
+            tr = *(lds_u32 *)(uintptr_t)((__float_as_uint(r) >> 11) & 0xffcu);
+            tg = *(lds_u32 *)(uintptr_t)((__float_as_uint(g) >> 11) & 0xffcu);
+            tb = *(lds_u32 *)(uintptr_t)((__float_as_uint(b) >> 11) & 0xffcu);
         }
         if (i == 0) { o[0].x = tr; o[1].x = tg; o[2].x = tb; }
         if (i == 1) { o[0].y = tr; o[1].y = tg; o[2].y = tb; }
@@ -576,7 +564,7 @@ __global__ __launch_bounds__(M_THREADS, M_WAVES / 2) void k_ingest_mfma(const MA
     const int tid = threadIdx.x;
     if (ABL & 32) return;
     // tables: (hi | lo << 16) decode LUT, encode thresholds + estimate table
-    if (tid < 256) ((u32 *)smem)[tid] = lut[tid];
+    for (int i = tid; i < M_LUT_ENTRIES; i += M_THREADS) ((u32 *)smem)[i] = lut[min(max(i - 256, 0), 255)];
     for (int i = tid; i < SMR_TABLE_FLOATS - 256; i += M_THREADS) ((float *)(smem + M_OFF_THR))[i] = tables[256 + i];
     const int total = args.unit_prefix[args.n_jobs];
     // XCD-aware order (as k_ingest_resample): ids that share an XCD are neighbours in the unit space
@@ -644,9 +632,10 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     const double c0 = full ? 0.0 : 16.0 * 16.0, half = full ? 16.0 * 127.5 : 16.0 * 112.0;  // 255 * (ue - 0.5) = cs * (U16 - c0 - half)
     J.ky = (float)ys;
     J.krv = (float)(1.5748 * cs); J.kgu = (float)(-0.1873 * cs); J.kgv = (float)(-0.4681 * cs); J.kbu = (float)(1.8556 * cs);
-    J.cr = (float)(-ys * y0 - 1.5748 * cs * (c0 + half));
-    J.cg = (float)(-ys * y0 + (0.1873 + 0.4681) * cs * (c0 + half));
-    J.cb = (float)(-ys * y0 - 1.8556 * cs * (c0 + half));
+    const double bias = 1024.0 + 256.0 + 0.5;  // see m_convert_block: fixed exponent, LUT offset, round half up
+    J.cr = (float)(bias - ys * y0 - 1.5748 * cs * (c0 + half));
+    J.cg = (float)(bias - ys * y0 + (0.1873 + 0.4681) * cs * (c0 + half));
+    J.cb = (float)(bias - ys * y0 - 1.8556 * cs * (c0 + half));
     J.ylo = full ? 0.0f : 16.0f; J.yhi = full ? 255.0f : 235.0f;
     J.clo = full ? 0 : 256; J.chi = full ? 4080 : 3840;
     J.h_meta = bh.meta; J.h_frag = bh.frag; J.KH = bh.K; J.n_htiles = bh.n_tiles;
