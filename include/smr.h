@@ -159,14 +159,17 @@ SMR_API void smr_ctx_destroy(smr_ctx *ctx);
 SMR_API const char *smr_last_error(const smr_ctx *ctx);
 SMR_API uint32_t smr_ctx_mode(const smr_ctx *ctx);  /* smr_mode the context was created with (RenderingMode, types.rs:8-18) */
 SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — render_loop.rs:177-183 */
-/* Arithmetic of the fused ingest + Lanczos kernel (wave A of smr_render_layouts / smr_ingest_resample*):
- *   SMR_INGEST_AUTO      matrix cores where the frame format / plan allow it, the f32 kernel elsewhere (default)
- *   SMR_INGEST_VALU_F32  exact f32 everywhere: bit-identical to the pass-per-launch kernels (smr_frame_to_rgba + smr_resample)
- *   SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
- * The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
- * layout/resampler.rs:25-28, u8 sRGB tile) and deviates from the f32 sequence of resample.wgsl:64-87 by at most 1 LSB. */
+/* Context options (RendererOptions has no counterpart: these select between equivalent implementations).
+ *   SMR_OPT_INGEST_IMPL         arithmetic of the fused ingest + Lanczos kernel (wave A of smr_render_layouts / smr_ingest_resample*):
+ *       SMR_INGEST_AUTO      matrix cores where the frame format / plan allow it, the f32 kernel elsewhere (default)
+ *       SMR_INGEST_VALU_F32  exact f32 everywhere: bit-identical to the pass-per-launch kernels (smr_frame_to_rgba + smr_resample)
+ *       SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
+ *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
+ *     layout/resampler.rs:25-28, u8 sRGB tile) and deviates from the f32 sequence of resample.wgsl:64-87 by at most 1 LSB.
+ *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling) */
 typedef enum smr_ingest_impl { SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2 } smr_ingest_impl;
-SMR_API int smr_ctx_set_ingest_impl(smr_ctx *ctx, uint32_t impl);
+typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1 } smr_option;
+SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
 SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */
 /* Per-kernel-class timing with HIP events on the ctx stream (off by default).
@@ -239,7 +242,7 @@ SMR_API int smr_apply_layouts(smr_ctx *ctx, smr_surface *target, const smr_layou
  * Equivalent to: for every texture layout resample_scaled_children (layout.rs:238-278) from the
  * raw frame / surface, LayoutShader::render, then rgba_to_yuv / rgba_to_nv12 into `out`
  * (or a copy into `out_rgba` when out == NULL).  Bit-identical to the unfused sequence with SMR_INGEST_VALU_F32,
- * within 1 LSB of it with the matrix-core resampler (smr_ctx_set_ingest_impl). */
+ * within 1 LSB of it with the matrix-core resampler (SMR_OPT_INGEST_IMPL). */
 SMR_API int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint32_t n, const smr_source *sources,
                                uint32_t n_sources, uint32_t out_w, uint32_t out_h, const smr_frame *out,
                                smr_surface *out_rgba);

@@ -35,7 +35,7 @@ EXPORTS = [
     "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_ingest_resample_batch", "smr_blit_glyphs", "smr_builtin_shader",
     "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update", "smr_scene_parse",
     "smr_scene_node_count", "smr_scene_node_info", "smr_scene_node_children", "smr_scene_node_layouts",
-    "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color", "smr_ctx_mode", "smr_ctx_set_ingest_impl",
+    "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color", "smr_ctx_mode", "smr_ctx_set_option",
     "smr_renderer_create", "smr_renderer_destroy", "smr_renderer_last_error", "smr_renderer_register_input",
     "smr_renderer_unregister_input", "smr_renderer_register_image", "smr_renderer_register_shader", "smr_renderer_update_scene",
     "smr_renderer_unregister_output", "smr_renderer_node_count", "smr_renderer_node_info", "smr_renderer_set_text",
@@ -183,7 +183,7 @@ def load():
         "smr_bounce_easing": ([C.c_double], C.c_double),
         "smr_parse_color": ([C.c_char_p, C.POINTER(C.c_uint8)], I),
         "smr_ctx_mode": ([P], U),
-        "smr_ctx_set_ingest_impl": ([P, U], I),
+        "smr_ctx_set_option": ([P, U], I),
         "smr_renderer_create": ([P, C.c_int64, PP], I),
         "smr_renderer_destroy": ([P], None),
         "smr_renderer_last_error": ([P], C.c_char_p),

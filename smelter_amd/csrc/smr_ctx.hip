@@ -196,6 +196,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         if (!strcmp(e, "valu")) ctx->ingest_impl = SMR_INGEST_VALU_F32;
         else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
     }
+    if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
     ctx->debug_ingest = getenv("SMR_DEBUG_INGEST") != nullptr;
@@ -238,11 +239,20 @@ void smr_ctx_destroy(smr_ctx *ctx) {
     delete ctx;
 }
 
-int smr_ctx_set_ingest_impl(smr_ctx *ctx, uint32_t impl) {
+int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     if (!ctx) return SMR_ERR_INVALID;
-    if (impl > SMR_INGEST_MFMA_F16) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_ingest_impl: unknown implementation %u", impl);
-    ctx->ingest_impl = impl;
-    return SMR_OK;
+    switch (option) {
+    case SMR_OPT_INGEST_IMPL:
+        if (value < 0 || value > SMR_INGEST_MFMA_F16) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
+        ctx->ingest_impl = (u32)value;
+        return SMR_OK;
+    case SMR_OPT_INGEST_STRIP_WIDTH:
+        if (value != 0 && value != 32 && value != 64) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: strip width %d", value);
+        ctx->force_tw = value;
+        return SMR_OK;
+    default:
+        return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown option %u", option);
+    }
 }
 
 const char *smr_last_error(const smr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }

@@ -33,8 +33,6 @@ bool fused_disabled(smr_ctx *ctx) {
         ctx->fused_disabled = (e && e[0] && e[0] != '0') ? 1 : 0;
         const char *a = getenv("SMR_ABLATE");
         ctx->ablate = a ? atoi(a) : 0;
-        const char *t = getenv("SMR_INGEST_TW");
-        ctx->force_tw = t ? atoi(t) : 0;
     }
     return ctx->fused_disabled == 1;
 }

@@ -649,7 +649,7 @@ int make_ingest_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &p
         J.nc_max = (int)ceilf(64.0f * fmaxf(plan.scale[0], 0.0f)) + wh.taps + 3;
         if (J.nc_max > J.src_w + 1) J.nc_max = J.src_w + 1;
     }
-    {  // tests / profiling: SMR_INGEST_TW pins the strip width (read once per ctx, smr_fused.hip:fused_disabled)
+    {  // tests / profiling: SMR_OPT_INGEST_STRIP_WIDTH pins the strip width
         const int tw = ctx->force_tw;
         if (tw == 32 || tw == 64) {
             J.tw = tw;

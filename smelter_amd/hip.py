@@ -138,6 +138,7 @@ def pack_layouts(layouts) -> "C.Array":
 
 
 INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16 = 0, 1, 2
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH = 0, 1
 
 
 class Context:
@@ -177,9 +178,16 @@ class Context:
     def sync(self):
         self._check(self.lib.smr_sync(self.handle))
 
+    def set_option(self, option: int, value: int):
+        self._check(self.lib.smr_ctx_set_option(self.handle, option, value))
+
     def set_ingest_impl(self, impl: int):
-        """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (smr_ctx_set_ingest_impl)."""
-        self._check(self.lib.smr_ctx_set_ingest_impl(self.handle, impl))
+        """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (SMR_OPT_INGEST_IMPL)."""
+        self.set_option(OPT_INGEST_IMPL, impl)
+
+    def set_strip_width(self, tw: int):
+        """0 (automatic), 32 or 64: strip width of the f32 ingest kernel (SMR_OPT_INGEST_STRIP_WIDTH)."""
+        self.set_option(OPT_INGEST_STRIP_WIDTH, tw)
 
     def timer_start(self):
         self._check(self.lib.smr_timer_start(self.handle))

@@ -1,6 +1,8 @@
-"""The fused hot path (smr_render_layouts): (1) bit-identical to the pass-per-launch path on the
-same device, (2) within 1 LSB of the CPU oracle's restatement of the reference's pass sequence,
-(3) size-independent properties at BASELINE.json's full sizes."""
+"""The fused hot path (smr_render_layouts), with both ingest implementations (SMR_OPT_INGEST_IMPL):
+  valu   exact f32 kernel: (1) bit-identical to the pass-per-launch path on the same device,
+  mfma   matrix-core kernel (the default): (1') within 1 LSB of the pass-per-launch path, >= 99 % of the bytes identical,
+and for both (2) within 1 LSB of the CPU oracle's restatement of the reference's pass sequence (>= 99.5 % identical on the
+scene cases, >= 99 % on the random-geometry sweeps), (3) size-independent properties at BASELINE.json's full sizes."""
 import os
 
 import numpy as np
@@ -19,11 +21,24 @@ def hip():
     return h
 
 
-@pytest.fixture(scope="module")
-def ctx(hip):
+@pytest.fixture(scope="module", params=["valu", "mfma"])
+def ctx(hip, request):
     c = hip.Context(0)
+    c.impl = request.param
+    c.set_ingest_impl(hip.INGEST_VALU_F32 if request.param == "valu" else hip.INGEST_MFMA_F16)
     yield c
     c.close()
+
+
+def _assert_matches_unfused(ctx, got, ref, what, identical=0.99):
+    """valu: bit for bit.  mfma: the tolerance BASELINE.json's north star gives the resampler (<= 1 LSB), and nearly all bytes equal
+    (`identical`: 0.99 on the scene content; 0.98 on full-range white noise, the worst case for an f16 weight — measured 0.985+)."""
+    for a, b, pl in zip(got, ref, "YUV"):
+        if ctx.impl == "valu":
+            assert (a == b).all(), f"{what}: fused and unfused paths differ on the same device (plane {pl})"
+        else:
+            assert refpipe.max_diff(a, b) <= 1, f"{what} plane {pl}: matrix-core path {refpipe.max_diff(a, b)} LSB off the f32 path"
+            assert refpipe.exact_fraction(a, b) >= identical, f"{what} plane {pl}: only {refpipe.exact_fraction(a, b):.4f} identical to the f32 path"
 
 
 @pytest.fixture(scope="module")
@@ -92,8 +107,7 @@ def test_fused_equals_unfused_and_oracle(ctx, ctx_unfused, hip, name, mk, iw, ih
 
     got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
     got_unfused = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
-    for a, b in zip(got, got_unfused):
-        assert (a == b).all(), f"{name}: fused and unfused paths differ on the same device"
+    _assert_matches_unfused(ctx, got, got_unfused, name)
     # oracle
     nodes, k = [], 0
     for r in res:
@@ -135,7 +149,9 @@ def test_nv12_and_rgba_outputs(ctx, ctx_unfused, hip):
 def test_narrow_strip_variant_of_the_ingest_kernel(ctx, ctx_unfused, hip, monkeypatch, name, mk, iw, ih, W, H):
     """The ingest kernel picks 32-column strips when 64-column ones no longer fit two workgroups per CU (large scale factors);
     pinned here on every geometry: still bit-identical to the pass-per-launch path."""
-    monkeypatch.setenv("SMR_INGEST_TW", "32")
+    if ctx.impl != "valu":
+        pytest.skip("strip width is a knob of the f32 kernel")
+    ctx.set_strip_width(32)
     layouts, res = mk()
     n_in = sum(1 for r in res if r == (iw, ih))
     planes, _ = _inputs(ctx, hip, n_in, iw, ih)
@@ -151,16 +167,30 @@ def test_narrow_strip_variant_of_the_ingest_kernel(ctx, ctx_unfused, hip, monkey
                 srcs.append(lt)
         return srcs
 
-    got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
+    try:
+        got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
+    finally:
+        ctx.set_strip_width(0)
     ref = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
     for a, b in zip(got, ref):
         assert (a == b).all(), name
+    # ... and the oracle (the narrow strips against the reference's pass sequence, not only against our other kernel)
+    nodes, k = [], 0
+    for r in res:
+        if r == (iw, ih):
+            nodes.append(orc.planar_yuv_to_rgba(*planes[k], iw, ih)); k += 1
+        else:
+            nodes.append(label_host)
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+    for g, w_, pl in zip(got, want, "YUV"):
+        assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.995, f"{name} plane {pl}"
 
 
 @pytest.mark.parametrize("seed", range(72))
 def test_random_geometries_fused_equals_unfused(ctx, ctx_unfused, hip, seed):
     """Random input sizes (even and odd), output sizes, fit / fill (cropping) rescalers, positions and strip widths: the fused
-    kernels must reproduce the pass-per-launch path bit for bit — footprints, crop offsets, edge clamps, ragged last strips."""
+    kernels must reproduce the pass-per-launch path (valu: bit for bit) AND the oracle's restatement of the reference's pass
+    sequence (<= 1 LSB) — footprints, crop offsets, edge clamps, ragged last strips."""
     import os
     rng = np.random.default_rng(1000 + seed)
     iw, ih = int(rng.integers(8, 700)), int(rng.integers(8, 500))
@@ -188,14 +218,18 @@ def test_random_geometries_fused_equals_unfused(ctx, ctx_unfused, hip, seed):
     def frames(c):
         return [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes]
 
-    os.environ["SMR_INGEST_TW"] = "32" if seed % 2 else "64"
+    ctx.set_strip_width(32 if seed % 2 else 64)
     try:
         got = _render(ctx, hip, layouts, frames(ctx), W, H)
     finally:
-        del os.environ["SMR_INGEST_TW"]
+        ctx.set_strip_width(0)
     ref = _render(ctx_unfused, hip, layouts, frames(ctx_unfused), W, H)
-    for a, b in zip(got, ref):
-        assert (a == b).all(), (seed, iw, ih, W, H, scene)
+    _assert_matches_unfused(ctx, got, ref, (seed, iw, ih, W, H, scene), identical=0.98)  # (white-noise planes)
+    nodes = [orc.planar_yuv_to_rgba(y, u, v, iw, ih) for y, u, v in planes]
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+    for g, w_, pl in zip(got, want, "YUV"):
+        assert refpipe.max_diff(g, w_) <= 1, (seed, pl, iw, ih, W, H)
+        assert refpipe.exact_fraction(g, w_) >= 0.98, (seed, pl, refpipe.exact_fraction(g, w_))
 
 
 INPUT_FORMATS = [
@@ -237,14 +271,14 @@ def test_fused_ingest_input_formats(ctx, ctx_unfused, hip, name, fmt_name, varia
     ctx.profile_enable(False)
     assert prof["fused_ingest_resample"][1] == 1 and prof["fused_compose_output"][1] == 1, f"{name} did not take the fused kernels: {prof}"
     got_unfused = _render(ctx_unfused, hip, layouts, frames(ctx_unfused), W, H)
-    for a, b in zip(got, got_unfused):
-        assert (a == b).all(), f"{name}: fused and unfused paths differ"
+    _assert_matches_unfused(ctx, got, got_unfused, name)
     nodes = [orc.nv12_to_rgba(y, np.stack([u, v], axis=-1), iw, ih) if name == "nv12" else orc.planar_yuv_to_rgba(y, u, v, iw, ih, variant)
              for y, u, v in inputs]
     want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+    floor = 0.995 if ctx.impl == "valu" else 0.99  # (white-noise chroma planes: the worst case for the f16 weights of pass 2)
     for g, w_, pl in zip(got, want, "YUV"):
         assert refpipe.max_diff(g, w_) <= 1, f"{name} plane {pl}"
-        assert refpipe.exact_fraction(g, w_) >= 0.995, f"{name} plane {pl}"
+        assert refpipe.exact_fraction(g, w_) >= floor, f"{name} plane {pl}"
 
 
 def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
@@ -331,8 +365,7 @@ def test_long_layout_lists_and_odd_output_sizes(ctx, ctx_unfused, hip):
         if W % 4 == 0:
             got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
             ref = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
-            for a, b in zip(got, ref):
-                assert (a == b).all()
+            _assert_matches_unfused(ctx, got, ref, (W, H, n))
         rgba = ctx.surface(W, H)
         ctx.render_layouts(layouts, sources_for(ctx), W, H, out_rgba=rgba)
         nodes, k = [], 0
@@ -439,8 +472,7 @@ def test_full_size_properties(ctx, ctx_unfused, hip):
     # fused == unfused at full size
     fr_u = [ctx_unfused.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes]
     c = _render(ctx_unfused, hip, layouts, srcs(ctx_unfused, fr_u), W, H)
-    for p, q in zip(a, c):
-        assert (p == q).all()
+    _assert_matches_unfused(ctx, a, c, "configs[2] at full size")
     # tile independence: permuting which input feeds which tile permutes the tiles (linearity of placement)
     perm = [3, 0, 1, 2, 7, 4, 5, 6]
     d = _render(ctx, hip, layouts, srcs(ctx, [frames[i] for i in perm]), W, H)
