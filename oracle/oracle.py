@@ -146,6 +146,9 @@ def _bind(lib):
     lib.orc_resample.restype = I
     lib.orc_rescale_bilinear.argtypes = [P, I, I, I, P, I, I]
     lib.orc_apply_layouts.argtypes = [P, I, I, C.POINTER(_Layout), I, C.POINTER(_Source), I, I]
+    lib.orc_render_frame_yuv420.argtypes = [C.POINTER(P), C.POINTER(P), C.POINTER(P), I, I, I, C.POINTER(_Layout), I, C.POINTER(_Source),
+                                            C.POINTER(I), I, I, I, P, P, P]
+    lib.orc_render_frame_yuv420.restype = I
     lib.orc_blit_glyphs.argtypes = [P, I, I, C.POINTER(C.c_float), C.POINTER(_Glyph), I, P, I, I, I]
     lib.orc_gaussian_blur.argtypes = [P, I, I, I, F, P, P]
     lib.orc_sizeof_layout.restype = I
@@ -419,6 +422,35 @@ class Glyph:
     atlas_x: int
     atlas_y: int
     color: Sequence[float]
+
+
+def render_frame_yuv420(planes, layouts: Sequence[Layout], sources, W: int, H: int, omp=False):
+    """One output frame of the reference's pass sequence in one C call (orc_render_frame_yuv420): `planes` = [(y, u, v)] of equally
+    sized 4:2:0 inputs, sources[i] = an int (input index: its node texture), an RGBA8 array (text / image node) or None."""
+    n_in = len(planes)
+    ih, iw = planes[0][0].shape
+    keep = [[_u8(p[k]) for k in range(3)] for p in planes]
+    ptrs = [(C.c_void_p * n_in)(*[kp[k].ctypes.data for kp in keep]) for k in range(3)]
+    arr = pack_layouts(layouts)
+    srcs = (_Source * max(len(sources), 1))()
+    src_in = (C.c_int * max(len(sources), 1))()
+    for i, s in enumerate(sources):
+        src_in[i] = -1
+        if s is None:
+            srcs[i].data, srcs[i].w, srcs[i].h = None, 1, 1
+        elif isinstance(s, (int, np.integer)):
+            srcs[i].data, srcs[i].w, srcs[i].h = None, iw, ih
+            src_in[i] = int(s)
+        else:
+            s = _u8(s)
+            keep.append(s)
+            srcs[i].data, srcs[i].w, srcs[i].h = s.ctypes.data, s.shape[1], s.shape[0]
+    oy, ou, ov = np.empty((H, W), np.uint8), np.empty((H // 2, W // 2), np.uint8), np.empty((H // 2, W // 2), np.uint8)
+    rc = _load(omp).orc_render_frame_yuv420(ptrs[0], ptrs[1], ptrs[2], n_in, iw, ih, arr, len(layouts), srcs, src_in, len(sources), W, H,
+                                            _p(oy), _p(ou), _p(ov))
+    if rc < 0:
+        raise RuntimeError(f"orc_render_frame_yuv420: {rc}")
+    return [oy, ou, ov]
 
 
 def blit_glyphs(W, H, bg, glyphs: Sequence[Glyph], atlas, srgb=True) -> np.ndarray:

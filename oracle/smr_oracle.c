@@ -995,6 +995,63 @@ ORC_API void orc_gaussian_blur(const u8 *src, int fmt, int w, int h, float sigma
     blur_axis(tmp, fmt, w, h, sigma, 1, dst);
 }
 
+/* One whole output frame of the reference's pass sequence without leaving C — the CPU baseline leg of bench.py (a frame loop
+ * with no Python between the passes): populate_inputs + convert_to_node_texture (render_loop.rs:19-42) for n_in planar 4:2:0
+ * frames, resample_scaled_children (layout.rs:238-278), LayoutShader::render, rgba_to_yuv (render_loop.rs:59-230).
+ * sources[i].data == NULL and source_input[i] >= 0: source i is the node texture of input source_input[i]; otherwise an RGBA8
+ * texture given by the caller (text / image nodes).  Every pass is row-parallel under OpenMP. */
+ORC_API int orc_render_frame_yuv420(const u8 *const *yp, const u8 *const *up, const u8 *const *vp, int n_in, int iw, int ih,
+                                    const orc_layout *layouts, int n_layouts, const orc_source *sources, const int *source_input,
+                                    int n_sources, int W, int H, u8 *out_y, u8 *out_u, u8 *out_v) {
+    orc_init();
+    int rc = 0;
+    u8 **nodes = (u8 **)calloc((size_t)n_in, sizeof(u8 *));
+    orc_source *srcs = (orc_source *)calloc((size_t)n_sources + (size_t)n_layouts, sizeof(orc_source));
+    orc_layout *eff = (orc_layout *)malloc((size_t)n_layouts * sizeof(orc_layout));
+    u8 **tiles = (u8 **)calloc((size_t)n_layouts, sizeof(u8 *));
+    u8 *target = (u8 *)malloc((size_t)W * H * 4);
+    for (int i = 0; i < n_in; i++) {
+        nodes[i] = (u8 *)malloc((size_t)iw * ih * 4);
+        orc_planar_yuv_to_rgba(yp[i], up[i], vp[i], iw, ih, 0, nodes[i]);
+    }
+    for (int i = 0; i < n_sources; i++) {
+        srcs[i] = sources[i];
+        if (!srcs[i].data && source_input[i] >= 0 && source_input[i] < n_in) {
+            srcs[i].data = nodes[source_input[i]];
+            srcs[i].w = iw;
+            srcs[i].h = ih;
+        }
+    }
+    int n_src = n_sources;
+    for (int li = 0; li < n_layouts; li++) {
+        eff[li] = layouts[li];
+        orc_layout *L = &eff[li];
+        if (L->type != 0 || L->source_index >= (uint32_t)n_sources || !srcs[L->source_index].data) continue;
+        const orc_source *S = &srcs[L->source_index];
+        int dw = (int)rust_round(L->width), dh = (int)rust_round(L->height); /* layout.rs:258-261 */
+        if (dw < 1) dw = 1;
+        if (dh < 1) dh = 1;
+        tiles[li] = (u8 *)malloc((size_t)dw * dh * 4);
+        int kind = orc_resample((const u8 *)S->data, ORC_PX_RGBA8_SRGB, S->w, S->h, L->crop, tiles[li], dw, dh);
+        if (kind < 0) { rc = kind; break; }
+        if (kind > 0) { /* ResampledChild::output_crop (resampler.rs:292-299) */
+            srcs[n_src].data = tiles[li];
+            srcs[n_src].w = dw;
+            srcs[n_src].h = dh;
+            L->crop[0] = 0.0f; L->crop[1] = 0.0f; L->crop[2] = (float)dw; L->crop[3] = (float)dh;
+            L->source_index = (uint32_t)n_src++;
+        }
+    }
+    if (rc == 0) {
+        orc_apply_layouts(target, W, H, eff, n_layouts, srcs, n_src, 1);
+        orc_rgba_to_planar_yuv(target, W, H, 0, out_y, out_u, out_v);
+    }
+    for (int i = 0; i < n_in; i++) free(nodes[i]);
+    for (int i = 0; i < n_layouts; i++) free(tiles[i]);
+    free(nodes); free(srcs); free(eff); free(tiles); free(target);
+    return rc;
+}
+
 ORC_API int orc_sizeof_layout(void) { return (int)sizeof(orc_layout); }
 ORC_API int orc_sizeof_plan(void) { return (int)sizeof(orc_resample_plan); }
 ORC_API int orc_num_threads(void) {

@@ -148,3 +148,25 @@ def test_f16_conversion_matches_numpy():
 def test_black_fallback_yuv():
     # render_loop.rs:127-139 -> RGBColor::BLACK.to_yuv(): Y=16, U=V=128
     assert orc.rgb_to_yuv_bytes(0, 0, 0) == (16, 128, 128)
+
+
+def test_c_frame_loop_equals_the_pass_by_pass_pipeline():
+    """orc_render_frame_yuv420 (the all-C frame loop timed as bench.py's cpu_baseline) is the same pass sequence as the
+    pass-by-pass Python pipeline the parity tests compare the GPU with: identical bytes."""
+    from tests import refpipe, scenes
+    iw, ih, W, H, n = 96, 54, 192, 108, 3
+    layouts, res = scenes.cfg3_scene(iw, ih, W, H, n)
+    planes = [scenes.test_input(i, iw, ih, noise_seed=5 + i) for i in range(n)]
+    rng = np.random.default_rng(3)
+    label = rng.integers(0, 256, (scenes.LABEL_H, scenes.LABEL_W, 4), dtype=np.uint8)
+    label[..., :3] = np.minimum(label[..., :3], label[..., 3:])  # premultiplied
+    nodes, sources, k = [], [], 0
+    for r in res:
+        if r == (iw, ih):
+            nodes.append(orc.planar_yuv_to_rgba(*planes[k], iw, ih)); sources.append(k); k += 1
+        else:
+            nodes.append(label); sources.append(label)
+    want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+    got = orc.render_frame_yuv420(planes, layouts, sources, W, H)
+    for g, w_ in zip(got, want):
+        assert (g == w_).all()
