@@ -284,7 +284,16 @@ def main():
             inner_s = [ctx.surface(LAYER_W, LAYER_H) for _ in range(2)] if rank == 0 else None
             layer_s = [ctx.surface(LAYER_W, LAYER_H) for _ in range(2)] if rank == 0 else None
             label = layer_s[0] if rank == 0 else None
-        sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist)
+        # the exchange goes through the C ABI (smr_comm_create_rank + smr_gather_tiles: RCCL send / recv on the ctx stream);
+        # torch.distributed only carries the 128-byte communicator id and the barriers
+        comm = None
+        if world > 1:
+            uid = torch.zeros(hip.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.tensor(list(hip.Comm.unique_id()), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, src=0)
+            comm = hip.Comm.rank(ctx, world, rank, bytes(uid.cpu().tolist()))
+        sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist, comm=comm)
 
         def step_fn(step):
             t = tick[0]
@@ -547,7 +556,7 @@ def main():
                 result["exchange"] = {"bytes_per_frame": sum(per_peer.values()), "peers": len(per_peer), "max_bytes_per_link": worst,
                                       "link_GBps_achieved": round(worst * fps / 1e9, 3), "link_peak_GBps": 153.0,
                                       "frac_of_link_peak": round(worst * fps / 1e9 / 153.0, 5),
-                                      "note": "RCCL send/recv of dst-sized RGBA8 tiles, one xGMI link per peer, overlapped with the kernels of the neighbouring frames"}
+                                      "note": "smr_gather_tiles (C ABI): RCCL send/recv of dst-sized RGBA8 tiles on the ctx stream, one xGMI link per peer"}
 
     if rank == 0:
         print(json.dumps(result))

@@ -255,6 +255,30 @@ SMR_API int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const float c
 SMR_API int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, const float *crops, smr_surface *const *dst, uint32_t n,
                                       int *kinds);
 
+/* ---- multi-GPU exchange step (no counterpart in the reference, which owns one wgpu device) -------
+ * Inputs are sharded over GPUs (input i -> GPU i mod N); each GPU turns its inputs into dst-sized tiles with
+ * smr_ingest_resample_batch (the per-input independence of render_loop.rs:24-41, layout.rs:250-275), the tiles are gathered
+ * on the GPU that composes (smr_render_layouts with the tiles as SMR_SOURCE_OPAQUE_SURFACE sources).  Everything is
+ * stream-ordered on the contexts' streams: no call below blocks the host.
+ *   smr_comm_create_local  ONE process driving n devices (what smelter-core's renderer thread would hold,
+ *                          smelter-core/src/pipeline/instance.rs:435-503): peer copies over xGMI, one link per sender.
+ *   smr_comm_create_rank   one process per GPU: RCCL point-to-point.  Rank 0 makes an id with smr_comm_unique_id and hands the
+ *                          128 bytes to the others by whatever means the host has.
+ * smr_gather_tiles: tile i was produced on rank owner[i] in src[i]; afterwards dst[i] on `root` holds it (tiles the root owns
+ * are skipped).  Local comm: one call moves everything.  Rank comm: every rank makes the same call; src[i] is read on its
+ * owner only, dst[i] written on the root only (other entries may be NULL there). */
+typedef struct smr_comm smr_comm;
+#define SMR_COMM_ID_BYTES 128
+SMR_API int smr_comm_create_local(smr_ctx *const *ctxs, uint32_t n, smr_comm **out);
+SMR_API int smr_comm_unique_id(uint8_t id[SMR_COMM_ID_BYTES]);
+SMR_API int smr_comm_create_rank(smr_ctx *ctx, uint32_t world, uint32_t rank, const uint8_t id[SMR_COMM_ID_BYTES], smr_comm **out);
+SMR_API void smr_comm_destroy(smr_comm *comm);
+SMR_API uint32_t smr_comm_world(const smr_comm *comm);
+SMR_API uint32_t smr_comm_rank(const smr_comm *comm);
+SMR_API const char *smr_comm_last_error(const smr_comm *comm);
+SMR_API int smr_gather_tiles(smr_comm *comm, uint32_t root, const uint32_t *owner, const smr_surface *const *src, smr_surface *const *dst,
+                             uint32_t n);
+
 /* ---- a12: text node blit (transformations/text_renderer.rs:72-167) ----------------- */
 SMR_API int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const smr_glyph *glyphs, uint32_t n,
                             const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);

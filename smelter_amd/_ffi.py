@@ -40,6 +40,8 @@ EXPORTS = [
     "smr_renderer_unregister_input", "smr_renderer_register_image", "smr_renderer_register_shader", "smr_renderer_update_scene",
     "smr_renderer_unregister_output", "smr_renderer_node_count", "smr_renderer_node_info", "smr_renderer_set_text",
     "smr_renderer_render", "smr_renderer_add_lane", "smr_renderer_sync",
+    "smr_comm_create_local", "smr_comm_unique_id", "smr_comm_create_rank", "smr_comm_destroy", "smr_comm_world", "smr_comm_rank",
+    "smr_comm_last_error", "smr_gather_tiles",
     "smr_abi_version", "smr_sizeof_layout",
 ]
 NO_RESOLUTION = 0xFFFFFFFF

@@ -390,14 +390,38 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
     Output &o = r->outputs[output_id];
     for (auto &kv : r->images) o.scene.register_image(kv.first, (float)kv.second.w, (float)kv.second.h);
     std::string err;
+    {
+        // Shader ids are resolved while the new scene is built (ShaderComponent::stateful_component, shader_component.rs:44-52):
+        // an unknown id is SceneError::ShaderNotFound and the previous scene stays.  So: convert the definition without
+        // touching the active scene (Scene::parse), look the ids up, and only then update.
+        std::string converted;
+        if (!o.scene.parse(scene_json, converted, err)) {
+            if (o.w == 0) r->outputs.erase(output_id);  // a failed first update leaves no output behind
+            return fail(r, -1, err);
+        }
+        Json tree;
+        JsonParser jp(converted);
+        std::string missing;
+        if (jp.parse(tree, err)) {
+            std::vector<const Json *> stack{&tree};
+            while (!stack.empty() && missing.empty()) {
+                const Json *j = stack.back();
+                stack.pop_back();
+                for (const Json &a : j->arr) stack.push_back(&a);
+                for (const auto &kv : j->obj) stack.push_back(&kv.second);
+                const Json *type = j->get("type"), *sid = j->get("shader_id");
+                if (type && sid && type->str == "Shader" && !r->shaders.count(sid->str)) missing = sid->str;
+            }
+        }
+        if (!missing.empty()) {
+            if (o.w == 0) r->outputs.erase(output_id);
+            return fail(r, -1, "Shader \"" + missing + "\" does not exist. You have to register it first before using it in the scene definition.");
+        }
+    }
     if (!o.scene.update(scene_json, width, height, err)) {
         if (o.w == 0) r->outputs.erase(output_id);  // a failed first update leaves no output behind
         return fail(r, -1, err);
     }
-    // shader ids are resolved at update time like ShaderComponent::stateful_component does
-    for (const GraphNode &g : o.scene.nodes())
-        if (g.kind == Kind::Shader && !r->shaders.count(g.component->ref_id))
-            r->err = "Shader \"" + g.component->ref_id + "\" does not exist. You have to register it first before using it in the scene definition.";
     // frames in flight read the surfaces dropped below
     sync_lanes(r);
     if (o.w != width || o.h != height || o.format != output_format)

@@ -186,6 +186,7 @@ u32 host_unorm8(float x) {
 extern "C" {
 
 int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
+    SMR_ENTER(ctx);
     if (!ctx || !in || !node) return SMR_ERR_INVALID;
     if (node->fmt != SMR_PX_RGBA8 || node->w != in->width || node->h != in->height)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
@@ -234,6 +235,7 @@ int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
 }
 
 static int premult_common(smr_ctx *ctx, const smr_surface *src, smr_surface *dst, int mode) {
+    SMR_ENTER(ctx);
     if (!ctx || !src || !dst) return SMR_ERR_INVALID;
     if (src->fmt != SMR_PX_RGBA8 || dst->fmt != SMR_PX_RGBA8 || src->w != dst->w || src->h != dst->h)
         return smr_fail(ctx, SMR_ERR_INVALID, "premultiply: surfaces must be RGBA8 of equal size");
@@ -248,6 +250,7 @@ int smr_add_premultiplied_alpha(smr_ctx *ctx, const smr_surface *src, smr_surfac
 int smr_remove_premultiplied_alpha(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) { return premult_common(ctx, src, dst, 1); }
 
 int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *out) {
+    SMR_ENTER(ctx);
     if (!ctx || !node || !out) return SMR_ERR_INVALID;
     if (node->fmt != SMR_PX_RGBA8 || node->w != out->width || node->h != out->height)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: node must be RGBA8 %ux%u", out->width, out->height);
@@ -281,6 +284,7 @@ int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *ou
 }
 
 int smr_frame_fill_black(smr_ctx *ctx, const smr_frame *out) {
+    SMR_ENTER(ctx);
     if (!ctx || !out || !out->planes[0]) return SMR_ERR_INVALID;
     // RGBColor::BLACK.to_yuv(), smelter-render/src/scene/types.rs:28-41
     const float y = (0.0f * 0.85882354f) + (16.0f / 255.0f);

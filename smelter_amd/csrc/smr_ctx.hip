@@ -258,18 +258,21 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
 const char *smr_last_error(const smr_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
 int smr_sync(smr_ctx *ctx) {
+    SMR_ENTER(ctx);
     if (!ctx) return SMR_ERR_INVALID;
     SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SMR_OK;
 }
 
 int smr_timer_start(smr_ctx *ctx) {
+    SMR_ENTER(ctx);
     if (!ctx) return SMR_ERR_INVALID;
     SMR_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     return SMR_OK;
 }
 
 int smr_timer_stop(smr_ctx *ctx, float *ms) {
+    SMR_ENTER(ctx);
     if (!ctx || !ms) return SMR_ERR_INVALID;
     SMR_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     SMR_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
@@ -278,6 +281,7 @@ int smr_timer_stop(smr_ctx *ctx, float *ms) {
 }
 
 int smr_profile_enable(smr_ctx *ctx, int enable) {
+    SMR_ENTER(ctx);
     if (!ctx) return SMR_ERR_INVALID;
     if (!enable) {
         SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -288,6 +292,7 @@ int smr_profile_enable(smr_ctx *ctx, int enable) {
 }
 
 int smr_profile_read(smr_ctx *ctx, int stage, float *total_ms, uint32_t *launches) {
+    SMR_ENTER(ctx);
     if (!ctx || stage < 0 || stage >= SMR_NUM_STAGES) return SMR_ERR_INVALID;
     SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain_profile(ctx);
@@ -297,6 +302,7 @@ int smr_profile_read(smr_ctx *ctx, int stage, float *total_ms, uint32_t *launche
 }
 
 int smr_profile_reset(smr_ctx *ctx) {
+    SMR_ENTER(ctx);
     if (!ctx) return SMR_ERR_INVALID;
     SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     drain_profile(ctx);
@@ -339,6 +345,7 @@ static int surface_create_with(smr_ctx *ctx, u32 w, u32 h, u32 format, size_t he
 
 int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
                      smr_surface **out) {
+    SMR_ENTER(ctx);
     if (!ctx || !out || !dptr) return SMR_ERR_INVALID;
     u32 bpp = bytes_per_px(format);
     if (!bpp || w == 0 || h == 0 || pitch < (size_t)w * bpp || (pitch % 4) != 0 || ((uintptr_t)dptr % 16) != 0)
@@ -379,6 +386,7 @@ int smr_surface_info_get(const smr_surface *s, smr_surface_info *out) {
 }
 
 int smr_surface_upload(smr_ctx *ctx, smr_surface *s, const void *host, size_t host_pitch) {
+    SMR_ENTER(ctx);
     if (!ctx || !s || !host) return SMR_ERR_INVALID;
     size_t row = (size_t)s->w * bytes_per_px(s->fmt);
     if (host_pitch == 0) host_pitch = row;
@@ -390,6 +398,7 @@ int smr_surface_upload(smr_ctx *ctx, smr_surface *s, const void *host, size_t ho
 }
 
 int smr_surface_download(smr_ctx *ctx, const smr_surface *s, void *host, size_t host_pitch) {
+    SMR_ENTER(ctx);
     if (!ctx || !s || !host) return SMR_ERR_INVALID;
     size_t row = (size_t)s->w * bytes_per_px(s->fmt);
     if (host_pitch == 0) host_pitch = row;
@@ -400,6 +409,7 @@ int smr_surface_download(smr_ctx *ctx, const smr_surface *s, void *host, size_t 
 }
 
 int smr_surface_clear(smr_ctx *ctx, smr_surface *s) {
+    SMR_ENTER(ctx);
     if (!ctx || !s) return SMR_ERR_INVALID;
     SMR_HIP(ctx, hipMemsetAsync(s->ptr, 0, s->pitch * s->h, ctx->stream));
     return SMR_OK;
@@ -432,6 +442,7 @@ static int plane_geometry(u32 format, u32 w, u32 h, u32 pw[3], u32 ph[3], u32 pf
 }
 
 int smr_frame_create(smr_ctx *ctx, uint32_t format, uint32_t w, uint32_t h, smr_frame *out) {
+    SMR_ENTER(ctx);
     if (!ctx || !out) return SMR_ERR_INVALID;
     memset(out, 0, sizeof(*out));
     u32 pw[3], ph[3], pf[3];
@@ -460,6 +471,7 @@ void smr_frame_destroy(smr_ctx *ctx, smr_frame *f) {
 }
 
 int smr_frame_upload(smr_ctx *ctx, const smr_frame *f, const void *const host_planes[3]) {
+    SMR_ENTER(ctx);
     if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
     u32 pw[3], ph[3], pf[3];
     int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);
@@ -478,6 +490,7 @@ int smr_frame_upload(smr_ctx *ctx, const smr_frame *f, const void *const host_pl
 // can place decoder output / encoder input in buffers from smr_host_alloc.  The copies are enqueued on the ctx stream and
 // return at once; the host buffers must stay untouched until smr_sync (or a later blocking call) has returned.
 int smr_host_alloc(smr_ctx *ctx, size_t bytes, void **out) {
+    SMR_ENTER(ctx);
     if (!ctx || !out || !bytes) return SMR_ERR_INVALID;
     *out = nullptr;
     if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) return smr_fail(ctx, SMR_ERR_OOM, "smr_host_alloc: %zu B of pinned memory", bytes);
@@ -488,6 +501,7 @@ void smr_host_free(smr_ctx *ctx, void *p) {
     if (p) (void)hipHostFree(p);
 }
 static int frame_copy_async(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3], bool to_device, const char *what) {
+    SMR_ENTER(ctx);
     if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
     u32 pw[3], ph[3], pf[3];
     int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);
@@ -509,6 +523,7 @@ int smr_frame_download_async(smr_ctx *ctx, const smr_frame *f, void *const host_
 }
 
 int smr_frame_download(smr_ctx *ctx, const smr_frame *f, void *const host_planes[3]) {
+    SMR_ENTER(ctx);
     if (!ctx || !f || !host_planes) return SMR_ERR_INVALID;
     u32 pw[3], ph[3], pf[3];
     int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);

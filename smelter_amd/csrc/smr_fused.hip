@@ -51,6 +51,7 @@ constexpr size_t SLOT_TILE0 = 2048;   // + layout index
 extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint32_t n, const smr_source *sources,
                                   uint32_t n_sources, uint32_t out_w, uint32_t out_h, const smr_frame *out,
                                   smr_surface *out_rgba) {
+    SMR_ENTER(ctx);
     if (!ctx || (n && !layouts) || (n_sources && !sources)) return SMR_ERR_INVALID;
     if (!out && !out_rgba) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: no output given");
     if (out_w == 0 || out_h == 0) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: empty output");
@@ -217,6 +218,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
 // plan allows it (wave A with a single job), otherwise convert + general resample.  This is the
 // per-shard step of the multi-GPU path: each GPU turns its inputs into dst-sized tiles.
 extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const float crop[4], smr_surface *dst) {
+    SMR_ENTER(ctx);
     if (!ctx || !in || !crop || !dst) return SMR_ERR_INVALID;
     if (dst->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample: dst must be RGBA8");
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample: CpuOptimized mode has no resampler");
@@ -253,6 +255,7 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
 // the blocks together), the others go one by one.  kinds[i] receives the plan kind of input i (0 = direct: dst untouched).
 extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, const float *crops, smr_surface *const *dst, uint32_t n,
                                          int *kinds) {
+    SMR_ENTER(ctx);
     if (!ctx || (n && (!in || !crops || !dst))) return SMR_ERR_INVALID;
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
     std::vector<IngestJob> jobs;

@@ -144,6 +144,16 @@ struct StageScope {
     ~StageScope();
 };
 
+// Every public entry point that touches the device binds the context's device first: a ctx may be used from any thread, and the
+// calling thread's current HIP device is whatever that thread last set (smr.h: "each call does hipSetDevice").
+#define SMR_ENTER(ctx)                                                                   \
+    do {                                                                                 \
+        if ((ctx) != nullptr) {                                                          \
+            hipError_t e_dev__ = hipSetDevice((ctx)->device);                            \
+            if (e_dev__ != hipSuccess) return smr_check_hip((ctx), e_dev__, "hipSetDevice"); \
+        }                                                                                \
+    } while (0)
+
 #define SMR_HIP(ctx, call)                                                    \
     do {                                                                      \
         hipError_t e__ = (call);                                              \

@@ -224,6 +224,7 @@ int smr_pack_done(smr_ctx *ctx, PackedLayouts *p) {
 
 extern "C" int smr_apply_layouts(smr_ctx *ctx, smr_surface *target, const smr_layout *layouts, uint32_t n,
                                  const smr_surface *const *sources, uint32_t n_sources) {
+    SMR_ENTER(ctx);
     if (!ctx || !target || (n && !layouts)) return SMR_ERR_INVALID;
     if (target->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_apply_layouts: target must be RGBA8");
     std::vector<SurfView> views(n_sources ? n_sources : 1);

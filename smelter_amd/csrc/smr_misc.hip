@@ -81,6 +81,7 @@ extern "C" {
 
 int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const smr_glyph *glyphs, uint32_t n,
                     const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h) {
+    SMR_ENTER(ctx);
     if (!ctx || !target || !bg || (n && (!glyphs || !atlas_host))) return SMR_ERR_INVALID;
     if (target->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_blit_glyphs: target must be RGBA8");
     for (u32 i = 0; i < n; i++) {
@@ -120,6 +121,7 @@ int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const 
 
 int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t params_size, const smr_surface *const *src,
                        uint32_t n_src, smr_surface *dst, float time_s) {
+    SMR_ENTER(ctx);
     (void)time_s;
     if (!ctx || !dst) return SMR_ERR_INVALID;
     switch (id) {

@@ -266,6 +266,7 @@ int smr_resample_plan_make(uint32_t src_w, uint32_t src_h, const float crop[4], 
 
 int smr_resample_pass(smr_ctx *ctx, const smr_surface *src, int axis, float scale, float offset, int perp_offset,
                       smr_surface *dst) {
+    SMR_ENTER(ctx);
     if (!ctx || !src || !dst) return SMR_ERR_INVALID;
     if ((src->fmt != SMR_PX_RGBA8 && src->fmt != SMR_PX_RGBA16F) || (dst->fmt != SMR_PX_RGBA8 && dst->fmt != SMR_PX_RGBA16F))
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_resample_pass: surfaces must be RGBA8 or RGBA16F");
@@ -277,6 +278,7 @@ int smr_resample_pass(smr_ctx *ctx, const smr_surface *src, int axis, float scal
 }
 
 int smr_downsample(smr_ctx *ctx, const smr_surface *src, uint32_t fx, uint32_t fy, smr_surface *dst) {
+    SMR_ENTER(ctx);
     if (!ctx || !src || !dst || fx == 0 || fy == 0) return SMR_ERR_INVALID;
     if (dst->fmt != SMR_PX_RGBA16F || (src->fmt != SMR_PX_RGBA8 && src->fmt != SMR_PX_RGBA16F))
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_downsample: src RGBA8/RGBA16F, dst RGBA16F");
@@ -288,6 +290,7 @@ int smr_downsample(smr_ctx *ctx, const smr_surface *src, uint32_t fx, uint32_t f
 }
 
 int smr_resample(smr_ctx *ctx, const smr_surface *src, const float crop[4], smr_surface *dst) {
+    SMR_ENTER(ctx);
     if (!ctx || !src || !crop || !dst) return SMR_ERR_INVALID;
     if (src->fmt != SMR_PX_RGBA8 || dst->fmt != SMR_PX_RGBA8)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_resample: node surfaces must be RGBA8");
@@ -328,6 +331,7 @@ int smr_resample(smr_ctx *ctx, const smr_surface *src, const float crop[4], smr_
 }
 
 int smr_rescale_bilinear(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) {
+    SMR_ENTER(ctx);
     if (!ctx || !src || !dst) return SMR_ERR_INVALID;
     if (src->fmt != SMR_PX_RGBA8 || dst->fmt != SMR_PX_RGBA8)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_rescale_bilinear: surfaces must be RGBA8");

@@ -84,8 +84,12 @@ class ShardedCompositor:
     _FRAME_STATE = ("root_layouts", "root_packed", "label", "slot_of_input", "input_of_slot")  # what a frame in flight keeps
 
     def __init__(self, ctx, hip, plan: ShardPlan, rank: int, layouts, res, input_source_slot: Sequence[int], label_surface,
-                 torch, dist, ingest_fn: Optional[Callable] = None, compose_fn: Optional[Callable] = None, device=None):
+                 torch, dist, ingest_fn: Optional[Callable] = None, compose_fn: Optional[Callable] = None, device=None, comm=None):
+        """comm: a hip.Comm (smr_comm_create_rank) — the exchange then goes through the C ABI (smr_gather_tiles: RCCL send / recv
+        enqueued on the ctx stream, no torch.distributed in the data path); None: torch.distributed point-to-point (`dist`),
+        which is also what the CPU tests run over gloo."""
         self.ctx, self.hip, self.plan, self.rank, self.dist, self.torch = ctx, hip, plan, rank, dist, torch
+        self.comm = comm
         self.layouts = list(layouts)
         self.res = list(res)
         self.slot_of_input = list(input_source_slot)
@@ -180,11 +184,23 @@ class ShardedCompositor:
             for k in mine:
                 self.ingest_fn(k, frames_row[k], self.tiles[k])
 
+    def _gather_c_abi(self, par: int):
+        """smr_gather_tiles on the ctx stream: tile k from rank owner(k) into the root's surface of the same set."""
+        ks = sorted(self.tile_geom)
+        owners = [self.plan.owner(k) for k in ks]
+        surf = self.surface_sets[par]
+        src = [surf.get(k) if self.plan.owner(k) == self.rank else None for k in ks]
+        dst = [surf.get(k) if self.rank == self.plan.root else None for k in ks]
+        self.comm.gather(self.plan.root, owners, src, dst)
+
     def step(self, frames_row: Dict[int, object], out):
         """One frame, start to finish: resample the local inputs, exchange, compose on the root."""
         self.flush()
         self._ingest_local(frames_row)
-        gather_tiles(self.dist, self.plan, self.rank, self.tiles)
+        if self.comm is not None:
+            self._gather_c_abi(0 if self.tiles is self.tile_sets[0] else 1)
+        else:
+            gather_tiles(self.dist, self.plan, self.rank, self.tiles)
         if self.rank == self.plan.root:
             self.compose_fn(self.tiles, out)
 
@@ -195,6 +211,14 @@ class ShardedCompositor:
         par = self.frame_no & 1
         self.tiles, self.tile_surfaces = self.tile_sets[par], self.surface_sets[par]
         self._ingest_local(frames_row)
+        if self.comm is not None:
+            # stream order on the root: ingest(k) . compose(k-1) . receive(k) — the frame composed now arrived during the previous
+            # call; the senders' ingest(k) runs while the root composes
+            prev, self.pending = self.pending, ([], par, out, {name: getattr(self, name) for name in self._FRAME_STATE})
+            self.frame_no += 1
+            self._finish(prev)
+            self._gather_c_abi(par)
+            return
         works = post_gather(self.dist, self.plan, self.rank, self.tiles)
         prev, self.pending = self.pending, (works, par, out, {name: getattr(self, name) for name in self._FRAME_STATE})
         self.frame_no += 1

@@ -138,6 +138,64 @@ def pack_layouts(layouts) -> "C.Array":
 
 
 INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16 = 0, 1, 2
+COMM_ID_BYTES = 128
+
+
+class Comm:
+    """smr_comm: the tile gather of the multi-GPU path behind the C ABI (include/smr.h).
+
+    Comm.local([ctx0, ctx1, ...])        one process, one context per device (peer copies)
+    Comm.rank(ctx, world, rank, id)      one process per GPU (RCCL); id = Comm.unique_id() made on one rank and distributed by the host
+    gather(root, owners, src, dst)       stream-ordered: dst[i] on the root holds tile i (produced in src[i] on rank owners[i])"""
+
+    def __init__(self, lib, handle, ctxs):
+        self.lib, self.handle, self.ctxs = lib, handle, ctxs
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = _ffi.load()
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        if lib.smr_comm_unique_id(buf) != 0:
+            raise SmrError(-3, "smr_comm_unique_id failed (is librccl.so present?)")
+        return bytes(buf)
+
+    @staticmethod
+    def local(ctxs: Sequence["Context"]) -> "Comm":
+        lib = _ffi.load()
+        arr = (C.c_void_p * len(ctxs))(*[c.handle.value for c in ctxs])
+        h = C.c_void_p()
+        rc = lib.smr_comm_create_local(arr, len(ctxs), C.byref(h))
+        if rc != 0:
+            raise SmrError(rc, lib.smr_last_error(ctxs[0].handle).decode())
+        return Comm(lib, h, list(ctxs))
+
+    @staticmethod
+    def rank(ctx: "Context", world: int, rank: int, uid: bytes) -> "Comm":
+        lib = _ffi.load()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        rc = lib.smr_comm_create_rank(ctx.handle, world, rank, buf, C.byref(h))
+        if rc != 0:
+            raise SmrError(rc, lib.smr_last_error(ctx.handle).decode())
+        return Comm(lib, h, [ctx])
+
+    @property
+    def world(self) -> int:
+        return self.lib.smr_comm_world(self.handle)
+
+    def gather(self, root: int, owners: Sequence[int], src: Sequence[Optional["Surface"]], dst: Sequence[Optional["Surface"]]):
+        n = len(owners)
+        own = (C.c_uint32 * max(n, 1))(*owners)
+        s = (C.c_void_p * max(n, 1))(*[(x.handle.value if x is not None else None) for x in src])
+        d = (C.c_void_p * max(n, 1))(*[(x.handle.value if x is not None else None) for x in dst])
+        rc = self.lib.smr_gather_tiles(self.handle, root, own, s, d, n)
+        if rc != 0:
+            raise SmrError(rc, self.lib.smr_comm_last_error(self.handle).decode())
+
+    def close(self):
+        if self.handle:
+            self.lib.smr_comm_destroy(self.handle)
+            self.handle = None
 OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH = 0, 1
 
 

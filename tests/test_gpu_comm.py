@@ -1,0 +1,121 @@
+"""The multi-GPU exchange step behind the C ABI (smr_comm_*, smr_gather_tiles): inputs sharded over contexts, tiles gathered on
+the root, root composes — bit-identical to rendering everything on one context.  A one-GPU box covers the code paths with two
+contexts on the same device (local comm) and a one-rank RCCL communicator; the two-device test runs where two GPUs are visible."""
+import numpy as np
+import pytest
+
+from tests import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from smelter_amd import hip as h
+    return h
+
+
+def _scene(ctx, hip, iw, ih, W, H, n):
+    layouts, res = scenes.cfg2_scene(iw, ih, W, H, n)
+    planes = [scenes.test_input(i, iw, ih, noise_seed=300 + i) for i in range(n)]
+    return layouts, res, planes
+
+
+def _sharded_render(hip, ctxs, layouts, res, planes, iw, ih, W, H, comm, root=0):
+    """input i -> ctxs[i % len(ctxs)]: smr_ingest_resample_batch per shard, smr_gather_tiles, smr_render_layouts on the root."""
+    from dataclasses import replace
+    from smelter_amd.dist import rust_round
+    n, world = len(planes), len(ctxs)
+    geom = {}
+    for L in layouts:
+        if L.type == 0:
+            geom[L.source_index] = (max(rust_round(L.width), 1), max(rust_round(L.height), 1), tuple(L.crop))
+    src, dst = [None] * n, [None] * n
+    for r, c in enumerate(ctxs):
+        mine = [i for i in range(n) if i % world == r]
+        frames = [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[i])) for i in mine]
+        tiles = [c.surface(geom[i][0], geom[i][1]) for i in mine]
+        kinds = c.ingest_resample_batch(frames, [geom[i][2] for i in mine], tiles)
+        assert all(k > 0 for k in kinds)
+        for i, t in zip(mine, tiles):
+            src[i] = t
+    for i in range(n):
+        dst[i] = src[i] if i % world == root else ctxs[root].surface(geom[i][0], geom[i][1])
+    comm.gather(root, [i % world for i in range(n)], src, dst)
+    for t in dst:
+        t.opaque = True
+    root_layouts = [replace(L, crop=(0.0, 0.0, float(geom[L.source_index][0]), float(geom[L.source_index][1]))) if L.type == 0 else L for L in layouts]
+    out = ctxs[root].frame(hip.FRAME_PLANAR_YUV420, W, H)
+    ctxs[root].render_layouts(root_layouts, dst, W, H, out=out)
+    for c in ctxs:
+        c.sync()
+    return out.download()
+
+
+def _single_render(hip, ctx, layouts, planes, iw, ih, W, H):
+    frames = [ctx.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes]
+    out = ctx.frame(hip.FRAME_PLANAR_YUV420, W, H)
+    ctx.render_layouts(layouts, frames, W, H, out=out)
+    return out.download()
+
+
+def test_local_comm_two_contexts_on_one_device(hip):
+    iw, ih, W, H, n = 320, 180, 480, 272, 4
+    a, b = hip.Context(0), hip.Context(0)
+    layouts, res, planes = _scene(a, hip, iw, ih, W, H, n)
+    comm = hip.Comm.local([a, b])
+    assert comm.world == 2
+    want = _single_render(hip, a, layouts, planes, iw, ih, W, H)
+    for root in (0, 1):
+        got = _sharded_render(hip, [a, b], layouts, res, planes, iw, ih, W, H, comm, root=root)
+        for g, w_ in zip(got, want):
+            assert (g == w_).all(), root
+    comm.close()
+    b.close()
+    a.close()
+
+
+def test_local_comm_two_devices(hip):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one process driving both: what a single renderer thread would hold)")
+    iw, ih, W, H, n = 320, 180, 480, 272, 4
+    a, b = hip.Context(0), hip.Context(1)
+    layouts, res, planes = _scene(a, hip, iw, ih, W, H, n)
+    comm = hip.Comm.local([a, b])
+    want = _single_render(hip, a, layouts, planes, iw, ih, W, H)
+    got = _sharded_render(hip, [a, b], layouts, res, planes, iw, ih, W, H, comm)
+    for g, w_ in zip(got, want):
+        assert (g == w_).all()
+    comm.close()
+    b.close()
+    a.close()
+
+
+def test_rank_comm_of_one_and_the_sharded_driver_over_it(hip):
+    """smr_comm_create_rank with world 1 (librccl is opened, a communicator is initialised, the gather has nothing to move), under
+    the same ShardedCompositor bench.py --gpus N drives."""
+    import torch
+    from smelter_amd import dist as smr_dist
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    c = hip.Context(0, stream=side.cuda_stream)
+    comm = hip.Comm.rank(c, 1, 0, hip.Comm.unique_id())
+    assert comm.world == 1
+    iw, ih, W, H, n = 320, 180, 480, 272, 4
+    layouts, res, planes = _scene(c, hip, iw, ih, W, H, n)
+    want = _single_render(hip, c, layouts, planes, iw, ih, W, H)
+    frames = {i: c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[i])) for i in range(n)}
+    plan = smr_dist.ShardPlan(n_inputs=n, world=1)
+    sharded = smr_dist.ShardedCompositor(c, hip, plan, 0, layouts, res, list(range(n)), None, torch, None, comm=comm)
+    outs = [c.frame(hip.FRAME_PLANAR_YUV420, W, H) for _ in range(2)]
+    sharded.step(frames, outs[0])
+    sharded.step_pipelined(frames, outs[1])
+    sharded.flush()
+    c.sync()
+    for o in outs:
+        for g, w_ in zip(o.download(), want):
+            assert (g == w_).all()
+    comm.close()
+    c.close()
+    torch.cuda.set_stream(torch.cuda.default_stream())

@@ -359,6 +359,30 @@ def test_scene_errors_surface_through_the_renderer(renderer):
     assert "does not exist" in str(e.value)
 
 
+def test_unknown_shader_is_rejected_and_the_previous_scene_keeps_rendering(ctx, hip, renderer):
+    """ShaderComponent::stateful_component (shader_component.rs:44-52): an unregistered shader_id is SceneError::ShaderNotFound at
+    update time — update_scene fails, the active scene and its surfaces are untouched, later frames still come out."""
+    from smelter_amd.scene import SceneError
+    iw, ih, W, H = 160, 90, 320, 180
+    _, frames = _frames(ctx, hip, 1, iw, ih)
+    renderer.register_input("in0")
+    good = {"type": "view", "background_color": "#203040FF", "children": [{"type": "rescaler", "child": {"type": "input_stream", "input_id": "in0"}}]}
+    renderer.update_scene("out", W, H, good)
+    before = renderer.render(0.0, frames)["out"].download()
+    bad = {"type": "view", "children": [{"type": "shader", "shader_id": "nope", "resolution": {"width": 64, "height": 64},
+                                         "children": [{"type": "input_stream", "input_id": "in0"}]}]}
+    with pytest.raises(SceneError) as e:
+        renderer.update_scene("out", W, H, bad)
+    assert 'Shader "nope" does not exist' in str(e.value)
+    after = renderer.render(1.0 / 60, frames)["out"].download()
+    for a, b in zip(before, after):
+        assert (a == b).all()
+    # a first update that fails leaves no output behind
+    with pytest.raises(SceneError):
+        renderer.update_scene("other", W, H, bad)
+    assert "other" not in renderer.render(2.0 / 60, frames)
+
+
 def test_c_example_runs(tmp_path):
     """examples/render_scene.c: the renderer driven from plain C."""
     import subprocess
