@@ -170,3 +170,31 @@ def test_c_frame_loop_equals_the_pass_by_pass_pipeline():
     got = orc.render_frame_yuv420(planes, layouts, sources, W, H)
     for g, w_ in zip(got, want):
         assert (g == w_).all()
+
+
+@pytest.mark.parametrize("sw,dw", [(192, 128), (180, 80), (100, 100 * 3 // 7), (64, 160)])
+def test_lanczos_pass_agrees_with_pillow_on_linear_planes(sw, dw):
+    """A third party's Lanczos3 (Pillow's Image.resize(..., LANCZOS) on mode-F planes: same kernel, a = 3, stretched by the scale
+    factor when shrinking, weights normalised) against the oracle's restatement of resample.wgsl:31-87 — the part of the oracle
+    no reference-held vector pins.  One axis at a time (the oracle rounds its intermediate to f16 as the reference does, Pillow
+    keeps f32), interior pixels only (edges: clamp-to-edge vs Pillow's truncated window).  Tolerance: the f16 rounding of the
+    oracle's input and output (2^-10 relative) plus 1e-4 absolute."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(sw * 1000 + dw)
+    sh = 24
+    plane = (0.5 + 0.35 * np.sin(np.arange(sw) / 7.0)[None, :] * np.cos(np.arange(sh) / 5.0)[:, None] + rng.uniform(-0.12, 0.12, (sh, sw))).astype(np.float16)
+    src = np.repeat(plane[:, :, None], 4, axis=2).view(np.uint16)  # RGBA16F, every channel the same plane
+    scale = sw / dw
+    got = orc.resample_pass(src, orc.PX_RGBA16F, 0, scale, 0.0, 0, orc.PX_RGBA16F, dw, sh).view(np.float16)[:, :, 0].astype(np.float64)
+    ref = np.asarray(Image.fromarray(plane.astype(np.float32), mode="F").resize((dw, sh), Image.LANCZOS, box=(0, 0, sw, sh)), dtype=np.float64)
+    # Pillow resizes both axes even when one is unchanged (identity there: size equal) — compare the interior columns
+    m = int(np.ceil(3 * max(scale, 1.0) / scale)) + 1
+    d = np.abs(got[:, m:-m] - ref[:, m:-m])
+    tol = 2.0 ** -10 * np.abs(ref[:, m:-m]) + 1e-4
+    assert (d <= tol).all(), f"max excess {(d - tol).max():.2e}"
+    # vertical pass: the same through a transposed plane
+    src_t = np.ascontiguousarray(np.repeat(plane.T[:, :, None], 4, axis=2)).view(np.uint16)
+    got_v = orc.resample_pass(src_t, orc.PX_RGBA16F, 1, scale, 0.0, 0, orc.PX_RGBA16F, sh, dw).view(np.float16)[:, :, 0].astype(np.float64)
+    d = np.abs(got_v[m:-m, :] - ref.T[m:-m, :])
+    assert (d <= 2.0 ** -10 * np.abs(ref.T[m:-m, :]) + 1e-4).all()
