@@ -190,7 +190,7 @@ int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
     if (!ctx || !in || !node) return SMR_ERR_INVALID;
     if (node->fmt != SMR_PX_RGBA8 || node->w != in->width || node->h != in->height)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
-    if (!in->planes[0]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: frame has no planes");
+    if (int rc = smr_validate_frame(ctx, in, "smr_frame_to_rgba")) return rc;
     StageScope scope(ctx, SMR_STAGE_INGEST);
     SurfView dst = view_of(node);
     const int w = (int)in->width, h = (int)in->height;
@@ -254,6 +254,7 @@ int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *ou
     if (!ctx || !node || !out) return SMR_ERR_INVALID;
     if (node->fmt != SMR_PX_RGBA8 || node->w != out->width || node->h != out->height)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: node must be RGBA8 %ux%u", out->width, out->height);
+    if (int rc = smr_validate_frame(ctx, out, "smr_rgba_to_frame")) return rc;
     StageScope scope(ctx, SMR_STAGE_OUTPUT);
     const int w = (int)out->width, h = (int)out->height;
     SurfView src = view_of(node);
@@ -285,6 +286,8 @@ int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *ou
 
 int smr_frame_fill_black(smr_ctx *ctx, const smr_frame *out) {
     SMR_ENTER(ctx);
+    if (ctx && out)
+        if (int rc = smr_validate_frame(ctx, out, "smr_frame_fill_black")) return rc;
     if (!ctx || !out || !out->planes[0]) return SMR_ERR_INVALID;
     // RGBColor::BLACK.to_yuv(), smelter-render/src/scene/types.rs:28-41
     const float y = (0.0f * 0.85882354f) + (16.0f / 255.0f);

@@ -441,6 +441,25 @@ static int plane_geometry(u32 format, u32 w, u32 h, u32 pw[3], u32 ph[3], u32 pf
     }
 }
 
+// A caller-filled smr_frame (planes may come from smr_surface_wrap): every plane must have the geometry and pixel format its
+// FrameData variant implies, or the kernels would read / write outside it.  (1x1 placeholders stand for empty chroma planes.)
+int smr_validate_frame(smr_ctx *ctx, const smr_frame *f, const char *what) {
+    if (!f) return smr_fail(ctx, SMR_ERR_INVALID, "%s: null frame", what);
+    u32 pw[3], ph[3], pf[3];
+    const int n = plane_geometry(f->format, f->width, f->height, pw, ph, pf);
+    if (n == 0) return smr_fail(ctx, SMR_ERR_INVALID, "%s: unknown frame format %u", what, f->format);
+    if (f->width == 0 || f->height == 0) return smr_fail(ctx, SMR_ERR_INVALID, "%s: empty frame", what);
+    for (int i = 0; i < n; i++) {
+        const smr_surface *s = f->planes[i];
+        if (!s || !s->ptr) return smr_fail(ctx, SMR_ERR_INVALID, "%s: plane %d is missing", what, i);
+        const u32 w = pw[i] ? pw[i] : 1, h = ph[i] ? ph[i] : 1;
+        if (s->w != w || s->h != h || s->fmt != pf[i] || s->pitch < (size_t)w * bytes_per_px(pf[i]))
+            return smr_fail(ctx, SMR_ERR_INVALID, "%s: plane %d is %ux%u fmt %u pitch %zu, a %ux%u frame of format %u needs %ux%u fmt %u", what, i, s->w,
+                            s->h, s->fmt, s->pitch, f->width, f->height, f->format, w, h, pf[i]);
+    }
+    return SMR_OK;
+}
+
 int smr_frame_create(smr_ctx *ctx, uint32_t format, uint32_t w, uint32_t h, smr_frame *out) {
     SMR_ENTER(ctx);
     if (!ctx || !out) return SMR_ERR_INVALID;

@@ -59,6 +59,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: output frame is %ux%u, expected %ux%u", out->width, out->height, out_w, out_h);
     if (out_rgba && (out_rgba->fmt != SMR_PX_RGBA8 || out_rgba->w != out_w || out_rgba->h != out_h))
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: out_rgba must be RGBA8 %ux%u", out_w, out_h);
+    if (out)
+        if (int rc = smr_validate_frame(ctx, out, "smr_render_layouts (output)")) return rc;
     if (n > ctx->max_layouts) n = ctx->max_layouts;
     if (n_sources > 1024) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: too many sources");
     const bool fused = !fused_disabled(ctx);
@@ -78,6 +80,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             src_h[i] = (int)s.surface->h;
             node_ready[i] = 1;
         } else if (s.kind == SMR_SOURCE_FRAME && s.frame && s.frame->planes[0]) {
+            if (int rc = smr_validate_frame(ctx, s.frame, "smr_render_layouts (source frame)")) return rc;
             kinds[i] = frame_is_opaque(s.frame->format) ? 2 : 1;  // view filled lazily by ensure_node
             src_w[i] = (int)s.frame->width;
             src_h[i] = (int)s.frame->height;
@@ -221,6 +224,7 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
     SMR_ENTER(ctx);
     if (!ctx || !in || !crop || !dst) return SMR_ERR_INVALID;
     if (dst->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample: dst must be RGBA8");
+    if (int rc = smr_validate_frame(ctx, in, "smr_ingest_resample")) return rc;
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample: CpuOptimized mode has no resampler");
     smr_resample_plan plan;
     int kind = smr_resample_plan_make(in->width, in->height, crop, dst->w, dst->h, &plan);
@@ -263,6 +267,7 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
     const uint64_t call = ++ctx->weight_call;
     for (uint32_t i = 0; i < n; i++) {
         if (!in[i] || !dst[i] || dst[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: bad input %u", i);
+        if (int rc = smr_validate_frame(ctx, in[i], "smr_ingest_resample_batch")) return rc;
         const float *crop = crops + 4 * i;
         smr_resample_plan plan;
         int kind = smr_resample_plan_make(in[i]->width, in[i]->height, crop, dst[i]->w, dst[i]->h, &plan);

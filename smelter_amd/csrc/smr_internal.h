@@ -134,6 +134,7 @@ smr_surface *smr_cached_surface(smr_ctx *ctx, size_t slot, u32 w, u32 h, u32 fmt
 int smr_fail(smr_ctx *ctx, int code, const char *fmt, ...);
 int smr_check_hip(smr_ctx *ctx, hipError_t e, const char *what);
 void *smr_scratch(smr_ctx *ctx, int slot, size_t bytes);  // nullptr on OOM (error set)
+extern "C" int smr_validate_frame(smr_ctx *ctx, const smr_frame *f, const char *what);  // plane geometry / formats against the frame's format
 
 // stage-timing helper: brackets kernel launches of one class with HIP events when profiling.
 struct StageScope {

@@ -90,6 +90,13 @@ class ShardedCompositor:
         which is also what the CPU tests run over gloo."""
         self.ctx, self.hip, self.plan, self.rank, self.dist, self.torch = ctx, hip, plan, rank, dist, torch
         self.comm = comm
+        if comm is None and dist is not None and ctx is not None and torch.cuda.is_available() and plan.world > 1:
+            # torch.distributed orders its send / recv against torch's CURRENT stream, the library enqueues on the ctx stream:
+            # unless they are the same stream a tile could be sent before the ingest kernel wrote it, or composed before it
+            # arrived.  (The C-ABI exchange, comm=..., runs on the ctx stream itself and has no such requirement.)
+            if getattr(ctx, "stream_handle", None) != torch.cuda.current_stream().cuda_stream:
+                raise ValueError("ShardedCompositor over torch.distributed needs the context on torch's current stream: create it with "
+                                 "hip.Context(device, stream=s.cuda_stream) under torch.cuda.stream(s) / torch.cuda.set_stream(s) — or pass comm=")
         self.layouts = list(layouts)
         self.res = list(res)
         self.slot_of_input = list(input_source_slot)

@@ -209,6 +209,7 @@ class Context:
         self.handle = h
         self.mode = mode
         self.device = device
+        self.stream_handle = stream  # the caller's hipStream_t, or None when the context created its own
         self._pinned = []
 
     # -- plumbing

@@ -383,6 +383,30 @@ def test_unknown_shader_is_rejected_and_the_previous_scene_keeps_rendering(ctx, 
     assert "other" not in renderer.render(2.0 / 60, frames)
 
 
+def test_frames_with_mismatched_planes_are_rejected(ctx, hip):
+    """smr_frame is a caller-filled struct (planes may be wrapped memory): a plane whose size or pixel format does not fit the
+    frame's format must be SMR_ERR_INVALID at the entry point, not an out-of-bounds access in a kernel."""
+    f = ctx.frame(hip.FRAME_PLANAR_YUV420, 64, 36)
+    small = ctx.surface(8, 8, hip.PX_R8)
+    node = ctx.surface(64, 36)
+    out = ctx.frame(hip.FRAME_PLANAR_YUV420, 64, 36)
+    keep = f.c.planes[1]
+    f.c.planes[1] = small.handle
+    try:
+        with pytest.raises(hip.SmrError) as e:
+            ctx.frame_to_rgba(f, node)
+        assert "plane 1" in str(e.value)
+        with pytest.raises(hip.SmrError):
+            ctx.ingest_resample(f, (0.0, 0.0, 64.0, 36.0), ctx.surface(32, 18))
+        with pytest.raises(hip.SmrError):
+            ctx.render_layouts([], [f], 64, 36, out=out)
+        with pytest.raises(hip.SmrError):
+            ctx.render_layouts([], [], 64, 36, out=f)
+    finally:
+        f.c.planes[1] = keep
+    ctx.frame_to_rgba(f, node)  # intact again
+
+
 def test_c_example_runs(tmp_path):
     """examples/render_scene.c: the renderer driven from plain C."""
     import subprocess
