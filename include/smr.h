@@ -284,7 +284,32 @@ SMR_API int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4]
                             const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
 
 /* ---- a13 stand-in: built-in "shader" kernels (user WGSL is out of scope) ------------ */
-typedef enum smr_builtin_shader_id { SMR_SHADER_GAUSSIAN_BLUR = 0 } smr_builtin_shader_id;
+/* Built-in kernels for ShaderNode::render (transformations/shader/node.rs:71-89, shader/pipeline.rs:81-141).  Arbitrary user
+ * WGSL needs a compiler this library does not carry; what ships are the shaders the reference keeps in its own tree,
+ * restated as HIP kernels with the node's semantics: the target is cleared to transparent, one full-target plane is drawn per
+ * source texture (plane_id 0..n-1; a single plane with plane_id -1 when there are none), premultiplied-alpha OVER, each plane
+ * stored to the RGBA8 target before the next is blended.  BaseShaderParameters {plane_id, time, output_resolution,
+ * texture_count} (shader/base_params.rs:7-12) are supplied by the library from time_s, dst and n_src.
+ *   GAUSSIAN_BLUR        params = smr_gaussian_blur_params                                     (no reference counterpart)
+ *   GRADIENT             integration-tests/src/render_tests/yuv_tests/gradient.wgsl
+ *   RED_BORDER           render_tests/shader/red_border.wgsl
+ *   CIRCLE_LAYOUT        render_tests/shader/circle_layout.wgsl; params = smr_circle_layout[n_src] (ShaderParam::to_bytes order)
+ *   FADE_TO_BALL         render_tests/shader/fade_to_ball.wgsl
+ *   LAYOUT_PLANES        render_tests/shader/layout_planes.wgsl
+ *   COLOR_BY_TEXTURE_COUNT  render_tests/shader/color_output_with_texture_count.wgsl
+ *   SILLY                integration-tests/examples/silly.wgsl */
+typedef enum smr_builtin_shader_id {
+    SMR_SHADER_GAUSSIAN_BLUR = 0,
+    SMR_SHADER_GRADIENT = 1,
+    SMR_SHADER_RED_BORDER = 2,
+    SMR_SHADER_CIRCLE_LAYOUT = 3,
+    SMR_SHADER_FADE_TO_BALL = 4,
+    SMR_SHADER_LAYOUT_PLANES = 5,
+    SMR_SHADER_COLOR_BY_TEXTURE_COUNT = 6,
+    SMR_SHADER_SILLY = 7
+} smr_builtin_shader_id;
+#define SMR_SHADER_MAX_SOURCES 16 /* binding_array<texture_2d<f32>, 16> */
+typedef struct smr_circle_layout { uint32_t left_px, top_px, width_px, height_px; float background_color[4]; } smr_circle_layout;
 typedef struct smr_gaussian_blur_params { float sigma; } smr_gaussian_blur_params;
 SMR_API int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t params_size,
                                const smr_surface *const *src, uint32_t n_src, smr_surface *dst, float time_s);

@@ -151,6 +151,8 @@ def _bind(lib):
     lib.orc_render_frame_yuv420.restype = I
     lib.orc_blit_glyphs.argtypes = [P, I, I, C.POINTER(C.c_float), C.POINTER(_Glyph), I, P, I, I, I]
     lib.orc_gaussian_blur.argtypes = [P, I, I, I, F, P, P]
+    lib.orc_builtin_shader.argtypes = [I, C.POINTER(_Source), I, P, F, I, I, I, P]
+    lib.orc_builtin_shader.restype = I
     lib.orc_sizeof_layout.restype = I
     lib.orc_sizeof_plan.restype = I
     lib.orc_num_threads.restype = I
@@ -472,4 +474,29 @@ def gaussian_blur(src, sigma, fmt=PX_RGBA8_SRGB) -> np.ndarray:
     tmp = np.empty_like(src)
     out = np.empty_like(src)
     _load().orc_gaussian_blur(_p(src), fmt, w, h, float(sigma), _p(tmp), _p(out))
+    return out
+
+
+SHADER_GAUSSIAN_BLUR, SHADER_GRADIENT, SHADER_RED_BORDER, SHADER_CIRCLE_LAYOUT = 0, 1, 2, 3
+SHADER_FADE_TO_BALL, SHADER_LAYOUT_PLANES, SHADER_COLOR_BY_TEXTURE_COUNT, SHADER_SILLY = 4, 5, 6, 7
+
+
+def circle_layout_params(circles) -> bytes:
+    """circles: [(left_px, top_px, width_px, height_px, (r, g, b, a))] -> the bytes ShaderParam::to_bytes gives for the
+    reference's list-of-struct parameter (types/shader.rs), 32 B per entry."""
+    import struct
+    return b"".join(struct.pack("<4I4f", int(l), int(t), int(w), int(h), *[float(c) for c in bg]) for (l, t, w, h, bg) in circles)
+
+
+def builtin_shader(shader_id: int, sources, W: int, H: int, params: bytes = b"", time: float = 0.0, srgb: bool = True) -> np.ndarray:
+    """One ShaderNode render of a built-in port of the reference's WGSL shaders (ids above) over RGBA8 sources -> HxWx4."""
+    srcs = [_u8(s) for s in sources]
+    arr = (_Source * max(1, len(srcs)))()
+    for i, s in enumerate(srcs):
+        arr[i].data, arr[i].w, arr[i].h = _p(s), s.shape[1], s.shape[0]
+    out = np.empty((H, W, 4), np.uint8)
+    buf = C.create_string_buffer(bytes(params), max(1, len(params)))
+    rc = _load().orc_builtin_shader(int(shader_id), arr, len(srcs), C.cast(buf, C.c_void_p), float(time), int(srgb), W, H, _p(out))
+    if rc != 0:
+        raise ValueError(f"unknown built-in shader id {shader_id}")
     return out

@@ -995,6 +995,135 @@ ORC_API void orc_gaussian_blur(const u8 *src, int fmt, int w, int h, float sigma
     blur_axis(tmp, fmt, w, h, sigma, 1, dst);
 }
 
+/* ------------------------------------------------------------------------- */
+/* a13: the reference's in-tree WGSL shaders                                     */
+/* ------------------------------------------------------------------------- */
+
+/* ShaderNode (transformations/shader/node.rs:71-89) -> ShaderPipeline::render (shader/pipeline.rs:81-141): the target is
+ * cleared to transparent, then one plane (two triangles over [-1, 1]^2, tex_coords (0, 0) at the top-left corner,
+ * wgpu_ctx/plane.rs:11-28) is drawn per source texture with push constant plane_id = its index — or a single plane with
+ * plane_id = -1 when the node has no sources — under premultiplied-alpha blending (common_pipeline.rs:125), clamp-to-edge
+ * linear sampler.  Rasterised the way the hardware does: per plane, the quad's framebuffer rectangle, pixel centres inside
+ * it (top-left rule), tex_coords interpolated across it; the RGBA8 (sRGB for GpuOptimized) target is written and read back
+ * between the planes. */
+enum { ORC_SHADER_GRADIENT = 1, ORC_SHADER_RED_BORDER = 2, ORC_SHADER_CIRCLE_LAYOUT = 3, ORC_SHADER_FADE_TO_BALL = 4,
+       ORC_SHADER_LAYOUT_PLANES = 5, ORC_SHADER_COLOR_BY_TEXTURE_COUNT = 6, ORC_SHADER_SILLY = 7 };
+
+typedef struct {
+    unsigned left_px, top_px, width_px, height_px; /* circle_layout.wgsl:16-22 */
+    float background_color[4];
+} orc_circle_layout;
+
+static void shader_fragment(int id, const orc_source *srcs, int n_src, const orc_circle_layout *circles, int plane, float time, int srgb,
+                            int W, int H, float u, float v, float fx, float fy, float out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    switch (id) {
+    case ORC_SHADER_GRADIENT: /* gradient.wgsl:36-38: vec4(input.tex_coords.x, 0, 0, 1) */
+        out[0] = u; out[3] = 1.0f;
+        return;
+    case ORC_SHADER_RED_BORDER: { /* red_border.wgsl:40-52 */
+        const float border = 50.0f;
+        if (fx > border && fx < (float)W - border && fy > border && fy < (float)H - border) {
+            sample_source(n_src > 0 ? &srcs[0] : NULL, srgb, u, v, out);
+        } else {
+            out[0] = 1.0f; out[3] = 1.0f;
+        }
+        return;
+    }
+    case ORC_SHADER_CIRCLE_LAYOUT: { /* circle_layout.wgsl:58-72 */
+        const orc_circle_layout *c = &circles[plane < 0 ? 0 : plane];
+        float du = u - 0.5f, dv = v - 0.5f;
+        float in_circle = sqrtf(du * du + dv * dv) < 0.5f ? 1.0f : 0.0f;
+        float s[4];
+        sample_source(plane >= 0 && plane < n_src ? &srcs[plane] : NULL, srgb, u, v, s);
+        for (int k = 0; k < 4; k++) out[k] = s[k] * in_circle + c->background_color[k] * (1.0f - in_circle);
+        return;
+    }
+    case ORC_SHADER_FADE_TO_BALL: { /* fade_to_ball.wgsl:38-52 */
+        float s[4];
+        sample_source(n_src > 0 ? &srcs[0] : NULL, srgb, u, v, s);
+        float radius = time / 5.0f, eps = 0.15f;
+        float du = u - 0.5f, dv = v - 0.5f;
+        float e0 = radius + eps, e1 = radius - eps;
+        float t = clampf((sqrtf(du * du + dv * dv) - e0) / (e1 - e0), 0.0f, 1.0f);
+        t = t * t * (3.0f - 2.0f * t);
+        for (int k = 0; k < 4; k++) out[k] = s[k] * t;
+        return;
+    }
+    case ORC_SHADER_LAYOUT_PLANES: /* layout_planes.wgsl:55-61 */
+        if (plane == -1) { out[0] = 1.0f; out[3] = 1.0f; return; }
+        sample_source(plane < n_src ? &srcs[plane] : NULL, srgb, u, v, out);
+        return;
+    case ORC_SHADER_COLOR_BY_TEXTURE_COUNT: /* color_output_with_texture_count.wgsl:42-50 */
+        out[n_src == 0 ? 0 : (n_src == 1 ? 1 : 2)] = 1.0f;
+        out[3] = 1.0f;
+        return;
+    case ORC_SHADER_SILLY: { /* examples/silly.wgsl:34-54 */
+        if (n_src != 1) return;
+        const float pi = 3.14159f;
+        float effect_radius = fabsf(sinf(time) / 2.0f);
+        float effect_angle = 2.0f * pi * fabsf(sinf(time) / 2.0f);
+        float du = u - 0.5f, dv = v - 0.5f;
+        float len = sqrtf(du * du + dv * dv);
+        float t = clampf((len - effect_radius) / (0.0f - effect_radius), 0.0f, 1.0f);
+        float angle = atan2f(dv, du) + effect_angle * (t * t * (3.0f - 2.0f * t));
+        sample_source(&srcs[0], srgb, len * cosf(angle) + 0.5f, len * sinf(angle) + 0.5f, out);
+        return;
+    }
+    default:
+        return;
+    }
+}
+
+ORC_API int orc_builtin_shader(int id, const orc_source *srcs, int n_src, const void *params, float time, int srgb, int W, int H, u8 *dst) {
+    orc_init();
+    if (id < ORC_SHADER_GRADIENT || id > ORC_SHADER_SILLY) return -1;
+    const orc_circle_layout *circles = (const orc_circle_layout *)params;
+    const int fmt = srgb ? ORC_PX_RGBA8_SRGB : ORC_PX_RGBA8_UNORM;
+    memset(dst, 0, (size_t)W * H * 4); /* LoadOp::Clear(TRANSPARENT) */
+    const int first = n_src == 0 ? -1 : 0, last = n_src == 0 ? -1 : n_src - 1;
+    for (int plane = first; plane <= last; plane++) {
+        /* vertex stage: the quad's clip-space rectangle [cx - sx, cx + sx] x [cy - sy, cy + sy] */
+        float sx = 1.0f, sy = 1.0f, cx = 0.0f, cy = 0.0f;
+        if (id == ORC_SHADER_CIRCLE_LAYOUT) { /* circle_layout.wgsl:31-56 */
+            const orc_circle_layout *c = &circles[plane < 0 ? 0 : plane];
+            sx = (float)c->width_px / (float)W;
+            sy = (float)c->height_px / (float)H;
+            cx = (((float)c->left_px + (float)c->width_px / 2.0f) / (float)W) * 2.0f - 1.0f;
+            cy = 1.0f - (((float)c->top_px + (float)c->height_px / 2.0f) / (float)H) * 2.0f;
+        } else if (id == ORC_SHADER_LAYOUT_PLANES && plane != -1) { /* layout_planes.wgsl:30-53 */
+            sx = sy = 0.5f;
+            if (plane == 0) { cx = -0.5f; cy = 0.5f; }
+            else if (plane == 1) { cx = 0.5f; cy = 0.5f; }
+            else if (plane == 2) { cx = -0.5f; cy = -0.5f; }
+            else if (plane == 3) { cx = 0.5f; cy = -0.5f; }
+        }
+        /* viewport transform: framebuffer x = (X + 1) / 2 * W, y = (1 - Y) / 2 * H */
+        const double x0 = ((double)cx - sx + 1.0) * 0.5 * W, x1 = ((double)cx + sx + 1.0) * 0.5 * W;
+        const double y0 = (1.0 - ((double)cy + sy)) * 0.5 * H, y1 = (1.0 - ((double)cy - sy)) * 0.5 * H;
+        if (!(x1 > x0) || !(y1 > y0)) continue;
+        int px0 = (int)ceil(x0 - 0.5), px1 = (int)ceil(x1 - 0.5); /* centres with x0 <= px + 0.5 < x1 */
+        int py0 = (int)ceil(y0 - 0.5), py1 = (int)ceil(y1 - 0.5);
+        if (px0 < 0) px0 = 0;
+        if (py0 < 0) py0 = 0;
+        if (px1 > W) px1 = W;
+        if (py1 > H) py1 = H;
+#pragma omp parallel for schedule(static)
+        for (int y = py0; y < py1; y++) {
+            for (int x = px0; x < px1; x++) {
+                const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+                const float u = (float)(((double)fx - x0) / (x1 - x0)), v = (float)(((double)fy - y0) / (y1 - y0));
+                float f[4], d[4], o[4];
+                shader_fragment(id, srcs, n_src, circles, plane, time, srgb, W, H, u, v, fx, fy, f);
+                load_texel(dst, fmt, W, x, y, d);
+                for (int k = 0; k < 4; k++) o[k] = f[k] + d[k] * (1.0f - f[3]);
+                store_texel(dst, fmt, W, x, y, o);
+            }
+        }
+    }
+    return 0;
+}
+
 /* One whole output frame of the reference's pass sequence without leaving C — the CPU baseline leg of bench.py (a frame loop
  * with no Python between the passes): populate_inputs + convert_to_node_texture (render_loop.rs:19-42) for n_in planar 4:2:0
  * frames, resample_scaled_children (layout.rs:238-278), LayoutShader::render, rgba_to_yuv (render_loop.rs:59-230).

@@ -19,7 +19,9 @@ PX_RGBA8, PX_RGBA16F, PX_R8, PX_RG8 = 0, 1, 2, 3
 MAX_MASKS = 20
 NO_SOURCE = 0xFFFFFFFF
 SOURCE_NONE, SOURCE_SURFACE, SOURCE_FRAME, SOURCE_OPAQUE_SURFACE = 0, 1, 2, 3
-SHADER_GAUSSIAN_BLUR = 0
+SHADER_GAUSSIAN_BLUR, SHADER_GRADIENT, SHADER_RED_BORDER, SHADER_CIRCLE_LAYOUT = 0, 1, 2, 3
+SHADER_FADE_TO_BALL, SHADER_LAYOUT_PLANES, SHADER_COLOR_BY_TEXTURE_COUNT, SHADER_SILLY = 4, 5, 6, 7
+SHADER_MAX_SOURCES = 16
 
 # every symbol include/smr.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTS = [

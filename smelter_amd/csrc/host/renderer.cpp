@@ -133,6 +133,17 @@ struct FrameSetView {
 };
 
 // RenderNode::render (state/node.rs) for one node of one output; returns what its parent samples
+// ShaderParam::to_bytes (shader/node.rs:95-112) over the API form {"type": f32|u32|i32|list|struct, "value": ...}
+static void flatten_shader_param(const Json &j, std::vector<uint8_t> &out) {
+    const Json *ty = j.get("type"), *v = j.get("value");
+    if (!ty || !v) return;
+    auto put = [&](const void *p) { const uint8_t *b = (const uint8_t *)p; out.insert(out.end(), b, b + 4); };
+    if (ty->str == "f32") { float f = (float)v->num; put(&f); }
+    else if (ty->str == "u32") { uint32_t u = (uint32_t)v->num; put(&u); }
+    else if (ty->str == "i32") { int32_t n = (int32_t)v->num; put(&n); }
+    else if (v->kind == Json::Array) for (const Json &e : v->arr) flatten_shader_param(e, out);
+}
+
 int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Source &out) {
     const GraphNode &g = o.scene.nodes()[idx];
     const Stateful &c = *g.component;
@@ -205,23 +216,26 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
                 srcs.push_back(kids[k].surface);
             }
         }
-        if (srcs.empty()) return 0;  // nothing to sample: the node stays empty
-        float value = 0.0f;
-        if (const Json *v = c.shader_param.get("value")) value = (float)v->num;  // {"type": "f32", "value": sigma}
-        smr_gaussian_blur_params params{value};
-        // the built-in kernels map texel to texel: a source of another size is first brought to the node's resolution
-        const smr_surface *src0 = srcs[0];
-        smr_surface_info si;
-        smr_surface_info_get(src0, &si);
-        if (si.width != w || si.height != h) {
-            smr_surface *&t = o.l->scaled_image[idx];
-            rc = ensure_surface(r, t, w, h);
-            if (rc < 0) return rc;
-            rc = gpu(r, smr_rescale_bilinear(r->ctx, src0, t), "shader source");
-            if (rc < 0) return rc;
-            srcs[0] = t;
+        // the @group(1) uniform: ShaderParam::to_bytes (shader/node.rs:95-112), the values in order, little endian, no padding
+        std::vector<uint8_t> params;
+        flatten_shader_param(c.shader_param, params);
+        if (it->second == SMR_SHADER_GAUSSIAN_BLUR) {
+            if (srcs.empty()) return 0;  // nothing to sample: the node stays empty
+            // the blur kernel maps texel to texel: a source of another size is first brought to the node's resolution
+            const smr_surface *src0 = srcs[0];
+            smr_surface_info si;
+            smr_surface_info_get(src0, &si);
+            if (si.width != w || si.height != h) {
+                smr_surface *&t = o.l->scaled_image[idx];
+                rc = ensure_surface(r, t, w, h);
+                if (rc < 0) return rc;
+                rc = gpu(r, smr_rescale_bilinear(r->ctx, src0, t), "shader source");
+                if (rc < 0) return rc;
+                srcs[0] = t;
+            }
+            if (params.size() < sizeof(smr_gaussian_blur_params)) params.assign(sizeof(smr_gaussian_blur_params), 0);
         }
-        rc = gpu(r, smr_builtin_shader(r->ctx, it->second, &params, sizeof(params), srcs.data(), (uint32_t)srcs.size(), o.l->node_surface[idx],
+        rc = gpu(r, smr_builtin_shader(r->ctx, it->second, params.data(), params.size(), srcs.data(), (uint32_t)srcs.size(), o.l->node_surface[idx],
                                        (float)((double)fs.pts_ns / 1e9)),
                  "shader node");
         if (rc < 0) return rc;
@@ -270,7 +284,7 @@ int render_output(smr_renderer *r, Output &o, const FrameSetView &fs, const smr_
         uint32_t w = 0, h = 0;
         std::string err;
         if (!o.scene.node_layouts(0, fs.pts_ns, res, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, r->layouts, w, h, err)) return fail(r, -1, err);
-        if (w == o.w && h == o.h) {
+        if (w == o.w && h == o.h && o.format != SMR_FRAME_RGBA) {
             // LayoutNode::render + read_outputs in one go: the root's RGBA target never exists
             return gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h,
                                              target, nullptr),
@@ -376,7 +390,7 @@ SMR_API int smr_renderer_register_image(smr_renderer *r, const char *image_id, c
 
 SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id, uint32_t builtin_id) {
     if (!r || !shader_id) return fail(r, -1, "smr_renderer_register_shader: null argument");
-    if (builtin_id != SMR_SHADER_GAUSSIAN_BLUR) return fail(r, -1, "smr_renderer_register_shader: unknown built-in shader (user WGSL is not supported)");
+    if (builtin_id > SMR_SHADER_SILLY) return fail(r, -1, "smr_renderer_register_shader: unknown built-in shader (user WGSL is not supported)");
     r->shaders[shader_id] = builtin_id;
     return 0;
 }
@@ -385,8 +399,8 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
                                       const char *scene_json) {
     if (!r || !output_id || !scene_json || !width || !height) return fail(r, -1, "smr_renderer_update_scene: null argument");
     if (output_format != SMR_FRAME_PLANAR_YUV420 && output_format != SMR_FRAME_PLANAR_YUV422 && output_format != SMR_FRAME_PLANAR_YUV444 &&
-        output_format != SMR_FRAME_NV12)
-        return fail(r, -1, "smr_renderer_update_scene: output format must be planar YUV 4:2:0 / 4:2:2 / 4:4:4 or NV12");
+        output_format != SMR_FRAME_NV12 && output_format != SMR_FRAME_RGBA)
+        return fail(r, -1, "smr_renderer_update_scene: output format must be planar YUV 4:2:0 / 4:2:2 / 4:4:4, NV12 or RGBA");
     Output &o = r->outputs[output_id];
     for (auto &kv : r->images) o.scene.register_image(kv.first, (float)kv.second.w, (float)kv.second.h);
     std::string err;

@@ -260,6 +260,11 @@ int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *ou
     SurfView src = view_of(node);
     int cw, ch;
     switch (out->format) {
+    case SMR_FRAME_RGBA:
+        // OutputTexture::Rgba8UnormWgpuTexture (render_loop.rs:81-103): the frame is a clone of the root node's texture, as it is
+        SMR_HIP(ctx, hipMemcpy2DAsync(out->planes[0]->ptr, out->planes[0]->pitch, node->ptr, node->pitch, (size_t)w * 4, (size_t)h,
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+        return SMR_OK;
     case SMR_FRAME_PLANAR_YUV420: cw = w / 2; ch = h / 2; break;
     case SMR_FRAME_PLANAR_YUV422: cw = w / 2; ch = h; break;
     case SMR_FRAME_PLANAR_YUV444: cw = w; ch = h; break;
@@ -294,6 +299,10 @@ int smr_frame_fill_black(smr_ctx *ctx, const smr_frame *out) {
     const float c = ((0.0f + 0.5f) * 0.8784314f) + (16.0f / 255.0f);
     const u32 yb = host_unorm8(y), cb = host_unorm8(c);
     StageScope scope(ctx, SMR_STAGE_OUTPUT);
+    if (out->format == SMR_FRAME_RGBA) {  // render_loop.rs:140-158: a fresh (all-zero) texture when the root is empty
+        SMR_HIP(ctx, hipMemset2DAsync(out->planes[0]->ptr, out->planes[0]->pitch, 0, (size_t)out->width * 4, out->height, ctx->stream));
+        return SMR_OK;
+    }
     for (int i = 0; i < 3; i++) {
         const smr_surface *s = out->planes[i];
         if (!s) continue;

@@ -9,6 +9,9 @@
 
 #include <cmath>
 
+int smr_launch_plane_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t params_size, const smr_surface *const *src, uint32_t n_src,
+                            smr_surface *dst, float time_s);
+
 namespace {
 
 __device__ __forceinline__ float srgb_to_linear_dev(float c) {
@@ -122,7 +125,6 @@ int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const 
 int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t params_size, const smr_surface *const *src,
                        uint32_t n_src, smr_surface *dst, float time_s) {
     SMR_ENTER(ctx);
-    (void)time_s;
     if (!ctx || !dst) return SMR_ERR_INVALID;
     switch (id) {
     case SMR_SHADER_GAUSSIAN_BLUR: {
@@ -147,6 +149,14 @@ int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t par
         SMR_HIP(ctx, hipGetLastError());
         return SMR_OK;
     }
+    case SMR_SHADER_GRADIENT:
+    case SMR_SHADER_RED_BORDER:
+    case SMR_SHADER_CIRCLE_LAYOUT:
+    case SMR_SHADER_FADE_TO_BALL:
+    case SMR_SHADER_LAYOUT_PLANES:
+    case SMR_SHADER_COLOR_BY_TEXTURE_COUNT:
+    case SMR_SHADER_SILLY:
+        return smr_launch_plane_shader(ctx, id, params, params_size, src, n_src, dst, time_s);  // smr_shaders.hip
     default:
         // RegisterRendererError for unknown shaders; arbitrary WGSL is not supported by this build
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_builtin_shader: unknown built-in shader id %u", id);

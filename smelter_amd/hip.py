@@ -14,6 +14,8 @@ from . import _ffi
 from ._ffi import (FRAME_ARGB, FRAME_BGRA, FRAME_NV12, FRAME_PLANAR_YUV420, FRAME_PLANAR_YUV422, FRAME_PLANAR_YUV444,
                    FRAME_PLANAR_YUVJ420, FRAME_RGBA, FRAME_UYVY422, FRAME_YUYV422, MODE_CPU_OPTIMIZED, MODE_GPU_OPTIMIZED,
                    PX_R8, PX_RG8, PX_RGBA8, PX_RGBA16F)
+from ._ffi import (SHADER_CIRCLE_LAYOUT, SHADER_COLOR_BY_TEXTURE_COUNT, SHADER_FADE_TO_BALL, SHADER_GAUSSIAN_BLUR,  # noqa: F401
+                   SHADER_GRADIENT, SHADER_LAYOUT_PLANES, SHADER_MAX_SOURCES, SHADER_RED_BORDER, SHADER_SILLY)
 
 STAGE_NAMES = {0: "ingest", 1: "resample", 2: "layouts", 3: "output", 4: "fused_ingest_resample", 5: "fused_compose_output"}
 
@@ -392,4 +394,13 @@ class Context:
         ptrs = (C.c_void_p * 1)(src.handle)
         self._check(self.lib.smr_builtin_shader(self.handle, _ffi.SHADER_GAUSSIAN_BLUR, C.byref(p), C.sizeof(p), ptrs, 1,
                                                 dst.handle, 0.0))
+        return dst
+
+    def builtin_shader(self, shader_id: int, sources, dst: Surface, params: bytes = b"", time_s: float = 0.0) -> Surface:
+        """One ShaderNode render of a built-in port of the reference's in-tree WGSL shaders (include/smr.h smr_builtin_shader_id):
+        `sources` are RGBA8 surfaces, `params` the bytes ShaderParam::to_bytes would bind at @group(1)."""
+        ptrs = (C.c_void_p * max(1, len(sources)))(*[s.handle for s in sources])
+        buf = C.create_string_buffer(bytes(params), max(1, len(params)))
+        self._check(self.lib.smr_builtin_shader(self.handle, int(shader_id), C.cast(buf, C.c_void_p), len(params), ptrs, len(sources),
+                                                dst.handle, float(time_s)))
         return dst

@@ -64,6 +64,37 @@ def test_yuv_gradient_rgba_output():
     _close(_gradient_node_texture(), GRADIENT_RGB_EXPECTED, 0)
 
 
+def test_yuv_gradient_through_the_shader_node_port():
+    # the same test driven through the ShaderNode restatement (one plane, plane_id -1, cleared target)
+    tex = orc.builtin_shader(orc.SHADER_GRADIENT, [], 8, 2)
+    assert np.array_equal(tex, _gradient_node_texture())
+    _close(tex, GRADIENT_RGB_EXPECTED, 0)
+
+
+def test_shader_ports_plane_rules():
+    """shader/pipeline.rs:81-141: plane_id -1 when the node has no sources, one plane per source otherwise, premultiplied OVER."""
+    rng = np.random.default_rng(5)
+    tex = [rng.integers(0, 256, (36, 64, 4), dtype=np.uint8) for _ in range(4)]
+    for t in tex:
+        t[..., 3] = 255
+    assert orc.builtin_shader(orc.SHADER_LAYOUT_PLANES, [], 64, 36)[7, 9].tolist() == [255, 0, 0, 255]
+    quad = orc.builtin_shader(orc.SHADER_LAYOUT_PLANES, tex, 128, 72)
+    # every quadrant is the source texel for texel (scale 1, sample positions on texel centres)
+    assert np.array_equal(quad[:36, :64], tex[0]) and np.array_equal(quad[:36, 64:], tex[1])
+    assert np.array_equal(quad[36:, :64], tex[2]) and np.array_equal(quad[36:, 64:], tex[3])
+    for n, want in ((0, [255, 0, 0, 255]), (1, [0, 255, 0, 255]), (2, [0, 0, 255, 255])):
+        assert orc.builtin_shader(orc.SHADER_COLOR_BY_TEXTURE_COUNT, tex[:n], 4, 4)[0, 0].tolist() == want
+    # silly.wgsl returns transparent unless it has exactly one texture; fade_to_ball at t = 0 keeps a disc of radius < eps
+    assert not orc.builtin_shader(orc.SHADER_SILLY, tex[:2], 16, 16).any()
+    ball = orc.builtin_shader(orc.SHADER_FADE_TO_BALL, tex[:1], 64, 36, time=0.0)
+    assert not ball[0, 0].any() and ball[18, 32, 3] > 0
+    # two half-transparent planes over each other: 0.5 + 0.5 * (1 - 0.5)
+    half = orc.circle_layout_params([(0, 0, 8, 8, (0.0, 0.0, 0.0, 0.5))] * 2)
+    sq = np.zeros((8, 8, 4), np.uint8)
+    out = orc.builtin_shader(orc.SHADER_CIRCLE_LAYOUT, [sq, sq], 8, 8, params=half)
+    assert out[0, 0, 3] in (191, 192) and out[4, 4, 3] == 0  # corners are outside the circle, the centre samples the empty texture
+
+
 def test_yuv_gradient_yuv_output():
     tex = _gradient_node_texture()
     y, u, v = orc.rgba_to_planar_yuv(tex, orc.YUV420)
