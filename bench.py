@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--latency-frames", type=int, default=2000)
     ap.add_argument("--ingest", choices=["auto", "valu", "mfma"], default="auto",
                     help="ingest + Lanczos kernel: matrix cores where applicable (auto, default), exact f32 (valu)")
+    ap.add_argument("--direct-output", action="store_true",
+                    help="SMR_OPT_DIRECT_OUTPUT: the resampling kernel writes Y'CbCr for the compositor's copy tiles (A/B; default off)")
     ap.add_argument("--no-target", action="store_true", help="skip the north-star target block (8x4K -> 4K on one GPU, run as a child process)")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight on one GPU (renderer contexts / HIP streams)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (ingest per shard, gather, compose) with the ranks given")
@@ -214,6 +216,7 @@ def main():
     ctx = hip.Context(local_rank, stream=side.cuda_stream if side is not None else None)
     ingest_impl = {"auto": hip.INGEST_AUTO, "valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_MFMA_F16}[args.ingest]
     ctx.set_ingest_impl(ingest_impl)
+    ctx.set_direct_output(args.direct_output)
     layouts, res = build_scene()
     packed = hip.pack_layouts(layouts)
     label = make_label(ctx)
@@ -242,6 +245,7 @@ def main():
         lanes += [hip.Context(local_rank) for _ in range(n_lanes - 1)]
         for c in lanes[1:]:
             c.set_ingest_impl(ingest_impl)
+            c.set_direct_output(args.direct_output)
         atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
 
         def make_renderer(c, extra=()):

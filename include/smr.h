@@ -166,9 +166,14 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *       SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
  *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
  *     layout/resampler.rs:25-28, u8 sRGB tile) and deviates from the f32 sequence of resample.wgsl:64-87 by at most 1 LSB.
- *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling) */
+ *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling)
+ *   SMR_OPT_DIRECT_OUTPUT       1: when smr_render_layouts sees the same layout list again (a scene at rest), the pixels the
+ *                               compositor would only copy from a freshly resampled input are converted to Y'CbCr by the resampling
+ *                               kernel itself and their RGBA8 form is never stored (HBM traffic per frame 1.2x instead of 2.7x the
+ *                               algorithmic bytes, at the price of vector-ALU time in that kernel: DESIGN.md); 0 (default): always through
+ *                               the RGBA8 tile.  Same output bytes either way. */
 typedef enum smr_ingest_impl { SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2 } smr_ingest_impl;
-typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1 } smr_option;
+typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
 SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */

@@ -233,6 +233,7 @@ void smr_ctx_destroy(smr_ctx *ctx) {
         if (l.done) (void)hipEventDestroy(l.done);
     }
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -245,6 +246,11 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     case SMR_OPT_INGEST_IMPL:
         if (value < 0 || value > SMR_INGEST_MFMA_F16) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
         ctx->ingest_impl = (u32)value;
+        return SMR_OK;
+    case SMR_OPT_DIRECT_OUTPUT:
+        ctx->direct_output = value != 0;
+        ctx->class_ready = false;
+        ctx->class_key.clear();
         return SMR_OK;
     case SMR_OPT_INGEST_STRIP_WIDTH:
         if (value != 0 && value != 32 && value != 64) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: strip width %d", value);

@@ -104,6 +104,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<smr_layout> eff(layouts, layouts + n);
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
+    std::vector<u32> mjob_layout;
     ctx->weight_call++;
     u32 next_view = n_sources;
     for (u32 li = 0; li < n; li++) {
@@ -128,7 +129,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     MJob J;
                     int rc = make_mfma_job(ctx, sources[si].frame, plan, tile, &J, &on_mfma);
                     if (rc != SMR_OK) return rc;
-                    if (on_mfma) mjobs.push_back(J);
+                    if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); }
                 }
                 if (on_mfma) {
                 } else if (fused && is_frame && can_fuse_ingest(sources[si].frame, plan)) {
@@ -165,17 +166,91 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- parameters -> device (one pinned staging slot, one copy)
     const u32 b_tiles_x = (out_w + B_TILE_W - 1) / B_TILE_W, b_tiles_y = (out_h + B_TILE_H - 1) / B_TILE_H;
     const u32 b_tiles = b_tiles_x * b_tiles_y;
-    const size_t order_bytes = sizeof(ComposeOrder) + (size_t)((b_tiles + 31) / 32) * 4;
+    const size_t order_bytes = (sizeof(ComposeOrder) + (size_t)((b_tiles + 31) / 32) * 4 + 15) & ~(size_t)15;
     PackedLayouts packed;
-    int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes, &packed);
+    int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes + sizeof(MDirect), &packed);
     if (rc != SMR_OK) return rc;
     const u32 n_first = compose_order(packed, (int)b_tiles_x, (int)b_tiles_y, (ComposeOrder *)packed.extra_host);
+    const bool fuse_out = fused && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
+                          (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= B_MAX_LAYOUTS && packed.n_masks <= B_MAX_MASKS &&
+                          out->planes[0] && out->planes[1] &&
+                          (out->format == SMR_FRAME_NV12 || out->planes[2]);
+
+    // ---- direct output: once a layout list repeats (a scene at rest), the tiles the compositor would only copy from a
+    //      resampled input are written as Y'CbCr by wave A itself and skipped by wave B (k_classify_tiles, MDirect).
+    //      A list seen for the first time renders the ordinary way; the class map is built when it comes back.
+    MDirect direct;
+    memset(&direct, 0, sizeof(direct));
+    bool classify_now = false;
+    unsigned long long direct_mask = 0;
+#ifdef SMR_ABLATION_BUILDS
+    const bool direct_allowed = false;
+#else
+    const bool direct_allowed = ctx->direct_output;
+#endif
+    if (fuse_out && direct_allowed && !mjobs.empty() && ctx->ablate == 0) {
+        unsigned long long mask = 0;
+        for (size_t j = 0; j < mjobs.size(); j++) {
+            const u32 li = mjob_layout[j];
+            const DevLayout &D = packed.host_layouts[li];
+            if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == mjobs[j].dst.ptr && D.ix % 4 == 0 &&
+                D.iy % 2 == 0) {
+                mask |= 1ull << li;
+                mjobs[j].layer = (int)li; mjobs[j].ox = D.ix; mjobs[j].oy = D.iy;
+            }
+        }
+        // key: everything the classification reads
+        const size_t lb = (size_t)packed.n * sizeof(DevLayout), mb = (size_t)packed.n_masks * sizeof(DevMask);
+        std::vector<u8> key(lb + mb + 24);
+        memcpy(key.data(), packed.host_layouts, lb);
+        if (mb) memcpy(key.data() + lb, packed.host_masks, mb);
+        const u32 tail[4] = {out_w, out_h, (u32)packed.n, (u32)packed.n_masks};
+        memcpy(key.data() + lb + mb, tail, 16);
+        memcpy(key.data() + lb + mb + 16, &mask, 8);
+        bool use = false;
+        if (mask && key == ctx->class_key) {
+            if (!ctx->class_ready) {
+                if (ctx->d_tile_class_bytes < b_tiles) {
+                    if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
+                    ctx->d_tile_class = nullptr; ctx->d_tile_class_bytes = 0;
+                    SMR_HIP(ctx, hipMalloc((void **)&ctx->d_tile_class, b_tiles));
+                    ctx->d_tile_class_bytes = b_tiles;
+                }
+                classify_now = true;  // (after the layout list is on the device)
+                direct_mask = mask;
+                ctx->class_ready = true;
+            }
+            use = true;
+        } else {
+            ctx->class_key.swap(key);
+            ctx->class_ready = false;
+        }
+        if (ctx->debug_ingest)
+            fprintf(stderr, "[smr] direct output: %zu resampled tiles, layer mask %llx, list %s, %s\n", mjobs.size(), mask,
+                    use ? "seen before" : "new", classify_now ? "classifying" : (use ? "class map cached" : "off this frame"));
+        if (use) {
+            direct.cls = ctx->d_tile_class;
+            direct.tiles_x = (int)b_tiles_x;
+            direct.nv = out->format == SMR_FRAME_NV12 ? 1 : 0;
+            direct.yp = view_of(out->planes[0]); direct.up = view_of(out->planes[1]);
+            direct.vp = direct.nv ? direct.up : view_of(out->planes[2]);
+        } else {
+            for (MJob &J : mjobs) J.layer = -1;
+        }
+    }
+    memcpy((u8 *)packed.extra_host + order_bytes, &direct, sizeof(direct));
+    const MDirect *direct_dev = direct.cls ? (const MDirect *)((const u8 *)packed.extra_dev + order_bytes) : nullptr;
     rc = smr_pack_commit(ctx, &packed);
     if (rc != SMR_OK) return rc;
+    if (classify_now) {
+        hipLaunchKernelGGL(k_classify_tiles, dim3(b_tiles), dim3(64), 0, ctx->stream, packed.layouts, packed.masks, packed.n, (int)out_w, (int)out_h,
+                           (int)b_tiles_x, direct_mask, ctx->d_tile_class);
+        SMR_HIP(ctx, hipGetLastError());
+    }
 
     // ---- wave A (job descriptors ride in the kernel arguments)
     if (!mjobs.empty()) {
-        rc = launch_mfma(ctx, mjobs);
+        rc = launch_mfma(ctx, mjobs, direct_dev);
         if (rc != SMR_OK) return rc;
     }
     if (!jobs.empty()) {
@@ -184,10 +259,6 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
 
     // ---- wave B (or the general compositor + output converters)
-    const bool fuse_out = fused && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
-                          (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= B_MAX_LAYOUTS && packed.n_masks <= B_MAX_MASKS &&
-                          out->planes[0] && out->planes[1] &&
-                          (out->format == SMR_FRAME_NV12 || out->planes[2]);
     if (fuse_out) {
         StageScope scope(ctx, SMR_STAGE_FUSED_COMPOSE);
         // 1-D grid: the tiles the host expects to need the (latency-bound) general path go first, then every tile in order
@@ -197,11 +268,11 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         if (out->format == SMR_FRAME_NV12) {
             hipLaunchKernelGGL(k_compose_output<1>, grid, dim3(256), 0, ctx->stream, yp, up, up, (int)out_w, (int)out_h, packed.layouts,
                                packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables, order,
-                               (int)b_tiles_x);
+                               (int)b_tiles_x, direct.cls);
         } else {
             hipLaunchKernelGGL(k_compose_output<0>, grid, dim3(256), 0, ctx->stream, yp, up, view_of(out->planes[2]), (int)out_w, (int)out_h,
                                packed.layouts, packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables,
-                               order, (int)b_tiles_x);
+                               order, (int)b_tiles_x, direct.cls);
         }
         SMR_HIP(ctx, hipGetLastError());
         return smr_pack_done(ctx, &packed);

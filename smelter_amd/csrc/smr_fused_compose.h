@@ -123,6 +123,47 @@ __device__ __forceinline__ void classify_layouts(u32 *s_touch, u32 *s_solid, int
     __syncthreads();
 }
 
+// What a tile needs beyond its start layer (after classify_layouts; the caller zeroes *s_general and syncs afterwards):
+// bit 0 — some touched layer at or above the start needs blending arithmetic, 2 — the start layer is an opaque texture that is not
+// a 1:1 blit.  0 = copy tile.
+__device__ __forceinline__ void tile_needs(const u32 *s_touch, int start, int *s_general, const DevLayout *__restrict__ layouts, int n, int tid,
+                                           int nthreads) {
+    for (int i = tid; i < n; i += nthreads) {
+        if (!((s_touch[i >> 5] >> (i & 31)) & 1u) || i < start) continue;
+        const DevLayout &L = layouts[i];
+        const bool copy_layer = i == start && (L.type != 0 || (L.flags & DL_ALIGNED));
+        const bool sample_layer = i == start && L.type == 0 && !(L.flags & DL_ALIGNED);  // opaque texture, solid over the tile, not a 1:1 blit
+        if (sample_layer) atomicOr(s_general, 2);
+        else if (!copy_layer) atomicOr(s_general, 1);
+    }
+}
+
+// Direct output (static scenes): the class of every tile, computed once per layout list.  cls[tile] = the start layer when the tile
+// is a copy tile of a texture layer in `direct_layers` (the tiles wave A resamples in the same call, at even output positions) —
+// wave A then writes that tile's Y'CbCr itself and k_compose_output skips it, so the RGBA8 bytes of those pixels never exist in
+// memory — else 0xff.  Same classification code as the compositor's, one 64-thread workgroup per tile.
+constexpr u32 B_CLASS_NONE = 0xffu;
+__global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks, int n, int W, int H,
+                                                       int tiles_x, unsigned long long direct_layers, u8 *__restrict__ cls) {
+    __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
+    __shared__ int s_start, s_general;
+    const int tid = threadIdx.x, tile = blockIdx.x;
+    const int tile_y = tile / tiles_x;
+    const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H;
+    if (tid == 0) s_general = 0;
+    classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + B_TILE_H, H), tid, 64);
+    const int start = s_start;
+    tile_needs(s_touch, start, &s_general, layouts, n, tid, 64);
+    __syncthreads();
+    if (tid == 0) {
+        u32 c = B_CLASS_NONE;
+        if (s_general == 0 && start >= 0 && start < 64 && layouts[start].type == 0 && ((direct_layers >> start) & 1ull) &&
+            tx0 + B_TILE_W <= W && ty0 + B_TILE_H <= H)
+            c = (u32)start;
+        cls[tile] = (u8)c;
+    }
+}
+
 // Wave-uniform copy of a record (LDS or global) into scalar registers: the dword loads are issued back to back
 // (one wait), v_readfirstlane moves them to SGPRs, and every later use is a scalar operand / a uniform branch.
 template <typename T>
@@ -185,7 +226,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
                                                         const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
                                                         int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
-                                                        const ComposeOrder *__restrict__ order, int tiles_x) {
+                                                        const ComposeOrder *__restrict__ order, int tiles_x, const u8 *__restrict__ cls) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;
     __shared__ float s_tab[SMR_TABLE_FLOATS];
@@ -199,6 +240,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     int tile = (int)blockIdx.x - (int)order->n_first;
     if (tile < 0) tile = order->first[blockIdx.x];
     else if ((order->taken[tile >> 5] >> (tile & 31)) & 1u) return;
+    if (cls && cls[tile] != B_CLASS_NONE) return;  // direct output: wave A wrote this tile's Y'CbCr
     {
         const uint4 *gl = (const uint4 *)layouts_g;
         uint4 *ll = (uint4 *)s_lay;
@@ -218,14 +260,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + B_TILE_H, H), tid, 256);
     const int start = s_start;
     // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
-    for (int i = tid; i < n; i += 256) {
-        if (!((s_touch[i >> 5] >> (i & 31)) & 1u) || i < start) continue;
-        const DevLayout &L = layouts[i];
-        const bool copy_layer = i == start && (L.type != 0 || (L.flags & DL_ALIGNED));
-        const bool sample_layer = i == start && L.type == 0 && !(L.flags & DL_ALIGNED);  // opaque texture, solid over the tile, not a 1:1 blit
-        if (sample_layer) atomicOr(&s_general, 2);
-        else if (!copy_layer) atomicOr(&s_general, 1);
-    }
+    tile_needs(s_touch, start, &s_general, layouts, n, tid, 256);
     __syncthreads();
     const bool general = (s_general & 1) != 0;
     const bool sampled = s_general == 2;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)

@@ -208,6 +208,17 @@ struct MJob {
     int ngm;  // column groups (4 texels) the LDS is sized for
     int RG;   // ring depth in 8-row granules (even)
     int ablate;  // profiling only (SMR_ABLATE): 1 skip convert, 2 skip pass 1, 4 skip pass 2, 8 skip encode + store, 16 skip staging, 32 dispatch only
+    // direct output (MDirect below): the layer this tile is blitted by, -1 = none, and its (even) position in the output frame
+    int layer, ox, oy;
+};
+
+// Direct output: where the compositor would only copy this tile's texels into the output frame (k_classify_tiles, cls[tile] ==
+// the job's layer), the filter waves convert their finished pixels to Y'CbCr themselves — the arithmetic of k_compose_output's
+// copy tiles on the same bytes — and the RGBA8 texels are not stored.
+struct MDirect {
+    const u8 *cls;   // class per 128x16 output tile, nullptr = off
+    int tiles_x, nv; // nv: 1 = NV12 (interleaved chroma in `up`)
+    SurfView yp, up, vp;
 };
 
 constexpr int MAX_MJOBS_PER_LAUNCH = 12;
@@ -216,6 +227,7 @@ struct MArgs {
     int unit_prefix[MAX_MJOBS_PER_LAUNCH + 1];  // units = strips_x * n_vtiles per job (strip-major)
     int n_jobs;
     int units_per_block;
+    const MDirect *direct;  // device record (rides behind the layout list), nullptr = off
 };
 
 constexpr int M_LUT_ENTRIES = 768;  // decode LUT indexed by the unclamped code + 256: entries below 256 / above 511 repeat the ends
@@ -300,7 +312,7 @@ __host__ __device__ inline MLds m_lds(int ts, int ngm, int RG) {
 //                                    sRGB encode + store of every output tile whose window is complete   — MFMA + LDS reads
 // A ring column is written and read by one wave only; T and the raw footprint are double-buffered across the barrier.
 template <int KH_T, int KV_T, int ABL>
-__device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, int vt1, u8 *smem, unsigned long long *dbg) {
+__device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restrict__ Dg, int strip, int vt0, int vt1, u8 *smem, unsigned long long *dbg) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: keeps per-wave addressing on the scalar unit)
     const bool is_conv = wave >= M_NT;
@@ -477,10 +489,23 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
     // (pass 2 takes the hi term of its weights only: its input rows are exact f16 and its result is rounded once, to 8 bits —
     //  on white noise the lo term moved 0.1 % of the bytes, the lo term of pass 1, whose result is rounded to f16, 1.4 %)
     uint4 bv[KV_N];
+    // direct output: the class of the 128x16 output tile this lane's four pixels of the next tile row fall into
+    constexpr bool DIRECT = (ABL & 2048) != 0;  // the direct-output build (the plain one carries none of its registers)
+    const bool dj = DIRECT && Dg != nullptr && J.layer >= 0;  // (uniform)
+    const int d_ox = J.ox, d_oy = J.oy, d_layer = J.layer;
+    u32 cls_next = 0xffu;
     auto fetch_bv = [&](int t) {
 #pragma unroll
         for (int j = 0; j < KV_N; j++)
             if (j < KV) bv[j] = v_frag[((size_t)t * 2 * KV + j) * 64 + lane];
+        if (dj) {
+            const MDirect *Dp = Dg;
+            asm volatile("" : "+s"(Dp));  // read the record where it is used: it must not sit in scalar registers for the whole piece
+            const int X = d_ox + tx0 + 4 * lq, Y = d_oy + 16 * t + l16;
+            const bool in = 16 * t + l16 < d_h && tx0 + 4 * lq < d_w && X >= 0 && Y >= 0 && X < Dp->yp.w && Y < Dp->yp.h;
+            cls_next = Dp->cls[in ? (Y >> 4) * Dp->tiles_x + (X >> 7) : 0];
+            cls_next = in ? cls_next : 0xffu;
+        }
     };
     fetch_bv(vt0);
     __syncthreads();  // (pairs with the convert waves' prologue barrier)
@@ -549,23 +574,71 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, int strip, int vt0, in
                     // the next tile's weights, before the stores below enter the memory queue: on gfx950 a wait for a load drains
                     // the stores issued before it too (one counter)
                     mark(3);
+                    const bool direct = cls_next == (u32)d_layer;  // (false everywhere unless dj: d_layer >= 0 never equals 0xff.. see host)
                     fetch_bv(min(vt + 1, vt1));
                     // lane holds columns tx0 + 4 lq .. + 3 of output row 16 vt + l16
                     const int y = 16 * vt + l16, x = tx0 + 4 * lq;
                     if (ablate & 8) {  // profiling: no encode, one dword store keeps the MFMAs alive
                         if (y < d_h && x < d_w) *(float *)(d_ptr + (size_t)y * d_pitch + (size_t)x * 4) = acc[0][0] + acc[1][1] + acc[2][2] + acc[0][3];
-                    } else if (y < d_h && x < d_w) {
+                    } else {
                         u32 px[4];
 #pragma unroll
                         for (int i = 0; i < 4; i++)
                             px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
-                        u8 *o = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
-                        if (x + 3 < d_w) {
-                            *(uint4 *)o = make_uint4(px[0], px[1], px[2], px[3]);
-                        } else {
+                        if (dj) {
+                            // rgba_to_yuv.wgsl:26-54 on the bytes above, operation for operation as k_compose_output's copy tiles
+                            // (smr_fused_compose.h): unorm -> BT.709 -> unorm8.  byte / 255 by div_cr is the IEEE quotient for every byte.
+                            // Chroma = the mean of a 2x2 block, (a/2 + b/2)/2 + (c/2 + d/2)/2 (the halvings are exact, either sum
+                            // commutes): the two rows of a block sit in neighbouring lanes (l16 even / odd; the tile's output
+                            // position is even).  The even row's lane finishes the block of columns 0-1, the odd row's that of 2-3.
+                            // (A real two-trip loop: unrolled, the twelve unpacked channels pushed the kernel over its 80 registers.)
+                            const bool odd = (l16 & 1) != 0;
+                            u32 yq = 0;
+                            float own_r = 0.f, own_g = 0.f, own_b = 0.f, snd_r = 0.f, snd_g = 0.f, snd_b = 0.f;
+#pragma nounroll
+                            for (int p = 0; p < 2; p++) {
+                                const u32 pa = p ? px[2] : px[0], pb = p ? px[3] : px[1];
+                                const float ar = div_cr((float)(pa & 0xffu), 255.0f, 1.0f / 255.0f), ag = div_cr((float)((pa >> 8) & 0xffu), 255.0f, 1.0f / 255.0f),
+                                            ab = div_cr((float)((pa >> 16) & 0xffu), 255.0f, 1.0f / 255.0f);
+                                const float br = div_cr((float)(pb & 0xffu), 255.0f, 1.0f / 255.0f), bg = div_cr((float)((pb >> 8) & 0xffu), 255.0f, 1.0f / 255.0f),
+                                            bb = div_cr((float)((pb >> 16) & 0xffu), 255.0f, 1.0f / 255.0f);
+                                const u32 y2 = unorm8(yuv_component(make_float4(ar, ag, ab, 0.0f), 0)) | (unorm8(yuv_component(make_float4(br, bg, bb, 0.0f), 0)) << 8);
+                                yq |= y2 << (16 * p);
+                                const float hr = ar * 0.5f + br * 0.5f, hg = ag * 0.5f + bg * 0.5f, hb = ab * 0.5f + bb * 0.5f;
+                                const bool mine_here = (p == 1) == odd;  // this lane finishes block p, the neighbour the other one
+                                own_r = mine_here ? hr : own_r; own_g = mine_here ? hg : own_g; own_b = mine_here ? hb : own_b;
+                                snd_r = mine_here ? snd_r : hr; snd_g = mine_here ? snd_g : hg; snd_b = mine_here ? snd_b : hb;
+                            }
+                            const float nb_r = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_r), 0xb1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+                            const float nb_g = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_g), 0xb1, 0xf, 0xf, true));
+                            const float nb_b = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_b), 0xb1, 0xf, 0xf, true));
+                            const float4 m = make_float4(own_r * 0.5f + nb_r * 0.5f, own_g * 0.5f + nb_g * 0.5f, own_b * 0.5f + nb_b * 0.5f, 0.0f);
+                            const u32 mine = unorm8(yuv_component(m, 1)) | (unorm8(yuv_component(m, 2)) << 8);  // (U, V) of this lane's block
+                            const u32 other = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0xb1, 0xf, 0xf, true);
+                            if (direct) {
+                                const MDirect *Dp = Dg;
+                                asm volatile("" : "+s"(Dp));
+                                const int X = d_ox + x, Y = d_oy + y;
+                                *(u32 *)(Dp->yp.ptr + (size_t)Y * Dp->yp.pitch + X) = yq;
+                                const int cx = X >> 1, cy = Y >> 1;
+                                if (Dp->nv) {  // U0 V0 U1 V1
+                                    if (!odd) *(u32 *)(Dp->up.ptr + (size_t)cy * Dp->up.pitch + (size_t)cx * 2) = (mine & 0xffffu) | (other << 16);
+                                } else if (!odd) {
+                                    *(u16 *)(Dp->up.ptr + (size_t)cy * Dp->up.pitch + cx) = (u16)((mine & 0xffu) | ((other & 0xffu) << 8));
+                                } else {
+                                    *(u16 *)(Dp->vp.ptr + (size_t)cy * Dp->vp.pitch + cx) = (u16)(((other >> 8) & 0xffu) | (mine & 0xff00u));
+                                }
+                            }
+                        }
+                        if (!direct && y < d_h && x < d_w) {
+                            u8 *o = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
+                            if (x + 3 < d_w) {
+                                *(uint4 *)o = make_uint4(px[0], px[1], px[2], px[3]);
+                            } else {
 #pragma unroll
-                            for (int i = 0; i < 4; i++)
-                                if (x + i < d_w) ((u32 *)o)[i] = px[i];
+                                for (int i = 0; i < 4; i++)
+                                    if (x + i < d_w) ((u32 *)o)[i] = px[i];
+                            }
                         }
                     }
                     mark(4);
@@ -611,7 +684,7 @@ __global__ __launch_bounds__(M_THREADS, KH_T ? M_WAVES / 2 : M_WAVES / 4) void k
             u32 *z = (u32 *)(smem + L.t);
             for (int i = tid; i < (L.raw - L.t) / 4; i += M_THREADS) z[i] = 0u;
         }
-        mfma_piece<KH_T, KV_T, ABL>(J, strip, vt0, vt1, smem, dbg);
+        mfma_piece<KH_T, KV_T, ABL>(J, args.direct, strip, vt0, vt1, smem, dbg);
         u += vt1 - vt0 + 1;
         first = false;
     }
@@ -666,6 +739,7 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.v_meta = bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_tiles;
     J.strips_x = (bh.n_tiles + M_NT - 1) / M_NT;
     J.ablate = ctx->ablate;
+    J.layer = -1; J.ox = 0; J.oy = 0;
     // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
     const int taps_h = host_taps(plan.scale[0]);
     int ngm = 1;
@@ -700,12 +774,12 @@ constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>,  k_ingest_mfma<3, 2,
                                     k_ingest_mfma<3, 2, 1024>, k_ingest_mfma<3, 2, 1088>, k_ingest_mfma<3, 2, 3>, k_ingest_mfma<3, 2, 9>, k_ingest_mfma<3, 2, 13>,
                                     k_ingest_mfma<3, 2, 8>, k_ingest_mfma<3, 2, 256>, k_ingest_mfma<3, 2, 512>, k_ingest_mfma<3, 2, 768>, k_ingest_mfma<3, 2, 39>};
 #else
-constexpr int M_ABL[] = {0, 0};
-constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>, k_ingest_mfma<3, 2, 0>};
+constexpr int M_ABL[] = {0, 0, 2048, 2048};
+constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>, k_ingest_mfma<3, 2, 0>, k_ingest_mfma<0, 0, 2048>, k_ingest_mfma<3, 2, 2048>};
 #endif
 constexpr int M_NKERNELS = (int)(sizeof(M_KERNELS) / sizeof(M_KERNELS[0]));
 
-int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
+int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs, const MDirect *direct = nullptr) {
     if (!ctx->mfma_attr_set) {  // per device, hence per ctx
         for (MfmaKernel k : M_KERNELS) {
             SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -733,11 +807,17 @@ int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs) {
         }
         args.unit_prefix[nj] = total;
         args.n_jobs = (int)nj;
+        args.direct = direct;
         bool all32 = true;
         for (size_t j = 0; j < nj; j++) all32 = all32 && args.jobs[j].KH == 3 && args.jobs[j].KV == 2;
         int ki = all32 ? 1 : 0;
+#ifdef SMR_ABLATION_BUILDS
         for (int i = 2; i < M_NKERNELS; i++)
             if (all32 && ctx->ablate == M_ABL[i]) ki = i;
+        if (direct) return smr_fail(ctx, SMR_ERR_INTERNAL, "direct output is not part of the ablation builds");
+#else
+        if (direct) ki += 2;
+#endif
         const MfmaKernel kern = M_KERNELS[ki];
         // as many workgroups as are resident at once (LDS and registers), minus the share left to the other stream's compose kernel
         int per_cu = 0;

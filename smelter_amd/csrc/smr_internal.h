@@ -123,6 +123,11 @@ struct smr_ctx {
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
+    bool direct_output = false;  // SMR_OPT_DIRECT_OUTPUT: wave A writes Y'CbCr for the compositor's copy tiles of a scene at rest
+    std::vector<uint8_t> class_key;  // the layout list the tile classes in d_tile_class were (or will be) computed for
+    bool class_ready = false;
+    uint8_t *d_tile_class = nullptr;
+    size_t d_tile_class_bytes = 0;
     int force_tw = 0;         // SMR_INGEST_TW (tests / profiling): strip width of k_ingest_resample, 0 = automatic
 
     bool srgb() const { return mode == SMR_MODE_GPU_OPTIMIZED; }

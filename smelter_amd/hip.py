@@ -198,7 +198,7 @@ class Comm:
         if self.handle:
             self.lib.smr_comm_destroy(self.handle)
             self.handle = None
-OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH = 0, 1
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT = 0, 1, 2
 
 
 class Context:
@@ -245,6 +245,10 @@ class Context:
     def set_ingest_impl(self, impl: int):
         """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (SMR_OPT_INGEST_IMPL)."""
         self.set_option(OPT_INGEST_IMPL, impl)
+
+    def set_direct_output(self, on: bool):
+        """SMR_OPT_DIRECT_OUTPUT: let the resampling kernel write Y'CbCr for the compositor's copy tiles of a scene at rest (default off)."""
+        self.set_option(OPT_DIRECT_OUTPUT, 1 if on else 0)
 
     def set_strip_width(self, tw: int):
         """0 (automatic), 32 or 64: strip width of the f32 ingest kernel (SMR_OPT_INGEST_STRIP_WIDTH)."""

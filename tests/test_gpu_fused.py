@@ -501,3 +501,67 @@ def test_full_size_properties(ctx, ctx_unfused, hip):
     want_full, _ = refpipe.render_yuv420(layouts, nodes_full, W, H, omp=True)
     for g, w_ in zip(a, want_full):
         assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.995
+
+
+DIRECT_CASES = [
+    ("cfg2_small", lambda: scenes.cfg2_scene(320, 180, 640, 360, 4), 320, 180, 640, 360),
+    ("cfg3_small", lambda: scenes.cfg3_scene(480, 270, 960, 540, 8), 480, 270, 960, 540),
+    ("cfg3_odd_positions", lambda: scenes.cfg3_scene(482, 274, 1000, 562, 5), 482, 274, 1000, 562),
+    ("cfg3_1080p", lambda: scenes.cfg3_scene(960, 540, 1920, 1080, 8), 960, 540, 1920, 1080),
+]
+
+
+@pytest.mark.parametrize("fmt_name", ["planar", "nv12"])
+@pytest.mark.parametrize("name,mk,iw,ih,W,H", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
+def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih, W, H, fmt_name):
+    """SMR_OPT_DIRECT_OUTPUT: from the second frame of an unchanged layout list on, the resampling kernel writes the Y'CbCr of the
+    compositor's copy tiles itself and their RGBA8 texels are never stored.  Every frame must equal the first one (rendered through
+    the RGBA8 tile) and the frames of a context with the option off, byte for byte; the output frames start out poisoned, so a
+    tile neither kernel wrote would show."""
+    fmt = hip.FRAME_PLANAR_YUV420 if fmt_name == "planar" else hip.FRAME_NV12
+    layouts, res = mk()
+    c_on, c_off = hip.Context(0), hip.Context(0)
+    try:
+        c_on.set_ingest_impl(hip.INGEST_MFMA_F16)
+        c_off.set_ingest_impl(hip.INGEST_MFMA_F16)
+        c_on.set_direct_output(True)
+        c_off.set_direct_output(False)
+        n_in = sum(1 for r in res if r == (iw, ih))
+        planes, _ = _inputs(c_on, hip, n_in, iw, ih)
+        _, label_host = _label_surfaces(c_on, 1)
+
+        def frames_of(c):
+            srcs, k = [], 0
+            lt = c.surface_from(label_host)
+            for r in res:
+                if r == (iw, ih):
+                    srcs.append(c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[k])))
+                    k += 1
+                else:
+                    srcs.append(lt)
+            return srcs
+
+        def render(c, srcs, poison):
+            out = c.frame(fmt, W, H)
+            out.upload([np.full(p.shape, poison, np.uint8) for p in out.download()])
+            c.render_layouts(layouts, srcs, W, H, out=out)
+            return out.download()
+
+        s_on, s_off = frames_of(c_on), frames_of(c_off)
+        ref = render(c_off, s_off, 0x11)
+        for i in range(4):
+            got = render(c_on, s_on, 0x33 + i)
+            for g, w_, pl in zip(got, ref, "YUV"):
+                assert np.array_equal(g, w_), f"{name} frame {i} plane {pl}: {int((g != w_).sum())} bytes differ"
+        # new input content under the same layout list: still direct, still equal
+        planes2, _ = _inputs(c_on, hip, n_in, iw, ih, seed=99)
+        for f_on, f_off, p in zip([s for s, r in zip(s_on, res) if r == (iw, ih)], [s for s, r in zip(s_off, res) if r == (iw, ih)], planes2):
+            f_on.upload(list(p))
+            f_off.upload(list(p))
+        ref2, got2 = render(c_off, s_off, 0x55), render(c_on, s_on, 0x77)
+        for g, w_, pl in zip(got2, ref2, "YUV"):
+            assert np.array_equal(g, w_), f"{name} new content plane {pl}: {int((g != w_).sum())} bytes differ"
+        assert not all(np.array_equal(a, b) for a, b in zip(ref, ref2))
+    finally:
+        c_on.close()
+        c_off.close()
