@@ -200,6 +200,10 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
     ctx->debug_ingest = getenv("SMR_DEBUG_INGEST") != nullptr;
+    if (const char *e = getenv("SMR_COMPOSE_SLICES")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) ctx->compose_slices = v;
+    }
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&ctx->d_lut16, sizeof(lut16)) != hipSuccess ||
@@ -233,7 +237,13 @@ void smr_ctx_destroy(smr_ctx *ctx) {
         if (l.done) (void)hipEventDestroy(l.done);
     }
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-    if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
+    for (TileClassMap &m : ctx->class_maps) {
+        if (m.d_class) (void)hipFree(m.d_class);
+        if (m.d_direct) (void)hipFree(m.d_direct);
+        if (m.d_list) (void)hipFree(m.d_list);
+        if (m.h_count) (void)hipHostFree(m.h_count);
+        if (m.count_ev) (void)hipEventDestroy(m.count_ev);
+    }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -249,8 +259,6 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
         return SMR_OK;
     case SMR_OPT_DIRECT_OUTPUT:
         ctx->direct_output = value != 0;
-        ctx->class_ready = false;
-        ctx->class_key.clear();
         return SMR_OK;
     case SMR_OPT_INGEST_STRIP_WIDTH:
         if (value != 0 && value != 32 && value != 64) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: strip width %d", value);

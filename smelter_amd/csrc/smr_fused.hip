@@ -171,71 +171,83 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes + sizeof(MDirect), &packed);
     if (rc != SMR_OK) return rc;
     const u32 n_first = compose_order(packed, (int)b_tiles_x, (int)b_tiles_y, (ComposeOrder *)packed.extra_host);
-    const bool fuse_out = fused && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
-                          (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= B_MAX_LAYOUTS && packed.n_masks <= B_MAX_MASKS &&
-                          out->planes[0] && out->planes[1] &&
-                          (out->format == SMR_FRAME_NV12 || out->planes[2]);
+    const bool fits_b = fused && (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= B_MAX_LAYOUTS && packed.n_masks <= B_MAX_MASKS;
+    const bool fuse_yuv = fits_b && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
+                          out->planes[0] && out->planes[1] && (out->format == SMR_FRAME_NV12 || out->planes[2]);
+    const bool fuse_rgba = fits_b && out_rgba && !out && (((uintptr_t)out_rgba->ptr) % 16 == 0) && (out_rgba->pitch % 16 == 0);  // a node's RGBA8 texture
+    const bool fuse_out = fuse_yuv || fuse_rgba;
 
-    // ---- direct output: once a layout list repeats (a scene at rest), the tiles the compositor would only copy from a
-    //      resampled input are written as Y'CbCr by wave A itself and skipped by wave B (k_classify_tiles, MDirect).
-    //      A list seen for the first time renders the ordinary way; the class map is built when it comes back.
+    // ---- tile classes (k_classify_tiles): kept while a layout list repeats (a scene at rest; a few lists per context, so a
+    //      nested node and the root do not evict each other), recomputed when it changes.
+    //      With SMR_OPT_DIRECT_OUTPUT the tiles the compositor would only copy from an input resampled in this call are written
+    //      as Y'CbCr by wave A itself (MDirect) and skipped by wave B.
     MDirect direct;
     memset(&direct, 0, sizeof(direct));
     bool classify_now = false;
     unsigned long long direct_mask = 0;
-#ifdef SMR_ABLATION_BUILDS
-    const bool direct_allowed = false;
-#else
-    const bool direct_allowed = ctx->direct_output;
-#endif
-    if (fuse_out && direct_allowed && !mjobs.empty() && ctx->ablate == 0) {
-        unsigned long long mask = 0;
-        for (size_t j = 0; j < mjobs.size(); j++) {
-            const u32 li = mjob_layout[j];
-            const DevLayout &D = packed.host_layouts[li];
-            if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == mjobs[j].dst.ptr && D.ix % 4 == 0 &&
-                D.iy % 2 == 0) {
-                mask |= 1ull << li;
-                mjobs[j].layer = (int)li; mjobs[j].ox = D.ix; mjobs[j].oy = D.iy;
+    TileClassMap *cm = nullptr;
+    if (fuse_out) {
+#ifndef SMR_ABLATION_BUILDS
+        if (fuse_yuv && ctx->direct_output && ctx->ablate == 0) {
+            for (size_t j = 0; j < mjobs.size(); j++) {
+                const u32 li = mjob_layout[j];
+                const DevLayout &D = packed.host_layouts[li];
+                if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == mjobs[j].dst.ptr && D.ix % 4 == 0 &&
+                    D.iy % 2 == 0) {
+                    direct_mask |= 1ull << li;
+                    mjobs[j].layer = (int)li; mjobs[j].ox = D.ix; mjobs[j].oy = D.iy;
+                }
             }
         }
+#endif
         // key: everything the classification reads
         const size_t lb = (size_t)packed.n * sizeof(DevLayout), mb = (size_t)packed.n_masks * sizeof(DevMask);
-        std::vector<u8> key(lb + mb + 24);
+        std::vector<u8> &key = ctx->class_key_scratch;
+        key.resize(lb + mb + 24);
         memcpy(key.data(), packed.host_layouts, lb);
         if (mb) memcpy(key.data() + lb, packed.host_masks, mb);
         const u32 tail[4] = {out_w, out_h, (u32)packed.n, (u32)packed.n_masks};
         memcpy(key.data() + lb + mb, tail, 16);
-        memcpy(key.data() + lb + mb + 16, &mask, 8);
-        bool use = false;
-        if (mask && key == ctx->class_key) {
-            if (!ctx->class_ready) {
-                if (ctx->d_tile_class_bytes < b_tiles) {
-                    if (ctx->d_tile_class) (void)hipFree(ctx->d_tile_class);
-                    ctx->d_tile_class = nullptr; ctx->d_tile_class_bytes = 0;
-                    SMR_HIP(ctx, hipMalloc((void **)&ctx->d_tile_class, b_tiles));
-                    ctx->d_tile_class_bytes = b_tiles;
-                }
-                classify_now = true;  // (after the layout list is on the device)
-                direct_mask = mask;
-                ctx->class_ready = true;
-            }
-            use = true;
-        } else {
-            ctx->class_key.swap(key);
-            ctx->class_ready = false;
+        memcpy(key.data() + lb + mb + 16, &direct_mask, 8);
+        if (ctx->class_maps.empty()) ctx->class_maps.resize(4);
+        ctx->class_clock++;
+        TileClassMap *lru = &ctx->class_maps[0];
+        for (TileClassMap &m : ctx->class_maps) {
+            if (m.ready && m.key == key) { cm = &m; break; }
+            if (m.last_use < lru->last_use) lru = &m;
         }
+        if (!cm) {
+            cm = lru;
+            if (cm->n < b_tiles) {
+                if (cm->d_class) (void)hipFree(cm->d_class);
+                if (cm->d_direct) (void)hipFree(cm->d_direct);
+                if (cm->d_list) (void)hipFree(cm->d_list);
+                cm->d_class = nullptr; cm->d_direct = nullptr; cm->d_list = nullptr; cm->n = 0;
+                SMR_HIP(ctx, hipMalloc((void **)&cm->d_class, (size_t)b_tiles * sizeof(TileClass)));
+                SMR_HIP(ctx, hipMalloc((void **)&cm->d_direct, b_tiles));
+                SMR_HIP(ctx, hipMalloc((void **)&cm->d_list, sizeof(TileList) + (size_t)b_tiles * 4));
+                cm->n = b_tiles;
+            }
+            if (!cm->h_count) {
+                SMR_HIP(ctx, hipHostMalloc((void **)&cm->h_count, 64, hipHostMallocDefault));
+                SMR_HIP(ctx, hipEventCreateWithFlags(&cm->count_ev, hipEventDisableTiming));
+            }
+            classify_now = true;  // (after the layout list is on the device)
+            cm->key = key;
+            cm->ready = true;
+            cm->count_known = false;
+            cm->class_serial++;
+        }
+        cm->last_use = ctx->class_clock;
         if (ctx->debug_ingest)
-            fprintf(stderr, "[smr] direct output: %zu resampled tiles, layer mask %llx, list %s, %s\n", mjobs.size(), mask,
-                    use ? "seen before" : "new", classify_now ? "classifying" : (use ? "class map cached" : "off this frame"));
-        if (use) {
-            direct.cls = ctx->d_tile_class;
+            fprintf(stderr, "[smr] tile classes: %s; direct output: layer mask %llx of %zu resampled tiles\n", classify_now ? "classifying" : "cached",
+                    direct_mask, mjobs.size());
+        if (direct_mask) {
+            direct.cls = cm->d_direct;
             direct.tiles_x = (int)b_tiles_x;
             direct.nv = out->format == SMR_FRAME_NV12 ? 1 : 0;
             direct.yp = view_of(out->planes[0]); direct.up = view_of(out->planes[1]);
             direct.vp = direct.nv ? direct.up : view_of(out->planes[2]);
-        } else {
-            for (MJob &J : mjobs) J.layer = -1;
         }
     }
     memcpy((u8 *)packed.extra_host + order_bytes, &direct, sizeof(direct));
@@ -243,9 +255,24 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     rc = smr_pack_commit(ctx, &packed);
     if (rc != SMR_OK) return rc;
     if (classify_now) {
+        SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_classify_tiles, dim3(b_tiles), dim3(64), 0, ctx->stream, packed.layouts, packed.masks, packed.n, (int)out_w, (int)out_h,
-                           (int)b_tiles_x, direct_mask, ctx->d_tile_class);
+                           (int)b_tiles_x, direct_mask, (TileClass *)cm->d_class, cm->d_direct, (TileList *)cm->d_list);
         SMR_HIP(ctx, hipGetLastError());
+    }
+    if (fuse_out) {
+        // the length of the list of tiles that need compositing comes back to the host for the frames that reuse these classes
+        // (never waited for: one copy in flight at a time, valid only if the map was not reclassified since it was issued)
+        if (cm->count_pending && hipEventQuery(cm->count_ev) == hipSuccess) {
+            cm->count_pending = false;
+            cm->count_known = cm->count_serial == cm->class_serial;
+        }
+        if (!cm->count_known && !cm->count_pending) {
+            SMR_HIP(ctx, hipMemcpyAsync(cm->h_count, cm->d_list, 4, hipMemcpyDeviceToHost, ctx->stream));
+            SMR_HIP(ctx, hipEventRecord(cm->count_ev, ctx->stream));
+            cm->count_pending = true;
+            cm->count_serial = cm->class_serial;
+        }
     }
 
     // ---- wave A (job descriptors ride in the kernel arguments)
@@ -261,18 +288,27 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- wave B (or the general compositor + output converters)
     if (fuse_out) {
         StageScope scope(ctx, SMR_STAGE_FUSED_COMPOSE);
-        // 1-D grid: the tiles the host expects to need the (latency-bound) general path go first, then every tile in order
-        dim3 grid(n_first + b_tiles, 1, 1);
-        const ComposeOrder *order = (const ComposeOrder *)packed.extra_dev;
-        SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
-        if (out->format == SMR_FRAME_NV12) {
-            hipLaunchKernelGGL(k_compose_output<1>, grid, dim3(256), 0, ctx->stream, yp, up, up, (int)out_w, (int)out_h, packed.layouts,
-                               packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables, order,
-                               (int)b_tiles_x, direct.cls);
+        // 1-D grid: bands of the tiles that need the (latency-bound) general path first — as many as the class list holds when its
+        // length is known, as many as the host's own prediction says otherwise — then every tile in order
+        u32 n_banded = cm->count_known ? *cm->h_count : (n_first <= B_MAX_FIRST ? n_first : B_MAX_FIRST);
+        if (n_banded > b_tiles) n_banded = b_tiles;
+        dim3 grid(ctx->compose_slices * n_banded + (b_tiles + B_COPY_TILES - 1) / B_COPY_TILES, 1, 1);
+        const TileList *full = (const TileList *)cm->d_list;
+        const TileClass *tc = (const TileClass *)cm->d_class;
+        const int flags = (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8);
+        if (fuse_rgba) {
+            const SurfView t = view_of(out_rgba);
+            hipLaunchKernelGGL(k_compose_output<2>, grid, dim3(256), 0, ctx->stream, t, t, t, (int)out_w, (int)out_h, packed.layouts, packed.masks, packed.n,
+                               packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
+        } else if (out->format == SMR_FRAME_NV12) {
+            const SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
+            hipLaunchKernelGGL(k_compose_output<1>, grid, dim3(256), 0, ctx->stream, yp, up, up, (int)out_w, (int)out_h, packed.layouts, packed.masks,
+                               packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
         } else {
+            const SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
             hipLaunchKernelGGL(k_compose_output<0>, grid, dim3(256), 0, ctx->stream, yp, up, view_of(out->planes[2]), (int)out_w, (int)out_h,
-                               packed.layouts, packed.masks, packed.n, packed.n_masks, (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8), ctx->d_tables,
-                               order, (int)b_tiles_x, direct.cls);
+                               packed.layouts, packed.masks, packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full,
+                               (int)n_banded, ctx->compose_slices);
         }
         SMR_HIP(ctx, hipGetLastError());
         return smr_pack_done(ctx, &packed);

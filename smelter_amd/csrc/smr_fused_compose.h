@@ -28,8 +28,14 @@ static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS cop
 // overlap the copy tiles.  The host predicts them from the layout geometry — only the order depends on the prediction,
 // every workgroup still classifies its tile itself.
 constexpr u32 B_MAX_FIRST = 1024;
+// A tile that needs compositing is rendered by B_SLICES workgroups, each taking a band of B_TILE_H / B_SLICES rows of it (classified
+// on its own, like a small tile): the general path is one pixel per thread and pure latency, so a band costs one sweep instead of eight.
+// Measured on configs[2] (kernel incl. ~6 us of stage timer, frames/s one / three in flight): 1 band 41.8 us, 10.1k / 13.9k;
+// 2 bands 29.2 us, 11.7k / 13.3k; 4 bands 30.1 us, 11.5k / 13.0k; 8 bands 33.6 us, 10.2k / 12.6k — every band repeats the
+// workgroup's fixed work (layout list, classification, tables), so two is the default.
+constexpr int B_SLICES = 2;  // ctx->compose_slices (1, 2, 4 or 8: a band holds whole 4x2 output blocks)
 struct ComposeOrder {
-    u32 n_first;             // workgroups [0, n_first) take first[]; workgroup n_first + t takes tile t unless it is in `taken`
+    u32 n_first;             // workgroups [0, B_SLICES * n_first) take the bands of first[]; workgroup B_SLICES * n_first + t takes tile t unless it is in `taken`
     u16 first[B_MAX_FIRST];  // linear tile indices
     u32 taken[1];            // bitmap over all tiles (really (tiles + 31) / 32 words)
 };
@@ -97,9 +103,10 @@ inline u32 compose_order(const PackedLayouts &p, int tiles_x, int tiles_y, Compo
             nf++;
         }
     }
-    if (nf > B_MAX_FIRST) {  // too many to matter: plain order
+    if (nf > B_MAX_FIRST) {  // too many to list
         for (int i = 0; i < words; i++) out->taken[i] = 0u;
-        nf = 0;
+        out->n_first = 0;
+        return B_MAX_FIRST + 1;
     }
     out->n_first = nf;
     return nf;
@@ -138,13 +145,33 @@ __device__ __forceinline__ void tile_needs(const u32 *s_touch, int start, int *s
     }
 }
 
-// Direct output (static scenes): the class of every tile, computed once per layout list.  cls[tile] = the start layer when the tile
-// is a copy tile of a texture layer in `direct_layers` (the tiles wave A resamples in the same call, at even output positions) —
-// wave A then writes that tile's Y'CbCr itself and k_compose_output skips it, so the RGBA8 bytes of those pixels never exist in
-// memory — else 0xff.  Same classification code as the compositor's, one 64-thread workgroup per tile.
+// The class of every 128x16 tile, computed once per layout list (smr_render_layouts keeps it while the list repeats — a scene at
+// rest — and recomputes it when the list changes): what k_compose_output needs to know to finish a copy tile without reading the
+// layout list at all.  Same classification code as the compositor's own (classify_layouts / tile_needs), one 64-thread workgroup
+// per tile.
+//   TC_CLEAR    no opaque layer and nothing touching: transparent black
+//   TC_COLOUR   an opaque colour, nothing above: px = its encoded bytes
+//   TC_TEXTURE  a 1:1 blit of an opaque texture, nothing above: base / pitch = the texel under the tile's top-left pixel
+//   TC_FULL     anything else: the compositor classifies and composites the tile itself; px = the tile's index in the list of
+//               such tiles (TileList), which the compositor's first workgroups take band by band
+//   TC_SKIP     wave A writes the tile's Y'CbCr (direct output)
+enum { TC_CLEAR = 0, TC_COLOUR = 1, TC_TEXTURE = 2, TC_FULL = 3, TC_SKIP = 4 };
+struct alignas(16) TileClass {
+    const u8 *base;
+    u32 pitch_or_px;
+    u32 kind;
+};
+struct TileList {
+    u32 count;      // zeroed before k_classify_tiles
+    u32 tiles[1];   // really one per tile
+};
+// Direct output: direct[tile] = the start layer when the tile is a copy tile of a texture layer in `direct_layers` (the tiles wave A
+// resamples in the same call, at even output positions) — wave A then writes that tile's Y'CbCr itself, the RGBA8 bytes of those
+// pixels never exist in memory — else 0xff.
 constexpr u32 B_CLASS_NONE = 0xffu;
 __global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks, int n, int W, int H,
-                                                       int tiles_x, unsigned long long direct_layers, u8 *__restrict__ cls) {
+                                                       int tiles_x, unsigned long long direct_layers, TileClass *__restrict__ tc,
+                                                       u8 *__restrict__ direct, TileList *__restrict__ full) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;
     const int tid = threadIdx.x, tile = blockIdx.x;
@@ -156,11 +183,32 @@ __global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restri
     tile_needs(s_touch, start, &s_general, layouts, n, tid, 64);
     __syncthreads();
     if (tid == 0) {
-        u32 c = B_CLASS_NONE;
-        if (s_general == 0 && start >= 0 && start < 64 && layouts[start].type == 0 && ((direct_layers >> start) & 1ull) &&
-            tx0 + B_TILE_W <= W && ty0 + B_TILE_H <= H)
-            c = (u32)start;
-        cls[tile] = (u8)c;
+        TileClass c;
+        c.base = nullptr; c.pitch_or_px = 0u; c.kind = TC_FULL;
+        u32 d = B_CLASS_NONE;
+        if (s_general == 0) {
+            if (start < 0) {
+                c.kind = TC_CLEAR;
+            } else if (layouts[start].type != 0) {
+                c.kind = TC_COLOUR;
+                c.pitch_or_px = layouts[start].solid_px;
+            } else {
+                const DevLayout &L = layouts[start];
+                c.kind = TC_TEXTURE;
+                c.base = L.src.ptr + (ptrdiff_t)(ty0 - L.iy) * (ptrdiff_t)L.src.pitch + (ptrdiff_t)(tx0 - L.ix) * 4;
+                c.pitch_or_px = (u32)L.src.pitch;
+                if (start < 64 && ((direct_layers >> start) & 1ull) && tx0 + B_TILE_W <= W && ty0 + B_TILE_H <= H) {
+                    c.kind = TC_SKIP;
+                    d = (u32)start;
+                }
+            }
+        }
+        if (c.kind == TC_FULL) {
+            c.pitch_or_px = atomicAdd(&full->count, 1u);
+            full->tiles[c.pitch_or_px] = (u32)tile;
+        }
+        tc[tile] = c;
+        direct[tile] = (u8)d;
     }
 }
 
@@ -221,167 +269,21 @@ __device__ __forceinline__ u32 compose_px(u32 a, const DevLayout &L, const DevMa
     return blend_store(a, frag, srgb, dec, thr);
 }
 
-// NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV)
 template <int NV>
-__global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
-                                                        const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
-                                                        int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
-                                                        const ComposeOrder *__restrict__ order, int tiles_x, const u8 *__restrict__ cls) {
-    __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
-    __shared__ int s_start, s_general;
-    __shared__ float s_tab[SMR_TABLE_FLOATS];
-    __shared__ u32 s_px[B_TILE_W * B_TILE_H];  // general tiles: composited RGBA8
-    // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
-    // dependent scalar-memory round trip per field per layer per wave
-    __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
-    __shared__ __attribute__((aligned(16))) DevMask s_mask[B_MAX_MASKS];
-    const int tid = threadIdx.x;
-    // which tile: the host's "general path first" list, then every tile not in it, in row-major order
-    int tile = (int)blockIdx.x - (int)order->n_first;
-    if (tile < 0) tile = order->first[blockIdx.x];
-    else if ((order->taken[tile >> 5] >> (tile & 31)) & 1u) return;
-    if (cls && cls[tile] != B_CLASS_NONE) return;  // direct output: wave A wrote this tile's Y'CbCr
-    {
-        const uint4 *gl = (const uint4 *)layouts_g;
-        uint4 *ll = (uint4 *)s_lay;
-        for (int i = tid; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
-        const uint4 *gm = (const uint4 *)masks_g;
-        uint4 *lm = (uint4 *)s_mask;
-        for (int i = tid; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
+__device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, int py0, const SurfView &yp, const SurfView &up, const SurfView &vp) {
+    if (NV == 2) {  // an RGBA8 node texture (LayoutNode::render into a NodeTexture): the composited bytes as they are
+        u8 *o = yp.ptr + (size_t)py0 * yp.pitch + (size_t)px0 * 4;
+        *(uint4 *)o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        *(uint4 *)(o + yp.pitch) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+        return;
     }
-    const DevLayout *layouts = s_lay;
-    const DevMask *masks = s_mask;
-    const int srgb = srgb_and_ablate & 1;
-    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
-    if (ablate & 1) return;
-    const int tile_y = tile / tiles_x;
-    const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H;
-    if (tid == 0) s_general = 0;
-    classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + B_TILE_H, H), tid, 256);
-    const int start = s_start;
-    // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
-    tile_needs(s_touch, start, &s_general, layouts, n, tid, 256);
-    __syncthreads();
-    const bool general = (s_general & 1) != 0;
-    const bool sampled = s_general == 2;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)
-    if (ablate & 2) return;
-    if ((ablate & 16) && general) return;   // profiling: copy tiles only
-    if ((ablate & 32) && !general) return;  // profiling: general tiles only
-    const int words = (n + 31) >> 5;
-    const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);  // this thread's 4x2 output block
-    u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};                     // [row][col]: acc[r * 4 + c]
-
-    if (general) {
-        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
-        __syncthreads();
-        const float *dec = s_tab, *thr = s_tab + 256;
-        // ---- one pixel per thread and sweep (a wave covers 64 consecutive pixels of one row); layers are the OUTER loop:
-        //      a layer's record is pulled into scalar registers once per wave and then applied to the wave's 8 sweeps.
-        //      Per-pixel state lives in LDS: s_px = running RGBA8, s_sp = per-pixel start layer.
-        constexpr int SWEEPS = (B_TILE_W * B_TILE_H) / 256;
-        __shared__ short s_sp[B_TILE_W * B_TILE_H];
-        __shared__ u32 s_raw[B_TILE_W * B_TILE_H];  // prefetched texels of the aligned texture layer being applied
-#pragma unroll 1
-        for (int sweep = 0; sweep < SWEEPS; sweep++) {
-            s_px[sweep * 256 + tid] = 0u;
-            s_sp[sweep * 256 + tid] = (short)start;
-        }
-        // (each thread only ever touches its own 8 pixels of s_px / s_sp: no barrier needed until the conversion phase)
-        // -- per-pixel start: the topmost touched layer above the tile's start whose solid region holds the pixel
-        for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {
-            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
-            if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
-            while (bits) {
-                const int b = 31 - __builtin_clz(bits);
-                bits &= ~(1u << b);
-                const int li = (wi << 5) + b;
-                const DevLayout L = load_uniform(&layouts[li]);
-                if (!layout_base_opaque(L) || !(L.flags & DL_UNROTATED)) continue;
-#pragma unroll 1
-                for (int sweep = 0; sweep < SWEEPS; sweep++) {
-                    const int idx = sweep * 256 + tid;
-                    const float fx = (float)(tx0 + (idx & (B_TILE_W - 1))) + 0.5f, fy = (float)(ty0 + (idx >> 7)) + 0.5f;
-                    if (s_sp[idx] == (short)start && layout_solid_box(L, masks, fx, fy, fx, fy)) s_sp[idx] = (short)li;
-                }
-            }
-        }
-        // -- composite upwards from the tile's start; a pixel joins at its own start layer
-        for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
-            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
-            if (start >= 0 && wi == (start >> 5)) bits &= ~((1u << (start & 31)) - 1u);
-            while (bits) {
-                const int li = (wi << 5) + __builtin_ctz(bits);
-                bits &= bits - 1;
-                const DevLayout L = load_uniform(&layouts[li]);
-                if (L.type == 0 && (L.flags & DL_ALIGNED) && L.src_kind != 0) {
-                    // aligned texture layer: all eight texel fetches of this thread are in flight together instead of one
-                    // exposed global-memory round trip per sweep (the addresses are clamped, so every lane may load)
-                    u32 pre[SWEEPS];
-#pragma unroll
-                    for (int sweep = 0; sweep < SWEEPS; sweep++) {
-                        const int idx = sweep * 256 + tid;
-                        pre[sweep] = aligned_texel(L, tx0 + (idx & (B_TILE_W - 1)), ty0 + (idx >> 7));
-                    }
-#pragma unroll
-                    for (int sweep = 0; sweep < SWEEPS; sweep++) s_raw[sweep * 256 + tid] = pre[sweep];
-                }
-#pragma unroll 1
-                for (int sweep = 0; sweep < SWEEPS; sweep++) {
-                    const int idx = sweep * 256 + tid;
-                    const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
-                    const int sp = s_sp[idx];
-                    if (px < W && py < H && li >= sp && !((ablate & 8) && li != sp))
-                        s_px[idx] = compose_px(s_px[idx], L, masks, px, py, li == sp, s_raw[idx], srgb, dec, thr);
-                }
-            }
-        }
-        __syncthreads();
-        if (px0 >= W || py0 >= H) return;
-        const int lx0 = px0 - tx0, ly0 = py0 - ty0;
-        const uint4 t0 = *(const uint4 *)&s_px[ly0 * B_TILE_W + lx0], t1 = *(const uint4 *)&s_px[(ly0 + 1) * B_TILE_W + lx0];
-        acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
-        acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
-    } else if (sampled) {
-        // ---- sampled tiles: the whole tile lies in the solid region of one opaque texture layer that is not a texel-aligned
-        //      blit (a video tile at a fractional position or another scale — every tile of a grid in mid-transition) and
-        //      nothing above touches it.  Per pixel this is exactly what the general path does for such a layer (coverage is
-        //      certain, the fragment is the sample, blended over the cleared target), without the per-pixel start search, the
-        //      LDS-resident running colour and the one-pixel-at-a-time sweeps: the eight pixels of a thread's 4x2 block are
-        //      independent, so their texel fetches overlap.
-        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
-        __syncthreads();
-        if (px0 >= W || py0 >= H) return;
-        const float *dec = s_tab, *thr = s_tab + 256;
-        const DevLayout L = load_uniform(&layouts[start]);
-#pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(0u, L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
-    } else {
-        if (px0 >= W || py0 >= H) return;  // W % 4 == 0, H % 2 == 0: a block is entirely inside or outside
-        if (start >= 0) {
-            const DevLayout &L = layouts[start];
-            if (L.type != 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
-            } else {
-                // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
-                const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
-                const u8 *r1 = r0 + L.src.pitch;
-                if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
-                    const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
-                    acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
-                    acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
-                }
-            }
-        }
-    }
-
     // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52
+    // (byte / 255 by div_cr: the IEEE quotient for every byte, three operations instead of a division)
     float4 c[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) c[k] = unpack_unorm(acc[k]);
+    for (int k = 0; k < 8; k++)
+        c[k] = make_float4(div_cr((float)(acc[k] & 0xffu), 255.0f, 1.0f / 255.0f), div_cr((float)((acc[k] >> 8) & 0xffu), 255.0f, 1.0f / 255.0f),
+                           div_cr((float)((acc[k] >> 16) & 0xffu), 255.0f, 1.0f / 255.0f), 0.0f);
     u32 yrow0 = 0, yrow1 = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -411,6 +313,253 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     } else {
         *(u32 *)(up.ptr + (size_t)cy * up.pitch + (size_t)cx * 2) = uv[0][0] | (uv[0][1] << 8) | (uv[1][0] << 16) | (uv[1][1] << 24);
     }
+}
+
+// Rows [band, band + rh) of tile `tile`, classified and composited by the whole workgroup (uniform call; may be called again).
+// NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV); NV = 2: RGBA8 surface (in `yp`)
+template <int NV>
+__device__ __forceinline__ void compose_full(int tile, int band, int rh, const SurfView &yp, const SurfView &up, const SurfView &vp, int W, int H,
+                                             const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g, int n, int n_masks,
+                                             int srgb_and_ablate, const float *__restrict__ tables, int tiles_x) {
+    __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
+    __shared__ int s_start, s_general;
+    __shared__ float s_tab[SMR_TABLE_FLOATS];
+    __shared__ u32 s_px[B_TILE_W * B_TILE_H];  // general tiles: composited RGBA8
+    // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
+    // dependent scalar-memory round trip per field per layer per wave
+    __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
+    __shared__ __attribute__((aligned(16))) DevMask s_mask[B_MAX_MASKS];
+    const int tid = threadIdx.x;
+    u32 acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // this thread's 4x2 output block, [row][col]: acc[r * 4 + c]
+    const int tile_y = tile / tiles_x;
+    const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H + band;
+    const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);  // this thread's 4x2 output block
+    __syncthreads();  // (a previous call's readers of the shared tile are done)
+    {
+        const uint4 *gl = (const uint4 *)layouts_g;
+        uint4 *ll = (uint4 *)s_lay;
+        for (int i = tid; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
+        const uint4 *gm = (const uint4 *)masks_g;
+        uint4 *lm = (uint4 *)s_mask;
+        for (int i = tid; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
+    }
+    const DevLayout *layouts = s_lay;
+    const DevMask *masks = s_mask;
+    const int srgb = srgb_and_ablate & 1;
+    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
+    if (ablate & 1) return;
+    if (ty0 >= H) return;
+    if (tid == 0) s_general = 0;
+    classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + rh, H), tid, 256);
+    const int start = s_start;
+    // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
+    tile_needs(s_touch, start, &s_general, layouts, n, tid, 256);
+    __syncthreads();
+    const bool general = (s_general & 1) != 0;
+    const bool sampled = s_general == 2;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)
+    if (ablate & 2) return;
+    if ((ablate & 16) && general) return;   // profiling: copy tiles only
+    if ((ablate & 32) && !general) return;  // profiling: general tiles only
+    const int words = (n + 31) >> 5;
+    const bool no_block = px0 >= W || py0 >= H || 2 * (tid >> 5) >= rh;      // (W % 4 == 0, H % 2 == 0: a block is entirely inside or outside)
+    const int nsweeps = (B_TILE_W * rh) / 256;
+
+    if (general) {
+        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
+        __syncthreads();
+        const float *dec = s_tab, *thr = s_tab + 256;
+        // ---- one pixel per thread and sweep (a wave covers 64 consecutive pixels of one row); layers are the OUTER loop:
+        //      a layer's record is pulled into scalar registers once per wave and then applied to the wave's 8 sweeps.
+        //      Per-pixel state lives in LDS: s_px = running RGBA8, s_sp = per-pixel start layer.
+        constexpr int SWEEPS = (B_TILE_W * B_TILE_H) / 256;
+        __shared__ short s_sp[B_TILE_W * B_TILE_H];
+        __shared__ u32 s_raw[B_TILE_W * B_TILE_H];  // prefetched texels of the aligned texture layer being applied
+#pragma unroll 1
+        for (int sweep = 0; sweep < nsweeps; sweep++) {
+            s_px[sweep * 256 + tid] = 0u;
+            s_sp[sweep * 256 + tid] = (short)start;
+        }
+        // (each thread only ever touches its own 8 pixels of s_px / s_sp: no barrier needed until the conversion phase)
+        // -- per-pixel start: the topmost touched layer above the tile's start whose solid region holds the pixel
+        for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {
+            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
+            if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
+            while (bits) {
+                const int b = 31 - __builtin_clz(bits);
+                bits &= ~(1u << b);
+                const int li = (wi << 5) + b;
+                const DevLayout L = load_uniform(&layouts[li]);
+                if (!layout_base_opaque(L) || !(L.flags & DL_UNROTATED)) continue;
+#pragma unroll 1
+                for (int sweep = 0; sweep < nsweeps; sweep++) {
+                    const int idx = sweep * 256 + tid;
+                    const float fx = (float)(tx0 + (idx & (B_TILE_W - 1))) + 0.5f, fy = (float)(ty0 + (idx >> 7)) + 0.5f;
+                    if (s_sp[idx] == (short)start && layout_solid_box(L, masks, fx, fy, fx, fy)) s_sp[idx] = (short)li;
+                }
+            }
+        }
+        // -- composite upwards from the tile's start; a pixel joins at its own start layer
+        for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
+            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
+            if (start >= 0 && wi == (start >> 5)) bits &= ~((1u << (start & 31)) - 1u);
+            while (bits) {
+                const int li = (wi << 5) + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const DevLayout L = load_uniform(&layouts[li]);
+                if (L.type == 0 && (L.flags & DL_ALIGNED) && L.src_kind != 0) {
+                    // aligned texture layer: all eight texel fetches of this thread are in flight together instead of one
+                    // exposed global-memory round trip per sweep (the addresses are clamped, so every lane may load)
+                    u32 pre[SWEEPS];
+#pragma unroll
+                    for (int sweep = 0; sweep < SWEEPS; sweep++) {
+                        const int idx = sweep * 256 + tid;
+                        if (sweep < nsweeps) pre[sweep] = aligned_texel(L, tx0 + (idx & (B_TILE_W - 1)), ty0 + (idx >> 7));
+                    }
+#pragma unroll
+                    for (int sweep = 0; sweep < SWEEPS; sweep++)
+                        if (sweep < nsweeps) s_raw[sweep * 256 + tid] = pre[sweep];
+                }
+#pragma unroll 1
+                for (int sweep = 0; sweep < nsweeps; sweep++) {
+                    const int idx = sweep * 256 + tid;
+                    const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
+                    const int sp = s_sp[idx];
+                    if (px < W && py < H && li >= sp && !((ablate & 8) && li != sp))
+                        s_px[idx] = compose_px(s_px[idx], L, masks, px, py, li == sp, s_raw[idx], srgb, dec, thr);
+                }
+            }
+        }
+        __syncthreads();
+        if (!no_block) {
+            const int lx0 = px0 - tx0, ly0 = py0 - ty0;
+            const uint4 t0 = *(const uint4 *)&s_px[ly0 * B_TILE_W + lx0], t1 = *(const uint4 *)&s_px[(ly0 + 1) * B_TILE_W + lx0];
+            acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+            acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+        }
+    } else if (sampled) {
+        // ---- sampled tiles: the whole tile lies in the solid region of one opaque texture layer that is not a texel-aligned
+        //      blit (a video tile at a fractional position or another scale — every tile of a grid in mid-transition) and
+        //      nothing above touches it.  Per pixel this is exactly what the general path does for such a layer (coverage is
+        //      certain, the fragment is the sample, blended over the cleared target), without the per-pixel start search, the
+        //      LDS-resident running colour and the one-pixel-at-a-time sweeps: the eight pixels of a thread's 4x2 block are
+        //      independent, so their texel fetches overlap.
+        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
+        __syncthreads();
+        const float *dec = s_tab, *thr = s_tab + 256;
+        const DevLayout L = load_uniform(&layouts[start]);
+        if (!no_block) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(0u, L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
+        }
+    } else {
+        if (!no_block && start >= 0) {
+            const DevLayout &L = layouts[start];
+            if (L.type != 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
+            } else {
+                // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
+                const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
+                const u8 *r1 = r0 + L.src.pitch;
+                if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
+                    const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
+                    acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+                    acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
+                }
+            }
+        }
+    }
+
+    if (!no_block) store_yuv_block<NV>(acc, px0, py0, yp, up, vp);
+}
+
+// Copy tiles per workgroup of the kernel's second part (their records, then all their texels, are fetched back to back).
+// Measured on configs[2]: 1 -> 29 us, 4 -> 37 us for the whole kernel — the conversion arithmetic of four tiles in one workgroup
+// outweighs the launches saved.
+constexpr int B_COPY_TILES = 1;
+
+template <int NV>
+__global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
+                                                        const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
+                                                        int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
+                                                        int tiles_x, int tiles, const TileClass *__restrict__ tc, const TileList *__restrict__ full,
+                                                        int n_banded, int slices) {
+    const int tid = threadIdx.x;
+    // The first `slices * n_banded` workgroups take the tiles that need compositing (TileList; the host sized the grid from the
+    // list's length when it knows it, from its own prediction otherwise), band by band — they are latency-bound and would be the
+    // tail of the kernel.  Every other workgroup takes B_COPY_TILES consecutive tiles of the row-major order.
+    const int rest = (int)blockIdx.x - slices * n_banded;
+    if (rest < 0) {
+        const u32 gi = blockIdx.x / (u32)slices;
+        if (gi >= full->count) return;
+        const int rh = B_TILE_H / slices;
+        compose_full<NV>((int)full->tiles[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
+                         tables, tiles_x);
+        return;
+    }
+    // ---- copy tiles, straight from their class records (k_classify_tiles): no layout list, no classification, no barrier
+    const int t0 = rest * B_COPY_TILES;
+    const int bx = 4 * (tid & 31), by = 2 * (tid >> 5);
+    TileClass c[B_COPY_TILES];
+#pragma unroll
+    for (int k = 0; k < B_COPY_TILES; k++) {
+        c[k] = tc[min(t0 + k, tiles - 1)];
+        if (t0 + k >= tiles) c[k].kind = TC_SKIP;
+    }
+    u32 acc[B_COPY_TILES][8];
+    bool on[B_COPY_TILES];
+    bool aligned = true;  // (uniform) every texture tile of the group can be read 16 bytes at a time
+#pragma unroll
+    for (int k = 0; k < B_COPY_TILES; k++) {
+        const int tile = t0 + k, ty = tile / tiles_x;
+        on[k] = c[k].kind <= TC_TEXTURE && !((srgb_and_ablate >> 8) & 64) && (tile - ty * tiles_x) * B_TILE_W + bx < W && ty * B_TILE_H + by < H;
+        if (c[k].kind == TC_TEXTURE && ((((uintptr_t)c[k].base) & 15) != 0 || (c[k].pitch_or_px & 15) != 0)) aligned = false;
+    }
+    if (aligned) {
+        // straight-line: the texel loads of all the group's tiles are in flight together (a lane with nothing to read reads the
+        // tables instead — no branch between the loads); 1:1 blit of an opaque texture: decode -> encode is the identity
+        uint4 ra[B_COPY_TILES], rb[B_COPY_TILES];
+#pragma unroll
+        for (int k = 0; k < B_COPY_TILES; k++) {
+            const bool tex = on[k] && c[k].kind == TC_TEXTURE;
+            const u8 *r0 = tex ? c[k].base + (size_t)by * c[k].pitch_or_px + (size_t)bx * 4 : (const u8 *)tables;
+            const u8 *r1 = tex ? r0 + c[k].pitch_or_px : (const u8 *)tables;
+            ra[k] = *(const uint4 *)r0;
+            rb[k] = *(const uint4 *)r1;
+        }
+#pragma unroll
+        for (int k = 0; k < B_COPY_TILES; k++) {
+            const bool tex = c[k].kind == TC_TEXTURE;
+            const u32 fill = c[k].kind == TC_COLOUR ? c[k].pitch_or_px : 0u;
+            acc[k][0] = tex ? ra[k].x : fill; acc[k][1] = tex ? ra[k].y : fill; acc[k][2] = tex ? ra[k].z : fill; acc[k][3] = tex ? ra[k].w : fill;
+            acc[k][4] = tex ? rb[k].x : fill; acc[k][5] = tex ? rb[k].y : fill; acc[k][6] = tex ? rb[k].z : fill; acc[k][7] = tex ? rb[k].w : fill;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < B_COPY_TILES; k++) {
+            const u32 fill = c[k].kind == TC_COLOUR ? c[k].pitch_or_px : 0u;
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc[k][q] = fill;
+            if (on[k] && c[k].kind == TC_TEXTURE) {
+                const u8 *r0 = c[k].base + (size_t)by * c[k].pitch_or_px + (size_t)bx * 4, *r1 = r0 + c[k].pitch_or_px;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { acc[k][q] = ((const u32 *)r0)[q]; acc[k][4 + q] = ((const u32 *)r1)[q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < B_COPY_TILES; k++) {
+        const int tile = t0 + k, ty = tile / tiles_x;
+        if (on[k]) store_yuv_block<NV>(acc[k], (tile - ty * tiles_x) * B_TILE_W + bx, ty * B_TILE_H + by, yp, up, vp);
+    }
+    // a tile that needs compositing and found no room on the band list (the host's bound was short): here, all sixteen rows
+#pragma unroll 1
+    for (int k = 0; k < B_COPY_TILES; k++)
+        if (c[k].kind == TC_FULL && (int)c[k].pitch_or_px >= n_banded)
+            compose_full<NV>(t0 + k, 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x);
 }
 
 }  // namespace

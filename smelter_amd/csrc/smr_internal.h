@@ -61,6 +61,21 @@ struct StagePending {
     int stage;
 };
 
+// Tile classes of one layout list (k_classify_tiles, smr_fused_compose.h), kept while the list repeats
+struct TileClassMap {
+    std::vector<uint8_t> key;      // the layout list (and output size) the classes were computed for
+    bool ready = false;
+    void *d_class = nullptr;       // TileClass per 128x16 output tile
+    uint8_t *d_direct = nullptr;   // direct output: the layer wave A writes the tile for, 0xff = none
+    void *d_list = nullptr;        // TileList: the tiles that need compositing
+    size_t n = 0;
+    uint32_t *h_count = nullptr;   // (pinned) the list's length, read back once per classification
+    hipEvent_t count_ev = nullptr;
+    bool count_pending = false, count_known = false;
+    uint64_t class_serial = 0, count_serial = 0;  // classifications so far / the one the copy in flight belongs to
+    uint64_t last_use = 0;
+};
+
 struct smr_ctx {
     int device = 0;
     u32 mode = 0;
@@ -123,11 +138,11 @@ struct smr_ctx {
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
+    int compose_slices = 2;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (1, 2, 4, 8)
     bool direct_output = false;  // SMR_OPT_DIRECT_OUTPUT: wave A writes Y'CbCr for the compositor's copy tiles of a scene at rest
-    std::vector<uint8_t> class_key;  // the layout list the tile classes in d_tile_class were (or will be) computed for
-    bool class_ready = false;
-    uint8_t *d_tile_class = nullptr;
-    size_t d_tile_class_bytes = 0;
+    std::vector<uint8_t> class_key_scratch;
+    std::vector<TileClassMap> class_maps;  // tile classes of the last few layout lists (smr_fused.hip)
+    uint64_t class_clock = 0;
     int force_tw = 0;         // SMR_INGEST_TW (tests / profiling): strip width of k_ingest_resample, 0 = automatic
 
     bool srgb() const { return mode == SMR_MODE_GPU_OPTIMIZED; }
