@@ -155,7 +155,9 @@ __device__ __forceinline__ void tile_needs(const u32 *s_touch, int start, int *s
 //   TC_FULL     anything else: the compositor classifies and composites the tile itself; px = the tile's index in the list of
 //               such tiles (TileList), which the compositor's first workgroups take band by band
 //   TC_SKIP     wave A writes the tile's Y'CbCr (direct output)
-enum { TC_CLEAR = 0, TC_COLOUR = 1, TC_TEXTURE = 2, TC_FULL = 3, TC_SKIP = 4 };
+//   TC_SAMPLED  the whole tile lies in the solid region of one opaque texture layer that is not a 1:1 blit (a video tile at a
+//               fractional position or another scale: every tile of a grid in mid-transition), nothing above: px = that layer
+enum { TC_CLEAR = 0, TC_COLOUR = 1, TC_TEXTURE = 2, TC_FULL = 3, TC_SKIP = 4, TC_SAMPLED = 5 };
 struct alignas(16) TileClass {
     const u8 *base;
     u32 pitch_or_px;
@@ -186,7 +188,10 @@ __global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restri
         TileClass c;
         c.base = nullptr; c.pitch_or_px = 0u; c.kind = TC_FULL;
         u32 d = B_CLASS_NONE;
-        if (s_general == 0) {
+        if (s_general == 2 && start >= 0) {
+            c.kind = TC_SAMPLED;
+            c.pitch_or_px = (u32)start;
+        } else if (s_general == 0) {
             if (start < 0) {
                 c.kind = TC_CLEAR;
             } else if (layouts[start].type != 0) {
@@ -320,10 +325,9 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
 template <int NV>
 __device__ __forceinline__ void compose_full(int tile, int band, int rh, const SurfView &yp, const SurfView &up, const SurfView &vp, int W, int H,
                                              const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g, int n, int n_masks,
-                                             int srgb_and_ablate, const float *__restrict__ tables, int tiles_x) {
+                                             int srgb_and_ablate, const float *__restrict__ tables, int tiles_x, float *s_tab) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
     __shared__ int s_start, s_general;
-    __shared__ float s_tab[SMR_TABLE_FLOATS];
     __shared__ u32 s_px[B_TILE_W * B_TILE_H];  // general tiles: composited RGBA8
     // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
     // dependent scalar-memory round trip per field per layer per wave
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
                                                         int tiles_x, int tiles, const TileClass *__restrict__ tc, const TileList *__restrict__ full,
                                                         int n_banded, int slices) {
     const int tid = threadIdx.x;
+    __shared__ float s_tab[SMR_TABLE_FLOATS];  // decode / encode tables (whoever needs them loads them)
     // The first `slices * n_banded` workgroups take the tiles that need compositing (TileList; the host sized the grid from the
     // list's length when it knows it, from its own prediction otherwise), band by band — they are latency-bound and would be the
     // tail of the kernel.  Every other workgroup takes B_COPY_TILES consecutive tiles of the row-major order.
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         if (gi >= full->count) return;
         const int rh = B_TILE_H / slices;
         compose_full<NV>((int)full->tiles[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
-                         tables, tiles_x);
+                         tables, tiles_x, s_tab);
         return;
     }
     // ---- copy tiles, straight from their class records (k_classify_tiles): no layout list, no classification, no barrier
@@ -555,11 +560,28 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         const int tile = t0 + k, ty = tile / tiles_x;
         if (on[k]) store_yuv_block<NV>(acc[k], (tile - ty * tiles_x) * B_TILE_W + bx, ty * B_TILE_H + by, yp, up, vp);
     }
+    // sampled tiles: one layer's record straight from the list in memory, eight independent pixels per thread
+#pragma unroll 1
+    for (int k = 0; k < B_COPY_TILES; k++) {
+        if (c[k].kind != TC_SAMPLED) continue;
+        __syncthreads();
+        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
+        __syncthreads();
+        const DevLayout L = load_uniform(&layouts_g[c[k].pitch_or_px]);
+        const int tile = t0 + k, ty = tile / tiles_x;
+        const int px0 = (tile - ty * tiles_x) * B_TILE_W + bx, py0 = ty * B_TILE_H + by;
+        if (px0 < W && py0 < H) {
+            u32 a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = composite_layout_solid(0u, L, px0 + (q & 3), py0 + (q >> 2), srgb_and_ablate & 1, s_tab, s_tab + 256);
+            store_yuv_block<NV>(a, px0, py0, yp, up, vp);
+        }
+    }
     // a tile that needs compositing and found no room on the band list (the host's bound was short): here, all sixteen rows
 #pragma unroll 1
     for (int k = 0; k < B_COPY_TILES; k++)
         if (c[k].kind == TC_FULL && (int)c[k].pitch_or_px >= n_banded)
-            compose_full<NV>(t0 + k, 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x);
+            compose_full<NV>(t0 + k, 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
 }
 
 }  // namespace
