@@ -350,6 +350,20 @@ typedef struct smr_scene_node {
 SMR_API int smr_scene_create(smr_scene **out);
 SMR_API void smr_scene_destroy(smr_scene *scene);
 SMR_API const char *smr_scene_last_error(const smr_scene *scene);
+/* Fitted text (TextDimensions::Fitted / FittedColumn, text_renderer.rs:282-346): the renderer sizes a Text node without
+ * "width"/"height" by the reference's rule (get_text_resolution, text_renderer.rs:348-368) —
+ *     width  = max over the laid-out lines of ceil(line width)             (FittedColumn: the given width)
+ *     height = trunc(lines * ceil(line_height) + font_size / 5)
+ * — from the line metrics the caller's shaper reports through this callback (glyphon / cosmic-text in the reference, third-party):
+ * lay `text` out at `font_size` with wrapping `wrap` ("None" | "Glyph" | "Word") inside max_width x max_height and return the
+ * widest line and the number of lines.  Return non-zero to fail the scene update.  Without a measurer such nodes are refused. */
+typedef struct smr_text_params {
+    const char *text, *font_family, *style, *weight, *wrap, *align;
+    float font_size, line_height;
+    float max_width, max_height;
+} smr_text_params;
+typedef int (*smr_text_measure_fn)(void *user, const smr_text_params *params, float *widest_line, uint32_t *line_count);
+SMR_API int smr_scene_set_text_measurer(smr_scene *scene, smr_text_measure_fn fn, void *user);
 /* Renderer::register_renderer(Image) as far as sizing goes (scene/image_component.rs) */
 SMR_API int smr_scene_register_image(smr_scene *scene, const char *image_id, uint32_t width, uint32_t height);
 /* Renderer::update_scene (state.rs:177-189).  On error the previous scene stays active. */
@@ -411,6 +425,7 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
 SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_id);
 SMR_API int smr_renderer_node_count(const smr_renderer *r, const char *output_id);
 SMR_API int smr_renderer_node_info(smr_renderer *r, const char *output_id, int node, smr_scene_node *out);
+SMR_API int smr_renderer_set_text_measurer(smr_renderer *r, smr_text_measure_fn fn, void *user);
 SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int node, const float bg[4], const smr_glyph *glyphs, uint32_t n,
                                   const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
 SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs,

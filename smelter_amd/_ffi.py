@@ -35,12 +35,13 @@ EXPORTS = [
     "smr_rgba_to_frame", "smr_frame_fill_black",
     "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear",
     "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_ingest_resample_batch", "smr_blit_glyphs", "smr_builtin_shader",
-    "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_update", "smr_scene_parse",
+    "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_set_text_measurer", "smr_scene_update",
+    "smr_scene_parse",
     "smr_scene_node_count", "smr_scene_node_info", "smr_scene_node_children", "smr_scene_node_layouts",
     "smr_cubic_bezier_easing", "smr_bounce_easing", "smr_parse_color", "smr_ctx_mode", "smr_ctx_set_option",
     "smr_renderer_create", "smr_renderer_destroy", "smr_renderer_last_error", "smr_renderer_register_input",
     "smr_renderer_unregister_input", "smr_renderer_register_image", "smr_renderer_register_shader", "smr_renderer_update_scene",
-    "smr_renderer_unregister_output", "smr_renderer_node_count", "smr_renderer_node_info", "smr_renderer_set_text",
+    "smr_renderer_unregister_output", "smr_renderer_node_count", "smr_renderer_node_info", "smr_renderer_set_text", "smr_renderer_set_text_measurer",
     "smr_renderer_render", "smr_renderer_add_lane", "smr_renderer_sync",
     "smr_comm_create_local", "smr_comm_unique_id", "smr_comm_create_rank", "smr_comm_destroy", "smr_comm_world", "smr_comm_rank",
     "smr_comm_last_error", "smr_gather_tiles",
@@ -96,6 +97,14 @@ class ResamplePlan(C.Structure):
 class Glyph(C.Structure):
     _fields_ = [("dst_x", C.c_int32), ("dst_y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
                 ("atlas_x", C.c_int32), ("atlas_y", C.c_int32), ("color", C.c_float * 4)]
+
+
+class TextParams(C.Structure):
+    _fields_ = [("text", C.c_char_p), ("font_family", C.c_char_p), ("style", C.c_char_p), ("weight", C.c_char_p), ("wrap", C.c_char_p),
+                ("align", C.c_char_p), ("font_size", C.c_float), ("line_height", C.c_float), ("max_width", C.c_float), ("max_height", C.c_float)]
+
+
+TEXT_MEASURE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TextParams), C.POINTER(C.c_float), C.POINTER(C.c_uint32))
 
 
 class Source(C.Structure):
@@ -176,6 +185,8 @@ def load():
         "smr_scene_destroy": ([P], None),
         "smr_scene_last_error": ([P], C.c_char_p),
         "smr_scene_register_image": ([P, C.c_char_p, U, U], I),
+        "smr_scene_set_text_measurer": ([P, TEXT_MEASURE_FN, P], I),
+        "smr_renderer_set_text_measurer": ([P, TEXT_MEASURE_FN, P], I),
         "smr_scene_update": ([P, C.c_char_p, U, U], I),
         "smr_scene_parse": ([P, C.c_char_p, C.POINTER(C.c_char_p)], I),
         "smr_scene_node_count": ([P], I),

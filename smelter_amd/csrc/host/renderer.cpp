@@ -56,6 +56,8 @@ struct smr_renderer {
     std::set<std::string> inputs;
     std::map<std::string, ImageRes> images;
     std::map<std::string, uint32_t> shaders;  // shader_id -> smr_builtin_shader_id
+    smr_text_measure_fn measure = nullptr;    // the caller's text shaper (fitted Text nodes)
+    void *measure_user = nullptr;
     std::map<std::string, Output> outputs;
     std::string err;
     std::vector<smr_layout> layouts;  // scratch
@@ -388,6 +390,14 @@ SMR_API int smr_renderer_register_image(smr_renderer *r, const char *image_id, c
     return 0;
 }
 
+SMR_API int smr_renderer_set_text_measurer(smr_renderer *r, smr_text_measure_fn fn, void *user) {
+    if (!r) return -1;
+    r->measure = fn;
+    r->measure_user = user;
+    for (auto &kv : r->outputs) kv.second.scene.set_text_measurer(fn, user);
+    return 0;
+}
+
 SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id, uint32_t builtin_id) {
     if (!r || !shader_id) return fail(r, -1, "smr_renderer_register_shader: null argument");
     if (builtin_id > SMR_SHADER_SILLY) return fail(r, -1, "smr_renderer_register_shader: unknown built-in shader (user WGSL is not supported)");
@@ -403,6 +413,7 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
         return fail(r, -1, "smr_renderer_update_scene: output format must be planar YUV 4:2:0 / 4:2:2 / 4:4:4, NV12 or RGBA");
     Output &o = r->outputs[output_id];
     for (auto &kv : r->images) o.scene.register_image(kv.first, (float)kv.second.w, (float)kv.second.h);
+    o.scene.set_text_measurer(r->measure, r->measure_user);
     std::string err;
     {
         // Shader ids are resolved while the new scene is built (ShaderComponent::stateful_component, shader_component.rs:44-52):

@@ -194,6 +194,8 @@ class Scene {
     // validates and returns the converted component tree as canonical JSON; the active scene is untouched.
     bool parse(const std::string &json, std::string &out, std::string &err) const;
     void register_image(const std::string &image_id, float w, float h) { images_[image_id] = Size{w, h}; }
+    // the caller's text shaper (include/smr.h smr_text_measure_fn): sizes Text nodes without explicit width / height
+    void set_text_measurer(smr_text_measure_fn fn, void *user) { measure_ = fn; measure_user_ = user; }
     const std::vector<GraphNode> &nodes() const { return nodes_; }
     // LayoutProvider::layouts + NestedLayout::flatten for one layout node (transformations/layout.rs:176-184);
     // also advances the render clock (SceneState::register_render_event).
@@ -206,6 +208,8 @@ class Scene {
     std::unique_ptr<Stateful> root_;
     std::vector<GraphNode> nodes_;
     std::map<std::string, Size> images_;
+    smr_text_measure_fn measure_ = nullptr;
+    void *measure_user_ = nullptr;
     std::map<std::string, Size> input_resolutions_;  // SceneState::input_resolutions — from the last render
     int64_t last_pts_ns_ = 0;
     uint32_t out_w_ = 0, out_h_ = 0;

@@ -104,6 +104,8 @@ struct BuildCtx {
     const std::map<std::string, Size> *images = nullptr;
     std::set<std::string> ids;  // validate_component_ids_uniqueness
     bool api_only = false;      // stop after the smelter-api conversion (TryFrom<Component>): no renderer registry, no shaper
+    smr_text_measure_fn measure = nullptr;  // the caller's text shaper
+    void *measure_user = nullptr;
     std::string err;
 };
 
@@ -564,8 +566,28 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             .set("wrap", Json::string(wrap)).set("background_color", jcolor(bg)).set("dimensions", dims);
         if (c.api_only) return s;
         if (!w || !h) {
-            fail(c, "Text components need \"width\" and \"height\" here: fitted text is measured by the caller's text shaper (SURVEY.md §8 a12)");
-            return nullptr;
+            // TextRendererCtx::layout_text (text_renderer.rs:282-346): Fitted { max_width, max_height } / FittedColumn { width, max_height }
+            if (!c.measure) {
+                fail(c, "Text components without \"width\" and \"height\" need a text shaper: smr_renderer_set_text_measurer (SURVEY.md §8 a12)");
+                return nullptr;
+            }
+            const float line_height = lh.value_or(*fs);
+            smr_text_params tp;
+            tp.text = s->text.c_str(); tp.font_family = family.c_str(); tp.style = style.c_str(); tp.weight = weight.c_str(); tp.wrap = wrap.c_str();
+            const std::string an = halign_name(align);
+            tp.align = an.c_str();
+            tp.font_size = *fs; tp.line_height = line_height;
+            tp.max_width = w ? *w : mw.value_or(MAX_W);
+            tp.max_height = mh.value_or(MAX_H);
+            float widest = 0.0f;
+            uint32_t lines = 0;
+            if (c.measure(c.measure_user, &tp, &widest, &lines) != 0) { fail(c, "the text shaper failed to lay out \"" + s->text + "\""); return nullptr; }
+            // get_text_resolution (text_renderer.rs:348-368)
+            const size_t tw = (size_t)std::ceil(widest > 0.0f ? widest : 0.0f);
+            const size_t th = (size_t)((float)lines * std::ceil(line_height) + *fs / 5.0f);
+            s->leaf_size = {(float)(w ? (size_t)*w : tw), (float)th};
+            s->shader_param = j;
+            return s;
         }
         s->leaf_size = {(float)(size_t)*w, (float)(size_t)*h};  // Resolution { width as usize, height as usize }
         s->shader_param = j;                                    // colours / font properties for the caller's shaper
@@ -671,6 +693,8 @@ bool Scene::update(const std::string &json, uint32_t out_w, uint32_t out_h, std:
     ctx.last_pts = last_pts_ns_;
     ctx.input_resolutions = &input_resolutions_;
     ctx.images = &images_;
+    ctx.measure = measure_;
+    ctx.measure_user = measure_user_;
     std::unique_ptr<Stateful> root = build(j, ctx);
     if (!root) { err = ctx.err; return false; }
     std::vector<GraphNode> nodes;

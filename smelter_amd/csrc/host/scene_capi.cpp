@@ -32,6 +32,12 @@ SMR_API int smr_scene_register_image(smr_scene *scene, const char *image_id, uin
     return 0;
 }
 
+SMR_API int smr_scene_set_text_measurer(smr_scene *scene, smr_text_measure_fn fn, void *user) {
+    if (!scene) return -1;
+    scene->scene.set_text_measurer(fn, user);
+    return 0;
+}
+
 SMR_API int smr_scene_update(smr_scene *scene, const char *scene_json, uint32_t out_width, uint32_t out_height) {
     if (!scene || !scene_json) return set_err(scene, "smr_scene_update: null argument");
     std::string err;

@@ -73,6 +73,11 @@ class Renderer:
         h, w = px.shape[:2]
         self._check(self.lib.smr_renderer_register_image(self._h, image_id.encode(), px.ctypes.data, w, h))
 
+    def set_text_measurer(self, measurer):
+        """The caller's text shaper for Text nodes without explicit width / height (smelter_amd.text.Shaper(...).measurer)."""
+        self._measurer = measurer  # keep the callback alive
+        self._check(self.lib.smr_renderer_set_text_measurer(self._h, measurer if measurer is not None else _ffi.TEXT_MEASURE_FN(0), None))
+
     def register_shader(self, shader_id: str, builtin_id: int = _ffi.SHADER_GAUSSIAN_BLUR):
         self._check(self.lib.smr_renderer_register_shader(self._h, shader_id.encode(), builtin_id))
 

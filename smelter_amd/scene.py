@@ -60,6 +60,11 @@ class Scene:
     def register_image(self, image_id: str, width: int, height: int):
         self._check(self._lib.smr_scene_register_image(self._h, image_id.encode(), width, height))
 
+    def set_text_measurer(self, measurer):
+        """`measurer`: an _ffi.TEXT_MEASURE_FN (e.g. smelter_amd.text.Shaper(...).measurer) or None; sizes fitted Text nodes."""
+        self._measurer = measurer  # keep the callback alive
+        self._check(self._lib.smr_scene_set_text_measurer(self._h, measurer if measurer is not None else _ffi.TEXT_MEASURE_FN(0), None))
+
     def update(self, scene: Union[str, dict], out_w: int, out_h: int) -> List[Node]:
         text = scene if isinstance(scene, str) else json.dumps(scene)
         self._check(self._lib.smr_scene_update(self._h, text.encode(), out_w, out_h))

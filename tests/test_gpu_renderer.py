@@ -418,3 +418,34 @@ def test_c_example_runs(tmp_path):
     assert "rendered 1280x720 from 4 inputs" in p.stdout
     data = np.fromfile(out, np.uint8)
     assert data.size == 1280 * 720 * 3 // 2 and data[: 1280 * 720].std() > 10
+
+
+def test_fitted_text_is_sized_by_the_shaper_and_drawn(ctx, hip, renderer):
+    """TextDimensions::Fitted end to end: the node is sized by get_text_resolution from the caller's shaper (smelter_amd/text.py over a
+    system TrueType font), the shaper's glyph run is blitted by smr_blit_glyphs, and the output equals the oracle's blit."""
+    import json
+
+    from smelter_amd import _ffi, text as T
+    try:
+        book = T.FontBook.system()
+    except FileNotFoundError:
+        pytest.skip("no TrueType fonts on this machine")
+    sh = T.Shaper(book)
+    renderer.set_text_measurer(sh.measurer)
+    W, H, fs, lh = 640, 360, 34.0, 40.0
+    txt = "Fitted text\nsized by the shaper"
+    scene = {"type": "view", "background_color": "#00000000",
+             "children": [{"type": "text", "text": txt, "font_size": fs, "line_height": lh, "align": "center", "color": "#FFCC33FF"}]}
+    nodes = renderer.update_scene("out", W, H, json.dumps(scene), output_format=hip.FRAME_RGBA)
+    tn = [n for n in nodes if n.kind == _ffi.NODE_TEXT][0]
+    font = book.match("Verdana")
+    assert (tn.width, tn.height) == T.text_resolution(T.layout(font, txt, fs), fs, lh)
+    color = orc.color_to_shader((0xFF, 0xCC, 0x33, 0xFF), True)
+    glyphs, atlas = sh.rasterise(txt, tn.width, tn.height, fs, lh, align="Center", color=color)
+    renderer.set_text("out", tn.index, glyphs, atlas)
+    got = np.asarray(renderer.render(0.0, {})["out"].download()[0]).reshape(H, W, 4)
+    want = orc.blit_glyphs(tn.width, tn.height, (0.0, 0.0, 0.0, 0.0), glyphs, atlas, True)
+    assert np.abs(got[:tn.height, :tn.width].astype(int) - want.astype(int)).max() <= 1
+    assert (got[:tn.height, :tn.width] == want).mean() > 0.999
+    assert not got[tn.height:].any() and not got[:, tn.width:].any()
+    assert want[..., 3].max() == 255 and (want[..., 3] > 0).mean() > 0.05  # the text is really there
