@@ -8,6 +8,7 @@
 template <int OP>
 __global__ void k(float *out, int iters, float a, unsigned b) {
     float x0 = threadIdx.x * 1e-3f, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7;
+    double d0 = x0, d1 = x1, d2 = x2, d3 = x3, dc = a;  // (64-bit register pairs for v_pk_fma_f32)
     unsigned u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3, u4 = u0 + 4, u5 = u0 + 5, u6 = u0 + 6, u7 = u0 + 7;
     for (int i = 0; i < iters; i++) {
         // 16 x 8 independent instructions per iteration
@@ -21,9 +22,11 @@ __global__ void k(float *out, int iters, float a, unsigned b) {
         if (OP == 6) { REP16(asm volatile("v_cvt_f32_ubyte0 %0, %0\nv_cvt_f32_ubyte0 %1, %1\nv_cvt_f32_ubyte0 %2, %2\nv_cvt_f32_ubyte0 %3, %3\nv_cvt_f32_ubyte0 %4, %4\nv_cvt_f32_ubyte0 %5, %5\nv_cvt_f32_ubyte0 %6, %6\nv_cvt_f32_ubyte0 %7, %7" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));) }
         if (OP == 7) { REP16(asm volatile("v_add_u32 %0, %0, %8\nv_add_u32 %1, %1, %8\nv_add_u32 %2, %2, %8\nv_add_u32 %3, %3, %8\nv_add_u32 %4, %4, %8\nv_add_u32 %5, %5, %8\nv_add_u32 %6, %6, %8\nv_add_u32 %7, %7, %8" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(b));) }
         if (OP == 8) { REP16(asm volatile("v_cvt_pk_u8_f32 %0, %8, 1, %0\nv_cvt_pk_u8_f32 %1, %8, 1, %1\nv_cvt_pk_u8_f32 %2, %8, 1, %2\nv_cvt_pk_u8_f32 %3, %8, 1, %3\nv_cvt_pk_u8_f32 %4, %8, 1, %4\nv_cvt_pk_u8_f32 %5, %8, 1, %5\nv_cvt_pk_u8_f32 %6, %8, 1, %6\nv_cvt_pk_u8_f32 %7, %8, 1, %7" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(a));) }
+        if (OP == 10) { REP16(asm volatile("v_pk_fma_f16 %0, %0, %8, %0\nv_pk_fma_f16 %1, %1, %8, %1\nv_pk_fma_f16 %2, %2, %8, %2\nv_pk_fma_f16 %3, %3, %8, %3\nv_pk_fma_f16 %4, %4, %8, %4\nv_pk_fma_f16 %5, %5, %8, %5\nv_pk_fma_f16 %6, %6, %8, %6\nv_pk_fma_f16 %7, %7, %8, %7" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : "v"(b));) }
+        if (OP == 11) { REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %0\nv_pk_fma_f32 %1, %1, %4, %1\nv_pk_fma_f32 %2, %2, %4, %2\nv_pk_fma_f32 %3, %3, %4, %3\nv_pk_fma_f32 %0, %0, %4, %0\nv_pk_fma_f32 %1, %1, %4, %1\nv_pk_fma_f32 %2, %2, %4, %2\nv_pk_fma_f32 %3, %3, %4, %3" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dc));) }
         if (OP == 9) { REP16(asm volatile("v_mul_f32 %0, %0, %8\nv_mul_f32 %1, %1, %8\nv_mul_f32 %2, %2, %8\nv_mul_f32 %3, %3, %8\nv_mul_f32 %4, %4, %8\nv_mul_f32 %5, %5, %8\nv_mul_f32 %6, %6, %8\nv_mul_f32 %7, %7, %8" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));) }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)(d0 + d1 + d2 + d3) + x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
 }
 template <int OP>
 void run(const char *name, int waves_per_simd) {
@@ -48,6 +51,7 @@ int main() {
     for (int w : {1, 2, 4}) {
         run<0>("v_fma_f32", w); run<9>("v_mul_f32", w); run<1>("v_med3_f32", w); run<2>("v_cvt_u32_f32", w); run<3>("v_dot4_u32_u8", w); run<4>("v_perm_b32", w);
         run<5>("v_lshl_add_u32", w); run<6>("v_cvt_f32_ubyte0", w); run<7>("v_add_u32", w); run<8>("v_cvt_pk_u8_f32", w);
+        run<10>("v_pk_fma_f16", w); run<11>("v_pk_fma_f32", w);
     }
     return 0;
 }
