@@ -210,6 +210,7 @@ struct MJob {
     int ablate;  // profiling only (SMR_ABLATE): 1 skip convert, 2 skip pass 1, 4 skip pass 2, 8 skip encode + store, 16 skip staging, 32 dispatch only
     // direct output (MDirect below): the layer this tile is blitted by, -1 = none, and its (even) position in the output frame
     int layer, ox, oy;
+    int nv12;  // `up` is the interleaved UV plane of an NV12 frame (2 bytes per chroma texel), `vp` aliases it
 };
 
 // Direct output: where the compositor would only copy this tile's texels into the output frame (k_classify_tiles, cls[tile] ==
@@ -362,7 +363,9 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
         // staging: luma = one row per wave and step (64 lanes x 4 B), chroma = 18 (plane, row) tasks of <= 64 dwords.
         // Every lane always loads (dead lanes re-read the last live dword: same cache line, no extra traffic).
         constexpr int NY = M_CH / CW, NC = (18 + CW - 1) / CW;
-        u32 py[NY], pc[NC];
+        constexpr bool NV = (ABL & 4096) != 0;  // the build that also reads NV12 frames (decoder hand-off: Y + interleaved UV)
+        const bool nv = NV && J.nv12 != 0;      // (uniform)
+        u32 py[NY], pc[NC], pc_hi[NV ? NC : 1];
         const int sw4 = (sw + 3) & ~3;
         const bool y_live = lane < ngroups && cbase + 4 * lane < sw4;
         const bool c_live = lane < ncd;
@@ -384,7 +387,12 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                 const int rt = min(cwave + CW * k, 17);  // (plane, row) task, uniform per wave; tasks past the 18th repeat the last one
                 const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
                 const u8 *rowp = (plane ? v_ptr : u_ptr) + (size_t)clampi(i0 + r, 0, chh - 1) * (plane ? v_pitch : u_pitch);
-                pc[k] = *(const u32 *)(rowp + c_off);
+                if (nv) {  // four chroma texels = eight interleaved bytes; the plane's four are picked when they land
+                    pc[k] = *(const u32 *)(rowp + 2 * c_off);
+                    pc_hi[NV ? k : 0] = *(const u32 *)(rowp + 2 * c_off + 4);
+                } else {
+                    pc[k] = *(const u32 *)(rowp + c_off);
+                }
             }
         };
         auto land = [&](u8 *raw) {
@@ -392,6 +400,13 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
             if (y_live) {
 #pragma unroll
                 for (int k = 0; k < NY; k++) *(u32 *)(rawY + (cwave + CW * k) * ys + 4 * lane) = (ablate & 128) ? 0x80808080u : py[k];
+            }
+            if (nv) {
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    const int rt = min(cwave + CW * k, 17);
+                    pc[k] = __builtin_amdgcn_perm(pc_hi[NV ? k : 0], pc[k], rt >= 9 ? 0x07050301u : 0x06040200u);  // V : U bytes
+                }
             }
             if (c_edge) {
 #pragma unroll
@@ -697,13 +712,21 @@ bool mfma_plane_ok(const SurfView &p, u32 bytes) { return (p.pitch % 4) == 0 && 
 // plan, horizontal pass first, no box pre-reduction, 16-byte aligned tile rows, footprints that fit the LDS.
 bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
     if (ctx->ingest_impl == SMR_INGEST_VALU_F32) return false;
-    if (!f || !f->planes[0] || !f->planes[1] || !f->planes[2]) return false;
-    if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420) return false;
+    const bool nv12 = f && f->format == SMR_FRAME_NV12;
+    if (!f || !f->planes[0] || !f->planes[1] || (!nv12 && !f->planes[2])) return false;
+#ifdef SMR_ABLATION_BUILDS
+    if (nv12) return false;
+#endif
+    if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return false;
     if (f->width % 2 || f->height % 2 || f->width < 8 || f->height < 2) return false;
     if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0)) return false;
-    if (!mfma_plane_ok(view_of(f->planes[0]), f->width) || !mfma_plane_ok(view_of(f->planes[1]), f->width / 2) ||
-        !mfma_plane_ok(view_of(f->planes[2]), f->width / 2))
+    if (!mfma_plane_ok(view_of(f->planes[0]), f->width)) return false;
+    if (nv12) {  // (the last staged dword pair may start up to 3 texels before the row's end: 8 bytes must be readable there)
+        const SurfView uv = view_of(f->planes[1]);
+        if ((uv.pitch % 4) || (((uintptr_t)uv.ptr) % 4) || uv.pitch < ((f->width + 7u) & ~7u)) return false;
+    } else if (!mfma_plane_ok(view_of(f->planes[1]), f->width / 2) || !mfma_plane_ok(view_of(f->planes[2]), f->width / 2)) {
         return false;
+    }
     if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
     int KH, KV, sh_, sv_;
     mfma_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 0, &KH, &sh_);
@@ -719,7 +742,7 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     rc = get_mfma_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 1, &bv);
     if (rc != SMR_OK) return rc;
     MJob &J = *out;
-    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = view_of(f->planes[2]);
+    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = f->planes[2] ? view_of(f->planes[2]) : J.up;
     J.dst = view_of(tile);
     J.src_w = (int)f->width; J.src_h = (int)f->height;
     // planar_yuv_to_rgba.wgsl:45-57 with every constant folded; chroma arrives in 1/16 u8 units (16 * 255 * u)
@@ -740,6 +763,8 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.strips_x = (bh.n_tiles + M_NT - 1) / M_NT;
     J.ablate = ctx->ablate;
     J.layer = -1; J.ox = 0; J.oy = 0;
+    J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
+    if (J.nv12) J.vp = J.up;
     // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
     const int taps_h = host_taps(plan.scale[0]);
     int ngm = 1;
@@ -774,8 +799,10 @@ constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>,  k_ingest_mfma<3, 2,
                                     k_ingest_mfma<3, 2, 1024>, k_ingest_mfma<3, 2, 1088>, k_ingest_mfma<3, 2, 3>, k_ingest_mfma<3, 2, 9>, k_ingest_mfma<3, 2, 13>,
                                     k_ingest_mfma<3, 2, 8>, k_ingest_mfma<3, 2, 256>, k_ingest_mfma<3, 2, 512>, k_ingest_mfma<3, 2, 768>, k_ingest_mfma<3, 2, 39>};
 #else
-constexpr int M_ABL[] = {0, 0, 2048, 2048};
-constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>, k_ingest_mfma<3, 2, 0>, k_ingest_mfma<0, 0, 2048>, k_ingest_mfma<3, 2, 2048>};
+// builds: plain | direct output (2048) | NV12-capable (4096) | both
+constexpr int M_ABL[] = {0, 0, 2048, 2048, 4096, 4096, 6144, 6144};
+constexpr MfmaKernel M_KERNELS[] = {k_ingest_mfma<0, 0, 0>,    k_ingest_mfma<3, 2, 0>,    k_ingest_mfma<0, 0, 2048>, k_ingest_mfma<3, 2, 2048>,
+                                    k_ingest_mfma<0, 0, 4096>, k_ingest_mfma<3, 2, 4096>, k_ingest_mfma<0, 0, 6144>, k_ingest_mfma<3, 2, 6144>};
 #endif
 constexpr int M_NKERNELS = (int)(sizeof(M_KERNELS) / sizeof(M_KERNELS[0]));
 
@@ -817,6 +844,8 @@ int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs, const MDirect *direct = n
         if (direct) return smr_fail(ctx, SMR_ERR_INTERNAL, "direct output is not part of the ablation builds");
 #else
         if (direct) ki += 2;
+        for (size_t j = 0; j < nj; j++)
+            if (args.jobs[j].nv12) { ki += 4; break; }
 #endif
         const MfmaKernel kern = M_KERNELS[ki];
         // as many workgroups as are resident at once (LDS and registers), minus the share left to the other stream's compose kernel
