@@ -171,7 +171,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes + sizeof(MDirect), &packed);
     if (rc != SMR_OK) return rc;
     const u32 n_first = compose_order(packed, (int)b_tiles_x, (int)b_tiles_y, (ComposeOrder *)packed.extra_host);
-    const bool fits_b = fused && (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= B_MAX_LAYOUTS && packed.n_masks <= B_MAX_MASKS;
+    const bool fits_b = fused && (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= MAX_LAYOUT_WORDS * 32;
+    const bool big_list = packed.n > B_MAX_LAYOUTS || packed.n_masks > B_MAX_MASKS;  // read in place instead of from an LDS copy
     const bool fuse_yuv = fits_b && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
                           out->planes[0] && out->planes[1] && (out->format == SMR_FRAME_NV12 || out->planes[2]);
     const bool fuse_rgba = fits_b && out_rgba && !out && (((uintptr_t)out_rgba->ptr) % 16 == 0) && (out_rgba->pitch % 16 == 0);  // a node's RGBA8 texture
@@ -296,20 +297,23 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         const TileList *full = (const TileList *)cm->d_list;
         const TileClass *tc = (const TileClass *)cm->d_class;
         const int flags = (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8);
+        SurfView p0, p1, p2;
+        int nv;
         if (fuse_rgba) {
-            const SurfView t = view_of(out_rgba);
-            hipLaunchKernelGGL(k_compose_output<2>, grid, dim3(256), 0, ctx->stream, t, t, t, (int)out_w, (int)out_h, packed.layouts, packed.masks, packed.n,
-                               packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
-        } else if (out->format == SMR_FRAME_NV12) {
-            const SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
-            hipLaunchKernelGGL(k_compose_output<1>, grid, dim3(256), 0, ctx->stream, yp, up, up, (int)out_w, (int)out_h, packed.layouts, packed.masks,
-                               packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
+            p0 = p1 = p2 = view_of(out_rgba);
+            nv = 2;
         } else {
-            const SurfView yp = view_of(out->planes[0]), up = view_of(out->planes[1]);
-            hipLaunchKernelGGL(k_compose_output<0>, grid, dim3(256), 0, ctx->stream, yp, up, view_of(out->planes[2]), (int)out_w, (int)out_h,
-                               packed.layouts, packed.masks, packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full,
-                               (int)n_banded, ctx->compose_slices);
+            p0 = view_of(out->planes[0]); p1 = view_of(out->planes[1]);
+            nv = out->format == SMR_FRAME_NV12 ? 1 : 0;
+            p2 = nv ? p1 : view_of(out->planes[2]);
         }
+        typedef void (*ComposeKernel)(SurfView, SurfView, SurfView, int, int, const DevLayout *, const DevMask *, int, int, int, const float *, int, int,
+                                      const TileClass *, const TileList *, int, int);
+        static const ComposeKernel kernels[3][2] = {{k_compose_output<0, false>, k_compose_output<0, true>},
+                                                    {k_compose_output<1, false>, k_compose_output<1, true>},
+                                                    {k_compose_output<2, false>, k_compose_output<2, true>}};
+        hipLaunchKernelGGL(kernels[nv][big_list ? 1 : 0], grid, dim3(256), 0, ctx->stream, p0, p1, p2, (int)out_w, (int)out_h, packed.layouts, packed.masks,
+                           packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
         SMR_HIP(ctx, hipGetLastError());
         return smr_pack_done(ctx, &packed);
     }

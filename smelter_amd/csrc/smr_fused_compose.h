@@ -322,7 +322,8 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
 
 // Rows [band, band + rh) of tile `tile`, classified and composited by the whole workgroup (uniform call; may be called again).
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV); NV = 2: RGBA8 surface (in `yp`)
-template <int NV>
+// BIG: the layout list is longer than the LDS copy (B_MAX_LAYOUTS / B_MAX_MASKS) and is read where it lies in memory
+template <int NV, bool BIG>
 __device__ __forceinline__ void compose_full(int tile, int band, int rh, const SurfView &yp, const SurfView &up, const SurfView &vp, int W, int H,
                                              const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g, int n, int n_masks,
                                              int srgb_and_ablate, const float *__restrict__ tables, int tiles_x, float *s_tab) {
@@ -339,7 +340,7 @@ __device__ __forceinline__ void compose_full(int tile, int band, int rh, const S
     const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H + band;
     const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);  // this thread's 4x2 output block
     __syncthreads();  // (a previous call's readers of the shared tile are done)
-    {
+    if (!BIG) {
         const uint4 *gl = (const uint4 *)layouts_g;
         uint4 *ll = (uint4 *)s_lay;
         for (int i = tid; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
@@ -347,8 +348,8 @@ __device__ __forceinline__ void compose_full(int tile, int band, int rh, const S
         uint4 *lm = (uint4 *)s_mask;
         for (int i = tid; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
     }
-    const DevLayout *layouts = s_lay;
-    const DevMask *masks = s_mask;
+    const DevLayout *layouts = BIG ? layouts_g : s_lay;
+    const DevMask *masks = BIG ? masks_g : s_mask;
     const int srgb = srgb_and_ablate & 1;
     const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
     if (ablate & 1) return;
@@ -485,7 +486,7 @@ __device__ __forceinline__ void compose_full(int tile, int band, int rh, const S
 // outweighs the launches saved.
 constexpr int B_COPY_TILES = 1;
 
-template <int NV>
+template <int NV, bool BIG>
 __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
                                                         const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
                                                         int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         const u32 gi = blockIdx.x / (u32)slices;
         if (gi >= full->count) return;
         const int rh = B_TILE_H / slices;
-        compose_full<NV>((int)full->tiles[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
+        compose_full<NV, BIG>((int)full->tiles[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
                          tables, tiles_x, s_tab);
         return;
     }
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
 #pragma unroll 1
     for (int k = 0; k < B_COPY_TILES; k++)
         if (c[k].kind == TC_FULL && (int)c[k].pitch_or_px >= n_banded)
-            compose_full<NV>(t0 + k, 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+            compose_full<NV, BIG>(t0 + k, 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
 }
 
 }  // namespace

@@ -343,8 +343,9 @@ def test_sharded_path_on_one_gpu_matches_the_fused_path(hip):
 
 
 def test_long_layout_lists_and_odd_output_sizes(ctx, ctx_unfused, hip):
-    """More layouts than the fused compose kernel keeps in LDS (48) and an output width that is not a multiple of 4: the library
-    must fall back to the general kernels on its own and still match the pass-per-launch path and the oracle."""
+    """More layouts than the fused compose kernel keeps in LDS (48): still one fused launch, the list read where it lies in memory.
+    An output width that is not a multiple of 4: the library falls back to the general kernels on its own.  Both match the
+    pass-per-launch path and the oracle."""
     iw, ih = 160, 90
     for (W, H, n) in [(1280, 720, 12), (642, 362, 3)]:
         layouts, res = scenes.cfg3_scene(iw, ih, W, H, n)
@@ -363,7 +364,13 @@ def test_long_layout_lists_and_odd_output_sizes(ctx, ctx_unfused, hip):
             return srcs
 
         if W % 4 == 0:
+            ctx.profile_reset()
+            ctx.profile_enable(True)
             got = _render(ctx, hip, layouts, sources_for(ctx), W, H)
+            ctx.sync()
+            prof = ctx.profile_read()
+            ctx.profile_enable(False)
+            assert prof["fused_compose_output"][1] == 1 and prof["layouts"][1] == 0, f"{len(layouts)} layouts left the fused compositor: {prof}"
             ref = _render(ctx_unfused, hip, layouts, sources_for(ctx_unfused), W, H)
             _assert_matches_unfused(ctx, got, ref, (W, H, n))
         rgba = ctx.surface(W, H)
