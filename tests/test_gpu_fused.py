@@ -598,3 +598,58 @@ def test_matrix_core_resampler_tail_on_full_size_white_noise(hip):
             assert (d == 0).mean() >= ident, f"impl {impl}: {(d == 0).mean():.5f} identical"
     finally:
         c.close()
+
+
+def test_tile_class_cache_survives_alternating_and_evicted_layout_lists(hip):
+    """The compositor keeps the tile classes of the last four layout lists per context (smr_fused.hip).  Lists that alternate (a
+    nested node and its root), come back after being evicted, or differ only in where a tile sits must each be composited with
+    their own classes: every frame equals the frame of a fresh context that has never seen another list."""
+    iw, ih, W, H = 320, 180, 640, 360
+    c = hip.Context(0)
+    try:
+        planes, _ = _inputs(c, hip, 4, iw, ih)
+        _, label_host = _label_surfaces(c, 1)
+        variants = []
+        for k in range(6):  # six lists: more than the cache holds
+            layouts, res = scenes.cfg3_scene(iw, ih, W, H, 2 + (k % 3))
+            if k >= 3:  # same structure, shifted: different copy-tile pointers for the same tile sizes
+                layouts = [Layout_shift(l, 8 * (k - 2), 4 * (k - 2)) for l in layouts]
+            variants.append((layouts, res))
+
+        def sources(ctx_, res):
+            srcs, k = [], 0
+            lt = ctx_.surface_from(label_host)
+            for r in res:
+                if r == (iw, ih):
+                    srcs.append(ctx_.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[k])))
+                    k += 1
+                else:
+                    srcs.append(lt)
+            return srcs
+
+        want = []
+        for layouts, res in variants:
+            f = hip.Context(0)
+            try:
+                want.append(_render(f, hip, layouts, sources(f, res), W, H))
+            finally:
+                f.close()
+        srcs = [sources(c, res) for _, res in variants]
+        order = [0, 1, 0, 1, 0, 2, 3, 4, 5, 0, 5, 1, 4, 2, 3, 3, 0]
+        for step, v in enumerate(order):
+            got = _render(c, hip, variants[v][0], srcs[v], W, H)
+            for g, w_, pl in zip(got, want[v], "YUV"):
+                assert np.array_equal(g, w_), f"step {step} list {v} plane {pl}: {int((g != w_).sum())} bytes differ"
+    finally:
+        c.close()
+
+
+def Layout_shift(l, dx, dy):
+    import copy
+    m = copy.deepcopy(l)
+    m.left += dx
+    m.top += dy
+    for k in m.masks:
+        k.left += dx
+        k.top += dy
+    return m
