@@ -39,4 +39,30 @@ __device__ __forceinline__ float4 unpack_unorm(u32 p) {
                        (float)(p >> 24) / 255.0f);
 }
 
+// ---- the output conversion for inputs that are bytes (the fused kernels: every channel is byte / 255), with the operations that
+//      cannot change the result left out.  Same values as yuv_component() / unorm8() / unpack_unorm() bit for bit:
+//  * byte / 255: RN(a * rb + a * -2^-33) with rb = RN(1 / 255) is the IEEE quotient for all 256 bytes (checked exhaustively,
+//    tests/test_oracle_golden.py) — one multiply by a power of two (exact) and one FMA instead of a division;
+//  * the clamps of yuv_component() and unorm8() never act: with channels in [0, 1], y' = dot(c, (0.2126, 0.7152, 0.0722)) <= 1 + 2 ulp
+//    gives 0.0627 <= y' * 0.8588 + 16/255 <= 0.9216, and |u'|, |v'| <= 0.5 (the negative and the positive coefficients each sum to
+//    0.5) gives 0.0627 <= (u' + 0.5) * 0.8784 + 16/255 <= 0.9412: inside (0, 1), never NaN.
+__device__ __forceinline__ float unorm_of_byte(u32 b) {
+    const float a = (float)b;
+    return __builtin_fmaf(a, 1.0f / 255.0f, a * -1.1641532182693481e-10f);
+}
+__device__ __forceinline__ u32 yuv_byte(float r, float g, float b, int plane) {
+    float comp;
+    if (plane == 0) {
+        const float y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
+        comp = (y * 0.85882352941f) + (16.0f / 255.0f);
+    } else if (plane == 1) {
+        const float u = r * -0.1146f + g * -0.3854f + b * 0.5f;
+        comp = ((u + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
+    } else {
+        const float v = r * 0.5f + g * -0.4542f + b * -0.0458f;
+        comp = ((v + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
+    }
+    return (u32)(int)(comp * 255.0f + 0.5f);
+}
+
 #endif

@@ -282,18 +282,20 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
         *(uint4 *)(o + yp.pitch) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
         return;
     }
-    // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52
-    // (byte / 255 by div_cr: the IEEE quotient for every byte, three operations instead of a division)
-    float4 c[8];
+    // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52, as yuv_component() /
+    // unorm8() compute it, minus the operations that cannot act on bytes (smr_convert_dev.h: unorm_of_byte, yuv_byte)
+    float cr[8], cg[8], cb[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++)
-        c[k] = make_float4(div_cr((float)(acc[k] & 0xffu), 255.0f, 1.0f / 255.0f), div_cr((float)((acc[k] >> 8) & 0xffu), 255.0f, 1.0f / 255.0f),
-                           div_cr((float)((acc[k] >> 16) & 0xffu), 255.0f, 1.0f / 255.0f), 0.0f);
+    for (int k = 0; k < 8; k++) {
+        cr[k] = unorm_of_byte(acc[k] & 0xffu);
+        cg[k] = unorm_of_byte((acc[k] >> 8) & 0xffu);
+        cb[k] = unorm_of_byte((acc[k] >> 16) & 0xffu);
+    }
     u32 yrow0 = 0, yrow1 = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        yrow0 |= unorm8(yuv_component(c[k], 0)) << (8 * k);
-        yrow1 |= unorm8(yuv_component(c[4 + k], 0)) << (8 * k);
+        yrow0 |= yuv_byte(cr[k], cg[k], cb[k], 0) << (8 * k);
+        yrow1 |= yuv_byte(cr[4 + k], cg[4 + k], cb[4 + k], 0) << (8 * k);
     }
     *(u32 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = yrow0;
     *(u32 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = yrow1;
@@ -302,14 +304,12 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     u32 uv[2][2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-        const float4 &p00 = c[2 * j], &p01 = c[2 * j + 1], &p10 = c[4 + 2 * j], &p11 = c[4 + 2 * j + 1];
-        float4 m;
-        m.x = (p00.x * gx + p01.x * fx) * gy + (p10.x * gx + p11.x * fx) * fy;
-        m.y = (p00.y * gx + p01.y * fx) * gy + (p10.y * gx + p11.y * fx) * fy;
-        m.z = (p00.z * gx + p01.z * fx) * gy + (p10.z * gx + p11.z * fx) * fy;
-        m.w = 0.0f;
-        uv[j][0] = unorm8(yuv_component(m, 1));
-        uv[j][1] = unorm8(yuv_component(m, 2));
+        const int a = 2 * j, b = 2 * j + 1, c = 4 + 2 * j, d = 4 + 2 * j + 1;
+        const float mr = (cr[a] * gx + cr[b] * fx) * gy + (cr[c] * gx + cr[d] * fx) * fy;
+        const float mg = (cg[a] * gx + cg[b] * fx) * gy + (cg[c] * gx + cg[d] * fx) * fy;
+        const float mb = (cb[a] * gx + cb[b] * fx) * gy + (cb[c] * gx + cb[d] * fx) * fy;
+        uv[j][0] = yuv_byte(mr, mg, mb, 1);
+        uv[j][1] = yuv_byte(mr, mg, mb, 2);
     }
     const int cx = px0 >> 1, cy = py0 >> 1;
     if (NV == 0) {

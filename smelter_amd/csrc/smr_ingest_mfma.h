@@ -602,7 +602,7 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                             px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
                         if (dj) {
                             // rgba_to_yuv.wgsl:26-54 on the bytes above, operation for operation as k_compose_output's copy tiles
-                            // (smr_fused_compose.h): unorm -> BT.709 -> unorm8.  byte / 255 by div_cr is the IEEE quotient for every byte.
+                            // (smr_fused_compose.h store_yuv_block; smr_convert_dev.h unorm_of_byte / yuv_byte): unorm -> BT.709 -> unorm8.
                             // Chroma = the mean of a 2x2 block, (a/2 + b/2)/2 + (c/2 + d/2)/2 (the halvings are exact, either sum
                             // commutes): the two rows of a block sit in neighbouring lanes (l16 even / odd; the tile's output
                             // position is even).  The even row's lane finishes the block of columns 0-1, the odd row's that of 2-3.
@@ -613,11 +613,9 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
 #pragma nounroll
                             for (int p = 0; p < 2; p++) {
                                 const u32 pa = p ? px[2] : px[0], pb = p ? px[3] : px[1];
-                                const float ar = div_cr((float)(pa & 0xffu), 255.0f, 1.0f / 255.0f), ag = div_cr((float)((pa >> 8) & 0xffu), 255.0f, 1.0f / 255.0f),
-                                            ab = div_cr((float)((pa >> 16) & 0xffu), 255.0f, 1.0f / 255.0f);
-                                const float br = div_cr((float)(pb & 0xffu), 255.0f, 1.0f / 255.0f), bg = div_cr((float)((pb >> 8) & 0xffu), 255.0f, 1.0f / 255.0f),
-                                            bb = div_cr((float)((pb >> 16) & 0xffu), 255.0f, 1.0f / 255.0f);
-                                const u32 y2 = unorm8(yuv_component(make_float4(ar, ag, ab, 0.0f), 0)) | (unorm8(yuv_component(make_float4(br, bg, bb, 0.0f), 0)) << 8);
+                                const float ar = unorm_of_byte(pa & 0xffu), ag = unorm_of_byte((pa >> 8) & 0xffu), ab = unorm_of_byte((pa >> 16) & 0xffu);
+                                const float br = unorm_of_byte(pb & 0xffu), bg = unorm_of_byte((pb >> 8) & 0xffu), bb = unorm_of_byte((pb >> 16) & 0xffu);
+                                const u32 y2 = yuv_byte(ar, ag, ab, 0) | (yuv_byte(br, bg, bb, 0) << 8);
                                 yq |= y2 << (16 * p);
                                 const float hr = ar * 0.5f + br * 0.5f, hg = ag * 0.5f + bg * 0.5f, hb = ab * 0.5f + bb * 0.5f;
                                 const bool mine_here = (p == 1) == odd;  // this lane finishes block p, the neighbour the other one
@@ -627,8 +625,8 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                             const float nb_r = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_r), 0xb1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
                             const float nb_g = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_g), 0xb1, 0xf, 0xf, true));
                             const float nb_b = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_b), 0xb1, 0xf, 0xf, true));
-                            const float4 m = make_float4(own_r * 0.5f + nb_r * 0.5f, own_g * 0.5f + nb_g * 0.5f, own_b * 0.5f + nb_b * 0.5f, 0.0f);
-                            const u32 mine = unorm8(yuv_component(m, 1)) | (unorm8(yuv_component(m, 2)) << 8);  // (U, V) of this lane's block
+                            const float m_r = own_r * 0.5f + nb_r * 0.5f, m_g = own_g * 0.5f + nb_g * 0.5f, m_b = own_b * 0.5f + nb_b * 0.5f;
+                            const u32 mine = yuv_byte(m_r, m_g, m_b, 1) | (yuv_byte(m_r, m_g, m_b, 2) << 8);  // (U, V) of this lane's block
                             const u32 other = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0xb1, 0xf, 0xf, true);
                             if (direct) {
                                 const MDirect *Dp = Dg;

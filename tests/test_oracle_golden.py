@@ -229,3 +229,31 @@ def test_lanczos_pass_agrees_with_pillow_on_linear_planes(sw, dw):
     got_v = orc.resample_pass(src_t, orc.PX_RGBA16F, 1, scale, 0.0, 0, orc.PX_RGBA16F, sh, dw).view(np.float16)[:, :, 0].astype(np.float64)
     d = np.abs(got_v[m:-m, :] - ref.T[m:-m, :])
     assert (d <= 2.0 ** -10 * np.abs(ref.T[m:-m, :]) + 1e-4).all()
+
+
+def test_byte_over_255_by_one_fma_is_the_ieee_quotient():
+    """smr_convert_dev.h unorm_of_byte: RN(a * RN(1/255) + a * -2^-33) == RN(a / 255) for every byte (exact rational arithmetic,
+    rounded to nearest-even f32 once — what v_fma_f32 does)."""
+    from fractions import Fraction
+
+    def rn_f32(q: Fraction) -> float:
+        if q == 0:
+            return 0.0
+        e = 0
+        while Fraction(2) ** (e + 1) <= q:
+            e += 1
+        while Fraction(2) ** e > q:
+            e -= 1
+        ulp = Fraction(2) ** (e - 23)
+        n, rem = divmod(q, ulp)
+        n = int(n)
+        if rem * 2 > ulp or (rem * 2 == ulp and n % 2 == 1):
+            n += 1
+        return float(Fraction(n) * ulp)
+
+    rb = Fraction(float(np.float32(1.0) / np.float32(255.0)))
+    c = -Fraction(1, 2 ** 33)
+    for a in range(256):
+        got = np.float32(rn_f32(a * rb + a * c))
+        want = np.float32(a) / np.float32(255.0)
+        assert got == want, a
