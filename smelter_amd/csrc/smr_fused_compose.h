@@ -299,15 +299,16 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     }
     *(u32 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = yrow0;
     *(u32 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = yrow1;
-    // chroma: the bilinear tap at the chroma texel centre = weights (1/2, 1/2) x (1/2, 1/2)
-    const float fx = 0.5f, gx = 1.0f - fx, fy = 0.5f, gy = 1.0f - fy;
+    // chroma: the bilinear tap at the chroma texel centre = weights (1/2, 1/2) x (1/2, 1/2):
+    //     (a * .5 + b * .5) * .5 + (c * .5 + d * .5) * .5  ==  ((a + b) + (c + d)) * .25   bit for bit
+    // (a power of two scales exactly and commutes with rounding — the operands are 0 or >= 1/255, nowhere near the subnormals)
     u32 uv[2][2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int a = 2 * j, b = 2 * j + 1, c = 4 + 2 * j, d = 4 + 2 * j + 1;
-        const float mr = (cr[a] * gx + cr[b] * fx) * gy + (cr[c] * gx + cr[d] * fx) * fy;
-        const float mg = (cg[a] * gx + cg[b] * fx) * gy + (cg[c] * gx + cg[d] * fx) * fy;
-        const float mb = (cb[a] * gx + cb[b] * fx) * gy + (cb[c] * gx + cb[d] * fx) * fy;
+        const float mr = ((cr[a] + cr[b]) + (cr[c] + cr[d])) * 0.25f;
+        const float mg = ((cg[a] + cg[b]) + (cg[c] + cg[d])) * 0.25f;
+        const float mb = ((cb[a] + cb[b]) + (cb[c] + cb[d])) * 0.25f;
         uv[j][0] = yuv_byte(mr, mg, mb, 1);
         uv[j][1] = yuv_byte(mr, mg, mb, 2);
     }

@@ -603,8 +603,8 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                         if (dj) {
                             // rgba_to_yuv.wgsl:26-54 on the bytes above, operation for operation as k_compose_output's copy tiles
                             // (smr_fused_compose.h store_yuv_block; smr_convert_dev.h unorm_of_byte / yuv_byte): unorm -> BT.709 -> unorm8.
-                            // Chroma = the mean of a 2x2 block, (a/2 + b/2)/2 + (c/2 + d/2)/2 (the halvings are exact, either sum
-                            // commutes): the two rows of a block sit in neighbouring lanes (l16 even / odd; the tile's output
+                            // Chroma = the mean of a 2x2 block, ((a + b) + (c + d)) / 4 — bit for bit (a/2 + b/2)/2 + (c/2 + d/2)/2, and
+                            // either sum commutes: the two rows of a block sit in neighbouring lanes (l16 even / odd; the tile's output
                             // position is even).  The even row's lane finishes the block of columns 0-1, the odd row's that of 2-3.
                             // (A real two-trip loop: unrolled, the twelve unpacked channels pushed the kernel over its 80 registers.)
                             const bool odd = (l16 & 1) != 0;
@@ -617,7 +617,7 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                                 const float br = unorm_of_byte(pb & 0xffu), bg = unorm_of_byte((pb >> 8) & 0xffu), bb = unorm_of_byte((pb >> 16) & 0xffu);
                                 const u32 y2 = yuv_byte(ar, ag, ab, 0) | (yuv_byte(br, bg, bb, 0) << 8);
                                 yq |= y2 << (16 * p);
-                                const float hr = ar * 0.5f + br * 0.5f, hg = ag * 0.5f + bg * 0.5f, hb = ab * 0.5f + bb * 0.5f;
+                                const float hr = ar + br, hg = ag + bg, hb = ab + bb;  // (row sums; the halvings are one exact * .25 at the end)
                                 const bool mine_here = (p == 1) == odd;  // this lane finishes block p, the neighbour the other one
                                 own_r = mine_here ? hr : own_r; own_g = mine_here ? hg : own_g; own_b = mine_here ? hb : own_b;
                                 snd_r = mine_here ? snd_r : hr; snd_g = mine_here ? snd_g : hg; snd_b = mine_here ? snd_b : hb;
@@ -625,7 +625,7 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                             const float nb_r = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_r), 0xb1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
                             const float nb_g = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_g), 0xb1, 0xf, 0xf, true));
                             const float nb_b = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_b), 0xb1, 0xf, 0xf, true));
-                            const float m_r = own_r * 0.5f + nb_r * 0.5f, m_g = own_g * 0.5f + nb_g * 0.5f, m_b = own_b * 0.5f + nb_b * 0.5f;
+                            const float m_r = (own_r + nb_r) * 0.25f, m_g = (own_g + nb_g) * 0.25f, m_b = (own_b + nb_b) * 0.25f;
                             const u32 mine = yuv_byte(m_r, m_g, m_b, 1) | (yuv_byte(m_r, m_g, m_b, 2) << 8);  // (U, V) of this lane's block
                             const u32 other = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0xb1, 0xf, 0xf, true);
                             if (direct) {
