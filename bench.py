@@ -296,7 +296,17 @@ def main():
             if rank == 0:
                 uid = torch.tensor(list(hip.Comm.unique_id()), dtype=torch.uint8, device="cuda")
             dist.broadcast(uid, src=0)
-            comm = hip.Comm.rank(ctx, world, rank, bytes(uid.cpu().tolist()))
+            try:
+                comm = hip.Comm.rank(ctx, world, rank, bytes(uid.cpu().tolist()))
+                ok = 1
+            except Exception as e:  # (e.g. librccl not loadable on this node): the torch.distributed send / recv twin of the same exchange
+                print(f"[bench] rank {rank}: smr_comm_create_rank failed ({e}); falling back to torch.distributed point-to-point", file=sys.stderr)
+                comm, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks use the same transport
+            if int(flag.item()) == 0 and comm is not None:
+                comm.close()
+                comm = None
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist, comm=comm)
 
         def step_fn(step):
@@ -560,7 +570,9 @@ def main():
                 result["exchange"] = {"bytes_per_frame": sum(per_peer.values()), "peers": len(per_peer), "max_bytes_per_link": worst,
                                       "link_GBps_achieved": round(worst * fps / 1e9, 3), "link_peak_GBps": 153.0,
                                       "frac_of_link_peak": round(worst * fps / 1e9 / 153.0, 5),
-                                      "note": "smr_gather_tiles (C ABI): RCCL send/recv of dst-sized RGBA8 tiles on the ctx stream, one xGMI link per peer"}
+                                      "transport": "smr_gather_tiles (C ABI, RCCL send / recv on the ctx stream)" if comm is not None
+                                      else "torch.distributed isend / irecv (fallback)",
+                                      "note": "dst-sized RGBA8 tiles gathered on the root, one xGMI link per peer"}
 
     if rank == 0:
         print(json.dumps(result))
