@@ -56,11 +56,31 @@ constexpr int M_WSPAN = 136;        // >= 32 * M_KV_MAX, >= 16 * M_KH_MAX
 //   every weight is an f16 pair (hi, lo): K fragments of each per tile.
 __host__ __device__ inline int mfma_window_base(int lo, int axis) { return axis == 0 ? (lo & ~3) : (((lo - 1) & ~7) + 1); }
 
-__global__ __launch_bounds__(64) void k_build_mfma_weights(float scale, float offset, int taps, int n_dst, int n_src, int axis, int K,
-                                                           int2 *__restrict__ meta, uint4 *__restrict__ frag) {
+// One launch builds every band the call is missing (a tile that resizes needs two new ones per frame; sixteen such tiles used to
+// be thirty-two launches of ~12 us each, back to back on the stream).
+struct WBuild {
+    float scale, offset;
+    int taps, n_dst, n_src, axis, K, tile0;  // tile0: first workgroup of this band
+    int2 *meta;
+    uint4 *frag;
+};
+constexpr int MAX_WBUILDS = 32;
+struct WBatch {
+    WBuild b[MAX_WBUILDS];
+    int n;
+};
+
+__global__ __launch_bounds__(64) void k_build_mfma_weights(const WBatch args) {
     __shared__ float s_w[16][M_WSPAN];
     __shared__ _Float16 s_q[16][M_WSPAN], s_r[16][M_WSPAN];
-    const int t = blockIdx.x, lane = threadIdx.x;
+    int bi = 0;
+    while (bi + 1 < args.n && args.b[bi + 1].tile0 <= (int)blockIdx.x) bi++;
+    const WBuild &B = args.b[bi];
+    const float scale = B.scale, offset = B.offset;
+    const int taps = B.taps, n_dst = B.n_dst, n_src = B.n_src, axis = B.axis, K = B.K;
+    int2 *__restrict__ meta = B.meta;
+    uint4 *__restrict__ frag = B.frag;
+    const int t = (int)blockIdx.x - B.tile0, lane = threadIdx.x;
     const int o0 = 16 * t, o1 = min(o0 + 15, n_dst - 1);
     const int lo = clampi(lanczos_first(o0, scale, offset), 0, n_src - 1);
     const int hi = clampi(lanczos_first(o1, scale, offset) + taps - 1, 0, n_src - 1);
@@ -163,6 +183,9 @@ int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
         }
         const size_t meta_bytes = ((size_t)n_tiles * sizeof(int2) + 15) & ~(size_t)15;
         const size_t need = meta_bytes + (size_t)n_tiles * 2 * K * 64 * sizeof(uint4);
+        // (a band of an earlier call that was allocated but never needed — its job did not fit — is dropped with its table)
+        for (size_t i = ctx->pending_bands.size(); i-- > 0;)
+            if (victim->dev && ctx->pending_bands[i].meta == victim->dev) ctx->pending_bands.erase(ctx->pending_bands.begin() + (long)i);
         if (victim->bytes < need) {
             if (victim->dev) {
                 SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a queued kernel may still read it
@@ -176,9 +199,11 @@ int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
         }
         victim->scale = scale; victim->offset = offset; victim->n_dst = n_dst; victim->n_src = n_src; victim->axis = axis;
         victim->K = K; victim->max_span = span; victim->meta_bytes = meta_bytes;
-        hipLaunchKernelGGL(k_build_mfma_weights, dim3((unsigned)n_tiles), dim3(64), 0, ctx->stream, scale, offset, host_taps(scale), n_dst, n_src,
-                           axis, K, (int2 *)victim->dev, (uint4 *)((u8 *)victim->dev + meta_bytes));
-        SMR_HIP(ctx, hipGetLastError());
+        // (built by flush_mfma_builds, one launch for all the bands a call misses, before the kernel that reads them)
+        smr_ctx::PendingBand pb;
+        pb.scale = scale; pb.offset = offset; pb.taps = host_taps(scale); pb.n_dst = n_dst; pb.n_src = n_src; pb.axis = axis; pb.K = K;
+        pb.n_tiles = n_tiles; pb.meta = victim->dev; pb.frag = (u8 *)victim->dev + meta_bytes;
+        ctx->pending_bands.push_back(pb);
         hit = victim;
     }
     hit->last_use = ++ctx->weight_clock;
@@ -188,6 +213,26 @@ int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
     out->K = hit->K;
     out->n_tiles = n_tiles;
     out->max_span = hit->max_span;
+    return SMR_OK;
+}
+
+int flush_mfma_builds(smr_ctx *ctx) {
+    size_t i = 0;
+    while (i < ctx->pending_bands.size()) {
+        WBatch args;
+        memset(&args, 0, sizeof(args));
+        int tiles = 0;
+        for (; i < ctx->pending_bands.size() && args.n < MAX_WBUILDS; i++) {
+            const smr_ctx::PendingBand &p = ctx->pending_bands[i];
+            WBuild &b = args.b[args.n++];
+            b.scale = p.scale; b.offset = p.offset; b.taps = p.taps; b.n_dst = p.n_dst; b.n_src = p.n_src; b.axis = p.axis; b.K = p.K;
+            b.tile0 = tiles; b.meta = (int2 *)p.meta; b.frag = (uint4 *)p.frag;
+            tiles += p.n_tiles;
+        }
+        hipLaunchKernelGGL(k_build_mfma_weights, dim3((unsigned)tiles), dim3(64), 0, ctx->stream, args);
+        SMR_HIP(ctx, hipGetLastError());
+    }
+    ctx->pending_bands.clear();
     return SMR_OK;
 }
 
@@ -717,7 +762,12 @@ bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pl
 #endif
     if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return false;
     if (f->width % 2 || f->height % 2 || f->width < 8 || f->height < 2) return false;
-    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0)) return false;
+    // Two filtered axes, horizontal pass first, no box pre-reduction.  (A plan the reference orders vertically first — the
+    // stronger shrink goes first, resampler.rs:123-145 — was tried through this kernel with the passes swapped: <= 1 LSB and
+    // 99.6 % identical on camera-like content, but 2 LSB on white noise even when the two scales differ by a rounding of the
+    // tile size only; it keeps the reference's order through the general kernels.)
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
+    const int hs = 0, vs = 1;  // plan slots of the horizontal / vertical pass
     if (!mfma_plane_ok(view_of(f->planes[0]), f->width)) return false;
     if (nv12) {  // (the last staged dword pair may start up to 3 texels before the row's end: 8 bytes must be readable there)
         const SurfView uv = view_of(f->planes[1]);
@@ -727,17 +777,18 @@ bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pl
     }
     if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
     int KH, KV, sh_, sv_;
-    mfma_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 0, &KH, &sh_);
-    mfma_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 1, &KV, &sv_);
+    mfma_band_geometry(plan.scale[hs], plan.offset[hs], (int)tile->w, (int)f->width, 0, &KH, &sh_);
+    mfma_band_geometry(plan.scale[vs], plan.offset[vs], (int)tile->h, (int)f->height, 1, &KV, &sv_);
     if (KH > M_KH_MAX || KV > M_KV_MAX) return false;
     return true;
 }
 
 int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, MJob *out, bool *fits) {
     MfmaBand bh, bv;
-    int rc = get_mfma_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 0, &bh);
+    const int hs = plan.axis[0] == 0 ? 0 : 1, vs = 1 - hs;  // plan slots of the horizontal / vertical pass (can_fuse_mfma)
+    int rc = get_mfma_band(ctx, plan.scale[hs], plan.offset[hs], (int)tile->w, (int)f->width, 0, &bh);
     if (rc != SMR_OK) return rc;
-    rc = get_mfma_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 1, &bv);
+    rc = get_mfma_band(ctx, plan.scale[vs], plan.offset[vs], (int)tile->h, (int)f->height, 1, &bv);
     if (rc != SMR_OK) return rc;
     MJob &J = *out;
     J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = f->planes[2] ? view_of(f->planes[2]) : J.up;
@@ -764,14 +815,14 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
     if (J.nv12) J.vp = J.up;
     // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
-    const int taps_h = host_taps(plan.scale[0]);
+    const int taps_h = host_taps(plan.scale[hs]);
     int ngm = 1;
     for (int s = 0; s < J.strips_x; s++) {
         const int t0 = s * M_NT, t1 = (t0 + M_NT < bh.n_tiles ? t0 + M_NT : bh.n_tiles) - 1;
-        int lo = lanczos_first(16 * t0, plan.scale[0], plan.offset[0]);
+        int lo = lanczos_first(16 * t0, plan.scale[hs], plan.offset[hs]);
         lo = lo < 0 ? 0 : (lo > J.src_w - 1 ? J.src_w - 1 : lo);
         const int o1 = 16 * t1 + 15 < (int)tile->w - 1 ? 16 * t1 + 15 : (int)tile->w - 1;
-        int hi = lanczos_first(o1, plan.scale[0], plan.offset[0]) + taps_h - 1;
+        int hi = lanczos_first(o1, plan.scale[hs], plan.offset[hs]) + taps_h - 1;
         hi = hi < 0 ? 0 : (hi > J.src_w - 1 ? J.src_w - 1 : hi);
         const int g = (hi - (mfma_window_base(lo, 0) & ~7) + 4) >> 2;
         ngm = g > ngm ? g : ngm;
@@ -815,6 +866,7 @@ int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs, const MDirect *direct = n
         }
         ctx->mfma_attr_set = true;
     }
+    if (int rc = flush_mfma_builds(ctx)) return rc;
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
     for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_MJOBS_PER_LAUNCH) {
         const size_t nj = jobs.size() - j0 < (size_t)MAX_MJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_MJOBS_PER_LAUNCH;

@@ -126,6 +126,8 @@ struct smr_ctx {
         uint64_t last_use = 0, last_call = 0;
     };
     std::vector<MfmaTable> mfma_tables;
+    struct PendingBand { float scale, offset; int taps, n_dst, n_src, axis, K, n_tiles; void *meta, *frag; };
+    std::vector<PendingBand> pending_bands;  // bands allocated by the current call, built in one launch before the kernel that reads them
     struct MfmaOccupancy { int kernel; size_t lds; int per_cu; };
     std::vector<MfmaOccupancy> mfma_occupancy;  // resident k_ingest_mfma workgroups per CU, per (kernel build, LDS bytes)
     u32 *d_lut16 = nullptr;      // 256 x (f16 hi | f16 lo << 16) of the sRGB decode table
