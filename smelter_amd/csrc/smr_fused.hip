@@ -171,7 +171,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes + sizeof(MDirect), &packed);
     if (rc != SMR_OK) return rc;
     const u32 n_first = compose_order(packed, (int)b_tiles_x, (int)b_tiles_y, (ComposeOrder *)packed.extra_host);
-    const bool fits_b = fused && (out_w % 4 == 0) && (out_h % 2 == 0) && packed.n <= MAX_LAYOUT_WORDS * 32;
+    const bool fits_b = fused && (out_w % 2 == 0) && (out_h % 2 == 0) && packed.n <= MAX_LAYOUT_WORDS * 32;
     const bool big_list = packed.n > B_MAX_LAYOUTS || packed.n_masks > B_MAX_MASKS;  // read in place instead of from an LDS copy
     const bool fuse_yuv = fits_b && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
                           out->planes[0] && out->planes[1] && (out->format == SMR_FRAME_NV12 || out->planes[2]);

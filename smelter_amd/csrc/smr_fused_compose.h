@@ -275,11 +275,18 @@ __device__ __forceinline__ u32 compose_px(u32 a, const DevLayout &L, const DevMa
 }
 
 template <int NV>
-__device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, int py0, const SurfView &yp, const SurfView &up, const SurfView &vp) {
+__device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, int py0, int W, const SurfView &yp, const SurfView &up, const SurfView &vp) {
+    // (W is even: the last block of a row holds four or two pixels)
+    const bool half = px0 + 3 >= W;
     if (NV == 2) {  // an RGBA8 node texture (LayoutNode::render into a NodeTexture): the composited bytes as they are
         u8 *o = yp.ptr + (size_t)py0 * yp.pitch + (size_t)px0 * 4;
-        *(uint4 *)o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-        *(uint4 *)(o + yp.pitch) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+        if (half) {
+            *(uint2 *)o = make_uint2(acc[0], acc[1]);
+            *(uint2 *)(o + yp.pitch) = make_uint2(acc[4], acc[5]);
+        } else {
+            *(uint4 *)o = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+            *(uint4 *)(o + yp.pitch) = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+        }
         return;
     }
     // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52, as yuv_component() /
@@ -297,8 +304,13 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
         yrow0 |= yuv_byte(cr[k], cg[k], cb[k], 0) << (8 * k);
         yrow1 |= yuv_byte(cr[4 + k], cg[4 + k], cb[4 + k], 0) << (8 * k);
     }
-    *(u32 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = yrow0;
-    *(u32 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = yrow1;
+    if (half) {
+        *(u16 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = (u16)yrow0;
+        *(u16 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = (u16)yrow1;
+    } else {
+        *(u32 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = yrow0;
+        *(u32 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = yrow1;
+    }
     // chroma: the bilinear tap at the chroma texel centre = weights (1/2, 1/2) x (1/2, 1/2):
     //     (a * .5 + b * .5) * .5 + (c * .5 + d * .5) * .5  ==  ((a + b) + (c + d)) * .25   bit for bit
     // (a power of two scales exactly and commutes with rounding — the operands are 0 or >= 1/255, nowhere near the subnormals)
@@ -314,8 +326,15 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     }
     const int cx = px0 >> 1, cy = py0 >> 1;
     if (NV == 0) {
-        *(u16 *)(up.ptr + (size_t)cy * up.pitch + cx) = (u16)(uv[0][0] | (uv[1][0] << 8));
-        *(u16 *)(vp.ptr + (size_t)cy * vp.pitch + cx) = (u16)(uv[0][1] | (uv[1][1] << 8));
+        if (half) {
+            up.ptr[(size_t)cy * up.pitch + cx] = (u8)uv[0][0];
+            vp.ptr[(size_t)cy * vp.pitch + cx] = (u8)uv[0][1];
+        } else {
+            *(u16 *)(up.ptr + (size_t)cy * up.pitch + cx) = (u16)(uv[0][0] | (uv[1][0] << 8));
+            *(u16 *)(vp.ptr + (size_t)cy * vp.pitch + cx) = (u16)(uv[0][1] | (uv[1][1] << 8));
+        }
+    } else if (half) {
+        *(u16 *)(up.ptr + (size_t)cy * up.pitch + (size_t)cx * 2) = (u16)(uv[0][0] | (uv[0][1] << 8));
     } else {
         *(u32 *)(up.ptr + (size_t)cy * up.pitch + (size_t)cx * 2) = uv[0][0] | (uv[0][1] << 8) | (uv[1][0] << 16) | (uv[1][1] << 24);
     }
@@ -367,7 +386,7 @@ __device__ __forceinline__ void compose_full(int tile, int band, int rh, const S
     if ((ablate & 16) && general) return;   // profiling: copy tiles only
     if ((ablate & 32) && !general) return;  // profiling: general tiles only
     const int words = (n + 31) >> 5;
-    const bool no_block = px0 >= W || py0 >= H || 2 * (tid >> 5) >= rh;      // (W % 4 == 0, H % 2 == 0: a block is entirely inside or outside)
+    const bool no_block = px0 >= W || py0 >= H || 2 * (tid >> 5) >= rh;      // (W, H even: a block has four or two columns, always two rows)
     const int nsweeps = (B_TILE_W * rh) / 256;
 
     if (general) {
@@ -467,19 +486,20 @@ __device__ __forceinline__ void compose_full(int tile, int band, int rh, const S
                 // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
                 const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
                 const u8 *r1 = r0 + L.src.pitch;
-                if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0) {
+                if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0 && px0 + 3 < W) {
                     const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
                     acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
                     acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; c++) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
+                    for (int c = 0; c < 4; c++)
+                        if (px0 + c < W) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
                 }
             }
         }
     }
 
-    if (!no_block) store_yuv_block<NV>(acc, px0, py0, yp, up, vp);
+    if (!no_block) store_yuv_block<NV>(acc, px0, py0, W, yp, up, vp);
 }
 
 // Copy tiles per workgroup of the kernel's second part (their records, then all their texels, are fetched back to back).
@@ -524,6 +544,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         const int tile = t0 + k, ty = tile / tiles_x;
         on[k] = c[k].kind <= TC_TEXTURE && !((srgb_and_ablate >> 8) & 64) && (tile - ty * tiles_x) * B_TILE_W + bx < W && ty * B_TILE_H + by < H;
         if (c[k].kind == TC_TEXTURE && ((((uintptr_t)c[k].base) & 15) != 0 || (c[k].pitch_or_px & 15) != 0)) aligned = false;
+        if ((W & 3) && (tile - ty * tiles_x) * B_TILE_W + B_TILE_W > W) aligned = false;  // the row's last block is two pixels wide
     }
     if (aligned) {
         // straight-line: the texel loads of all the group's tiles are in flight together (a lane with nothing to read reads the
@@ -552,15 +573,17 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
             for (int q = 0; q < 8; q++) acc[k][q] = fill;
             if (on[k] && c[k].kind == TC_TEXTURE) {
                 const u8 *r0 = c[k].base + (size_t)by * c[k].pitch_or_px + (size_t)bx * 4, *r1 = r0 + c[k].pitch_or_px;
+                const int tile = t0 + k, cols = W - ((tile - (tile / tiles_x) * tiles_x) * B_TILE_W + bx);  // >= 2
 #pragma unroll
-                for (int q = 0; q < 4; q++) { acc[k][q] = ((const u32 *)r0)[q]; acc[k][4 + q] = ((const u32 *)r1)[q]; }
+                for (int q = 0; q < 4; q++)
+                    if (q < cols) { acc[k][q] = ((const u32 *)r0)[q]; acc[k][4 + q] = ((const u32 *)r1)[q]; }
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < B_COPY_TILES; k++) {
         const int tile = t0 + k, ty = tile / tiles_x;
-        if (on[k]) store_yuv_block<NV>(acc[k], (tile - ty * tiles_x) * B_TILE_W + bx, ty * B_TILE_H + by, yp, up, vp);
+        if (on[k]) store_yuv_block<NV>(acc[k], (tile - ty * tiles_x) * B_TILE_W + bx, ty * B_TILE_H + by, W, yp, up, vp);
     }
     // sampled tiles: one layer's record straight from the list in memory, eight independent pixels per thread
 #pragma unroll 1
@@ -576,7 +599,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
             u32 a[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) a[q] = composite_layout_solid(0u, L, px0 + (q & 3), py0 + (q >> 2), srgb_and_ablate & 1, s_tab, s_tab + 256);
-            store_yuv_block<NV>(a, px0, py0, yp, up, vp);
+            store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
         }
     }
     // a tile that needs compositing and found no room on the band list (the host's bound was short): here, all sixteen rows
