@@ -7,18 +7,19 @@
 // 37 MB of algorithmic bytes).
 //
 // Here:
-//   wave A  k_ingest_resample (smr_fused_ingest.h)  — raw Y/U/V planes -> dst-sized RGBA8 tiles, all inputs
-//           of the frame in one launch; node texture and f16 intermediate live only in LDS.
-//   wave B  k_compose_output (smr_fused_compose.h)  — all layouts + RGBA->Y'CbCr in one launch; the RGBA8
-//           output frame lives only in registers.
-// Every quantisation point of the reference pipeline (u8 node texture, f16 intermediate, u8 sRGB tile, u8
-// render target after each draw) is reproduced in registers, with the same f32 operation sequence as the
-// general kernels; the only substitutions are exact ones (LUTs for u8 -> f32, correctly rounded division
-// through a reciprocal + two FMAs, skipping layers an opaque layer overwrites).  tests/test_gpu_fused.py
-// checks fused == pass-per-launch bit for bit.
-// Anything the fused kernels do not cover (single-pass plans, box pre-reduction, vertical-first plans,
-// packed / NV12 inputs, output widths not divisible by 4, 4:2:2 / 4:4:4 / RGBA outputs) falls back to the
-// general kernels of smr_convert / smr_resample / smr_layout per layout — never to the CPU.
+//   wave A  k_ingest_mfma (smr_ingest_mfma.h; k_ingest_resample of smr_fused_ingest.h is its exact-f32 twin) — raw Y/U/V planes
+//           -> dst-sized RGBA8 tiles, all inputs of the frame in one launch; node texture and f16 intermediate live only in LDS.
+//   wave B  k_compose_output (smr_fused_compose.h) — all layouts + RGBA->Y'CbCr (or an RGBA8 node target) in one launch, driven
+//           by per-tile class records (k_classify_tiles) that are kept while the layout list repeats; the RGBA8 output frame
+//           lives only in registers.
+// Every quantisation point of the reference pipeline (u8 node texture, f16 intermediate, u8 sRGB tile, u8 render target after
+// each draw) is reproduced; the compositor and the f32 ingest kernel keep the f32 operation sequence of the general kernels
+// (the only substitutions are exact ones: LUTs for u8 -> f32, correctly rounded division through a reciprocal + FMAs, operations
+// that cannot act on the operands at hand, layers an opaque layer overwrites) — tests/test_gpu_fused.py checks fused ==
+// pass-per-launch bit for bit; the matrix-core ingest kernel spends the resampler's 1-LSB budget.
+// Anything the fused kernels do not cover (single-pass plans, box pre-reduction, vertical-first plans, packed inputs, odd
+// output sizes, 4:2:2 / 4:4:4 outputs) falls back to the general kernels of smr_convert / smr_resample / smr_layout per
+// layout — never to the CPU.
 #include "smr_fused_compose.h"
 #include "smr_fused_ingest.h"
 #include "smr_ingest_mfma.h"
