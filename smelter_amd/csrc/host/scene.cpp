@@ -4,6 +4,7 @@
 #include "scene.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 
@@ -247,10 +248,10 @@ void Stateful::node_children(std::vector<Stateful *> &out) {  // scene/layout.rs
         else out.push_back(c.get());
     }
 }
-size_t Stateful::node_children_count() {
-    std::vector<Stateful *> v;
-    node_children(v);
-    return v.size();
+size_t Stateful::node_children_count() {  // (counted, not collected: this runs for every layout component of every frame)
+    size_t n = 0;
+    for (auto &c : children) n += c->is_layout() ? c->node_children_count() : 1;
+    return n;
 }
 void Stateful::update_state(const std::vector<std::optional<Size>> &res, size_t begin) {  // scene/layout.rs:103-137
     size_t off = begin;
@@ -581,23 +582,23 @@ NestedLayout Stateful::layout(Size size, int64_t pts) {
 
 // ------------------------------------------------------------------------------------------------ flatten (layout/flatten.rs)
 namespace {
-std::vector<MaskL> child_parent_masks(const NestedLayout &n, const std::vector<MaskL> &masks) {  // :358-371
-    std::vector<MaskL> out;
+// (this code runs once per frame and output on the renderer thread: lists are transformed in place and moved, not rebuilt)
+void child_parent_masks(const NestedLayout &n, std::vector<MaskL> &masks) {  // :358-371
     float s = rmin(n.scale_x, n.scale_y);
     for (auto &m : masks)
-        out.push_back({radius_mul(m.radius, 1.0f / s), (m.top - n.top) / n.scale_y, (m.left - n.left) / n.scale_x, m.width / n.scale_x,
-                       m.height / n.scale_y});
-    return out;
+        m = {radius_mul(m.radius, 1.0f / s), (m.top - n.top) / n.scale_y, (m.left - n.left) / n.scale_x, m.width / n.scale_x,
+             m.height / n.scale_y};
 }
-std::vector<MaskL> parent_parent_masks(const NestedLayout &n, const std::vector<MaskL> &masks) {  // :373-389
-    std::vector<MaskL> out;
+void parent_parent_masks(const NestedLayout &n, std::vector<MaskL> &masks) {  // :373-389
     float s = rmin(n.scale_x, n.scale_y);
     for (auto &m : masks)
-        out.push_back({radius_mul(m.radius, s), (m.top * n.scale_y) + n.top, (m.left * n.scale_x) + n.left, m.width * n.scale_x,
-                       m.height * n.scale_y});
-    return out;
+        m = {radius_mul(m.radius, s), (m.top * n.scale_y) + n.top, (m.left * n.scale_x) + n.left, m.width * n.scale_x,
+             m.height * n.scale_y};
 }
-RenderLayout flatten_child(const NestedLayout &n, const RenderLayout &c) {  // :167-305
+RenderLayout flatten_child(const NestedLayout &n, RenderLayout &&child) {  // :167-305
+    std::vector<MaskL> masks = std::move(child.masks);  // (the list travels; the child's own values are read from a mask-less copy)
+    child.masks.clear();
+    const RenderLayout &c = child;
     RenderLayout o = c;
     float us = rmin(n.scale_x, n.scale_y);
     if (!n.crop) {
@@ -624,7 +625,8 @@ RenderLayout flatten_child(const NestedLayout &n, const RenderLayout &c) {  // :
     }
     o.rotation_degrees = c.rotation_degrees + n.rotation_degrees;
     o.border_radius = radius_mul(c.border_radius, us);
-    o.masks = parent_parent_masks(n, c.masks);
+    o.masks = std::move(masks);
+    parent_parent_masks(n, o.masks);
     return o;
 }
 void inner_flatten(const NestedLayout &n, size_t offset, const std::vector<MaskL> &parent_masks, std::vector<RenderLayout> &shadows,
@@ -646,20 +648,23 @@ void inner_flatten(const NestedLayout &n, size_t offset, const std::vector<MaskL
         sh.rotation_degrees = n.rotation_degrees;
         sh.border_radius = radius_add(n.border_radius, s.blur_radius / 2.0f);
         sh.content = 2; sh.color = s.color; sh.blur_radius = s.blur_radius; sh.masks = parent_masks;
-        shadows.push_back(sh);
+        shadows.push_back(std::move(sh));
     }
-    std::vector<MaskL> masks = parent_masks;
+    std::vector<MaskL> masks;
+    masks.reserve(parent_masks.size() + 1);
+    masks = parent_masks;
     if (n.mask) masks.push_back(*n.mask);
-    masks = child_parent_masks(n, masks);
+    child_parent_masks(n, masks);
     std::vector<RenderLayout> child_shadows, child_layouts;
     for (auto &ch : n.children) {
         size_t cnt = ch.child_nodes_count;
         inner_flatten(ch, offset, masks, child_shadows, child_layouts);
         offset += cnt;
     }
-    layouts.push_back(me);
-    for (auto &c : child_shadows) layouts.push_back(flatten_child(n, c));
-    for (auto &c : child_layouts) layouts.push_back(flatten_child(n, c));
+    layouts.reserve(layouts.size() + 1 + child_shadows.size() + child_layouts.size());
+    layouts.push_back(std::move(me));
+    for (auto &c : child_shadows) layouts.push_back(flatten_child(n, std::move(c)));
+    for (auto &c : child_layouts) layouts.push_back(flatten_child(n, std::move(c)));
 }
 bool should_render(const RenderLayout &l, const std::vector<std::optional<Size>> &res, uint32_t W, uint32_t H) {  // :121-164
     if (l.width <= 0.0f || l.height <= 0.0f || l.top > (float)H || l.left > (float)W) return false;
@@ -679,15 +684,15 @@ bool should_render(const RenderLayout &l, const std::vector<std::optional<Size>>
 }
 void fix_final(RenderLayout &l) {  // :84-116
     if (l.content != 2 && l.border_width < 1.0f) l.border_width = 0.0f;
-    std::vector<MaskL> keep;
+    size_t kept = 0;
     for (auto &m : l.masks) {
         float mt = rmax(m.radius.tl, m.radius.tr), mb = rmax(m.radius.bl, m.radius.br);
         float ml = rmax(m.radius.tl, m.radius.bl), mr = rmax(m.radius.tr, m.radius.br);
         bool skip = m.top + mt <= l.top && m.left + ml <= l.left && m.left + m.width - mr >= l.left + l.width &&
                     m.top + m.height - mb >= l.top + l.height;
-        if (!skip) keep.push_back(m);
+        if (!skip) l.masks[kept++] = m;
     }
-    l.masks = keep;
+    l.masks.resize(kept);
 }
 }  // namespace
 
@@ -695,16 +700,24 @@ std::vector<RenderLayout> NestedLayout::flatten(const std::vector<std::optional<
     std::vector<RenderLayout> shadows, layouts, out;
     // inner_flatten's child accumulation must not see this node's own entries: collect into fresh vectors
     inner_flatten(*this, 0, {}, shadows, layouts);
+    out.reserve(shadows.size() + layouts.size());
     for (auto *v : {&shadows, &layouts})
         for (auto &l : *v)
-            if (should_render(l, res, W, H)) { fix_final(l); out.push_back(l); }
+            if (should_render(l, res, W, H)) { fix_final(l); out.push_back(std::move(l)); }
     return out;
 }
 
 // ------------------------------------------------------------------------------------------------ colours
-static double srgb_to_linear(uint8_t c8) {  // wgpu/utils.rs:74-81
-    double c = (double)c8 / 255.0;
-    return c < 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+static double srgb_to_linear(uint8_t c8) {  // wgpu/utils.rs:74-81 (the 256 values, computed once)
+    static const std::array<double, 256> table = [] {
+        std::array<double, 256> t{};
+        for (int i = 0; i < 256; i++) {
+            double c = (double)i / 255.0;
+            t[i] = c < 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+        }
+        return t;
+    }();
+    return table[c8];
 }
 void convert_to_shader_color(RGBA c, bool srgb, float out[4]) {  // wgpu/utils.rs:51-72
     double a = (double)c.a / 255.0;

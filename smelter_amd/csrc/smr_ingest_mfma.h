@@ -166,14 +166,20 @@ void mfma_band_geometry(float scale, float offset, int n_dst, int n_src, int axi
     *K = axis == 0 ? (2 * span + 31) / 32 : (span + 31) / 32;
 }
 
-int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis, MfmaBand *out) {
-    int K, span;
-    mfma_band_geometry(scale, offset, n_dst, n_src, axis, &K, &span);
-    const int n_tiles = (n_dst + 15) / 16;
-    smr_ctx::MfmaTable *hit = nullptr, *victim = nullptr;
+// the cached band of (scale, offset, n_dst, n_src, axis), if any: a frame of a scene at rest finds all of its bands here and
+// never walks the tile geometry on the host
+smr_ctx::MfmaTable *find_mfma_table(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis) {
     for (auto &t : ctx->mfma_tables)
-        if (t.dev && t.n_dst == n_dst && t.n_src == n_src && t.axis == axis && t.scale == scale && t.offset == offset) { hit = &t; break; }
+        if (t.dev && t.n_dst == n_dst && t.n_src == n_src && t.axis == axis && t.scale == scale && t.offset == offset) return &t;
+    return nullptr;
+}
+
+int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis, MfmaBand *out) {
+    const int n_tiles = (n_dst + 15) / 16;
+    smr_ctx::MfmaTable *hit = find_mfma_table(ctx, scale, offset, n_dst, n_src, axis), *victim = nullptr;
     if (!hit) {
+        int K, span;
+        mfma_band_geometry(scale, offset, n_dst, n_src, axis, &K, &span);
         // never evict a table the current call already handed to a job that is not launched yet
         for (auto &t : ctx->mfma_tables)
             if (t.last_call != ctx->weight_call && (!victim || t.last_use < victim->last_use)) victim = &t;
@@ -198,7 +204,7 @@ int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
             victim->bytes = want;
         }
         victim->scale = scale; victim->offset = offset; victim->n_dst = n_dst; victim->n_src = n_src; victim->axis = axis;
-        victim->K = K; victim->max_span = span; victim->meta_bytes = meta_bytes;
+        victim->K = K; victim->max_span = span; victim->meta_bytes = meta_bytes; victim->ngm = 0;
         // (built by flush_mfma_builds, one launch for all the bands a call misses, before the kernel that reads them)
         smr_ctx::PendingBand pb;
         pb.scale = scale; pb.offset = offset; pb.taps = host_taps(scale); pb.n_dst = n_dst; pb.n_src = n_src; pb.axis = axis; pb.K = K;
@@ -777,8 +783,10 @@ bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pl
     }
     if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
     int KH, KV, sh_, sv_;
-    mfma_band_geometry(plan.scale[hs], plan.offset[hs], (int)tile->w, (int)f->width, 0, &KH, &sh_);
-    mfma_band_geometry(plan.scale[vs], plan.offset[vs], (int)tile->h, (int)f->height, 1, &KV, &sv_);
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[hs], plan.offset[hs], (int)tile->w, (int)f->width, 0)) KH = t->K;
+    else mfma_band_geometry(plan.scale[hs], plan.offset[hs], (int)tile->w, (int)f->width, 0, &KH, &sh_);
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[vs], plan.offset[vs], (int)tile->h, (int)f->height, 1)) KV = t->K;
+    else mfma_band_geometry(plan.scale[vs], plan.offset[vs], (int)tile->h, (int)f->height, 1, &KV, &sv_);
     if (KH > M_KH_MAX || KV > M_KV_MAX) return false;
     return true;
 }
@@ -814,10 +822,11 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.layer = -1; J.ox = 0; J.oy = 0;
     J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
     if (J.nv12) J.vp = J.up;
-    // LDS sizing: the widest strip footprint (host twin of the kernel's geometry)
+    // LDS sizing: the widest strip footprint (host twin of the kernel's geometry), kept with the horizontal band
+    smr_ctx::MfmaTable *th = find_mfma_table(ctx, plan.scale[hs], plan.offset[hs], (int)tile->w, (int)f->width, 0);
     const int taps_h = host_taps(plan.scale[hs]);
-    int ngm = 1;
-    for (int s = 0; s < J.strips_x; s++) {
+    int ngm = th && th->ngm > 0 ? th->ngm : 1;
+    for (int s = 0; s < J.strips_x && !(th && th->ngm > 0); s++) {
         const int t0 = s * M_NT, t1 = (t0 + M_NT < bh.n_tiles ? t0 + M_NT : bh.n_tiles) - 1;
         int lo = lanczos_first(16 * t0, plan.scale[hs], plan.offset[hs]);
         lo = lo < 0 ? 0 : (lo > J.src_w - 1 ? J.src_w - 1 : lo);
@@ -827,6 +836,7 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
         const int g = (hi - (mfma_window_base(lo, 0) & ~7) + 4) >> 2;
         ngm = g > ngm ? g : ngm;
     }
+    if (th) th->ngm = ngm;
     J.ngm = ngm;
     J.ts = ((4 * ngm + 7) & ~15) + 8;  // >= 4 * ngm and = 8 mod 16
     if (J.ts < 4 * ngm) J.ts += 16;

@@ -121,6 +121,7 @@ struct smr_ctx {
     struct MfmaTable {
         float scale = 0.f, offset = 0.f;
         int n_dst = 0, n_src = 0, axis = 0, K = 0, max_span = 0;
+        int ngm = 0;          // axis 0: column groups of the widest strip footprint (0 = not computed yet)
         void *dev = nullptr;  // int2 meta[n_tiles] (padded to 16 B); uint4 frag[n_tiles][K][64]
         size_t bytes = 0, meta_bytes = 0;
         uint64_t last_use = 0, last_call = 0;

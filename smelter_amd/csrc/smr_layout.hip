@@ -13,6 +13,8 @@
 // target is written once and never read.
 #include "smr_layout_dev.h"
 
+#include <algorithm>
+
 namespace {
 
 __global__ __launch_bounds__(LAYOUT_TILE_W *LAYOUT_TILE_H) void k_apply_layouts(SurfView target, const DevLayout *__restrict__ layouts,
@@ -163,9 +165,7 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
             auto enc = [&](float x) -> u32 {
                 if (ctx->srgb()) {
                     if (!(x > 0.0f)) return 0u;
-                    u32 c = 0;
-                    while (c < 255 && thr[c + 1] <= x) c++;
-                    return c;
+                    return (u32)(std::upper_bound(thr + 1, thr + 256, x) - (thr + 1));  // #{i in 1..255 : thr[i] <= x}
                 }
                 x = !(x > 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x);
                 return (u32)(int)(x * 255.0f + 0.5f);
