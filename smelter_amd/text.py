@@ -18,7 +18,6 @@ TrueType fonts read with fontTools (the reference bundles Inter: smelter-render/
 Pure host code: no GPU, no oracle.  The GPU path (smr_blit_glyphs) is exercised with its output in tests/."""
 from __future__ import annotations
 
-import ctypes as C
 import math
 import os
 from dataclasses import dataclass
