@@ -17,7 +17,7 @@
 // (the only substitutions are exact ones: LUTs for u8 -> f32, correctly rounded division through a reciprocal + FMAs, operations
 // that cannot act on the operands at hand, layers an opaque layer overwrites) — tests/test_gpu_fused.py checks fused ==
 // pass-per-launch bit for bit; the matrix-core ingest kernel spends the resampler's 1-LSB budget.
-// Anything the fused kernels do not cover (single-pass plans, box pre-reduction, vertical-first plans, packed inputs, odd
+// Anything the fused kernels do not cover (single-pass plans, box pre-reduction, packed inputs, odd
 // output sizes, 4:2:2 / 4:4:4 outputs) falls back to the general kernels of smr_convert / smr_resample / smr_layout per
 // layout — never to the CPU.
 #include "smr_fused_compose.h"
@@ -46,6 +46,8 @@ constexpr size_t SLOT_TARGET = 0;
 constexpr size_t SLOT_INGEST_NODE = 1;
 constexpr size_t SLOT_NODE0 = 16;     // + source index
 constexpr size_t SLOT_TILE0 = 2048;   // + layout index
+constexpr size_t SLOT_TRANSPOSED0 = 4096;  // + 4 * layout index: transposed planes and tile of a vertical-first plan
+constexpr size_t SLOT_TRANSPOSED_SINGLE = 3200;  // smr_ingest_resample's own four
 
 }  // namespace
 
@@ -106,6 +108,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
+    std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
     u32 next_view = n_sources;
     for (u32 li = 0; li < n; li++) {
@@ -131,6 +134,13 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     int rc = make_mfma_job(ctx, sources[si].frame, plan, tile, &J, &on_mfma);
                     if (rc != SMR_OK) return rc;
                     if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); }
+                }
+                if (!on_mfma && fused && is_frame) {  // a vertical-first plan: the same kernel on the transposed frame
+                    MJob J;
+                    MTransposeBack back;
+                    int rc = make_mfma_job_transposed(ctx, sources[si].frame, plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
+                    if (rc != SMR_OK) return rc;
+                    if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); transposed.push_back(back); }
                 }
                 if (on_mfma) {
                 } else if (fused && is_frame && can_fuse_ingest(sources[si].frame, plan)) {
@@ -281,6 +291,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (!mjobs.empty()) {
         rc = launch_mfma(ctx, mjobs, direct_dev);
         if (rc != SMR_OK) return rc;
+        for (const MTransposeBack &b : transposed) {
+            rc = launch_transpose<u32>(ctx, b.tile_t, b.tile);
+            if (rc != SMR_OK) return rc;
+        }
     }
     if (!jobs.empty()) {
         rc = launch_ingest(ctx, jobs);
@@ -350,6 +364,18 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
         if (rc != SMR_OK) return rc;
         if (fits) {
             rc = launch_mfma(ctx, mjobs);
+            return rc == SMR_OK ? kind : rc;
+        }
+    }
+    if (!fused_disabled(ctx)) {  // a vertical-first plan: the same kernel on the transposed frame
+        std::vector<MJob> mjobs(1);
+        MTransposeBack back;
+        bool ok = false;
+        int rc = make_mfma_job_transposed(ctx, in, plan, dst, SLOT_TRANSPOSED_SINGLE, &mjobs[0], &ok, &back);
+        if (rc != SMR_OK) return rc;
+        if (ok) {
+            rc = launch_mfma(ctx, mjobs);
+            if (rc == SMR_OK) rc = launch_transpose<u32>(ctx, back.tile_t, back.tile);
             return rc == SMR_OK ? kind : rc;
         }
     }

@@ -768,10 +768,9 @@ bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pl
 #endif
     if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return false;
     if (f->width % 2 || f->height % 2 || f->width < 8 || f->height < 2) return false;
-    // Two filtered axes, horizontal pass first, no box pre-reduction.  (A plan the reference orders vertically first — the
-    // stronger shrink goes first, resampler.rs:123-145 — was tried through this kernel with the passes swapped: <= 1 LSB and
-    // 99.6 % identical on camera-like content, but 2 LSB on white noise even when the two scales differ by a rounding of the
-    // tile size only; it keeps the reference's order through the general kernels.)
+    // Two filtered axes, horizontal pass first, no box pre-reduction.  (A plan the reference orders vertically first comes back
+    // here on the transposed frame: make_mfma_job_transposed.  Running it with the passes swapped instead was measured: <= 1 LSB
+    // and 99.6 % identical on camera-like content, but 2 LSB on white noise.)
     if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
     const int hs = 0, vs = 1;  // plan slots of the horizontal / vertical pass
     if (!mfma_plane_ok(view_of(f->planes[0]), f->width)) return false;
@@ -844,6 +843,80 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     int rg = (bv.max_span + M_CH - 1 + 7) / 8;
     J.RG = rg < 2 ? 2 : rg;
     *fits = ngm <= M_NG_MAX && (size_t)m_lds(J.ts, J.ngm, J.RG).total <= 160 * 1024;
+    return SMR_OK;
+}
+
+// ------------------------------------------------------------------ vertical-first plans: the same kernel on the transposed problem
+// The reference filters the axis with the stronger shrink first (resampler.rs:123-145); for aspect-preserving fits that order hangs
+// on the rounding of the tile size, so a tile that resizes flips between the two from frame to frame.  The kernel above filters
+// horizontally first.  Filtering an image vertically first is filtering its transpose horizontally first — the colour conversion is
+// per pixel, the chroma up-sampling weights are the same along both axes, every tap loop runs along one axis — so a vertical-first
+// plan is run as: transpose the planes (3.1 MB for 1080p), the horizontal-first kernel on the transposed frame into a transposed
+// tile, transpose the tile back.  Same quantisation points in the same places as the reference's order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose(const u8 *__restrict__ src, u32 spitch, int w, int h, u8 *__restrict__ dst, u32 dpitch) {
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (bx + tx < w && by + r < h) tile[r][tx] = *(const T *)(src + (size_t)(by + r) * spitch + (size_t)(bx + tx) * sizeof(T));
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)  // dst row = src column bx + r, dst column = src row by + tx
+        if (by + tx < h && bx + r < w) *(T *)(dst + (size_t)(bx + r) * dpitch + (size_t)(by + tx) * sizeof(T)) = tile[tx][r];
+}
+
+template <typename T>
+int launch_transpose(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) {  // dst is src->h x src->w
+    hipLaunchKernelGGL(k_transpose<T>, dim3((src->w + 31) / 32, (src->h + 31) / 32), dim3(256), 0, ctx->stream, (const u8 *)src->ptr, (u32)src->pitch,
+                       (int)src->w, (int)src->h, (u8 *)dst->ptr, (u32)dst->pitch);
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}
+
+struct MTransposeBack {
+    smr_surface *tile_t;  // what the kernel writes (tile->h x tile->w)
+    smr_surface *tile;    // what the caller asked for
+};
+
+bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile);
+int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, MJob *out, bool *fits);
+
+// A job for a vertical-first plan (see above).  `slot0`: four surface-cache slots of the caller's for the transposed planes and tile.
+// *ok = false: not a case for this route (the caller goes on to the general kernels).  The plane transposes are enqueued here; the
+// caller launches the job with its others and then runs launch_transpose<u32> on every MTransposeBack.
+int make_mfma_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, MJob *out, bool *ok,
+                             MTransposeBack *back) {
+    *ok = false;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || !f || !f->planes[0] || !f->planes[1]) return SMR_OK;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
+    const bool nv12 = f->format == SMR_FRAME_NV12;
+    if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return SMR_OK;
+    if (!nv12 && !f->planes[2]) return SMR_OK;
+    if (f->width % 2 || f->height % 2) return SMR_OK;
+    const u32 cw = f->width / 2, ch = f->height / 2;
+    smr_frame ft;
+    memset(&ft, 0, sizeof(ft));
+    ft.format = f->format; ft.width = f->height; ft.height = f->width;
+    ft.planes[0] = smr_cached_surface(ctx, slot0, f->height, f->width, SMR_PX_R8);
+    ft.planes[1] = smr_cached_surface(ctx, slot0 + 1, ch, cw, nv12 ? SMR_PX_RG8 : SMR_PX_R8);
+    if (!nv12) ft.planes[2] = smr_cached_surface(ctx, slot0 + 2, ch, cw, SMR_PX_R8);
+    smr_surface *tile_t = smr_cached_surface(ctx, slot0 + 3, tile->h, tile->w, SMR_PX_RGBA8);
+    if (!ft.planes[0] || !ft.planes[1] || (!nv12 && !ft.planes[2]) || !tile_t) return SMR_ERR_OOM;
+    smr_resample_plan pt = plan;  // the first pass of the plan (the source's rows) is the transposed frame's horizontal pass
+    pt.axis[0] = 0; pt.axis[1] = 1;
+    if (!can_fuse_mfma(ctx, &ft, pt, tile_t)) return SMR_OK;
+    bool fits = false;
+    if (int rc = make_mfma_job(ctx, &ft, pt, tile_t, out, &fits)) return rc;
+    if (!fits) return SMR_OK;
+    if (int rc = launch_transpose<u8>(ctx, f->planes[0], ft.planes[0])) return rc;
+    if (nv12) {
+        if (int rc = launch_transpose<u16>(ctx, f->planes[1], ft.planes[1])) return rc;
+    } else {
+        if (int rc = launch_transpose<u8>(ctx, f->planes[1], ft.planes[1])) return rc;
+        if (int rc = launch_transpose<u8>(ctx, f->planes[2], ft.planes[2])) return rc;
+    }
+    back->tile_t = tile_t;
+    back->tile = tile;
+    *ok = true;
     return SMR_OK;
 }
 
