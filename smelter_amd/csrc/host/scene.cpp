@@ -7,6 +7,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <deque>
 
 namespace smr_host {
 
@@ -583,23 +584,25 @@ NestedLayout Stateful::layout(Size size, int64_t pts) {
 // ------------------------------------------------------------------------------------------------ flatten (layout/flatten.rs)
 namespace {
 // (this code runs once per frame and output on the renderer thread: lists are transformed in place and moved, not rebuilt)
-void child_parent_masks(const NestedLayout &n, std::vector<MaskL> &masks) {  // :358-371
+void child_parent_masks(const NestedLayout &n, MaskList &masks) {  // :358-371
     float s = rmin(n.scale_x, n.scale_y);
     for (auto &m : masks)
         m = {radius_mul(m.radius, 1.0f / s), (m.top - n.top) / n.scale_y, (m.left - n.left) / n.scale_x, m.width / n.scale_x,
              m.height / n.scale_y};
 }
-void parent_parent_masks(const NestedLayout &n, std::vector<MaskL> &masks) {  // :373-389
+void parent_parent_masks(const NestedLayout &n, MaskList &masks) {  // :373-389
     float s = rmin(n.scale_x, n.scale_y);
     for (auto &m : masks)
         m = {radius_mul(m.radius, s), (m.top * n.scale_y) + n.top, (m.left * n.scale_x) + n.left, m.width * n.scale_x,
              m.height * n.scale_y};
 }
-RenderLayout flatten_child(const NestedLayout &n, RenderLayout &&child) {  // :167-305
-    std::vector<MaskL> masks = std::move(child.masks);  // (the list travels; the child's own values are read from a mask-less copy)
-    child.masks.clear();
-    const RenderLayout &c = child;
-    RenderLayout o = c;
+void flatten_child(const NestedLayout &n, RenderLayout &o) {  // :167-305 (in place: the record is large, it travels once per level)
+    const RenderLayout c = [&] {  // the child's own values (without its mask list)
+        RenderLayout t;
+        t.top = o.top; t.left = o.left; t.width = o.width; t.height = o.height; t.rotation_degrees = o.rotation_degrees;
+        t.border_radius = o.border_radius; t.content = o.content; t.border_width = o.border_width; t.crop = o.crop; t.blur_radius = o.blur_radius;
+        return t;
+    }();
     float us = rmin(n.scale_x, n.scale_y);
     if (!n.crop) {
         o.top = n.top + (c.top * n.scale_y); o.left = n.left + (c.left * n.scale_x);
@@ -625,12 +628,20 @@ RenderLayout flatten_child(const NestedLayout &n, RenderLayout &&child) {  // :1
     }
     o.rotation_degrees = c.rotation_degrees + n.rotation_degrees;
     o.border_radius = radius_mul(c.border_radius, us);
-    o.masks = std::move(masks);
     parent_parent_masks(n, o.masks);
-    return o;
 }
-void inner_flatten(const NestedLayout &n, size_t offset, const std::vector<MaskL> &parent_masks, std::vector<RenderLayout> &shadows,
-                   std::vector<RenderLayout> &layouts) {  // :24-82
+// scratch lists of the recursion, one pair per depth, reused from frame to frame (the lists of a level are complete before its
+// parent reads them, and a level never sees another level's pair)
+struct FlattenScratch {
+    std::deque<std::vector<RenderLayout>> lists;  // (a deque: growing it leaves the references handed out to the outer levels valid)
+    std::vector<RenderLayout> &get(size_t i) {
+        while (lists.size() <= i) lists.emplace_back();
+        lists[i].clear();
+        return lists[i];
+    }
+};
+void inner_flatten(const NestedLayout &n, size_t offset, const MaskList &parent_masks, std::vector<RenderLayout> &shadows,
+                   std::vector<RenderLayout> &layouts, FlattenScratch &scratch, size_t depth) {  // :24-82
     RenderLayout me;
     me.top = n.top; me.left = n.left; me.width = n.width; me.height = n.height; me.rotation_degrees = n.rotation_degrees;
     me.border_radius = n.border_radius; me.masks = parent_masks;
@@ -650,21 +661,19 @@ void inner_flatten(const NestedLayout &n, size_t offset, const std::vector<MaskL
         sh.content = 2; sh.color = s.color; sh.blur_radius = s.blur_radius; sh.masks = parent_masks;
         shadows.push_back(std::move(sh));
     }
-    std::vector<MaskL> masks;
-    masks.reserve(parent_masks.size() + 1);
-    masks = parent_masks;
+    MaskList masks = parent_masks;
     if (n.mask) masks.push_back(*n.mask);
     child_parent_masks(n, masks);
-    std::vector<RenderLayout> child_shadows, child_layouts;
+    std::vector<RenderLayout> &child_shadows = scratch.get(2 * depth), &child_layouts = scratch.get(2 * depth + 1);
     for (auto &ch : n.children) {
         size_t cnt = ch.child_nodes_count;
-        inner_flatten(ch, offset, masks, child_shadows, child_layouts);
+        inner_flatten(ch, offset, masks, child_shadows, child_layouts, scratch, depth + 1);
         offset += cnt;
     }
     layouts.reserve(layouts.size() + 1 + child_shadows.size() + child_layouts.size());
     layouts.push_back(std::move(me));
-    for (auto &c : child_shadows) layouts.push_back(flatten_child(n, std::move(c)));
-    for (auto &c : child_layouts) layouts.push_back(flatten_child(n, std::move(c)));
+    for (auto &c : child_shadows) { flatten_child(n, c); layouts.push_back(std::move(c)); }
+    for (auto &c : child_layouts) { flatten_child(n, c); layouts.push_back(std::move(c)); }
 }
 bool should_render(const RenderLayout &l, const std::vector<std::optional<Size>> &res, uint32_t W, uint32_t H) {  // :121-164
     if (l.width <= 0.0f || l.height <= 0.0f || l.top > (float)H || l.left > (float)W) return false;
@@ -697,9 +706,10 @@ void fix_final(RenderLayout &l) {  // :84-116
 }  // namespace
 
 std::vector<RenderLayout> NestedLayout::flatten(const std::vector<std::optional<Size>> &res, uint32_t W, uint32_t H) const {  // :10-22
-    std::vector<RenderLayout> shadows, layouts, out;
-    // inner_flatten's child accumulation must not see this node's own entries: collect into fresh vectors
-    inner_flatten(*this, 0, {}, shadows, layouts);
+    static thread_local FlattenScratch scratch;
+    std::vector<RenderLayout> &shadows = scratch.get(0), &layouts = scratch.get(1), out;
+    // inner_flatten's child accumulation must not see this node's own entries: every level collects into lists of its own
+    inner_flatten(*this, 0, MaskList{}, shadows, layouts, scratch, 1);
     out.reserve(shadows.size() + layouts.size());
     for (auto *v : {&shadows, &layouts})
         for (auto &l : *v)

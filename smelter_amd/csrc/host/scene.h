@@ -149,10 +149,50 @@ struct Stateful {
 // transformations/layout.rs:37-158
 struct Crop { float top, left, width, height; };
 struct MaskL { BorderRadius radius; float top, left, width, height; };
+// The parent masks of one layout (at most SMR_MAX_MASKS reach the kernels; real scenes nest two or three deep).  The flatten step
+// runs for every output and frame on the renderer thread, and with a heap vector here most of its time went to the allocator:
+// the first few masks live inside the record.
+class MaskList {
+  public:
+    static constexpr size_t INLINE = 2;
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    MaskL *begin() { return data(); }
+    MaskL *end() { return data() + n_; }
+    const MaskL *begin() const { return data(); }
+    const MaskL *end() const { return data() + n_; }
+    MaskL &operator[](size_t i) { return data()[i]; }
+    const MaskL &operator[](size_t i) const { return data()[i]; }
+    void clear() { n_ = 0; heap_.clear(); }
+    void reserve(size_t) {}
+    void push_back(const MaskL &m) {
+        if (n_ < INLINE) { inl_[n_++] = m; return; }
+        if (n_ == INLINE) heap_.assign(inl_, inl_ + INLINE);
+        heap_.push_back(m);
+        n_++;
+    }
+    void resize(size_t k) {  // (shrinks only)
+        if (k >= n_) return;
+        if (n_ > INLINE && k <= INLINE) {
+            for (size_t i = 0; i < k; i++) inl_[i] = heap_[i];
+            heap_.clear();
+        } else if (n_ > INLINE) {
+            heap_.resize(k);
+        }
+        n_ = k;
+    }
+
+  private:
+    MaskL *data() { return n_ > INLINE ? heap_.data() : inl_; }
+    const MaskL *data() const { return n_ > INLINE ? heap_.data() : inl_; }
+    MaskL inl_[INLINE];
+    size_t n_ = 0;
+    std::vector<MaskL> heap_;  // all the masks once there are more than INLINE
+};
 struct RenderLayout {
     float top, left, width, height, rotation_degrees;
     BorderRadius border_radius;
-    std::vector<MaskL> masks;
+    MaskList masks;
     int content = 1;  // 0 ChildNode, 1 Color, 2 BoxShadow
     RGBA color, border_color;
     float border_width = 0;
