@@ -361,6 +361,7 @@ static NestedLayout view_layout(const ViewParam &v, Size size, std::vector<std::
     float static_offset = bw / scale;
     const float parent_bw = bw / scale;
     NestedLayout out;
+    out.children.reserve(children.size());
     for (auto &cp : children) {
         Stateful &c = *cp;
         Position pos = c.position(pts);
@@ -550,6 +551,7 @@ NestedLayout Stateful::layout(Size size, int64_t pts) {
         tl = interp_tiles(st, tl, transition->state(pts));
     }
     NestedLayout out;
+    out.children.reserve(children.size());
     for (size_t i = 0; i < children.size() && i < tl.size(); i++) {
         Stateful &ch = *children[i];
         const Tile &tile = tl[i];
