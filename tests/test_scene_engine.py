@@ -443,3 +443,18 @@ def test_failed_update_keeps_previous_scene():
         sc.update("{not json", 64, 64)
     arr, n, _, _ = sc.node_layouts(0, 0, [])
     assert n == 1 and tuple(arr[0].color) == (1.0, 1.0, 1.0, 1.0)
+
+
+def test_rgba_deserialization_reference_vectors():
+    """smelter-api/src/video/color.rs:264-288 (test_rgba_deserialization), values and error strings."""
+    assert parse_color("#00000000") == (0, 0, 0, 0)
+    assert parse_color("#01020304") == (1, 2, 3, 4)
+    assert parse_color("#01FF0304") == (1, 255, 3, 4)
+    assert parse_color("#FFffFFff") == (255, 255, 255, 255)
+    for bad, msg in (("#0000000G", "Invalid format. Color representation is not a valid number."),
+                     ("#000", "Invalid format. Color has to be in #RRGGBB or #RRGGBBAA format.")):
+        with pytest.raises(SceneError):
+            parse_color(bad)
+        with pytest.raises(SceneError) as e:  # (the message travels with a scene update, as the TypeError does in the reference)
+            Scene().update({"type": "view", "background_color": bad}, 64, 64)
+        assert msg in str(e.value)
