@@ -8,9 +8,9 @@ TrueType fonts read with fontTools (the reference bundles Inter: smelter-render/
 
 * `FontBook`   — (family, weight, style) -> font file, like the reference's font database (`TextRendererCtx::add_font`)
 * `layout`     — cosmic-text's line model as far as the reference uses it: explicit newlines, `Wrap::None | Glyph | Word`
-                 against the buffer width, advance widths from `hmtx` scaled by font_size / unitsPerEm.  NOT restated: GPOS
-                 kerning, GSUB ligatures, bidi and font fallback (rustybuzz, `Shaping::Advanced`) — widths of kerned pairs
-                 differ from the reference by the kerning value.
+                 against the buffer width, advance widths from `hmtx` plus the pair kerning of the font's GPOS `kern` feature
+                 (what rustybuzz applies under `Shaping::Advanced`), scaled by font_size / unitsPerEm.  NOT restated: GSUB
+                 ligatures / contextual alternates, mark positioning, bidi and font fallback.
 * `measurer`   — the `smr_text_measure_fn` for `Scene.set_text_measurer` / `Renderer.set_text_measurer`
 * `rasterise`  — glyph outlines (quadratic B-splines of `glyf`) -> exact-area coverage (signed-area accumulation, one pass per
                  edge) -> R8 atlas + glyph run for `smr_renderer_set_text` / `Context.blit_glyphs`
@@ -50,6 +50,62 @@ class Font:
         self.weight = int(os2.usWeightClass) if os2 is not None else 400
         self.italic = bool(os2.fsSelection & 1) if os2 is not None else False
         self._outlines: Dict[str, List[List[Tuple[float, float]]]] = {}
+        self._kern_lookups = self._gpos_kern_lookups()
+        self._kern_cache: Dict[Tuple[str, str], float] = {}
+
+    def _gpos_kern_lookups(self):
+        """PairPos subtables (GPOS lookup type 2, through extension lookups too) of the `kern` feature, default script first."""
+        if "GPOS" not in self.tt:
+            return []
+        table = self.tt["GPOS"].table
+        if not table.FeatureList or not table.LookupList:
+            return []
+        wanted: List[int] = []
+        scripts = {sr.ScriptTag: sr.Script for sr in (table.ScriptList.ScriptRecord if table.ScriptList else [])}
+        script = scripts.get("latn") or scripts.get("DFLT")
+        feature_indices = script.DefaultLangSys.FeatureIndex if script is not None and script.DefaultLangSys else range(len(table.FeatureList.FeatureRecord))
+        for fi in feature_indices:
+            fr = table.FeatureList.FeatureRecord[fi]
+            if fr.FeatureTag == "kern":
+                wanted += [i for i in fr.Feature.LookupListIndex if i not in wanted]
+        lookups = []
+        for li in sorted(wanted):  # (lookups apply in lookup-list order)
+            subs = []
+            for st in table.LookupList.Lookup[li].SubTable:
+                if getattr(st, "LookupType", None) == 9:
+                    st = st.ExtSubTable
+                if getattr(st, "LookupType", None) == 2:
+                    subs.append(st)
+            if subs:
+                lookups.append(subs)
+        return lookups
+
+    def kerning(self, left: str, right: str) -> float:
+        """x-advance adjustment of `left` when followed by `right`, font units (GPOS PairPos formats 1 and 2)."""
+        key = (left, right)
+        if key in self._kern_cache:
+            return self._kern_cache[key]
+        total = 0.0
+        for subs in self._kern_lookups:
+            for st in subs:  # the first subtable of a lookup that covers the pair decides
+                if left not in st.Coverage.glyphs:
+                    continue
+                value = None
+                if st.Format == 1:
+                    for rec in st.PairSet[st.Coverage.glyphs.index(left)].PairValueRecord:
+                        if rec.SecondGlyph == right:
+                            value = rec.Value1
+                            break
+                    if value is None:
+                        continue
+                else:
+                    c1 = st.ClassDef1.classDefs.get(left, 0)
+                    c2 = st.ClassDef2.classDefs.get(right, 0)
+                    value = st.Class1Record[c1].Class2Record[c2].Value1
+                total += float(getattr(value, "XAdvance", 0) or 0) if value is not None else 0.0
+                break
+        self._kern_cache[key] = total
+        return total
 
     def glyph_name(self, ch: str) -> str:
         return self.cmap.get(ord(ch), ".notdef")
@@ -143,7 +199,7 @@ class Line:
     width: float
 
 
-def layout(font: Font, text: str, font_size: float, wrap: str = "None", max_width: float = math.inf) -> List[Line]:
+def layout(font: Font, text: str, font_size: float, wrap: str = "None", max_width: float = math.inf, kerning: bool = True) -> List[Line]:
     """Buffer::set_text + set_wrap + shape_until_scroll as far as widths and line breaks go (one Line per LayoutLine)."""
     scale = font_size / font.upem
     lines: List[Line] = []
@@ -156,6 +212,8 @@ def layout(font: Font, text: str, font_size: float, wrap: str = "None", max_widt
         while i < len(chars):
             ch = chars[i]
             g = font.glyph_name(ch)
+            if cur and kerning:  # the previous glyph's advance, adjusted for this pair
+                x += font.kerning(cur[-1][0], g) * scale
             adv = font.advance(g) * scale
             if wrap != "None" and cur and x + adv > max_width and not ch.isspace():
                 if wrap == "Word" and last_space >= 0:

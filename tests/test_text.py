@@ -82,9 +82,10 @@ def test_shaper_measures_through_the_c_abi():
     n = _text_node({"type": "text", "text": txt, "font_size": fs, "line_height": lh, "font_family": "Inter 18pt"}, sh.measurer)
     assert (n.width, n.height) == T.text_resolution(lines, fs, lh)
     assert len(lines) == 2
-    # advance widths: hmtx * font_size / unitsPerEm
-    want = sum(font.advance(font.glyph_name(c)) for c in "The quick brown fox") * fs / font.upem
-    assert abs(lines[0].width - want) < 1e-6
+    # advance widths (hmtx) + pair kerning (GPOS `kern`), * font_size / unitsPerEm
+    names = [font.glyph_name(c) for c in "The quick brown fox"]
+    want = (sum(font.advance(g) for g in names) + sum(font.kerning(a, b) for a, b in zip(names, names[1:]))) * fs / font.upem
+    assert abs(lines[0].width - want) < 1e-4
 
 
 def test_word_and_glyph_wrap():
@@ -137,3 +138,18 @@ def test_glyph_run_fits_the_node_and_the_atlas():
     # the second line sits one line_height below the first
     second = [g for g in glyphs if g.dst_y >= 36]
     assert abs(min(g.dst_y for g in second) - min(g.dst_y for g in first) - 36) <= 3
+
+
+def test_pair_kerning_comes_from_the_gpos_kern_feature():
+    """rustybuzz applies the font's `kern` feature under Shaping::Advanced: Inter tucks V under A and o under T; pairs without an
+    entry keep their advances; the adjustment is in font units and scales with the size."""
+    if not os.path.isdir(REF_FONTS):
+        pytest.skip("needs the reference's bundled Inter")
+    font = T.FontBook.from_dir(REF_FONTS).match("Inter 18pt")
+    g = font.glyph_name
+    assert font.kerning(g("A"), g("V")) < -50 and font.kerning(g("T"), g("o")) < -50
+    assert font.kerning(g("a"), g("b")) == 0.0 and font.kerning(g("o"), g("o")) == 0.0
+    kerned, plain = T.layout(font, "AVATAR", 40.0)[0].width, T.layout(font, "AVATAR", 40.0, kerning=False)[0].width
+    pairs = sum(font.kerning(g(a), g(b)) for a, b in zip("AVATAR", "VATAR"))
+    assert abs((kerned - plain) - pairs * 40.0 / font.upem) < 1e-4 and kerned < plain
+    assert abs(T.layout(font, "AVATAR", 80.0)[0].width - 2.0 * kerned) < 1e-3
