@@ -15,14 +15,18 @@
 //   to two.  The reference's own quantisation points are kept: u8 node texture, f16 (RTNE)
 //   between the passes, u8 sRGB tile.  Deviation from the oracle: <= 1 LSB, > 99.9 % of the bytes identical (tests/).
 // * Clamp-to-edge is folded into the weight band (taps that clamp onto the same texel are summed), out-of-band entries are 0.
-// * A 256-thread workgroup owns a 64-column strip of the tile (one 16-column N tile per wave) over a range of 16-row output
-//   tiles and streams the source rows through LDS in chunks of 16:
-//     stage    raw Y/U/V dwords of the chunk (prefetched into registers one chunk ahead)
-//     convert  4x2 pixel blocks per lane: chroma by v_dot4_u32_u8 (9/3/3/1 bilinear in 1/16 units, exact), BT.709 matrix with
-//              folded constants (one FMA per term), u8 quantisation, (hi, lo) LUT lookup, 16-byte stores into T
-//     pass 1   per wave: 3 channels x KH k-steps of MFMA, result -> f16 -> ring of rows Mh (LDS, [8-row granule][column])
-//     pass 2   for every 16-row output tile whose window is now complete: 3 x KV MFMAs, sRGB encode, 16-byte stores
-//   The ring columns of a wave are written and read by that wave only, so a chunk costs two barriers.
+// * A 768-thread workgroup (12 waves) owns a 64-column strip of the tile over a range of 16-row output tiles and streams the
+//   source rows through LDS in chunks of 16, as a two-stage pipeline with one barrier per chunk (mfma_piece below):
+//     8 convert waves   stage the raw Y/U/V dwords of the next chunks (loads issued two chunks ahead), convert chunk k — one 4x1 pixel
+//                       block per lane: chroma by v_dot4_u32_u8 (9/3/3/1 bilinear in 1/16 units, exact), BT.709 with folded
+//                       constants (one FMA per term), u8 quantisation + sRGB decode + (hi, lo) split in one LDS lookup, 16-byte
+//                       stores into T[k & 1]
+//     4 filter waves    (one 16-column N tile each) pass 1 of chunk k - 1: 3 channels x KH k-steps x 2 MFMAs, result -> f16 -> a ring
+//                       of rows Mh (LDS, [8-row granule][column]); then, for every 16-row output tile whose window is complete,
+//                       pass 2: 3 x KV MFMAs, sRGB encode, 16-byte stores (or Y'CbCr: direct output)
+//   A ring column is written and read by one wave only; T and the raw footprint are double-buffered across the barrier.
+// * Vertical-first plans run on the transposed frame (make_mfma_job_transposed); NV12 frames and direct output are separate builds
+//   of the kernel (template flags), so the plain build carries none of their registers.
 #pragma once
 
 #include "smr_convert_dev.h"
