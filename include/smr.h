@@ -164,15 +164,18 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *       SMR_INGEST_AUTO      matrix cores where the frame format / plan allow it, the f32 kernel elsewhere (default)
  *       SMR_INGEST_VALU_F32  exact f32 everywhere: bit-identical to the pass-per-launch kernels (smr_frame_to_rgba + smr_resample)
  *       SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
+ *       SMR_INGEST_MFMA_F16_WG  the first matrix-core kernel (k_ingest_mfma: a workgroup pipeline of convert and filter waves
+ *                            around LDS) instead of the wave-autonomous one (k_ingest_wave) AUTO prefers; same arithmetic
  *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
- *     layout/resampler.rs:25-28, u8 sRGB tile) and deviates from the f32 sequence of resample.wgsl:64-87 by at most 1 LSB.
+ *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated
+ *     in f32: it deviates from the f32 sequence of resample.wgsl:64-87 by at most 1 LSB on every content class (tests).
  *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling)
  *   SMR_OPT_DIRECT_OUTPUT       1: when smr_render_layouts sees the same layout list again (a scene at rest), the pixels the
  *                               compositor would only copy from a freshly resampled input are converted to Y'CbCr by the resampling
  *                               kernel itself and their RGBA8 form is never stored (HBM traffic per frame 1.2x instead of 2.7x the
  *                               algorithmic bytes, at the price of vector-ALU time in that kernel: DESIGN.md); 0 (default): always through
  *                               the RGBA8 tile.  Same output bytes either way. */
-typedef enum smr_ingest_impl { SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2 } smr_ingest_impl;
+typedef enum smr_ingest_impl { SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, SMR_INGEST_MFMA_F16_WG = 3 } smr_ingest_impl;
 typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
@@ -271,7 +274,9 @@ SMR_API int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, 
  *                          128 bytes to the others by whatever means the host has.
  * smr_gather_tiles: tile i was produced on rank owner[i] in src[i]; afterwards dst[i] on `root` holds it (tiles the root owns
  * are skipped).  Local comm: one call moves everything.  Rank comm: every rank makes the same call; src[i] is read on its
- * owner only, dst[i] written on the root only (other entries may be NULL there). */
+ * owner only, dst[i] written on the root only (other entries may be NULL there); in rank mode a tile travels as one block of
+ * pitch * h bytes, so src[i] and dst[i] must both have the canonical pitch (w * bytes per pixel rounded up to 256, what
+ * smr_surface_create gives) — anything else is SMR_ERR_INVALID. */
 typedef struct smr_comm smr_comm;
 #define SMR_COMM_ID_BYTES 128
 SMR_API int smr_comm_create_local(smr_ctx *const *ctxs, uint32_t n, smr_comm **out);

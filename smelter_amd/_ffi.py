@@ -198,7 +198,15 @@ def load():
         "smr_bounce_easing": ([C.c_double], C.c_double),
         "smr_parse_color": ([C.c_char_p, C.POINTER(C.c_uint8)], I),
         "smr_ctx_mode": ([P], U),
-        "smr_ctx_set_option": ([P, U], I),
+        "smr_ctx_set_option": ([P, U, C.c_int32], I),
+        "smr_comm_create_local": ([PP, U, PP], I),
+        "smr_comm_unique_id": ([C.POINTER(C.c_uint8)], I),
+        "smr_comm_create_rank": ([P, U, U, C.POINTER(C.c_uint8), PP], I),
+        "smr_comm_destroy": ([P], None),
+        "smr_comm_world": ([P], U),
+        "smr_comm_rank": ([P], U),
+        "smr_comm_last_error": ([P], C.c_char_p),
+        "smr_gather_tiles": ([P, U, C.POINTER(U), PP, PP, U], I),
         "smr_renderer_create": ([P, C.c_int64, PP], I),
         "smr_renderer_destroy": ([P], None),
         "smr_renderer_last_error": ([P], C.c_char_p),

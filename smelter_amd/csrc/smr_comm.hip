@@ -13,6 +13,7 @@
 #include "smr_internal.h"
 
 #include <dlfcn.h>
+#include <mutex>
 
 #include <cstdlib>
 
@@ -36,16 +37,17 @@ struct Rccl {
 
 const Rccl *rccl(std::string *err) {
     static Rccl r;
-    static bool tried = false, ok = false;
+    static std::once_flag once;
+    static bool ok = false;
     static std::string why;
-    if (!tried) {
-        tried = true;
+    std::call_once(once, [] {
         for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
         }
         if (!r.lib) {
-            why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?");
+            const char *e = dlerror();  // (one call: dlerror() clears the message it returns)
+            why = std::string("librccl.so could not be loaded: ") + (e ? e : "?");
         } else {
             bool all = true;
             auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p) { all = false; why = std::string("librccl.so lacks ") + n; } return p; };
@@ -59,7 +61,7 @@ const Rccl *rccl(std::string *err) {
             r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
             ok = all;
         }
-    }
+    });
     if (!ok && err) *err = why;
     return ok ? &r : nullptr;
 }
@@ -221,6 +223,17 @@ int smr_gather_tiles(smr_comm *c, uint32_t root, const uint32_t *owner, const sm
     for (uint32_t i = 0; i < n; i++)
         any = any || (owner[i] != root && (c->rank == root || c->rank == owner[i]));
     if (!any) return SMR_OK;
+    // Sender and receiver are different processes: the byte counts of a send / recv pair must agree without either side seeing
+    // the other's surface, so both sides require the library's own pitch rule (rows padded to 256 bytes, smr_surface_create).
+    for (uint32_t i = 0; i < n; i++) {
+        if (owner[i] == root) continue;
+        const smr_surface *s = c->rank == owner[i] ? src[i] : (c->rank == root ? dst[i] : nullptr);
+        if (!s) continue;
+        const size_t canon = (((size_t)s->w * bytes_per_px(s->fmt)) + 255) & ~(size_t)255;
+        if (s->pitch != canon)
+            return comm_fail(c, me, SMR_ERR_INVALID, "smr_gather_tiles: tile " + std::to_string(i) + " has pitch " + std::to_string(s->pitch) +
+                                                         ", the rank-mode gather needs the canonical pitch " + std::to_string(canon) + " on both sides");
+    }
     int rc = r->GroupStart();
     for (uint32_t i = 0; i < n && rc == ncclSuccess; i++) {
         if (owner[i] == root) continue;

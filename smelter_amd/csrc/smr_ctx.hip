@@ -4,6 +4,7 @@
 // (wgpu/texture/*.rs), queue.write_texture (texture/base.rs:61-77) and the padded-row
 // read-back (texture/base.rs:97-118, state/output_texture.rs:85-113).
 #include "smr_internal.h"
+#include "smr_tables.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -118,12 +119,6 @@ static void drain_profile(smr_ctx *ctx) {
     ctx->pending.clear();
 }
 
-static double srgb_to_linear_f64(double c) {
-    // smelter-render/src/wgpu/utils.rs:74-81
-    if (c < 0.04045) return c / 12.92;
-    return pow((c + 0.055) / 1.055, 2.4);
-}
-
 extern "C" {
 
 uint32_t smr_abi_version(void) { return 1; }
@@ -152,49 +147,18 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         }
         ctx->own_stream = true;
     }
-    // (a local buffer: two threads creating contexts at once must not share a half-built table)
+    // (local buffers: two threads creating contexts at once must not share a half-built table)
     float tables[SMR_TABLE_FLOATS];
-    memset(tables, 0, sizeof(tables));
-    for (int i = 0; i < 256; i++) tables[i] = (float)srgb_to_linear_f64((double)i / 255.0);
-    float *thr = tables + 256;
-    thr[0] = -INFINITY;
-    for (int i = 1; i < 256; i++) thr[i] = (float)srgb_to_linear_f64(((double)i - 0.5) / 255.0);
-    thr[256] = INFINITY;
-    {
-        // encode estimate table: code of the lowest float of every (exponent, 7-bit mantissa) bucket in [2^-13, 1)
-        u8 *enc = (u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
-        auto code_of = [&](float x) {
-            int c = 0;
-            while (c < 255 && thr[c + 1] <= x) c++;
-            return c;
-        };
-        for (u32 idx = 0; idx < SMR_ENC_ENTRIES; idx++) {
-            u32 lo_bits = 0x39000000u + (idx << 16), hi_bits = lo_bits + 0xffffu;
-            float lo, hi;
-            memcpy(&lo, &lo_bits, 4);
-            memcpy(&hi, &hi_bits, 4);
-            int cl = code_of(lo), chh = code_of(hi);
-            if (chh - cl > 1) {  // the one-step fix-up in srgb_encode8 would not suffice
-                smr_ctx_destroy(ctx);
-                return SMR_ERR_INTERNAL;
-            }
-            enc[idx] = (u8)cl;
-        }
+    u32 lut16[256];  // decode table as an f16 pair per entry (hi, lo = t - hi): the A operand of the matrix-core resamplers
+    if (!smr_build_tables(tables, lut16)) {
+        smr_ctx_destroy(ctx);
+        return SMR_ERR_INTERNAL;
     }
     memcpy(ctx->h_tables, tables, sizeof(tables));
-    // decode table as an f16 pair per entry (hi, lo = t - hi): the A operand of the matrix-core resampler (smr_ingest_mfma.h)
-    u32 lut16[256];
-    for (int i = 0; i < 256; i++) {
-        const _Float16 hi = (_Float16)tables[i];
-        const _Float16 lo = (_Float16)(tables[i] - (float)hi);
-        u16 hb, lb;
-        memcpy(&hb, &hi, 2);
-        memcpy(&lb, &lo, 2);
-        lut16[i] = (u32)hb | ((u32)lb << 16);
-    }
     if (const char *e = getenv("SMR_INGEST_IMPL")) {  // tools / A-B runs: "valu" or "mfma"; smr_ctx_set_ingest_impl overrides
         if (!strcmp(e, "valu")) ctx->ingest_impl = SMR_INGEST_VALU_F32;
         else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
+        else if (!strcmp(e, "mfma_wg")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_WG;
     }
     if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
@@ -254,7 +218,7 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     if (!ctx) return SMR_ERR_INVALID;
     switch (option) {
     case SMR_OPT_INGEST_IMPL:
-        if (value < 0 || value > SMR_INGEST_MFMA_F16) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
+        if (value < 0 || value > SMR_INGEST_MFMA_F16_WG) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
         ctx->ingest_impl = (u32)value;
         return SMR_OK;
     case SMR_OPT_DIRECT_OUTPUT:

@@ -23,6 +23,7 @@
 #include "smr_fused_compose.h"
 #include "smr_fused_ingest.h"
 #include "smr_ingest_mfma.h"
+#include "smr_ingest_wave.h"
 
 #include <cstdlib>
 
@@ -108,6 +109,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
+    std::vector<WJob> wjobs;
+    std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
     u32 next_view = n_sources;
@@ -129,7 +132,21 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 smr_surface *tile = smr_cached_surface(ctx, SLOT_TILE0 + li, dw, dh, SMR_PX_RGBA8);
                 if (!tile) return SMR_ERR_OOM;
                 bool on_mfma = false;
-                if (fused && is_frame && can_fuse_mfma(ctx, sources[si].frame, plan, tile)) {
+                if (fused && is_frame && can_fuse_wave(ctx, sources[si].frame, plan, tile)) {  // the wave-autonomous matrix-core kernel
+                    WJob J;
+                    int rc = make_wave_job(ctx, sources[si].frame, plan, tile, &J);
+                    if (rc != SMR_OK) return rc;
+                    wjobs.push_back(J); wjob_layout.push_back(li);
+                    on_mfma = true;
+                }
+                if (!on_mfma && fused && is_frame) {  // a vertical-first plan: the same kernel on the transposed frame
+                    WJob J;
+                    MTransposeBack back;
+                    int rc = make_wave_job_transposed(ctx, sources[si].frame, plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
+                    if (rc != SMR_OK) return rc;
+                    if (on_mfma) { wjobs.push_back(J); wjob_layout.push_back(li); transposed.push_back(back); }
+                }
+                if (!on_mfma && fused && is_frame && can_fuse_mfma(ctx, sources[si].frame, plan, tile)) {
                     MJob J;
                     int rc = make_mfma_job(ctx, sources[si].frame, plan, tile, &J, &on_mfma);
                     if (rc != SMR_OK) return rc;
@@ -210,6 +227,15 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     mjobs[j].layer = (int)li; mjobs[j].ox = D.ix; mjobs[j].oy = D.iy;
                 }
             }
+            for (size_t j = 0; j < wjobs.size(); j++) {
+                const u32 li = wjob_layout[j];
+                const DevLayout &D = packed.host_layouts[li];
+                if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == wjobs[j].dst.ptr && D.ix % 4 == 0 &&
+                    D.iy % 2 == 0) {
+                    direct_mask |= 1ull << li;
+                    wjobs[j].layer = (int)li; wjobs[j].ox = D.ix; wjobs[j].oy = D.iy;
+                }
+            }
         }
 #endif
         // key: everything the classification reads
@@ -253,7 +279,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         cm->last_use = ctx->class_clock;
         if (ctx->debug_ingest)
             fprintf(stderr, "[smr] tile classes: %s; direct output: layer mask %llx of %zu resampled tiles\n", classify_now ? "classifying" : "cached",
-                    direct_mask, mjobs.size());
+                    direct_mask, mjobs.size() + wjobs.size());
         if (direct_mask) {
             direct.cls = cm->d_direct;
             direct.tiles_x = (int)b_tiles_x;
@@ -288,13 +314,17 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
 
     // ---- wave A (job descriptors ride in the kernel arguments)
+    if (!wjobs.empty()) {
+        rc = launch_wave(ctx, wjobs, direct_dev);
+        if (rc != SMR_OK) return rc;
+    }
     if (!mjobs.empty()) {
         rc = launch_mfma(ctx, mjobs, direct_dev);
         if (rc != SMR_OK) return rc;
-        for (const MTransposeBack &b : transposed) {
-            rc = launch_transpose<u32>(ctx, b.tile_t, b.tile);
-            if (rc != SMR_OK) return rc;
-        }
+    }
+    for (const MTransposeBack &b : transposed) {
+        rc = launch_transpose<u32>(ctx, b.tile_t, b.tile);
+        if (rc != SMR_OK) return rc;
     }
     if (!jobs.empty()) {
         rc = launch_ingest(ctx, jobs);
@@ -346,8 +376,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
 // InputTexture::convert_to_node_texture + ResampledChild::render for one input, fused when the
 // plan allows it (wave A with a single job), otherwise convert + general resample.  This is the
 // per-shard step of the multi-GPU path: each GPU turns its inputs into dst-sized tiles.
-extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const float crop[4], smr_surface *dst) {
-    SMR_ENTER(ctx);
+//
+// `new_call`: open a weight-cache call of its own.  The batch entry point passes false: the bands it already handed to jobs that are
+// not launched yet carry the batch's call id and must keep their eviction protection while this input builds its own.
+static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float crop[4], smr_surface *dst, bool new_call) {
     if (!ctx || !in || !crop || !dst) return SMR_ERR_INVALID;
     if (dst->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample: dst must be RGBA8");
     if (int rc = smr_validate_frame(ctx, in, "smr_ingest_resample")) return rc;
@@ -356,7 +388,26 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
     int kind = smr_resample_plan_make(in->width, in->height, crop, dst->w, dst->h, &plan);
     if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample: degenerate plan");
     if (kind == 0) return 0;
-    ctx->weight_call++;
+    if (new_call) ctx->weight_call++;
+    if (!fused_disabled(ctx) && can_fuse_wave(ctx, in, plan, dst)) {
+        std::vector<WJob> wjobs(1);
+        int rc = make_wave_job(ctx, in, plan, dst, &wjobs[0]);
+        if (rc != SMR_OK) return rc;
+        rc = launch_wave(ctx, wjobs);
+        return rc == SMR_OK ? kind : rc;
+    }
+    if (!fused_disabled(ctx)) {  // a vertical-first plan: the same kernel on the transposed frame
+        std::vector<WJob> wjobs(1);
+        MTransposeBack back;
+        bool ok = false;
+        int rc = make_wave_job_transposed(ctx, in, plan, dst, SLOT_TRANSPOSED_SINGLE, &wjobs[0], &ok, &back);
+        if (rc != SMR_OK) return rc;
+        if (ok) {
+            rc = launch_wave(ctx, wjobs);
+            if (rc == SMR_OK) rc = launch_transpose<u32>(ctx, back.tile_t, back.tile);
+            return rc == SMR_OK ? kind : rc;
+        }
+    }
     if (!fused_disabled(ctx) && can_fuse_mfma(ctx, in, plan, dst)) {
         std::vector<MJob> mjobs(1);
         bool fits = false;
@@ -393,6 +444,11 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
     return smr_resample(ctx, node, crop, dst);
 }
 
+extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const float crop[4], smr_surface *dst) {
+    SMR_ENTER(ctx);
+    return ingest_resample_one(ctx, in, crop, dst, true);
+}
+
 // The same for all inputs of a shard at once: every fusable input rides in one launch of wave A (its rows are balanced over
 // the blocks together), the others go one by one.  kinds[i] receives the plan kind of input i (0 = direct: dst untouched).
 extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, const float *crops, smr_surface *const *dst, uint32_t n,
@@ -402,7 +458,8 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
-    const uint64_t call = ++ctx->weight_call;
+    std::vector<WJob> wjobs;
+    ++ctx->weight_call;
     for (uint32_t i = 0; i < n; i++) {
         if (!in[i] || !dst[i] || dst[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: bad input %u", i);
         if (int rc = smr_validate_frame(ctx, in[i], "smr_ingest_resample_batch")) return rc;
@@ -413,7 +470,14 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         if (kinds) kinds[i] = kind;
         if (kind == 0) continue;
         bool on_mfma = false;
-        if (!fused_disabled(ctx) && can_fuse_mfma(ctx, in[i], plan, dst[i])) {
+        if (!fused_disabled(ctx) && can_fuse_wave(ctx, in[i], plan, dst[i])) {
+            WJob J;
+            int rc = make_wave_job(ctx, in[i], plan, dst[i], &J);
+            if (rc != SMR_OK) return rc;
+            wjobs.push_back(J);
+            on_mfma = true;
+        }
+        if (!on_mfma && !fused_disabled(ctx) && can_fuse_mfma(ctx, in[i], plan, dst[i])) {
             MJob J;
             int rc = make_mfma_job(ctx, in[i], plan, dst[i], &J, &on_mfma);
             if (rc != SMR_OK) return rc;
@@ -426,10 +490,13 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
             if (rc != SMR_OK) return rc;
             jobs.push_back(J);
         } else {
-            int rc = smr_ingest_resample(ctx, in[i], crop, dst[i]);
+            int rc = ingest_resample_one(ctx, in[i], crop, dst[i], false);  // (inside this call: pending jobs' bands stay protected)
             if (rc < 0) return rc;
-            ctx->weight_call = call;  // (the single-input entry point opened a call of its own; pending jobs stay protected)
         }
+    }
+    if (!wjobs.empty()) {
+        int rc = launch_wave(ctx, wjobs);
+        if (rc != SMR_OK) return rc;
     }
     if (!mjobs.empty()) {
         int rc = launch_mfma(ctx, mjobs);

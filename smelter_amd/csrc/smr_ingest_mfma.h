@@ -29,16 +29,12 @@
 //   of the kernel (template flags), so the plain build carries none of their registers.
 #pragma once
 
-#include "smr_convert_dev.h"
-#include "smr_resample_dev.h"
+#include "smr_ingest_common.h"
 
 #include <cmath>
 #include <vector>
 
 namespace {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int M_NT = 4;             // 16-column N tiles per strip = filter waves of a workgroup
 #ifndef SMR_MFMA_CONV_WAVES
@@ -227,13 +223,16 @@ int get_mfma_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
 }
 
 int flush_mfma_builds(smr_ctx *ctx) {
+    // (bands in the layouts of k_ingest_wave — axis 2 / 3 — are built by flush_wave_builds and stay on the list)
+    std::vector<smr_ctx::PendingBand> mine, rest;
+    for (const auto &p : ctx->pending_bands) (p.axis < 2 ? mine : rest).push_back(p);
     size_t i = 0;
-    while (i < ctx->pending_bands.size()) {
+    while (i < mine.size()) {
         WBatch args;
         memset(&args, 0, sizeof(args));
         int tiles = 0;
-        for (; i < ctx->pending_bands.size() && args.n < MAX_WBUILDS; i++) {
-            const smr_ctx::PendingBand &p = ctx->pending_bands[i];
+        for (; i < mine.size() && args.n < MAX_WBUILDS; i++) {
+            const smr_ctx::PendingBand &p = mine[i];
             WBuild &b = args.b[args.n++];
             b.scale = p.scale; b.offset = p.offset; b.taps = p.taps; b.n_dst = p.n_dst; b.n_src = p.n_src; b.axis = p.axis; b.K = p.K;
             b.tile0 = tiles; b.meta = (int2 *)p.meta; b.frag = (uint4 *)p.frag;
@@ -242,7 +241,7 @@ int flush_mfma_builds(smr_ctx *ctx) {
         hipLaunchKernelGGL(k_build_mfma_weights, dim3((unsigned)tiles), dim3(64), 0, ctx->stream, args);
         SMR_HIP(ctx, hipGetLastError());
     }
-    ctx->pending_bands.clear();
+    ctx->pending_bands = rest;
     return SMR_OK;
 }
 
@@ -268,16 +267,7 @@ struct MJob {
     int nv12;  // `up` is the interleaved UV plane of an NV12 frame (2 bytes per chroma texel), `vp` aliases it
 };
 
-// Direct output: where the compositor would only copy this tile's texels into the output frame (k_classify_tiles, cls[tile] ==
-// the job's layer), the filter waves convert their finished pixels to Y'CbCr themselves — the arithmetic of k_compose_output's
-// copy tiles on the same bytes — and the RGBA8 texels are not stored.
-struct MDirect {
-    const u8 *cls;   // class per 128x16 output tile, nullptr = off
-    int tiles_x, nv; // nv: 1 = NV12 (interleaved chroma in `up`)
-    SurfView yp, up, vp;
-};
-
-constexpr int MAX_MJOBS_PER_LAUNCH = 12;
+constexpr int MAX_MJOBS_PER_LAUNCH = 16;
 struct MArgs {
     MJob jobs[MAX_MJOBS_PER_LAUNCH];
     int unit_prefix[MAX_MJOBS_PER_LAUNCH + 1];  // units = strips_x * n_vtiles per job (strip-major)
@@ -286,53 +276,18 @@ struct MArgs {
     const MDirect *direct;  // device record (rides behind the layout list), nullptr = off
 };
 
-constexpr int M_LUT_ENTRIES = 768;  // decode LUT indexed by the unclamped code + 256: entries below 256 / above 511 repeat the ends
 constexpr int M_OFF_THR = M_LUT_ENTRIES * 4;
 constexpr int M_OFF_T = M_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
 static_assert(M_OFF_THR % 16 == 0 && M_OFF_T % 16 == 0, "T must start on a 16-byte boundary");
 __host__ __device__ inline int m_ncd(int ngm) { return ((2 * (ngm - 1) + 3) >> 2) + 2; }  // staged chroma dwords per row
 constexpr int M_PIECE_TILES = 64;   // output tiles of one piece (their window table sits in LDS)
 
-struct MConv {  // the job's colour constants, read once per piece (scalar registers)
-    float ky, krv, kgu, kgv, kbu, cr, cg, cb, ylo, yhi, clo, chi;
-};
-
-// One 4x1 pixel block: luma dword yy, chroma neighbourhoods (4 bytes: columns 2q-1 .. 2q+2) of chroma rows p (ua, va) and p + 1
-// (ub, vb), w13 / w31 = the row's bilinear weight vectors -> (hi, lo) linear texels, 3 channels x 16 bytes into T.
+// One 4x1 pixel block (m_convert_px, smr_ingest_common.h) -> 3 channels x 16 bytes into T.
 template <int ABL>
 __device__ __forceinline__ void m_convert_block(const MConv &J, const u32 *__restrict__ lut, u32 yy, u32 ua, u32 ub, u32 va, u32 vb, u32 w13, u32 w31,
                                                 u32 *__restrict__ Trow /* T + row * ts + 4g, channel stride 16 * ts */, int ts) {
-    const u32 pu0 = __builtin_amdgcn_perm(ub, ua, 0x05040100u), pu1 = __builtin_amdgcn_perm(ub, ua, 0x06050201u), pu2 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
-    const u32 pv0 = __builtin_amdgcn_perm(vb, va, 0x05040100u), pv1 = __builtin_amdgcn_perm(vb, va, 0x06050201u), pv2 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
-    const u32 pus[4] = {pu0, pu1, pu1, pu2}, pvs[4] = {pv0, pv1, pv1, pv2};
     uint4 o[3];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const u32 wgt = (i & 1) ? w31 : w13;
-        const int u16 = (int)__builtin_amdgcn_udot4(pus[i], wgt, 0u, false), v16 = (int)__builtin_amdgcn_udot4(pvs[i], wgt, 0u, false);
-        const float uf = __builtin_amdgcn_fmed3f((float)u16, J.clo, J.chi), vf = __builtin_amdgcn_fmed3f((float)v16, J.clo, J.chi);
-        const float yf = __builtin_amdgcn_fmed3f((float)((yy >> (8 * i)) & 0xffu), J.ylo, J.yhi);
-        const float r = __builtin_fmaf(yf, J.ky, __builtin_fmaf(vf, J.krv, J.cr));
-        const float g = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kgu, __builtin_fmaf(vf, J.kgv, J.cg)));
-        const float b = __builtin_fmaf(yf, J.ky, __builtin_fmaf(uf, J.kbu, J.cb));
-        // u8 quantisation of the node texture + decode in one lookup: the constants carry + 1280.5, so r = 1024 + 256 + floor(255 R' + 0.5)
-        // + fraction with a fixed exponent — the code sits in mantissa bits [22:13], its LDS offset is (bits >> 11) & 0xffc, and the
-        // clamp to [0, 255] is folded into the table (768 entries: the matrix cannot leave [-237, 492]).  Two full-rate integer
-        // ops per channel instead of clamp + convert + shift.
-        u32 tr, tg, tb;
-        if (ABL & 256) {  // profiling: no LUT gathers
-            tr = __float_as_uint(r) >> 13; tg = __float_as_uint(g) >> 13; tb = __float_as_uint(b) >> 13;
-        } else {
-            typedef __attribute__((address_space(3))) const u32 lds_u32;  // (the LUT sits at LDS offset 0: launch_mfma checks it)
-            tr = *(lds_u32 *)(uintptr_t)((__float_as_uint(r) >> 11) & 0xffcu);
-            tg = *(lds_u32 *)(uintptr_t)((__float_as_uint(g) >> 11) & 0xffcu);
-            tb = *(lds_u32 *)(uintptr_t)((__float_as_uint(b) >> 11) & 0xffcu);
-        }
-        if (i == 0) { o[0].x = tr; o[1].x = tg; o[2].x = tb; }
-        if (i == 1) { o[0].y = tr; o[1].y = tg; o[2].y = tb; }
-        if (i == 2) { o[0].z = tr; o[1].z = tg; o[2].z = tb; }
-        if (i == 3) { o[0].w = tr; o[1].w = tg; o[2].w = tb; }
-    }
+    m_convert_px<(ABL & 256) != 0>(J, yy, ua, ub, va, vb, w13, w31, o);  // (the LUT sits at LDS offset 0: launch_mfma checks it)
     if (ABL & 512) {  // profiling: one dword instead of 48 bytes
         *Trow = o[0].x ^ o[0].y ^ o[0].z ^ o[0].w ^ o[1].x ^ o[1].y ^ o[1].z ^ o[1].w ^ o[2].x ^ o[2].y ^ o[2].z ^ o[2].w;
         return;
@@ -656,46 +611,15 @@ __device__ __forceinline__ void mfma_piece(const MJob &J, const MDirect *__restr
                         for (int i = 0; i < 4; i++)
                             px[i] = srgb_encode8(acc[0][i], s_thr) | (srgb_encode8(acc[1][i], s_thr) << 8) | (srgb_encode8(acc[2][i], s_thr) << 16) | 0xff000000u;
                         if (dj) {
-                            // rgba_to_yuv.wgsl:26-54 on the bytes above, operation for operation as k_compose_output's copy tiles
-                            // (smr_fused_compose.h store_yuv_block; smr_convert_dev.h unorm_of_byte / yuv_byte): unorm -> BT.709 -> unorm8.
-                            // Chroma = the mean of a 2x2 block, ((a + b) + (c + d)) / 4 — bit for bit (a/2 + b/2)/2 + (c/2 + d/2)/2, and
-                            // either sum commutes: the two rows of a block sit in neighbouring lanes (l16 even / odd; the tile's output
-                            // position is even).  The even row's lane finishes the block of columns 0-1, the odd row's that of 2-3.
-                            // (A real two-trip loop: unrolled, the twelve unpacked channels pushed the kernel over its 80 registers.)
+                            // (m_direct_yuv: the arithmetic of k_compose_output's copy tiles on the bytes above; every lane takes part
+                            //  in its lane swaps, the lanes of a direct tile store)
                             const bool odd = (l16 & 1) != 0;
-                            u32 yq = 0;
-                            float own_r = 0.f, own_g = 0.f, own_b = 0.f, snd_r = 0.f, snd_g = 0.f, snd_b = 0.f;
-#pragma nounroll
-                            for (int p = 0; p < 2; p++) {
-                                const u32 pa = p ? px[2] : px[0], pb = p ? px[3] : px[1];
-                                const float ar = unorm_of_byte(pa & 0xffu), ag = unorm_of_byte((pa >> 8) & 0xffu), ab = unorm_of_byte((pa >> 16) & 0xffu);
-                                const float br = unorm_of_byte(pb & 0xffu), bg = unorm_of_byte((pb >> 8) & 0xffu), bb = unorm_of_byte((pb >> 16) & 0xffu);
-                                const u32 y2 = yuv_byte(ar, ag, ab, 0) | (yuv_byte(br, bg, bb, 0) << 8);
-                                yq |= y2 << (16 * p);
-                                const float hr = ar + br, hg = ag + bg, hb = ab + bb;  // (row sums; the halvings are one exact * .25 at the end)
-                                const bool mine_here = (p == 1) == odd;  // this lane finishes block p, the neighbour the other one
-                                own_r = mine_here ? hr : own_r; own_g = mine_here ? hg : own_g; own_b = mine_here ? hb : own_b;
-                                snd_r = mine_here ? snd_r : hr; snd_g = mine_here ? snd_g : hg; snd_b = mine_here ? snd_b : hb;
-                            }
-                            const float nb_r = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_r), 0xb1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
-                            const float nb_g = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_g), 0xb1, 0xf, 0xf, true));
-                            const float nb_b = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(snd_b), 0xb1, 0xf, 0xf, true));
-                            const float m_r = (own_r + nb_r) * 0.25f, m_g = (own_g + nb_g) * 0.25f, m_b = (own_b + nb_b) * 0.25f;
-                            const u32 mine = yuv_byte(m_r, m_g, m_b, 1) | (yuv_byte(m_r, m_g, m_b, 2) << 8);  // (U, V) of this lane's block
-                            const u32 other = (u32)__builtin_amdgcn_mov_dpp((int)mine, 0xb1, 0xf, 0xf, true);
+                            u32 mine, other;
+                            const u32 yq = m_direct_yuv(px, odd, &mine, &other);
                             if (direct) {
                                 const MDirect *Dp = Dg;
                                 asm volatile("" : "+s"(Dp));
-                                const int X = d_ox + x, Y = d_oy + y;
-                                *(u32 *)(Dp->yp.ptr + (size_t)Y * Dp->yp.pitch + X) = yq;
-                                const int cx = X >> 1, cy = Y >> 1;
-                                if (Dp->nv) {  // U0 V0 U1 V1
-                                    if (!odd) *(u32 *)(Dp->up.ptr + (size_t)cy * Dp->up.pitch + (size_t)cx * 2) = (mine & 0xffffu) | (other << 16);
-                                } else if (!odd) {
-                                    *(u16 *)(Dp->up.ptr + (size_t)cy * Dp->up.pitch + cx) = (u16)((mine & 0xffu) | ((other & 0xffu) << 8));
-                                } else {
-                                    *(u16 *)(Dp->vp.ptr + (size_t)cy * Dp->vp.pitch + cx) = (u16)(((other >> 8) & 0xffu) | (mine & 0xff00u));
-                                }
+                                m_direct_store(Dp, d_ox + x, d_oy + y, odd, yq, mine, other);
                             }
                         }
                         if (!direct && y < d_h && x < d_w) {
@@ -806,18 +730,9 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.dst = view_of(tile);
     J.src_w = (int)f->width; J.src_h = (int)f->height;
     // planar_yuv_to_rgba.wgsl:45-57 with every constant folded; chroma arrives in 1/16 u8 units (16 * 255 * u)
-    const bool full = f->format == SMR_FRAME_PLANAR_YUVJ420;
-    const double ys = full ? 1.0 : 255.0 / 219.0, y0 = full ? 0.0 : 16.0;          // 255 * ye = ys * (Y - y0)
-    const double cs = full ? 1.0 / 16.0 : 255.0 / (16.0 * 224.0);                  // 255 * ue = cs * (U16 - 16 * c0)
-    const double c0 = full ? 0.0 : 16.0 * 16.0, half = full ? 16.0 * 127.5 : 16.0 * 112.0;  // 255 * (ue - 0.5) = cs * (U16 - c0 - half)
-    J.ky = (float)ys;
-    J.krv = (float)(1.5748 * cs); J.kgu = (float)(-0.1873 * cs); J.kgv = (float)(-0.4681 * cs); J.kbu = (float)(1.8556 * cs);
-    const double bias = 1024.0 + 256.0 + 0.5;  // see m_convert_block: fixed exponent, LUT offset, round half up
-    J.cr = (float)(bias - ys * y0 - 1.5748 * cs * (c0 + half));
-    J.cg = (float)(bias - ys * y0 + (0.1873 + 0.4681) * cs * (c0 + half));
-    J.cb = (float)(bias - ys * y0 - 1.8556 * cs * (c0 + half));
-    J.ylo = full ? 0.0f : 16.0f; J.yhi = full ? 255.0f : 235.0f;
-    J.clo = full ? 0 : 256; J.chi = full ? 4080 : 3840;
+    const MConv C = m_conv_constants(f->format == SMR_FRAME_PLANAR_YUVJ420);
+    J.ky = C.ky; J.krv = C.krv; J.kgu = C.kgu; J.kgv = C.kgv; J.kbu = C.kbu; J.cr = C.cr; J.cg = C.cg; J.cb = C.cb;
+    J.ylo = C.ylo; J.yhi = C.yhi; J.clo = (int)C.clo; J.chi = (int)C.chi;
     J.h_meta = bh.meta; J.h_frag = bh.frag; J.KH = bh.K; J.n_htiles = bh.n_tiles;
     J.v_meta = bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_tiles;
     J.strips_x = (bh.n_tiles + M_NT - 1) / M_NT;

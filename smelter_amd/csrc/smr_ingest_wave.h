@@ -1,0 +1,799 @@
+// smr_ingest_wave.h — wave A of the hot path, second generation: k_ingest_wave (included by smr_fused.hip only).
+//
+// Same job and the same arithmetic as k_ingest_mfma (smr_ingest_mfma.h): planar 4:2:0 / NV12 frame -> dst-sized sRGB RGBA8 tile, i.e.
+// planar_yuv_to_rgba.wgsl:35-58 followed by the two Lanczos3 passes of transformations/layout/resample.wgsl:31-87 with their
+// Rgba16Float intermediate (layout/resampler.rs:25-28), both passes as banded GEMMs on v_mfma_f32_16x16x32_f16 with f16-pair
+// operands — but organised so that a wave never waits for another wave:
+//
+//   * A WAVE owns two neighbouring 16-column output tiles (a "column pair", 32 output columns) over a range of 16-row output tiles
+//     and streams the source rows in chunks of 16.  There is no barrier in the main loop and nothing but tables in LDS.
+//   * Conversion feeds the matrix cores from registers.  Lane (m, q) = (lane & 15, lane >> 4) converts the 4x1 pixel block of chunk
+//     row m, texels 4 (4 j + q) .. + 3 of the pair's source window: its (hi, lo) f16 pairs ARE the lane's eight K values of the
+//     A operand of k-step j (m_convert_px).  The node texture never exists, not even in LDS.
+//   * Pass 1: H[r][x] = sum_k T[r][k] Wh[k][x] accumulates over the k-steps of the pair's window into one accumulator set per
+//     tile (weights (w_hi, w_hi) and (w_lo, 0) per texel pair, read from LDS where the workgroup keeps its pair's band).
+//   * Pass 2 straight from registers: the f32 accumulator of pass 1 holds, per lane, rows 4 q .. 4 q + 3 of one output column
+//     of the chunk.  Rounded to f16 (the reference's Rgba16Float store) that is half of an A operand of the second GEMM
+//     O[x][y] = sum_r H[x][r] Wv[r][y] — provided K runs over the rows in the order the lanes happen to hold them.  K is a
+//     summation index, so the weight bands are simply built in that order (k_build_wave_weights, axis 3): K slot (q, e) of the k-step
+//     made of chunks (c0, c1) is row 4 q + e of c0 for e < 4 and row 4 q + e - 4 of c1 for e >= 4.  A tile's window is the 2 KV
+//     chunks that end with the chunk of its last row; chunk c lives in ring slot c mod 2 KV (an absolute grid, so one band per
+//     tile serves every piece), the ring is 2 KV register pairs per channel and tile.  No f16 intermediate in LDS either.
+//   * Pass-2 weights are f16 pairs too (w_hi + w_lo, two MFMAs on the same A operand): with single-f16 weights a dark output that is
+//     a cancelling sum of bright rows was off by up to 4 LSB on white noise (round 2); with pairs every content class is within 1.
+//   * The reference's own quantisation points are kept: u8 node texture, f16 (RTNE) between the passes, u8 sRGB tile.
+//
+// Work split: a workgroup = W_WAVES waves on the same column pair (they share its pass-1 band in LDS), each with its own vertical
+// piece; workgroups are ordered pair-fastest within a band of rows, so neighbouring pairs read the same source lines at the same
+// time on the same XCD.  Per-wave state is registers (~48 for the ring, 24 accumulators); LDS per workgroup = decode / encode
+// tables (5.8 KB) + the pair's band (4 KB per k-step) + 2 KB of raw Y/U/V staging per wave.
+#pragma once
+
+#include "smr_ingest_common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+#ifndef SMR_WAVE_WAVES
+#define SMR_WAVE_WAVES 2
+#endif
+constexpr int W_WAVES = SMR_WAVE_WAVES;   // waves per workgroup (same column pair, consecutive vertical pieces)
+constexpr int W_THREADS = 64 * W_WAVES;
+constexpr int W_NKS_MAX = 8;              // k-steps (16 texels as hi/lo pairs) of a pair's source window
+constexpr int W_KT_MAX = 6;               // k-steps a single tile's band may span
+constexpr int W_KV_MAX = 4;               // k-steps (two chunks of 16 rows) of a pass-2 window
+constexpr int W_WSPAN = 136;              // >= 16 * W_KT_MAX, >= 32 * W_KV_MAX
+
+// ------------------------------------------------------------------ geometry (host + device: one f32 sequence)
+// chunk c = source rows 16 c - 1 .. 16 c + 14 (row 0 of a chunk is an odd luma row: rows (2 p + 1, 2 p + 2) share chroma rows p, p + 1)
+__host__ __device__ inline int w_chunk_of_row(int r) { return (r + 1) >> 4; }
+__host__ __device__ inline int w_posmod(int a, int n) { const int r = a % n; return r < 0 ? r + n : r; }
+__host__ __device__ inline int w_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__host__ __device__ inline int w_taps(float scale) {
+    const float kernel_scale = scale > 1.0f ? scale : 1.0f;
+    const int taps = (int)ceilf(2.0f * (3.0f * kernel_scale)) + 1;
+    return taps > MAX_TAPS ? MAX_TAPS : taps;
+}
+// first / last source texel that carries a weight for outputs [o0, o1]
+__host__ __device__ inline void w_span(int o0, int o1, float scale, float offset, int taps, int n_src, int *lo, int *hi) {
+    *lo = w_clampi(lanczos_first(o0, scale, offset), 0, n_src - 1);
+    *hi = w_clampi(lanczos_first(o1, scale, offset) + taps - 1, 0, n_src - 1);
+}
+
+// A column pair: tiles 2 pair, 2 pair + 1 (the second may not exist).  base = first texel of the window (multiple of 4), tile i's
+// band starts at k-step klo[i] (-1: no such tile) and needs kt[i] k-steps; nks = k-steps of the whole window.
+struct WPairGeom {
+    int base, klo[2], kt[2], last, nks;
+};
+__host__ __device__ inline WPairGeom w_pair_geometry(int pair, float scale, float offset, int taps, int n_dst, int n_src) {
+    WPairGeom g;
+    const int n_tiles = (n_dst + 15) >> 4;
+    g.base = 0; g.last = 0;
+    for (int i = 0; i < 2; i++) {
+        const int t = 2 * pair + i;
+        g.klo[i] = -1; g.kt[i] = 0;
+        if (t >= n_tiles) continue;
+        const int o0 = 16 * t, o1 = o0 + 15 < n_dst - 1 ? o0 + 15 : n_dst - 1;
+        int lo, hi;
+        w_span(o0, o1, scale, offset, taps, n_src, &lo, &hi);
+        if (i == 0) g.base = lo & ~3;
+        if (lo < g.base) lo = g.base;  // (cannot happen: the first texel grows with the output column)
+        g.klo[i] = (lo - g.base) >> 4;
+        g.kt[i] = ((hi - g.base) >> 4) - g.klo[i] + 1;
+        g.last = hi > g.last ? hi : g.last;
+    }
+    g.nks = ((g.last - g.base) >> 4) + 1;
+    return g;
+}
+// A 16-row output tile of pass 2: first / last chunk that carries a weight
+__host__ __device__ inline void w_vtile_chunks(int t, float scale, float offset, int taps, int n_dst, int n_src, int *cs, int *ce) {
+    const int o0 = 16 * t, o1 = o0 + 15 < n_dst - 1 ? o0 + 15 : n_dst - 1;
+    int lo, hi;
+    w_span(o0, o1, scale, offset, taps, n_src, &lo, &hi);
+    *cs = w_chunk_of_row(lo);
+    *ce = w_chunk_of_row(hi);
+}
+
+// host twin of the geometry the builder uses (same f32 sequence: lanczos_first is __host__ __device__)
+inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, int axis, int *K, int *nks) {
+    const int taps = w_taps(scale);
+    const int n_tiles = (n_dst + 15) / 16;
+    int k = 1, n = 1;
+    if (axis == 2) {
+        for (int p = 0; p < (n_tiles + 1) / 2; p++) {
+            const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src);
+            for (int i = 0; i < 2; i++) k = g.kt[i] > k ? g.kt[i] : k;
+            n = g.nks > n ? g.nks : n;
+        }
+    } else {
+        for (int t = 0; t < n_tiles; t++) {
+            int cs, ce;
+            w_vtile_chunks(t, scale, offset, taps, n_dst, n_src, &cs, &ce);
+            const int need = (ce - cs + 2) / 2;
+            k = need > k ? need : k;
+        }
+    }
+    *K = k;
+    *nks = n;
+}
+
+// ------------------------------------------------------------------ weight bands (device cache, one launch per call for all misses)
+// axis 2 (pass 1, per column pair):  meta int4 (base, klo0, klo1, last);  frag[pair][tile i][k-step kk < KT][hi | lo][64 lanes]:
+//   lane l holds W[k = 8 (l >> 4) + e][n = l & 15], texel = base + 16 (klo_i + kk) + (k >> 1); the (w_hi, w_hi) fragment multiplies
+//   the (t_hi, t_lo) pair, the (w_lo, 0) fragment adds t_hi w_lo (t_lo w_lo is below 2^-22).
+// axis 3 (pass 2, per 16-row output tile):  meta int2 (first chunk, last chunk);  frag[tile][k-step p < KV][hi | lo][64 lanes]:
+//   lane l = (output row n = l & 15, q = l >> 4), element e: ring slot s = 2 p + (e >> 2), chunk cc = the chunk of the tile's window
+//   [ce - 2 KV + 1, ce] with cc mod 2 KV == s, source row 16 cc - 1 + 4 q + (e & 3).
+struct WWBuild {
+    float scale, offset;
+    int taps, n_dst, n_src, axis, K, unit0;  // unit0: first workgroup of this band (units = pairs or tiles)
+    void *meta;
+    uint4 *frag;
+};
+constexpr int MAX_WWBUILDS = 32;
+struct WWBatch {
+    WWBuild b[MAX_WWBUILDS];
+    int n;
+};
+
+#ifdef __HIPCC__
+__global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
+    __shared__ float s_w[16][W_WSPAN];
+    __shared__ _Float16 s_q[16][W_WSPAN], s_r[16][W_WSPAN];
+    int bi = 0;
+    while (bi + 1 < args.n && args.b[bi + 1].unit0 <= (int)blockIdx.x) bi++;
+    const WWBuild &B = args.b[bi];
+    const float scale = B.scale, offset = B.offset;
+    const int taps = B.taps, n_dst = B.n_dst, n_src = B.n_src, K = B.K;
+    const int u = (int)blockIdx.x - B.unit0, lane = threadIdx.x;
+    const int n16 = lane & 15, q = lane >> 4;
+    const int n_sub = B.axis == 2 ? 2 : 1;
+    WPairGeom G;
+    int v_cs = 0, v_ce = 0;
+    if (B.axis == 2) G = w_pair_geometry(u, scale, offset, taps, n_dst, n_src);
+    else w_vtile_chunks(u, scale, offset, taps, n_dst, n_src, &v_cs, &v_ce);
+    for (int sub = 0; sub < n_sub; sub++) {
+        const int tile = B.axis == 2 ? 2 * u + sub : u;
+        // origin of the window in source texels / rows, and its length
+        const int wlo = v_ce - 2 * K + 1;  // (axis 3) first chunk of the window; may be negative: those chunks do not exist
+        const int origin = B.axis == 2 ? G.base + 16 * (G.klo[sub] < 0 ? 0 : G.klo[sub]) : 16 * wlo - 1;
+        const int span = B.axis == 2 ? 16 * K : 32 * K;
+        for (int i = lane; i < 16 * W_WSPAN; i += 64) {
+            (&s_w[0][0])[i] = 0.0f;
+            (&s_q[0][0])[i] = (_Float16)0.0f;
+            (&s_r[0][0])[i] = (_Float16)0.0f;
+        }
+        __syncthreads();
+        const bool present = B.axis == 3 || G.klo[sub] >= 0;
+        if (present && lane < 16 && 16 * tile + lane < n_dst) {
+            float w[MAX_TAPS];
+            float ws;
+            const int first = lanczos_weights(16 * tile + lane, scale, offset, taps, w, &ws);
+            for (int i = 0; i < taps; i++) {  // clamp-to-edge folded into the band: taps that clamp onto one texel are summed
+                const int idx = w_clampi(first + i, 0, n_src - 1) - origin;
+                if (idx >= 0 && idx < span) s_w[lane][idx] += w[i] / ws;
+            }
+            // two f16 terms per weight: hi = f16(w), lo = f16(w - hi) — the pair carries 22 bits
+            for (int i = 0; i < span; i++) {
+                const _Float16 qh = (_Float16)s_w[lane][i];
+                s_q[lane][i] = qh;
+                s_r[lane][i] = (_Float16)(s_w[lane][i] - (float)qh);
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < K; j++) {
+            f16x8 v, r;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                if (B.axis == 2) {
+                    const int kk = 32 * j + 8 * q + e;
+                    v[e] = s_q[n16][kk >> 1];
+                    r[e] = (kk & 1) ? (_Float16)0.0f : s_r[n16][kk >> 1];
+                } else {
+                    const int s = 2 * j + (e >> 2);
+                    const int cc = wlo + w_posmod(s - wlo, 2 * K);
+                    const int idx = 16 * (cc - wlo) + 4 * q + (e & 3);
+                    v[e] = s_q[n16][idx];
+                    r[e] = s_r[n16][idx];
+                }
+            }
+            const size_t f = B.axis == 2 ? (((size_t)u * 2 + sub) * K + j) * 2 : ((size_t)u * K + j) * 2;
+            B.frag[f * 64 + lane] = __builtin_bit_cast(uint4, v);
+            B.frag[(f + 1) * 64 + lane] = __builtin_bit_cast(uint4, r);
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (B.axis == 2) ((int4 *)B.meta)[u] = make_int4(G.base, G.klo[0], G.klo[1], G.last);
+        else ((int2 *)B.meta)[u] = make_int2(v_cs, v_ce);
+    }
+}
+#endif  // __HIPCC__
+
+// ------------------------------------------------------------------ kernel
+struct WJob {
+    SurfView yp, up, vp;  // source planes (chroma views carry the chroma size; NV12: `up` = interleaved UV, `vp` aliases it)
+    SurfView dst;         // RGBA8 tile, dst-sized
+    int src_w, src_h;
+    MConv conv;
+    const int4 *h_meta; const uint4 *h_frag;
+    const int2 *v_meta; const uint4 *v_frag;
+    int NKS, KT, KV;      // k-steps: of the widest pair window, per tile band, per pass-2 window
+    int n_pairs, n_htiles, n_vtiles;
+    int pieces;           // vertical pieces per column pair (a multiple of W_WAVES)
+    int nv12;
+    int layer, ox, oy;    // direct output: the layer this tile is blitted by (-1 = none) and its (even) position in the output frame
+};
+
+constexpr int MAX_WJOBS_PER_LAUNCH = 12;
+struct WArgs {
+    WJob jobs[MAX_WJOBS_PER_LAUNCH];
+    int wg_prefix[MAX_WJOBS_PER_LAUNCH + 1];  // workgroups per job = n_pairs * pieces / W_WAVES, piece-group major, pair fastest
+    int n_jobs;
+    int b_bytes;      // LDS bytes reserved for a pair's pass-1 band
+    int raw_bytes;    // ... for one wave's raw footprint
+    const MDirect *direct;  // device record (rides behind the layout list), nullptr = off
+};
+
+constexpr int W_OFF_THR = M_LUT_ENTRIES * 4;
+constexpr int W_OFF_B = W_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
+static_assert(W_OFF_B % 16 == 0, "the band must start on a 16-byte boundary");
+__host__ __device__ inline int w_ys(int nks) { return 4 * nks + 1; }  // staged luma dwords per chunk row (+ 1: rows fall on different banks)
+__host__ __device__ inline int w_cs(int nks) { return 2 * nks + 2; }  // staged chroma dwords per row: columns base/2 - 1 .. base/2 + 8 nks, from a 4-aligned start
+__host__ __device__ inline int w_raw_bytes(int nks) { return 4 * (16 * w_ys(nks) + 2 * 9 * w_cs(nks)); }
+__host__ __device__ inline int w_band_bytes(int kt) { return 2 * kt * 2 * 64 * 16; }
+
+#ifdef __HIPCC__
+
+// Output tiles [vt0, vt1] of column pair `pair` of job J, by one wave.  NKS_T / KT_T / KV_T: the k-step counts when every job of the
+// launch shares them (0 = read them from the job: loops unrolled to the maximum and predicated).
+// FL: 2048 direct output, 4096 NV12-capable staging.
+template <int NKS_T, int KT_T, int KV_T, int FL>
+__device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restrict__ Dg, int pair, int vt0, int vt1, u8 *smem, u32 b_off, u32 raw_off) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
+    const int NKS = NKS_T ? NKS_T : J.NKS, KT = KT_T ? KT_T : J.KT, KV = KV_T ? KV_T : J.KV;
+    constexpr int NKS_N = NKS_T ? NKS_T : W_NKS_MAX, KV_N = KV_T ? KV_T : W_KV_MAX;
+    constexpr bool NV = (FL & 4096) != 0, DIRECT = (FL & 2048) != 0;
+    const float *s_thr = (const float *)(smem + W_OFF_THR);
+    const uint4 *Bs = (const uint4 *)(smem + b_off);
+
+    // ---- pair geometry
+    const int4 hm = J.h_meta[pair];
+    const int base = hm.x, klo0 = hm.y, klo1 = hm.z;
+    const int nks = min(((hm.w - base) >> 4) + 1, NKS);
+    const int tx0 = 32 * pair;
+    const int d_w = J.dst.w, d_h = J.dst.h;
+    u8 *const d_ptr = J.dst.ptr;
+    const u32 d_pitch = J.dst.pitch;
+
+    // ---- staging: loads of the next chunk's raw footprint into registers, landed in LDS after the chunk at hand is converted
+    const int ys = w_ys(NKS), cs = w_cs(NKS);
+    u32 *const rawY = (u32 *)(smem + raw_off), *const rawU = rawY + 16 * ys, *const rawV = rawU + 9 * cs;
+    const u8 *const y_ptr = J.yp.ptr, *const u_ptr = J.up.ptr, *const v_ptr = J.vp.ptr;
+    const u32 y_pitch = J.yp.pitch, u_pitch = J.up.pitch, v_pitch = J.vp.pitch;
+    const int sw = J.src_w, sh = J.src_h, cw = J.up.w, chh = J.up.h;
+    const bool nv = NV && J.nv12 != 0;  // (uniform)
+    // luma: lane (row 4 rb + lq, dword 16 cb + l16) of the chunk, rb < 4, cb < ceil(NKS / 4)
+    constexpr int NCB = (NKS_N + 3) / 4, NYL = 4 * NCB;
+    u32 py[NYL];
+    const int sw4 = (sw + 3) & ~3;
+    // chroma: 18 (plane, row) tasks; LPRC lanes per row
+    constexpr int CSN = 2 * NKS_N + 2, LPRC = CSN <= 16 ? 16 : 32, RPLC = 64 / LPRC, NCL = (18 + RPLC - 1) / RPLC;
+    u32 pc[NCL], pc_hi[NV ? NCL : 1];
+    const int c_d = lane & (LPRC - 1), c_t = lane / LPRC;  // dword within the staged row, task within the load
+    const int cc0 = ((base >> 1) - 1) & ~3;               // first staged chroma column (4-aligned, may be -4)
+    const int c_col0 = cc0 + 4 * c_d;                      // first chroma column of this lane's staged dword
+    const int c_col0c = w_clampi(c_col0, 0, (cw - 1) & ~3);  // ... of the dword actually loaded (clamp-to-edge)
+    const bool c_live = c_d < cs;
+    const bool c_edge = c_live && (c_col0 < 0 || c_col0 + 3 > cw - 1);
+    auto issue = [&](int c) {
+        const int r0 = 16 * c - 1;
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++) {
+            const u8 *rowp = y_ptr + (size_t)w_clampi(r0 + 4 * rb + lq, 0, sh - 1) * y_pitch;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                py[rb * NCB + cb] = *(const u32 *)(rowp + min(base + 4 * (16 * cb + l16), sw4 - 4));
+        }
+        const int i0 = 8 * c - 1;  // chroma row of the chunk's first row pair
+#pragma unroll
+        for (int k = 0; k < NCL; k++) {
+            const int rt = min(RPLC * k + c_t, 17);  // (plane, row) task; tasks past the 18th repeat the last one
+            const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
+            const u8 *rowp = (plane ? v_ptr : u_ptr) + (size_t)w_clampi(i0 + r, 0, chh - 1) * (plane ? v_pitch : u_pitch);
+            if (nv) {  // four chroma texels = eight interleaved bytes; the plane's four are picked when they land
+                pc[k] = *(const u32 *)(rowp + 2 * (u32)c_col0c);
+                pc_hi[NV ? k : 0] = *(const u32 *)(rowp + 2 * (u32)c_col0c + 4);
+            } else {
+                pc[k] = *(const u32 *)(rowp + (u32)c_col0c);
+            }
+        }
+    };
+    auto land = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < 4; rb++)
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                if (16 * cb + l16 < 4 * NKS) rawY[(4 * rb + lq) * ys + 16 * cb + l16] = py[rb * NCB + cb];
+#pragma unroll
+        for (int k = 0; k < NCL; k++) {
+            const int rt = RPLC * k + c_t;
+            u32 v = pc[k];
+            if (nv) v = dev_perm(pc_hi[NV ? k : 0], v, rt >= 9 ? 0x07050301u : 0x06040200u);  // V : U bytes
+            if (c_edge) {
+                u32 o = 0;
+#pragma unroll
+                for (int b = 0; b < 4; b++) o |= ((v >> (8 * (w_clampi(c_col0 + b, 0, cw - 1) - c_col0c))) & 0xffu) << (8 * b);
+                v = o;
+            }
+            if (c_live && rt < 18) {
+                const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
+                (plane ? rawV : rawU)[r * cs + c_d] = v;
+            }
+        }
+    };
+
+    // ---- conversion: lane (m, q) = (l16, lq) converts chunk row m, texels base + 16 j + 4 q .. + 3 for k-step j
+    const MConv K = J.conv;
+    const int bi0 = ((base >> 1) - 1 - cc0) + 2 * lq;  // byte of the staged chroma row where this lane's neighbourhood starts (k-step 0)
+    const u32 shb = (u32)(bi0 & 3);
+    const u32 *const yrow = rawY + l16 * ys + lq;
+    const u32 *const urow = rawU + (l16 >> 1) * cs + (bi0 >> 2), *const vrow = rawV + (l16 >> 1) * cs + (bi0 >> 2);
+    // Row 0 of a chunk is an odd luma row: 3/4 of chroma row p = row / 2 (weights A); odd chunk rows take 3/4 of row p + 1 (B).
+    constexpr u32 WA13 = 0x03010903u, WA31 = 0x01030309u, WB13 = 0x09030301u, WB31 = 0x03090103u;
+    const u32 w13 = (l16 & 1) ? WB13 : WA13, w31 = (l16 & 1) ? WB31 : WA31;
+
+    // ---- pass-2 state: the ring of f16 rows (two chunks per register quad) and the weights of the next tile to finish
+    uint4 ring[2][3][KV_N];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int p = 0; p < KV_N; p++) ring[i][c][p] = make_uint4(0u, 0u, 0u, 0u);
+    uint4 bvh[KV_N], bvl[KV_N];
+    const uint4 *const v_frag = J.v_frag;
+    const bool dj = DIRECT && Dg != nullptr && J.layer >= 0;  // (uniform)
+    const int d_ox = J.ox, d_oy = J.oy, d_layer = J.layer;
+    u32 cls_next[2] = {0xffu, 0xffu};
+    auto fetch_bv = [&](int t) {
+#pragma unroll
+        for (int p = 0; p < KV_N; p++)
+            if (p < KV) {
+                bvh[p] = v_frag[(((size_t)t * KV + p) * 2) * 64 + lane];
+                bvl[p] = v_frag[(((size_t)t * KV + p) * 2 + 1) * 64 + lane];
+            }
+        if (dj) {  // direct output: the class of the 128x16 output tile this lane's four pixels of tile row t fall into
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int x = tx0 + 16 * i + 4 * lq, y = 16 * t + l16;
+                const int X = d_ox + x, Y = d_oy + y;
+                const bool in = y < d_h && x < d_w && X >= 0 && Y >= 0 && X < Dg->yp.w && Y < Dg->yp.h;
+                const u32 cl = Dg->cls[in ? (Y >> 4) * Dg->tiles_x + (X >> 7) : 0];
+                cls_next[i] = in ? cl : 0xffu;
+            }
+        }
+    };
+
+    int vt = vt0;
+    int2 vm = J.v_meta[vt0];
+    const int c_first = vm.x, c_last = J.v_meta[vt1].y;
+    fetch_bv(vt0);
+    issue(c_first);
+    dev_wait_vmcnt0();
+    land();
+    dev_wave_lds_sync();
+    if (c_first < c_last) issue(c_first + 1);
+    int slot = w_posmod(c_first, 2 * KV);  // ring slot of the chunk at hand
+
+    for (int c = c_first; c <= c_last; c++) {
+        // ---- conversion + pass 1 of chunk c: k-step by k-step, straight into the accumulators of the tiles it feeds
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) acc[i][ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NKS_N; j++) {
+            if (j < nks) {
+                const u32 yy = yrow[4 * j];
+                const u32 ua = dev_alignbyte(urow[2 * j + 1], urow[2 * j], shb), ub = dev_alignbyte(urow[cs + 2 * j + 1], urow[cs + 2 * j], shb);
+                const u32 va = dev_alignbyte(vrow[2 * j + 1], vrow[2 * j], shb), vb = dev_alignbyte(vrow[cs + 2 * j + 1], vrow[cs + 2 * j], shb);
+                uint4 a[3];
+                m_convert_px<false>(K, yy, ua, ub, va, vb, w13, w31, a);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int kk = j - (i ? klo1 : klo0);
+                    if ((i ? klo1 : klo0) >= 0 && kk >= 0 && kk < KT) {  // (uniform)
+                        const uint4 bh = Bs[((i * KT + kk) * 2) * 64 + lane], bl = Bs[((i * KT + kk) * 2 + 1) * 64 + lane];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bh), acc[i][ch]);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bl), acc[i][ch]);
+                    }
+                }
+            }
+        }
+        // ---- the next chunk's footprint: issued a whole conversion ago; the one after it goes out now
+        if (c < c_last) {
+            dev_wait_vmcnt0();
+            dev_wave_lds_sync();  // (every lane has read its blocks of chunk c)
+            land();
+            dev_wave_lds_sync();
+            if (c + 1 < c_last) issue(c + 2);
+        }
+        // ---- the chunk's 16 rows of H, rounded to f16 (resampler.rs:25-28), into ring slot c mod 2 KV: lane holds rows 4 lq .. + 3 of
+        //      output column l16 of either tile
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const __half2 h0 = __floats2half2_rn(acc[i][ch][0], acc[i][ch][1]), h1 = __floats2half2_rn(acc[i][ch][2], acc[i][ch][3]);
+                const u32 lo = *(const u32 *)&h0, hi = *(const u32 *)&h1;
+#pragma unroll
+                for (int s = 0; s < 2 * KV_N; s++)
+                    if (s == slot) {  // (uniform)
+                        if (s & 1) { ring[i][ch][s >> 1].z = lo; ring[i][ch][s >> 1].w = hi; }
+                        else { ring[i][ch][s >> 1].x = lo; ring[i][ch][s >> 1].y = hi; }
+                    }
+            }
+        slot = slot + 1 == 2 * KV ? 0 : slot + 1;
+        // ---- pass 2 + encode + store of every output tile whose window ends with chunk c
+        while (vt <= vt1 && vm.y == c) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if ((i ? klo1 : klo0) < 0) continue;  // (uniform: no second tile in the last pair of an odd tile count)
+                f32x4 o[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) o[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < KV_N; p++) {
+                    if (p < KV) {
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring[i][ch][p]), __builtin_bit_cast(f16x8, bvh[p]), o[ch]);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++)
+                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring[i][ch][p]), __builtin_bit_cast(f16x8, bvl[p]), o[ch]);
+                    }
+                }
+                // lane holds columns x .. x + 3 of output row y
+                const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
+                u32 px[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    px[k] = srgb_encode8(o[0][k], s_thr) | (srgb_encode8(o[1][k], s_thr) << 8) | (srgb_encode8(o[2][k], s_thr) << 16) | 0xff000000u;
+                bool direct = false;
+                if (dj) {
+                    // (m_direct_yuv: the arithmetic of k_compose_output's copy tiles on the bytes above; every lane takes part in its
+                    //  lane swaps, the lanes of a direct tile store)
+                    direct = cls_next[i] == (u32)d_layer;
+                    const bool odd = (l16 & 1) != 0;
+                    u32 mine, other;
+                    const u32 yq = m_direct_yuv(px, odd, &mine, &other);
+                    if (direct) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);
+                }
+                if (!direct && y < d_h && x < d_w) {
+                    u8 *op = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
+                    if (x + 3 < d_w) {
+                        *(uint4 *)op = make_uint4(px[0], px[1], px[2], px[3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (x + k < d_w) ((u32 *)op)[k] = px[k];
+                    }
+                }
+            }
+            vt++;
+            if (vt <= vt1) {
+                vm = J.v_meta[vt];
+                fetch_bv(vt);
+            }
+        }
+    }
+}
+
+template <int NKS_T, int KT_T, int KV_T, int FL>
+__global__ __launch_bounds__(W_THREADS) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
+#ifdef SMR_EMU
+    u8 *smem = emu_smem;
+#else
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+#endif
+    const int tid = threadIdx.x;
+    const int wave = dev_readfirstlane(tid >> 6);
+    // tables: (hi | lo << 16) decode LUT with the clamp folded in, encode thresholds + estimate table
+    for (int i = tid; i < M_LUT_ENTRIES; i += W_THREADS) ((u32 *)smem)[i] = lut[min(max(i - 256, 0), 255)];
+    for (int i = tid; i < SMR_TABLE_FLOATS - 256; i += W_THREADS) ((float *)(smem + W_OFF_THR))[i] = tables[256 + i];
+    // XCD-aware order: workgroup ids that share an XCD are neighbours in unit space (piece-group major, pair fastest: neighbouring
+    // pairs read the same source lines at the same time)
+    const int per_xcd = ((int)gridDim.x + 7) >> 3;
+    const int v = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    const int total = args.wg_prefix[args.n_jobs];
+    if (v < total) {
+        int j = 0;
+        while (j + 1 < args.n_jobs && args.wg_prefix[j + 1] <= v) j++;
+        const WJob &J = args.jobs[j];
+        const int local = v - args.wg_prefix[j];
+        const int group = local / J.n_pairs, pair = local - group * J.n_pairs;
+        // the pair's pass-1 band -> LDS (shared by the workgroup's waves)
+        const int KT = KT_T ? KT_T : J.KT;
+        const uint4 *src = J.h_frag + (size_t)pair * 2 * KT * 2 * 64;
+        uint4 *Bs = (uint4 *)(smem + W_OFF_B);
+        for (int i = tid; i < 2 * KT * 2 * 64; i += W_THREADS) Bs[i] = src[i];
+        __syncthreads();
+        const int piece = group * W_WAVES + wave;
+        const int vt0 = (int)(((long long)piece * J.n_vtiles) / J.pieces), vt1 = (int)(((long long)(piece + 1) * J.n_vtiles) / J.pieces) - 1;
+        if (vt0 <= vt1)
+            wave_piece<NKS_T, KT_T, KV_T, FL>(J, args.direct, pair, vt0, vt1, smem, (u32)W_OFF_B, (u32)(W_OFF_B + args.b_bytes + wave * args.raw_bytes));
+    }
+}
+
+#endif  // __HIPCC__
+
+}  // namespace
+
+#ifndef SMR_EMU
+namespace {
+
+// ------------------------------------------------------------------ host side: band cache
+struct WaveBand {
+    const void *meta;
+    const uint4 *frag;
+    int K;        // k-steps per tile band (axis 2) / per window (axis 3)
+    int nks;      // axis 2: k-steps of the widest pair window
+    int n_units;  // pairs / tiles
+};
+
+int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis, WaveBand *out) {
+    const int n_tiles = (n_dst + 15) / 16;
+    const int n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;
+    smr_ctx::MfmaTable *hit = find_mfma_table(ctx, scale, offset, n_dst, n_src, axis), *victim = nullptr;
+    if (!hit) {
+        int K, nks;
+        wave_band_geometry(scale, offset, n_dst, n_src, axis, &K, &nks);
+        for (auto &t : ctx->mfma_tables)  // never evict a table the current call already handed to a job that is not launched yet
+            if (t.last_call != ctx->weight_call && (!victim || t.last_use < victim->last_use)) victim = &t;
+        if (!victim || ctx->mfma_tables.size() < 64) {
+            ctx->mfma_tables.emplace_back();
+            victim = &ctx->mfma_tables.back();
+        }
+        const size_t meta_bytes = ((size_t)n_units * (axis == 2 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
+        const size_t frags = axis == 2 ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;
+        const size_t need = meta_bytes + frags * 64 * sizeof(uint4);
+        for (size_t i = ctx->pending_bands.size(); i-- > 0;)
+            if (victim->dev && ctx->pending_bands[i].meta == victim->dev) ctx->pending_bands.erase(ctx->pending_bands.begin() + (long)i);
+        if (victim->bytes < need) {
+            if (victim->dev) {
+                SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // a queued kernel may still read it
+                (void)hipFree(victim->dev);
+                victim->dev = nullptr;
+                victim->bytes = 0;
+            }
+            const size_t want = (need + 4095) & ~(size_t)4095;
+            SMR_HIP(ctx, hipMalloc(&victim->dev, want));
+            victim->bytes = want;
+        }
+        victim->scale = scale; victim->offset = offset; victim->n_dst = n_dst; victim->n_src = n_src; victim->axis = axis;
+        victim->K = K; victim->max_span = 0; victim->meta_bytes = meta_bytes; victim->ngm = nks;
+        smr_ctx::PendingBand pb;
+        pb.scale = scale; pb.offset = offset; pb.taps = w_taps(scale); pb.n_dst = n_dst; pb.n_src = n_src; pb.axis = axis; pb.K = K;
+        pb.n_tiles = n_units; pb.meta = victim->dev; pb.frag = (u8 *)victim->dev + meta_bytes;
+        ctx->pending_bands.push_back(pb);
+        hit = victim;
+    }
+    hit->last_use = ++ctx->weight_clock;
+    hit->last_call = ctx->weight_call;
+    out->meta = hit->dev;
+    out->frag = (const uint4 *)((const u8 *)hit->dev + hit->meta_bytes);
+    out->K = hit->K;
+    out->nks = hit->ngm;
+    out->n_units = n_units;
+    return SMR_OK;
+}
+
+// builds the bands of the wave kernel's layouts (axis 2 / 3) the call is missing; the others stay for flush_mfma_builds
+int flush_wave_builds(smr_ctx *ctx) {
+    std::vector<smr_ctx::PendingBand> rest, mine;
+    for (const auto &p : ctx->pending_bands) (p.axis >= 2 ? mine : rest).push_back(p);
+    size_t i = 0;
+    while (i < mine.size()) {
+        WWBatch args;
+        memset(&args, 0, sizeof(args));
+        int units = 0;
+        for (; i < mine.size() && args.n < MAX_WWBUILDS; i++) {
+            const smr_ctx::PendingBand &p = mine[i];
+            WWBuild &b = args.b[args.n++];
+            b.scale = p.scale; b.offset = p.offset; b.taps = p.taps; b.n_dst = p.n_dst; b.n_src = p.n_src; b.axis = p.axis; b.K = p.K;
+            b.unit0 = units; b.meta = p.meta; b.frag = (uint4 *)p.frag;
+            units += p.n_tiles;
+        }
+        hipLaunchKernelGGL(k_build_wave_weights, dim3((unsigned)units), dim3(64), 0, ctx->stream, args);
+        SMR_HIP(ctx, hipGetLastError());
+    }
+    ctx->pending_bands = rest;
+    return SMR_OK;
+}
+
+// ------------------------------------------------------------------ host side: jobs
+// What k_ingest_wave covers: planar 4:2:0 (limited or full range) or NV12 with even luma size and dword-aligned planes, a separable
+// two-pass plan with the horizontal pass first and no box pre-reduction (vertical-first plans come back on the transposed frame,
+// as for k_ingest_mfma), 16-byte aligned tile rows, k-step counts within the kernel's limits.
+bool can_fuse_wave(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return false;
+    const bool nv12 = f && f->format == SMR_FRAME_NV12;
+    if (!f || !f->planes[0] || !f->planes[1] || (!nv12 && !f->planes[2])) return false;
+    if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return false;
+    if (f->width % 2 || f->height % 2 || f->width < 8 || f->height < 2) return false;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
+    if (!mfma_plane_ok(view_of(f->planes[0]), f->width)) return false;
+    if (nv12) {  // (the last staged dword pair may start up to 3 texels before the row's end: 8 bytes must be readable there)
+        const SurfView uv = view_of(f->planes[1]);
+        if ((uv.pitch % 4) || (((uintptr_t)uv.ptr) % 4) || uv.pitch < ((f->width + 7u) & ~7u)) return false;
+    } else if (!mfma_plane_ok(view_of(f->planes[1]), f->width / 2) || !mfma_plane_ok(view_of(f->planes[2]), f->width / 2)) {
+        return false;
+    }
+    if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
+    int KT, NKS, KV, unused;
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2)) { KT = t->K; NKS = t->ngm; }
+    else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &KT, &NKS);
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3)) KV = t->K;
+    else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3, &KV, &unused);
+    return KT <= W_KT_MAX && NKS <= W_NKS_MAX && KV <= W_KV_MAX;
+}
+
+int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, WJob *out) {
+    WaveBand bh, bv;
+    int rc = get_wave_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &bh);
+    if (rc != SMR_OK) return rc;
+    rc = get_wave_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3, &bv);
+    if (rc != SMR_OK) return rc;
+    WJob &J = *out;
+    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = f->planes[2] ? view_of(f->planes[2]) : J.up;
+    J.dst = view_of(tile);
+    J.src_w = (int)f->width; J.src_h = (int)f->height;
+    J.conv = m_conv_constants(f->format == SMR_FRAME_PLANAR_YUVJ420);
+    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.KT = bh.K; J.NKS = bh.nks; J.n_pairs = bh.n_units;
+    J.n_htiles = ((int)tile->w + 15) / 16;
+    J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
+    J.pieces = W_WAVES;
+    J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
+    if (J.nv12) J.vp = J.up;
+    J.layer = -1; J.ox = 0; J.oy = 0;
+    return SMR_OK;
+}
+
+// A job for a vertical-first plan: the same kernel on the transposed frame (see make_mfma_job_transposed).
+int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, WJob *out, bool *ok,
+                             MTransposeBack *back) {
+    *ok = false;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG || !f || !f->planes[0] || !f->planes[1]) return SMR_OK;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
+    const bool nv12 = f->format == SMR_FRAME_NV12;
+    if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return SMR_OK;
+    if (!nv12 && !f->planes[2]) return SMR_OK;
+    if (f->width % 2 || f->height % 2) return SMR_OK;
+    const u32 cw = f->width / 2, ch = f->height / 2;
+    smr_frame ft;
+    memset(&ft, 0, sizeof(ft));
+    ft.format = f->format; ft.width = f->height; ft.height = f->width;
+    ft.planes[0] = smr_cached_surface(ctx, slot0, f->height, f->width, SMR_PX_R8);
+    ft.planes[1] = smr_cached_surface(ctx, slot0 + 1, ch, cw, nv12 ? SMR_PX_RG8 : SMR_PX_R8);
+    if (!nv12) ft.planes[2] = smr_cached_surface(ctx, slot0 + 2, ch, cw, SMR_PX_R8);
+    smr_surface *tile_t = smr_cached_surface(ctx, slot0 + 3, tile->h, tile->w, SMR_PX_RGBA8);
+    if (!ft.planes[0] || !ft.planes[1] || (!nv12 && !ft.planes[2]) || !tile_t) return SMR_ERR_OOM;
+    smr_resample_plan pt = plan;  // the first pass of the plan (the source's rows) is the transposed frame's horizontal pass
+    pt.axis[0] = 0; pt.axis[1] = 1;
+    if (!can_fuse_wave(ctx, &ft, pt, tile_t)) return SMR_OK;
+    if (int rc = make_wave_job(ctx, &ft, pt, tile_t, out)) return rc;
+    if (int rc = launch_transpose<u8>(ctx, f->planes[0], ft.planes[0])) return rc;
+    if (nv12) {
+        if (int rc = launch_transpose<u16>(ctx, f->planes[1], ft.planes[1])) return rc;
+    } else {
+        if (int rc = launch_transpose<u8>(ctx, f->planes[1], ft.planes[1])) return rc;
+        if (int rc = launch_transpose<u8>(ctx, f->planes[2], ft.planes[2])) return rc;
+    }
+    back->tile_t = tile_t;
+    back->tile = tile;
+    *ok = true;
+    return SMR_OK;
+}
+
+// builds: generic | the benchmark scenes' class (pair windows of <= 4 k-steps, 3 per tile, 2 per pass-2 window: scales 1.5 .. 2)
+//         each plain | direct output (2048) | NV12-capable (4096) | both
+typedef void (*WaveKernel)(const WArgs, const float *, const u32 *);
+constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0, 0>,    k_ingest_wave<4, 3, 2, 0>,    k_ingest_wave<0, 0, 0, 2048>, k_ingest_wave<4, 3, 2, 2048>,
+                                    k_ingest_wave<0, 0, 0, 4096>, k_ingest_wave<4, 3, 2, 4096>, k_ingest_wave<0, 0, 0, 6144>, k_ingest_wave<4, 3, 2, 6144>};
+constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
+
+int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr) {
+    if (!ctx->wave_attr_set) {  // per device, hence per ctx
+        for (WaveKernel k : W_KERNELS) {
+            SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipFuncAttributes fa;
+            SMR_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)k));
+            // the decode LUT is addressed by its LDS offset 0: holds while the kernel declares no static LDS
+            if (fa.sharedSizeBytes != 0) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of static LDS in front of the dynamic segment", (size_t)fa.sharedSizeBytes);
+        }
+        ctx->wave_attr_set = true;
+    }
+    if (int rc = flush_wave_builds(ctx)) return rc;
+    StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_WJOBS_PER_LAUNCH) {
+        const size_t nj = jobs.size() - j0 < (size_t)MAX_WJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_WJOBS_PER_LAUNCH;
+        WArgs args;
+        memset(&args, 0, sizeof(args));
+        bool cls432 = true, any_nv = false;
+        int kt_max = 1, nks_max = 1;
+        long long tile_rows = 0;  // sum over jobs of pairs x tile rows: the unit of work
+        for (size_t j = 0; j < nj; j++) {
+            const WJob &J = jobs[j0 + j];
+            cls432 = cls432 && J.NKS <= 4 && J.KT == 3 && J.KV == 2;
+            any_nv = any_nv || J.nv12;
+            kt_max = J.KT > kt_max ? J.KT : kt_max;
+            nks_max = J.NKS > nks_max ? J.NKS : nks_max;
+            tile_rows += (long long)J.n_pairs * J.n_vtiles;
+        }
+        int ki = cls432 ? 1 : 0;
+        if (direct) ki += 2;
+        if (any_nv) ki += 4;
+        const WaveKernel kern = W_KERNELS[ki];
+        args.b_bytes = w_band_bytes(cls432 ? 3 : kt_max);
+        args.raw_bytes = (w_raw_bytes(cls432 ? 4 : nks_max) + 15) & ~15;
+        const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
+        if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of LDS", lds);
+        // as many waves as are resident at once (registers and LDS), one piece each: every wave starts and ends with the launch
+        int per_cu = 0;
+        for (auto &o : ctx->mfma_occupancy)
+            if (o.kernel == 1000 + ki && o.lds == lds) per_cu = o.per_cu;
+        if (!per_cu) {
+            SMR_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, W_THREADS, lds));
+            if (per_cu < 1) per_cu = 1;
+            ctx->mfma_occupancy.push_back({1000 + ki, lds, per_cu});
+        }
+        const int reserve = ctx->ingest_reserve_cus >= 0 && ctx->ingest_reserve_cus < ctx->cu_count ? ctx->ingest_reserve_cus : 0;
+        const int wg_cap = ctx->ingest_wg_per_cu > 0 ? ctx->ingest_wg_per_cu : 64;
+        const long long slots = (long long)(per_cu > wg_cap ? wg_cap : per_cu) * (ctx->cu_count - reserve) * W_WAVES;  // resident waves
+        // pieces per column pair: the same number of tile rows per wave for every job, rounded so that the launch fits the resident set
+        double rows_per_wave = (double)tile_rows / (double)slots;
+        if (rows_per_wave < 2.0) rows_per_wave = 2.0;  // (a piece re-converts its window's head: not below two tile rows)
+        int total = 0;
+        for (int pass = 0; pass < 8; pass++) {
+            total = 0;
+            for (size_t j = 0; j < nj; j++) {
+                WJob &J = jobs[j0 + j];
+                int p = (int)floor((double)J.n_vtiles / rows_per_wave);
+                p = p / W_WAVES * W_WAVES;
+                if (p < W_WAVES) p = W_WAVES;
+                J.pieces = p;
+                total += J.n_pairs * (p / W_WAVES);
+            }
+            if ((long long)total * W_WAVES <= slots || rows_per_wave > 1e6) break;
+            rows_per_wave *= 1.0 + 1.0 / 16.0;
+        }
+        total = 0;
+        for (size_t j = 0; j < nj; j++) {
+            args.jobs[j] = jobs[j0 + j];
+            args.wg_prefix[j] = total;
+            total += jobs[j0 + j].n_pairs * (jobs[j0 + j].pieces / W_WAVES);
+        }
+        args.wg_prefix[nj] = total;
+        args.n_jobs = (int)nj;
+        args.direct = direct;
+        const int blocks = (total + 7) & ~7;
+        if (ctx->debug_ingest)
+            fprintf(stderr, "k_ingest_wave[%d]: %zu jobs, lds %zu B (%d WG/CU), %d workgroups of %d waves, job0: NKS %d KT %d KV %d pairs %d vtiles %d pieces %d\n", ki,
+                    nj, lds, per_cu, total, W_WAVES, args.jobs[0].NKS, args.jobs[0].KT, args.jobs[0].KV, args.jobs[0].n_pairs, args.jobs[0].n_vtiles,
+                    args.jobs[0].pieces);
+        if (blocks > 0) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16);
+        SMR_HIP(ctx, hipGetLastError());
+    }
+    return SMR_OK;
+}
+
+}  // namespace
+#endif  // !SMR_EMU

@@ -134,6 +134,7 @@ struct smr_ctx {
     u32 *d_lut16 = nullptr;      // 256 x (f16 hi | f16 lo << 16) of the sRGB decode table
     u32 ingest_impl = 0;         // smr_ingest_impl
     bool mfma_attr_set = false;  // hipFuncSetAttribute is per device: kept per ctx, not per process
+    bool wave_attr_set = false;
     bool valu_attr_set = false;
     int ingest_reserve_cus = -1; // SMR_INGEST_RESERVE_CUS (profiling), read once per ctx
     int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (profiling): cap on resident k_ingest_mfma workgroups per CU, 0 = as many as fit

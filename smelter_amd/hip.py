@@ -139,7 +139,7 @@ def pack_layouts(layouts) -> "C.Array":
     return arr
 
 
-INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16 = 0, 1, 2
+INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_WG = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
 
@@ -243,7 +243,8 @@ class Context:
         self._check(self.lib.smr_ctx_set_option(self.handle, option, value))
 
     def set_ingest_impl(self, impl: int):
-        """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (SMR_OPT_INGEST_IMPL)."""
+        """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (matrix cores, wave-autonomous
+        kernel where it applies) / INGEST_MFMA_F16_WG (the workgroup-pipelined matrix-core kernel) — SMR_OPT_INGEST_IMPL."""
         self.set_option(OPT_INGEST_IMPL, impl)
 
     def set_direct_output(self, on: bool):

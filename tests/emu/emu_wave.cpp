@@ -1,0 +1,155 @@
+// TEST INFRASTRUCTURE — not part of the product; nothing in smelter_amd/ builds, links or loads this.
+//
+// Lane emulator for k_ingest_wave / k_build_wave_weights: compiles the kernel source of smelter_amd/csrc/smr_ingest_wave.h for the
+// CPU (SMR_EMU: builtins -> emu_device.h, <hip/hip_runtime.h> -> shim/) and runs every workgroup with one host thread per lane.
+// It exists to check the kernels' index logic (window geometry, K permutation of pass 2, ring slots, staging, piece splits) on
+// machines without a GPU; arithmetic follows the instruction semantics, except that the MFMA sums its 32 products in order.
+#include <pthread.h>
+
+#include <thread>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+thread_local dim3 threadIdx, blockIdx;
+dim3 gridDim, blockDim;
+
+#include "emu_device.h"
+EmuBlock *emu_blk = nullptr;
+thread_local unsigned char *emu_smem = nullptr;
+void __syncthreads() { pthread_barrier_wait(&emu_blk->bar); }
+
+#include "smr_ingest_wave.h"
+#include "smr_tables.h"
+
+namespace {
+
+template <typename F>
+void run_grid(unsigned blocks, unsigned threads, size_t lds, F kernel) {
+    gridDim = dim3(blocks);
+    blockDim = dim3(threads);
+    std::vector<unsigned char> smem(lds + 64);
+    for (unsigned b = 0; b < blocks; b++) {
+        EmuBlock blk;
+        pthread_barrier_init(&blk.bar, nullptr, threads);
+        for (unsigned w = 0; w < (threads + 63) / 64; w++) pthread_barrier_init(&blk.waves[w].bar, nullptr, 64);
+        blk.smem = smem.data();
+        emu_blk = &blk;
+        std::vector<std::thread> ts;
+        for (unsigned t = 0; t < threads; t++)
+            ts.emplace_back([&, t] {
+                threadIdx = dim3(t);
+                blockIdx = dim3(b);
+                emu_smem = blk.smem;
+                kernel();
+            });
+        for (auto &t : ts) t.join();
+        pthread_barrier_destroy(&blk.bar);
+        for (unsigned w = 0; w < (threads + 63) / 64; w++) pthread_barrier_destroy(&blk.waves[w].bar);
+    }
+}
+
+struct Plane {
+    std::vector<u8> buf;
+    SurfView view;
+};
+Plane make_plane(const u8 *tight, int w, int h, int bpp) {
+    Plane p;
+    const u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
+    p.buf.assign((size_t)pitch * h + 64, 0xcd);
+    for (int y = 0; y < h; y++) memcpy(p.buf.data() + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
+    p.view.ptr = p.buf.data(); p.view.pitch = pitch; p.view.w = w; p.view.h = h;
+    return p;
+}
+
+struct Band {
+    std::vector<u8> mem;
+    void *meta;
+    uint4 *frag;
+    int K, nks, n_units;
+};
+Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
+    Band B;
+    wave_band_geometry(scale, offset, n_dst, n_src, axis, &B.K, &B.nks);
+    const int n_tiles = (n_dst + 15) / 16;
+    B.n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;
+    const size_t meta_bytes = ((size_t)B.n_units * (axis == 2 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
+    const size_t frags = axis == 2 ? (size_t)B.n_units * 2 * B.K * 2 : (size_t)B.n_units * B.K * 2;
+    B.mem.assign(meta_bytes + frags * 64 * sizeof(uint4) + 32, 0);
+    u8 *base = (u8 *)(((uintptr_t)B.mem.data() + 15) & ~(uintptr_t)15);
+    B.meta = base;
+    B.frag = (uint4 *)(base + meta_bytes);
+    WWBatch args;
+    memset(&args, 0, sizeof(args));
+    WWBuild &b = args.b[0];
+    b.scale = scale; b.offset = offset; b.taps = w_taps(scale); b.n_dst = n_dst; b.n_src = n_src; b.axis = axis; b.K = B.K; b.unit0 = 0;
+    b.meta = B.meta; b.frag = B.frag;
+    args.n = 1;
+    run_grid((unsigned)B.n_units, 64, 0, [&] { k_build_wave_weights(args); });
+    return B;
+}
+
+}  // namespace
+
+// One job through k_ingest_wave.  Planes tightly packed (NV12: u = interleaved UV, v ignored); dst = dw x dh RGBA8, tight.
+// (scale, offset) per axis as smr_resample_plan_make gives them for a two-pass, horizontal-first plan.  `pieces`: vertical pieces
+// per column pair (rounded up to a multiple of the workgroup's waves); `specialised` != 0 asks for the <4, 3, 2> build when the
+// job's k-step counts allow it.  Returns 0, or a negative number when the job is outside the kernel's limits:
+// -1 k-steps, -2 specialised build not applicable.  info[0..3] = NKS, KT, KV, workgroups.
+extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, int sh, int full_range, int nv12, float scale_h, float off_h, float scale_v,
+                               float off_v, u8 *dst, int dw, int dh, int pieces, int specialised, int *info) {
+    static float tables[SMR_TABLE_FLOATS];
+    static u32 lut16[256];
+    static bool have_tables = false;
+    if (!have_tables) {
+        if (!smr_build_tables(tables, lut16)) return -9;
+        have_tables = true;
+    }
+    Plane py = make_plane(y, sw, sh, 1);
+    Plane pu = nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1);
+    Plane pv = nv12 ? pu : make_plane(v, sw / 2, sh / 2, 1);
+    std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
+    Band bh = build_band(scale_h, off_h, dw, sw, 2), bv = build_band(scale_v, off_v, dh, sh, 3);
+    if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
+    if (bh.K > W_KT_MAX || bh.nks > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
+    const bool cls432 = bh.nks <= 4 && bh.K == 3 && bv.K == 2;
+    if (specialised && !cls432) return -2;
+
+    WArgs args;
+    memset(&args, 0, sizeof(args));
+    WJob &J = args.jobs[0];
+    J.yp = py.view; J.up = pu.view; J.vp = nv12 ? pu.view : pv.view;
+    if (nv12) { J.up.w = sw / 2; J.vp = J.up; }
+    J.dst.ptr = (u8 *)(((uintptr_t)tile.data() + 15) & ~(uintptr_t)15);
+    J.dst.pitch = (u32)(((size_t)dw * 4 + 255) & ~(size_t)255); J.dst.w = dw; J.dst.h = dh;
+    J.src_w = sw; J.src_h = sh;
+    J.conv = m_conv_constants(full_range != 0);
+    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.KT = bh.K; J.NKS = bh.nks; J.n_pairs = bh.n_units;
+    J.n_htiles = (dw + 15) / 16;
+    J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
+    int p = pieces < 1 ? 1 : pieces;
+    p = (p + W_WAVES - 1) / W_WAVES * W_WAVES;
+    J.pieces = p;
+    J.nv12 = nv12;
+    J.layer = -1;
+    args.wg_prefix[0] = 0;
+    args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
+    args.n_jobs = 1;
+    const bool spec = specialised && cls432;
+    args.b_bytes = w_band_bytes(spec ? 3 : bh.K);
+    args.raw_bytes = (w_raw_bytes(spec ? 4 : bh.nks) + 15) & ~15;
+    args.direct = nullptr;
+    const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
+    const int total = args.wg_prefix[1];
+    if (info) info[3] = total;
+    const unsigned blocks = (unsigned)((total + 7) & ~7);
+    if (spec) {
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 3, 2, 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 3, 2, 0>(args, tables, lut16); });
+    } else {
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 0, 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 0, 0>(args, tables, lut16); });
+    }
+    for (int yy = 0; yy < dh; yy++) memcpy(dst + (size_t)yy * dw * 4, J.dst.ptr + (size_t)yy * J.dst.pitch, (size_t)dw * 4);
+    return 0;
+}

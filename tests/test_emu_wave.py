@@ -1,0 +1,97 @@
+"""k_ingest_wave's index logic on the CPU: the kernel source run by the lane emulator of tests/emu (one host thread per lane, the
+gfx950 instructions restated in C++) against the oracle's planar_yuv_to_rgba + resample.  Test infrastructure only — the product
+has no CPU path; the -m gpu suite checks the real kernel on the device."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu")
+ROOT = os.path.dirname(HERE)
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+P8 = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ to build the emulator with")
+    out_dir = os.path.join(EMU, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libsmr_emu.so")
+    srcs = [os.path.join(EMU, "emu_wave.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_wave.h"),
+            os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_common.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function", "-I", os.path.join(EMU, "shim"),
+               "-I", EMU, "-I", os.path.join(ROOT, "smelter_amd/csrc"), "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0], "-lpthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    h = C.CDLL(lib)
+    h.emu_ingest_wave.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, P8, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.POINTER(C.c_int)]
+    orc.build()
+    return h
+
+
+def _planes(sw, sh, noise, seed):
+    rng = np.random.default_rng(seed)
+    if noise:
+        return (rng.integers(0, 256, (sh, sw), dtype=np.uint8), rng.integers(0, 256, (sh // 2, sw // 2), dtype=np.uint8),
+                rng.integers(0, 256, (sh // 2, sw // 2), dtype=np.uint8))
+    xx, yy = np.meshgrid(np.arange(sw), np.arange(sh))
+    y = (16 + (xx * 3 + yy * 2) % 200 + rng.integers(0, 8, (sh, sw))).astype(np.uint8)
+    u = (100 + (np.arange(sw // 2)[None, :] + np.arange(sh // 2)[:, None]) % 60).astype(np.uint8)
+    v = (140 - (np.arange(sw // 2)[None, :] * 2 + np.arange(sh // 2)[:, None]) % 70).astype(np.uint8)
+    return y, u, v
+
+
+def _p(a):
+    return a.ctypes.data_as(P8)
+
+
+# (source, tile, crop or None, pieces, specialised build, white noise, NV12, expected (NKS, KT, KV) or None)
+CASES = [
+    ((96, 60), (64, 40), None, 1, 1, False, False, (4, 3, 2)),      # the benchmark's class: scale 1.5
+    ((96, 60), (64, 40), None, 6, 0, True, False, (4, 3, 2)),       # same through the generic build, more pieces than tile rows
+    ((192, 120), (128, 80), None, 4, 1, True, False, (4, 3, 2)),    # several pairs, pieces that cut between tiles
+    ((130, 74), (86, 49), None, 2, 0, False, False, None),           # odd tile sizes: a last pair with one tile, partial tiles
+    ((64, 36), (96, 54), None, 2, 0, True, False, None),             # upscale (7 taps, several tiles per chunk)
+    ((256, 144), (128, 72), None, 2, 0, True, False, None),          # scale 2
+    ((384, 216), (128, 72), None, 2, 0, True, False, (7, 5, 3)),     # scale 3: the north-star target's class
+    ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1, True, False, (4, 3, 2)),  # crop: windows inside the frame
+    ((96, 60), (64, 40), None, 2, 1, True, True, (4, 3, 2)),        # NV12
+    ((16, 8), (12, 6), None, 1, 0, True, False, None),               # smaller than a chunk
+]
+
+
+@pytest.mark.parametrize("src,dst,crop,pieces,spec,noise,nv12,ks", CASES)
+def test_emulated_kernel_matches_the_oracle(emu, src, dst, crop, pieces, spec, noise, nv12, ks):
+    (sw, sh), (dw, dh) = src, dst
+    y, u, v = _planes(sw, sh, noise, seed=sw * 131 + dh)
+    crop = crop or (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 2 and plan.levels == (0, 0) and tuple(plan.axis[:2]) == (0, 1), "the case must be a two-pass, horizontal-first plan"
+    if nv12:
+        node = orc.nv12_to_rgba(y, np.stack([u, v], axis=-1), sw, sh)
+        uu = np.ascontiguousarray(np.stack([u, v], axis=-1))
+    else:
+        node = orc.planar_yuv_to_rgba(y, u, v, sw, sh)
+        uu = u
+    _, want = orc.resample(node, crop, dw, dh)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    rc = emu.emu_ingest_wave(_p(y), _p(uu), _p(v), sw, sh, 0, 1 if nv12 else 0, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh,
+                             pieces, spec, info)
+    assert rc == 0, (rc, list(info))
+    if ks:
+        assert tuple(info[:3]) == ks, list(info)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
+    assert (d == 0).mean() >= 0.999, (d == 0).mean()
+    assert (got[..., 3] == 255).all()
