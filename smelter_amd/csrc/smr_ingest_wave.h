@@ -39,12 +39,33 @@ namespace {
 #ifndef SMR_WAVE_WAVES
 #define SMR_WAVE_WAVES 2
 #endif
+#ifndef SMR_WAVE_MIN_WAVES
+#define SMR_WAVE_MIN_WAVES 2   // waves per SIMD the register allocation must leave room for
+#endif
+#ifndef SMR_WAVE_ABL
+#define SMR_WAVE_ABL 0  // profiling builds only (tools/variant.sh): 1 no LUT gathers, 2 no pass-1 MFMAs, 4 no conversion, 8 no pass 2 / encode, 16 no stores, 32 no staging
+#endif
+#ifndef SMR_WAVE_EXPLICIT_WAIT
+#define SMR_WAVE_EXPLICIT_WAIT 0  // 0: leave the wait for the staged loads to the compiler (it waits for the loads only, not for the stores behind them)
+#endif
+#ifndef SMR_WAVE_PIPE
+#define SMR_WAVE_PIPE 1  // class build: the k-steps of a chunk as a software pipeline (LDS reads of the next step and the weights of the last
+                         // one go out before a block is converted, the last step's MFMAs follow the conversion): a wave does not wait for LDS
+#endif
+#ifndef SMR_WAVE_PIPE_FENCE
+#define SMR_WAVE_PIPE_FENCE 1  // keep the compiler from re-ordering the pipeline's phases
+#endif
+#ifndef SMR_WAVE_TIMING
+#define SMR_WAVE_TIMING 0  // profiling build (tools/variant.sh): shader cycles per phase of the first wave of every workgroup -> WArgs::dbg
+#endif
+#ifndef SMR_WAVE_PREFETCH_B
+#define SMR_WAVE_PREFETCH_B 0  // 1: a k-step's weight fragments are read from LDS before its block is converted (A/B knob)
+#endif
 constexpr int W_WAVES = SMR_WAVE_WAVES;   // waves per workgroup (same column pair, consecutive vertical pieces)
 constexpr int W_THREADS = 64 * W_WAVES;
 constexpr int W_NKS_MAX = 8;              // k-steps (16 texels as hi/lo pairs) of a pair's source window
-constexpr int W_KT_MAX = 6;               // k-steps a single tile's band may span
 constexpr int W_KV_MAX = 4;               // k-steps (two chunks of 16 rows) of a pass-2 window
-constexpr int W_WSPAN = 136;              // >= 16 * W_KT_MAX, >= 32 * W_KV_MAX
+constexpr int W_WSPAN = 136;              // >= 16 * W_NKS_MAX, >= 32 * W_KV_MAX
 
 // ------------------------------------------------------------------ geometry (host + device: one f32 sequence)
 // chunk c = source rows 16 c - 1 .. 16 c + 14 (row 0 of a chunk is an odd luma row: rows (2 p + 1, 2 p + 2) share chroma rows p, p + 1)
@@ -97,16 +118,25 @@ __host__ __device__ inline void w_vtile_chunks(int t, float scale, float offset,
 }
 
 // host twin of the geometry the builder uses (same f32 sequence: lanczos_first is __host__ __device__)
-inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, int axis, int *K, int *nks) {
+// *k01 (axis 2, may be null): every pair's first tile stays clear of the window's last k-step and its second tile of the first one
+// (true for the benchmark's scale: the class build then skips those two fragments)
+inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, int axis, int *K, int *nks, bool *k01 = nullptr) {
     const int taps = w_taps(scale);
     const int n_tiles = (n_dst + 15) / 16;
     int k = 1, n = 1;
+    bool pat = true;
     if (axis == 2) {
         for (int p = 0; p < (n_tiles + 1) / 2; p++) {
             const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src);
             for (int i = 0; i < 2; i++) k = g.kt[i] > k ? g.kt[i] : k;
             n = g.nks > n ? g.nks : n;
         }
+        for (int p = 0; p < (n_tiles + 1) / 2; p++) {  // (against the job's k-step count n: the class build runs min(n, 4) .. 4 steps)
+            const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src);
+            if (g.klo[0] + g.kt[0] - 1 > 2) pat = false;          // tile 0 reaches k-step 3
+            if (g.klo[1] >= 0 && g.klo[1] < 1) pat = false;       // tile 1 starts in k-step 0
+        }
+        if (k01) *k01 = pat;
     } else {
         for (int t = 0; t < n_tiles; t++) {
             int cs, ce;
@@ -115,14 +145,16 @@ inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, 
             k = need > k ? need : k;
         }
     }
-    *K = k;
+    *K = axis == 2 ? n : k;  // (axis 2: the band is dense over the pair's window)
     *nks = n;
 }
 
 // ------------------------------------------------------------------ weight bands (device cache, one launch per call for all misses)
-// axis 2 (pass 1, per column pair):  meta int4 (base, klo0, klo1, last);  frag[pair][tile i][k-step kk < KT][hi | lo][64 lanes]:
-//   lane l holds W[k = 8 (l >> 4) + e][n = l & 15], texel = base + 16 (klo_i + kk) + (k >> 1); the (w_hi, w_hi) fragment multiplies
-//   the (t_hi, t_lo) pair, the (w_lo, 0) fragment adds t_hi w_lo (t_lo w_lo is below 2^-22).
+// axis 2 (pass 1, per column pair):  meta int4 (base, last, klo0 | khi0 << 8, klo1 | khi1 << 8) — tile i's band touches k-steps
+//   klo_i .. khi_i of the pair's window (0xffff: no such tile);  frag[pair][tile i][k-step j < NKS][hi | lo][64 lanes], dense over the
+//   window (zero fragments where a tile's band does not reach: the benchmark's class runs them all and has no branch in its loop):
+//   lane l holds W[k = 8 (l >> 4) + e][n = l & 15], texel = base + 16 j + (k >> 1); the (w_hi, w_hi) fragment multiplies the
+//   (t_hi, t_lo) pair, the (w_lo, 0) fragment adds t_hi w_lo (t_lo w_lo is below 2^-22).
 // axis 3 (pass 2, per 16-row output tile):  meta int2 (first chunk, last chunk);  frag[tile][k-step p < KV][hi | lo][64 lanes]:
 //   lane l = (output row n = l & 15, q = l >> 4), element e: ring slot s = 2 p + (e >> 2), chunk cc = the chunk of the tile's window
 //   [ce - 2 KV + 1, ce] with cc mod 2 KV == s, source row 16 cc - 1 + 4 q + (e & 3).
@@ -158,7 +190,7 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
         const int tile = B.axis == 2 ? 2 * u + sub : u;
         // origin of the window in source texels / rows, and its length
         const int wlo = v_ce - 2 * K + 1;  // (axis 3) first chunk of the window; may be negative: those chunks do not exist
-        const int origin = B.axis == 2 ? G.base + 16 * (G.klo[sub] < 0 ? 0 : G.klo[sub]) : 16 * wlo - 1;
+        const int origin = B.axis == 2 ? G.base : 16 * wlo - 1;
         const int span = B.axis == 2 ? 16 * K : 32 * K;
         for (int i = lane; i < 16 * W_WSPAN; i += 64) {
             (&s_w[0][0])[i] = 0.0f;
@@ -206,8 +238,13 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
         __syncthreads();
     }
     if (lane == 0) {
-        if (B.axis == 2) ((int4 *)B.meta)[u] = make_int4(G.base, G.klo[0], G.klo[1], G.last);
-        else ((int2 *)B.meta)[u] = make_int2(v_cs, v_ce);
+        if (B.axis == 2) {
+            int r[2];
+            for (int i = 0; i < 2; i++) r[i] = G.klo[i] < 0 ? 0xffff : (G.klo[i] | ((G.klo[i] + G.kt[i] - 1) << 8));
+            ((int4 *)B.meta)[u] = make_int4(G.base, G.last, r[0], r[1]);
+        } else {
+            ((int2 *)B.meta)[u] = make_int2(v_cs, v_ce);
+        }
     }
 }
 #endif  // __HIPCC__
@@ -220,8 +257,9 @@ struct WJob {
     MConv conv;
     const int4 *h_meta; const uint4 *h_frag;
     const int2 *v_meta; const uint4 *v_frag;
-    int NKS, KT, KV;      // k-steps: of the widest pair window, per tile band, per pass-2 window
+    int NKS, KV;          // k-steps: of the widest pair window, per pass-2 window
     int n_pairs, n_htiles, n_vtiles;
+    int k01;              // host only: the job's bands fit the class build's FL & 1 pattern
     int pieces;           // vertical pieces per column pair (a multiple of W_WAVES)
     int nv12;
     int layer, ox, oy;    // direct output: the layer this tile is blitted by (-1 = none) and its (even) position in the output frame
@@ -235,6 +273,7 @@ struct WArgs {
     int b_bytes;      // LDS bytes reserved for a pair's pass-1 band
     int raw_bytes;    // ... for one wave's raw footprint
     const MDirect *direct;  // device record (rides behind the layout list), nullptr = off
+    unsigned long long *dbg;  // profiling builds only (SMR_WAVE_TIMING)
 };
 
 constexpr int W_OFF_THR = M_LUT_ENTRIES * 4;
@@ -243,26 +282,46 @@ static_assert(W_OFF_B % 16 == 0, "the band must start on a 16-byte boundary");
 __host__ __device__ inline int w_ys(int nks) { return 4 * nks + 1; }  // staged luma dwords per chunk row (+ 1: rows fall on different banks)
 __host__ __device__ inline int w_cs(int nks) { return 2 * nks + 2; }  // staged chroma dwords per row: columns base/2 - 1 .. base/2 + 8 nks, from a 4-aligned start
 __host__ __device__ inline int w_raw_bytes(int nks) { return 4 * (16 * w_ys(nks) + 2 * 9 * w_cs(nks)); }
-__host__ __device__ inline int w_band_bytes(int kt) { return 2 * kt * 2 * 64 * 16; }
+__host__ __device__ inline int w_band_bytes(int nks) { return 2 * nks * 2 * 64 * 16; }
 
 #ifdef __HIPCC__
 
-// Output tiles [vt0, vt1] of column pair `pair` of job J, by one wave.  NKS_T / KT_T / KV_T: the k-step counts when every job of the
-// launch shares them (0 = read them from the job: loops unrolled to the maximum and predicated).
-// FL: 2048 direct output, 4096 NV12-capable staging.
-template <int NKS_T, int KT_T, int KV_T, int FL>
-__device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restrict__ Dg, int pair, int vt0, int vt1, u8 *smem, u32 b_off, u32 raw_off) {
+// Output tiles [vt0, vt1] of column pair `pair` of job J, by one wave.  NKS_T / KV_T: the k-step counts of the launch's class (every
+// pair window within NKS_T k-steps, pass-2 windows of exactly KV_T: no branch in the chunk loop); 0 = read them from the job
+// (loops unrolled to the maximum and predicated).  FL: 1 class build only: no pair's first tile reaches k-step 3 and no second tile
+// starts in k-step 0 (those two zero fragments are skipped), 2048 direct output, 4096 NV12-capable staging.
+// `finish_prologue`: stores the workgroup's tables into LDS and meets the other waves — called once, after this wave's first global
+// loads are in flight and before its first LDS access.
+template <int NKS_T, int KV_T, int FL, typename Pro>
+__device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restrict__ Dg, int pair, int vt0, int vt1, u8 *smem, u32 b_off, u32 raw_off,
+                                           unsigned long long *dbg, Pro finish_prologue) {
     const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
-    const int NKS = NKS_T ? NKS_T : J.NKS, KT = KT_T ? KT_T : J.KT, KV = KV_T ? KV_T : J.KV;
+#if SMR_WAVE_TIMING
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    const bool timing = dbg != nullptr && threadIdx.x < 64;
+#define W_MARK(ph)                                                   \
+    do {                                                             \
+        if (timing) {                                                \
+            __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0) */     \
+            const unsigned long long now = __builtin_readcyclecounter(); \
+            tph[ph] += now - tlast;                                  \
+            tlast = now;                                             \
+        }                                                            \
+    } while (0)
+#else
+#define W_MARK(ph) do { } while (0)
+#endif
+    const int NKS = NKS_T ? NKS_T : J.NKS, KV = KV_T ? KV_T : J.KV;
     constexpr int NKS_N = NKS_T ? NKS_T : W_NKS_MAX, KV_N = KV_T ? KV_T : W_KV_MAX;
-    constexpr bool NV = (FL & 4096) != 0, DIRECT = (FL & 2048) != 0;
+    constexpr bool NV = (FL & 4096) != 0, DIRECT = (FL & 2048) != 0, K01 = (FL & 1) != 0;
     const float *s_thr = (const float *)(smem + W_OFF_THR);
     const uint4 *Bs = (const uint4 *)(smem + b_off);
 
     // ---- pair geometry
     const int4 hm = J.h_meta[pair];
-    const int base = hm.x, klo0 = hm.y, klo1 = hm.z;
-    const int nks = min(((hm.w - base) >> 4) + 1, NKS);
+    const int base = hm.x;
+    const int nks = min(((hm.y - base) >> 4) + 1, NKS);  // k-steps of this pair's window
+    const int klo[2] = {hm.z & 0xff, hm.w & 0xff}, khi[2] = {(hm.z >> 8) & 0xff, (hm.w >> 8) & 0xff};  // (0xff / 0xff: no such tile)
     const int tx0 = 32 * pair;
     const int d_w = J.dst.w, d_h = J.dst.h;
     u8 *const d_ptr = J.dst.ptr;
@@ -289,6 +348,14 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     const bool c_live = c_d < cs;
     const bool c_edge = c_live && (c_col0 < 0 || c_col0 + 3 > cw - 1);
     auto issue = [&](int c) {
+        if (SMR_WAVE_ABL & 256) c = J.v_meta[vt0].x;  // profiling: always the same rows (cache hits)
+        if (SMR_WAVE_ABL & 128) {                       // profiling: no global loads
+#pragma unroll
+            for (int k = 0; k < NYL; k++) py[k] = 0x80808080u + (u32)c;
+#pragma unroll
+            for (int k = 0; k < NCL; k++) pc[k] = 0x80808080u + (u32)c;
+            return;
+        }
         const int r0 = 16 * c - 1;
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) {
@@ -312,6 +379,15 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
     };
     auto land = [&]() {
+        if (SMR_WAVE_ABL & 64) {  // profiling: no LDS writes (one keeps the loads alive)
+            u32 x = 0;
+#pragma unroll
+            for (int k = 0; k < NYL; k++) x ^= py[k];
+#pragma unroll
+            for (int k = 0; k < NCL; k++) x ^= pc[k];
+            if (x == 0x12345u) rawY[lane] = x;
+            return;
+        }
 #pragma unroll
         for (int rb = 0; rb < 4; rb++)
 #pragma unroll
@@ -379,15 +455,18 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 
     int vt = vt0;
     int2 vm = J.v_meta[vt0];
+    int2 vm_next = J.v_meta[min(vt0 + 1, vt1)];  // (read a tile ahead: a scalar load the loop never waits for)
     const int c_first = vm.x, c_last = J.v_meta[vt1].y;
     fetch_bv(vt0);
     issue(c_first);
+    finish_prologue();
     dev_wait_vmcnt0();
     land();
     dev_wave_lds_sync();
     if (c_first < c_last) issue(c_first + 1);
     int slot = w_posmod(c_first, 2 * KV);  // ring slot of the chunk at hand
 
+    W_MARK(0);
     for (int c = c_first; c <= c_last; c++) {
         // ---- conversion + pass 1 of chunk c: k-step by k-step, straight into the accumulators of the tiles it feeds
         f32x4 acc[2][3];
@@ -395,36 +474,121 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) acc[i][ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < NKS_N; j++) {
-            if (j < nks) {
-                const u32 yy = yrow[4 * j];
-                const u32 ua = dev_alignbyte(urow[2 * j + 1], urow[2 * j], shb), ub = dev_alignbyte(urow[cs + 2 * j + 1], urow[cs + 2 * j], shb);
-                const u32 va = dev_alignbyte(vrow[2 * j + 1], vrow[2 * j], shb), vb = dev_alignbyte(vrow[cs + 2 * j + 1], vrow[cs + 2 * j], shb);
-                uint4 a[3];
-                m_convert_px<false>(K, yy, ua, ub, va, vb, w13, w31, a);
+        if (NKS_T && SMR_WAVE_PIPE) {
+            // ---- class build: software pipeline over the k-steps.  Step j: the LDS reads of block j + 1 and of the weights of step
+            //      j - 1 go out, block j is converted (vector ALU + table gathers), then the MFMAs of step j - 1 are issued — their
+            //      operands arrived long ago, and the tail of block j's gathers lands behind them.
+            struct Raw { u32 yy, u0, u1, u2, u3, v0, v1, v2, v3; };
+            auto read_raw = [&](int j, Raw &r) {
+                r.yy = yrow[4 * j];
+                r.u0 = urow[2 * j]; r.u1 = urow[2 * j + 1]; r.u2 = urow[cs + 2 * j]; r.u3 = urow[cs + 2 * j + 1];
+                r.v0 = vrow[2 * j]; r.v1 = vrow[2 * j + 1]; r.v2 = vrow[cs + 2 * j]; r.v3 = vrow[cs + 2 * j + 1];
+            };
+            auto read_b = [&](int j, uint4 (&bq)[2][2]) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    const int kk = j - (i ? klo1 : klo0);
-                    if ((i ? klo1 : klo0) >= 0 && kk >= 0 && kk < KT) {  // (uniform)
-                        const uint4 bh = Bs[((i * KT + kk) * 2) * 64 + lane], bl = Bs[((i * KT + kk) * 2 + 1) * 64 + lane];
+                    bq[i][0] = Bs[((i * NKS + j) * 2) * 64 + lane];
+                    bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
+                }
+            };
+            auto convert = [&](const Raw &r, uint4 (&a)[3]) {
+                const u32 ua = dev_alignbyte(r.u1, r.u0, shb), ub = dev_alignbyte(r.u3, r.u2, shb);
+                const u32 va = dev_alignbyte(r.v1, r.v0, shb), vb = dev_alignbyte(r.v3, r.v2, shb);
+                m_convert_px<false>(K, r.yy, ua, ub, va, vb, w13, w31, a);
+            };
+            auto mfmas = [&](int j, const uint4 (&a)[3], const uint4 (&bq)[2][2]) {
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                            acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bh), acc[i][ch]);
+                for (int i = 0; i < 2; i++) {
+                    if (K01 && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
-                            acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bl), acc[i][ch]);
+                    for (int ch = 0; ch < 3; ch++)
+                        acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][0]), acc[i][ch]);
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++)
+                        acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][1]), acc[i][ch]);
+                }
+            };
+            Raw cur, nxt;
+            uint4 a[3], a_prev[3], bq[2][2];
+            read_raw(0, cur);
+#pragma unroll
+            for (int j = 0; j < NKS_T; j++) {
+                if (j + 1 < NKS_T) read_raw(j + 1, nxt);
+                if (j > 0) read_b(j - 1, bq);
+                if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
+                convert(cur, a);
+                if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
+                if (j > 0) mfmas(j - 1, a_prev, bq);
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) a_prev[ch] = a[ch];
+                cur = nxt;
+            }
+            read_b(NKS_T - 1, bq);
+            if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
+            W_MARK(1);
+            // ---- the next chunk's footprint (issued a whole conversion ago; the one after it goes out now) while the weights arrive
+            if (c < c_last) {
+                if (SMR_WAVE_EXPLICIT_WAIT) dev_wait_vmcnt0();
+                dev_wave_lds_sync();  // (every lane has read its blocks of chunk c)
+                land();
+                dev_wave_lds_sync();
+            }
+            W_MARK(2);
+            if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
+            mfmas(NKS_T - 1, a_prev, bq);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NKS_N; j++) {
+                if (NKS_T || j < nks) {  // (uniform; the class build converts its NKS_T k-steps unconditionally: texels past a window meet zero weights)
+                    uint4 bq[2][2];
+                    if (SMR_WAVE_PREFETCH_B) {
+    #pragma unroll
+                        for (int i = 0; i < 2; i++) {
+                            bq[i][0] = Bs[((i * NKS + j) * 2) * 64 + lane];
+                            bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
+                        }
+                    }
+                    const u32 yy = yrow[4 * j];
+                    const u32 ua = dev_alignbyte(urow[2 * j + 1], urow[2 * j], shb), ub = dev_alignbyte(urow[cs + 2 * j + 1], urow[cs + 2 * j], shb);
+                    const u32 va = dev_alignbyte(vrow[2 * j + 1], vrow[2 * j], shb), vb = dev_alignbyte(vrow[cs + 2 * j + 1], vrow[cs + 2 * j], shb);
+                    uint4 a[3];
+                    if (SMR_WAVE_ABL & 4) {
+                        a[0] = make_uint4(yy, ua, ub, va); a[1] = make_uint4(vb, yy, ua, ub); a[2] = make_uint4(va, vb, yy, ua);
+                    } else {
+                        m_convert_px<(SMR_WAVE_ABL & 1) != 0>(K, yy, ua, ub, va, vb, w13, w31, a);
+                    }
+                    if (SMR_WAVE_ABL & 2) {
+    #pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            acc[0][ch][0] += __uint_as_float(a[ch].x ^ a[ch].y); acc[1][ch][0] += __uint_as_float(a[ch].z ^ a[ch].w);
+                        }
+                        continue;
+                    }
+    #pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        if (K01 && NKS_T && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
+                        if (NKS_T || (j >= klo[i] && j <= khi[i])) {  // (uniform)
+                            if (!SMR_WAVE_PREFETCH_B) {
+                                bq[i][0] = Bs[((i * NKS + j) * 2) * 64 + lane];
+                                bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
+                            }
+    #pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                                acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][0]), acc[i][ch]);
+    #pragma unroll
+                            for (int ch = 0; ch < 3; ch++)
+                                acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][1]), acc[i][ch]);
+                        }
                     }
                 }
             }
-        }
-        // ---- the next chunk's footprint: issued a whole conversion ago; the one after it goes out now
-        if (c < c_last) {
-            dev_wait_vmcnt0();
-            dev_wave_lds_sync();  // (every lane has read its blocks of chunk c)
-            land();
-            dev_wave_lds_sync();
-            if (c + 1 < c_last) issue(c + 2);
+            // ---- the next chunk's footprint: issued a whole conversion ago; the one after it goes out now
+            if (c < c_last && !(SMR_WAVE_ABL & 32)) {
+                if (SMR_WAVE_EXPLICIT_WAIT) dev_wait_vmcnt0();
+                dev_wave_lds_sync();  // (every lane has read its blocks of chunk c)
+                land();
+                dev_wave_lds_sync();
+            }
         }
         // ---- the chunk's 16 rows of H, rounded to f16 (resampler.rs:25-28), into ring slot c mod 2 KV: lane holds rows 4 lq .. + 3 of
         //      output column l16 of either tile
@@ -442,14 +606,21 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     }
             }
         slot = slot + 1 == 2 * KV ? 0 : slot + 1;
+        W_MARK(3);
         // ---- pass 2 + encode + store of every output tile whose window ends with chunk c
         while (vt <= vt1 && vm.y == c) {
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                if ((i ? klo1 : klo0) < 0) continue;  // (uniform: no second tile in the last pair of an odd tile count)
+                if (klo[i] == 0xff) continue;  // (uniform: no second tile in the last pair of an odd tile count)
                 f32x4 o[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) o[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (SMR_WAVE_ABL & 8) {
+                    const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
+                    if (!(SMR_WAVE_ABL & 16) && y < d_h && x + 3 < d_w)
+                        *(uint4 *)(d_ptr + (size_t)y * d_pitch + (size_t)x * 4) = make_uint4(ring[i][0][0].x ^ ring[i][1][0].y, ring[i][2][0].z, ring[i][0][KV_N - 1].w, ring[i][1][KV_N - 1].x);
+                    continue;
+                }
 #pragma unroll
                 for (int p = 0; p < KV_N; p++) {
                     if (p < KV) {
@@ -461,12 +632,18 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                             o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring[i][ch][p]), __builtin_bit_cast(f16x8, bvl[p]), o[ch]);
                     }
                 }
+                W_MARK(4);
                 // lane holds columns x .. x + 3 of output row y
                 const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
                 u32 px[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++)
                     px[k] = srgb_encode8(o[0][k], s_thr) | (srgb_encode8(o[1][k], s_thr) << 8) | (srgb_encode8(o[2][k], s_thr) << 16) | 0xff000000u;
+#ifndef SMR_EMU
+#pragma unroll
+                for (int k = 0; k < 4; k++) asm volatile("" : "+v"(px[k]));  // (all twelve lookups in flight together: not sunk into the store branches)
+#endif
+                W_MARK(6);
                 bool direct = false;
                 if (dj) {
                     // (m_direct_yuv: the arithmetic of k_compose_output's copy tiles on the bytes above; every lane takes part in its
@@ -477,7 +654,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     const u32 yq = m_direct_yuv(px, odd, &mine, &other);
                     if (direct) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);
                 }
-                if (!direct && y < d_h && x < d_w) {
+                if (!direct && y < d_h && x < d_w && (!(SMR_WAVE_ABL & 16) || px[0] == 0x12345678u)) {  // (16: profiling, all work but no store traffic)
                     u8 *op = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
                     if (x + 3 < d_w) {
                         *(uint4 *)op = make_uint4(px[0], px[1], px[2], px[3]);
@@ -490,15 +667,30 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             }
             vt++;
             if (vt <= vt1) {
-                vm = J.v_meta[vt];
-                fetch_bv(vt);
+                vm = vm_next;
+                vm_next = J.v_meta[min(vt + 1, vt1)];
+                if (!(SMR_WAVE_ABL & 512)) fetch_bv(vt);  // (512: profiling, every tile with the first tile's weights)
             }
         }
+        W_MARK(7);
+        // ---- the footprint of chunk c + 2 goes out now: it has the whole next conversion to arrive, and the loop's waits for the pass-2
+        //      weights above never stand behind it (the memory counter is in order)
+        if (c + 1 < c_last && !(SMR_WAVE_ABL & 32)) issue(c + 2);
+        W_MARK(5);
     }
+#if SMR_WAVE_TIMING
+    if (timing && lane == 0) {
+        for (int i = 0; i < 8; i++) atomicAdd(dbg + i, tph[i]);
+        atomicAdd(dbg + 8, (unsigned long long)(c_last - c_first + 1));
+        atomicAdd(dbg + 9, (unsigned long long)(vt1 - vt0 + 1));
+        atomicAdd(dbg + 10, 1ull);
+    }
+#endif
+#undef W_MARK
 }
 
-template <int NKS_T, int KT_T, int KV_T, int FL>
-__global__ __launch_bounds__(W_THREADS) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
+template <int NKS_T, int KV_T, int FL>
+__global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
 #ifdef SMR_EMU
     u8 *smem = emu_smem;
 #else
@@ -506,31 +698,68 @@ __global__ __launch_bounds__(W_THREADS) void k_ingest_wave(const WArgs args, con
 #endif
     const int tid = threadIdx.x;
     const int wave = dev_readfirstlane(tid >> 6);
-    // tables: (hi | lo << 16) decode LUT with the clamp folded in, encode thresholds + estimate table
-    for (int i = tid; i < M_LUT_ENTRIES; i += W_THREADS) ((u32 *)smem)[i] = lut[min(max(i - 256, 0), 255)];
-    for (int i = tid; i < SMR_TABLE_FLOATS - 256; i += W_THREADS) ((float *)(smem + W_OFF_THR))[i] = tables[256 + i];
     // XCD-aware order: workgroup ids that share an XCD are neighbours in unit space (piece-group major, pair fastest: neighbouring
     // pairs read the same source lines at the same time)
     const int per_xcd = ((int)gridDim.x + 7) >> 3;
     const int v = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     const int total = args.wg_prefix[args.n_jobs];
-    if (v < total) {
-        int j = 0;
-        while (j + 1 < args.n_jobs && args.wg_prefix[j + 1] <= v) j++;
-        const WJob &J = args.jobs[j];
-        const int local = v - args.wg_prefix[j];
-        const int group = local / J.n_pairs, pair = local - group * J.n_pairs;
-        // the pair's pass-1 band -> LDS (shared by the workgroup's waves)
-        const int KT = KT_T ? KT_T : J.KT;
-        const uint4 *src = J.h_frag + (size_t)pair * 2 * KT * 2 * 64;
-        uint4 *Bs = (uint4 *)(smem + W_OFF_B);
-        for (int i = tid; i < 2 * KT * 2 * 64; i += W_THREADS) Bs[i] = src[i];
-        __syncthreads();
-        const int piece = group * W_WAVES + wave;
-        const int vt0 = (int)(((long long)piece * J.n_vtiles) / J.pieces), vt1 = (int)(((long long)(piece + 1) * J.n_vtiles) / J.pieces) - 1;
-        if (vt0 <= vt1)
-            wave_piece<NKS_T, KT_T, KV_T, FL>(J, args.direct, pair, vt0, vt1, smem, (u32)W_OFF_B, (u32)(W_OFF_B + args.b_bytes + wave * args.raw_bytes));
+    if (v >= total) return;
+    int j = 0;
+    while (j + 1 < args.n_jobs && args.wg_prefix[j + 1] <= v) j++;
+    const WJob &J = args.jobs[j];
+    const int local = v - args.wg_prefix[j];
+    const int group = local / J.n_pairs, pair = local - group * J.n_pairs;
+    // ---- prologue: the decode LUT ((hi | lo << 16), clamp folded in), the encode tables and the pair's pass-1 band go to LDS.  Every
+    //      load is issued before the first store, and the piece's own first loads (its weights, its first chunk) go out in between:
+    //      the workgroup pays one memory latency, not four.
+    const int NKS = NKS_T ? NKS_T : J.NKS;
+    const uint4 *src = J.h_frag + (size_t)pair * 2 * J.NKS * 2 * 64;
+    uint4 *Bs = (uint4 *)(smem + W_OFF_B);
+    constexpr int NL = (M_LUT_ENTRIES + W_THREADS - 1) / W_THREADS, NT = (SMR_TABLE_FLOATS - 256 + W_THREADS - 1) / W_THREADS;
+    constexpr int NB = NKS_T ? (2 * NKS_T * 2 * 64 + W_THREADS - 1) / W_THREADS : 1;
+    u32 r_lut[NL];
+    float r_thr[NT];
+    uint4 r_b[NB];
+#pragma unroll
+    for (int k = 0; k < NL; k++) r_lut[k] = lut[min(max(tid + k * W_THREADS - 256, 0), 255)];
+#pragma unroll
+    for (int k = 0; k < NT; k++) r_thr[k] = tables[256 + min(tid + k * W_THREADS, SMR_TABLE_FLOATS - 257)];
+    if (NKS_T) {
+#pragma unroll
+        for (int k = 0; k < NB; k++) {  // (a job of the class with a narrower window: its band in the class's layout, zero beyond)
+            const int i = tid + k * W_THREADS, t = i / (NKS * 128), r = i - t * (NKS * 128);
+            r_b[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (t < 2 && r < J.NKS * 128) r_b[k] = src[t * J.NKS * 128 + r];
+        }
     }
+    auto finish_prologue = [&]() {
+#pragma unroll
+        for (int k = 0; k < NL; k++)
+            if (tid + k * W_THREADS < M_LUT_ENTRIES) ((u32 *)smem)[tid + k * W_THREADS] = r_lut[k];
+#pragma unroll
+        for (int k = 0; k < NT; k++)
+            if (tid + k * W_THREADS < SMR_TABLE_FLOATS - 256) ((float *)(smem + W_OFF_THR))[tid + k * W_THREADS] = r_thr[k];
+        if (NKS_T) {
+#pragma unroll
+            for (int k = 0; k < NB; k++)
+                if (tid + k * W_THREADS < 2 * NKS * 2 * 64) Bs[tid + k * W_THREADS] = r_b[k];
+        } else {
+            for (int i = tid; i < 2 * NKS * 2 * 64; i += W_THREADS) Bs[i] = src[i];
+        }
+        __syncthreads();
+    };
+    if (SMR_WAVE_ABL & 1024) {  // profiling: launch + prologue only
+        finish_prologue();
+        if (tid == 0 && Bs[5].x == 0x12345678u) J.dst.ptr[0] = 1;
+        return;
+    }
+    const int piece = group * W_WAVES + wave;
+    const int vt0 = (int)(((long long)piece * J.n_vtiles) / J.pieces), vt1 = (int)(((long long)(piece + 1) * J.n_vtiles) / J.pieces) - 1;
+    if (vt0 <= vt1)
+        wave_piece<NKS_T, KV_T, FL>(J, args.direct, pair, vt0, vt1, smem, (u32)W_OFF_B, (u32)(W_OFF_B + args.b_bytes + wave * args.raw_bytes), args.dbg,
+                                    finish_prologue);
+    else
+        finish_prologue();
 }
 
 #endif  // __HIPCC__
@@ -546,6 +775,7 @@ struct WaveBand {
     const uint4 *frag;
     int K;        // k-steps per tile band (axis 2) / per window (axis 3)
     int nks;      // axis 2: k-steps of the widest pair window
+    bool k01;     // axis 2: see wave_band_geometry
     int n_units;  // pairs / tiles
 };
 
@@ -555,7 +785,8 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
     smr_ctx::MfmaTable *hit = find_mfma_table(ctx, scale, offset, n_dst, n_src, axis), *victim = nullptr;
     if (!hit) {
         int K, nks;
-        wave_band_geometry(scale, offset, n_dst, n_src, axis, &K, &nks);
+        bool k01 = false;
+        wave_band_geometry(scale, offset, n_dst, n_src, axis, &K, &nks, &k01);
         for (auto &t : ctx->mfma_tables)  // never evict a table the current call already handed to a job that is not launched yet
             if (t.last_call != ctx->weight_call && (!victim || t.last_use < victim->last_use)) victim = &t;
         if (!victim || ctx->mfma_tables.size() < 64) {
@@ -563,7 +794,7 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
             victim = &ctx->mfma_tables.back();
         }
         const size_t meta_bytes = ((size_t)n_units * (axis == 2 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
-        const size_t frags = axis == 2 ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;
+        const size_t frags = axis == 2 ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;  // (axis 2: K = k-steps of the widest window)
         const size_t need = meta_bytes + frags * 64 * sizeof(uint4);
         for (size_t i = ctx->pending_bands.size(); i-- > 0;)
             if (victim->dev && ctx->pending_bands[i].meta == victim->dev) ctx->pending_bands.erase(ctx->pending_bands.begin() + (long)i);
@@ -579,7 +810,7 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
             victim->bytes = want;
         }
         victim->scale = scale; victim->offset = offset; victim->n_dst = n_dst; victim->n_src = n_src; victim->axis = axis;
-        victim->K = K; victim->max_span = 0; victim->meta_bytes = meta_bytes; victim->ngm = nks;
+        victim->K = K; victim->max_span = k01 ? 1 : 0; victim->meta_bytes = meta_bytes; victim->ngm = nks;
         smr_ctx::PendingBand pb;
         pb.scale = scale; pb.offset = offset; pb.taps = w_taps(scale); pb.n_dst = n_dst; pb.n_src = n_src; pb.axis = axis; pb.K = K;
         pb.n_tiles = n_units; pb.meta = victim->dev; pb.frag = (u8 *)victim->dev + meta_bytes;
@@ -592,6 +823,7 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
     out->frag = (const uint4 *)((const u8 *)hit->dev + hit->meta_bytes);
     out->K = hit->K;
     out->nks = hit->ngm;
+    out->k01 = hit->max_span != 0;
     out->n_units = n_units;
     return SMR_OK;
 }
@@ -638,12 +870,12 @@ bool can_fuse_wave(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pl
         return false;
     }
     if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
-    int KT, NKS, KV, unused;
-    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2)) { KT = t->K; NKS = t->ngm; }
-    else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &KT, &NKS);
+    int NKS, KV, unused;
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2)) NKS = t->K;
+    else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &NKS, &unused);
     if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3)) KV = t->K;
     else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3, &KV, &unused);
-    return KT <= W_KT_MAX && NKS <= W_NKS_MAX && KV <= W_KV_MAX;
+    return NKS <= W_NKS_MAX && KV <= W_KV_MAX;
 }
 
 int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, WJob *out) {
@@ -657,7 +889,8 @@ int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.dst = view_of(tile);
     J.src_w = (int)f->width; J.src_h = (int)f->height;
     J.conv = m_conv_constants(f->format == SMR_FRAME_PLANAR_YUVJ420);
-    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.KT = bh.K; J.NKS = bh.nks; J.n_pairs = bh.n_units;
+    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.NKS = bh.K; J.n_pairs = bh.n_units;
+    J.k01 = bh.k01 ? 1 : 0;
     J.n_htiles = ((int)tile->w + 15) / 16;
     J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
     J.pieces = W_WAVES;
@@ -703,11 +936,13 @@ int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resampl
     return SMR_OK;
 }
 
-// builds: generic | the benchmark scenes' class (pair windows of <= 4 k-steps, 3 per tile, 2 per pass-2 window: scales 1.5 .. 2)
-//         each plain | direct output (2048) | NV12-capable (4096) | both
+// builds: generic | the benchmark scenes' class (pair windows of <= 4 k-steps, pass-2 windows of 2: scales around 1.5) | the class
+//         with its two always-zero weight fragments skipped;  each plain | direct output (2048) | NV12-capable (4096) | both
 typedef void (*WaveKernel)(const WArgs, const float *, const u32 *);
-constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0, 0>,    k_ingest_wave<4, 3, 2, 0>,    k_ingest_wave<0, 0, 0, 2048>, k_ingest_wave<4, 3, 2, 2048>,
-                                    k_ingest_wave<0, 0, 0, 4096>, k_ingest_wave<4, 3, 2, 4096>, k_ingest_wave<0, 0, 0, 6144>, k_ingest_wave<4, 3, 2, 6144>};
+constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 2, 0>,    k_ingest_wave<4, 2, 1>,
+                                    k_ingest_wave<0, 0, 2048>, k_ingest_wave<4, 2, 2048>, k_ingest_wave<4, 2, 2049>,
+                                    k_ingest_wave<0, 0, 4096>, k_ingest_wave<4, 2, 4096>, k_ingest_wave<4, 2, 4097>,
+                                    k_ingest_wave<0, 0, 6144>, k_ingest_wave<4, 2, 6144>, k_ingest_wave<4, 2, 6145>};
 constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 
 int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr) {
@@ -727,22 +962,22 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         const size_t nj = jobs.size() - j0 < (size_t)MAX_WJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_WJOBS_PER_LAUNCH;
         WArgs args;
         memset(&args, 0, sizeof(args));
-        bool cls432 = true, any_nv = false;
-        int kt_max = 1, nks_max = 1;
+        bool cls432 = true, any_nv = false, k01 = true;
+        int nks_max = 1;
         long long tile_rows = 0;  // sum over jobs of pairs x tile rows: the unit of work
         for (size_t j = 0; j < nj; j++) {
             const WJob &J = jobs[j0 + j];
-            cls432 = cls432 && J.NKS <= 4 && J.KT == 3 && J.KV == 2;
+            cls432 = cls432 && J.NKS <= 4 && J.KV == 2;
             any_nv = any_nv || J.nv12;
-            kt_max = J.KT > kt_max ? J.KT : kt_max;
+            k01 = k01 && J.k01;
             nks_max = J.NKS > nks_max ? J.NKS : nks_max;
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
-        int ki = cls432 ? 1 : 0;
-        if (direct) ki += 2;
-        if (any_nv) ki += 4;
+        int ki = cls432 ? (k01 ? 2 : 1) : 0;
+        if (direct) ki += 3;
+        if (any_nv) ki += 6;
         const WaveKernel kern = W_KERNELS[ki];
-        args.b_bytes = w_band_bytes(cls432 ? 3 : kt_max);
+        args.b_bytes = w_band_bytes(cls432 ? 4 : nks_max);
         args.raw_bytes = (w_raw_bytes(cls432 ? 4 : nks_max) + 15) & ~15;
         const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
         if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of LDS", lds);
@@ -786,11 +1021,26 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         args.direct = direct;
         const int blocks = (total + 7) & ~7;
         if (ctx->debug_ingest)
-            fprintf(stderr, "k_ingest_wave[%d]: %zu jobs, lds %zu B (%d WG/CU), %d workgroups of %d waves, job0: NKS %d KT %d KV %d pairs %d vtiles %d pieces %d\n", ki,
-                    nj, lds, per_cu, total, W_WAVES, args.jobs[0].NKS, args.jobs[0].KT, args.jobs[0].KV, args.jobs[0].n_pairs, args.jobs[0].n_vtiles,
+            fprintf(stderr, "k_ingest_wave[%d]: %zu jobs, lds %zu B (%d WG/CU), %d workgroups of %d waves, job0: NKS %d KV %d pairs %d vtiles %d pieces %d\n", ki,
+                    nj, lds, per_cu, total, W_WAVES, args.jobs[0].NKS, args.jobs[0].KV, args.jobs[0].n_pairs, args.jobs[0].n_vtiles,
                     args.jobs[0].pieces);
+#if SMR_WAVE_TIMING
+        args.dbg = (unsigned long long *)smr_scratch(ctx, 7, 128);
+        if (args.dbg) SMR_HIP(ctx, hipMemsetAsync(args.dbg, 0, 128, ctx->stream));
+#endif
         if (blocks > 0) hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(W_THREADS), lds, ctx->stream, args, ctx->d_tables, ctx->d_lut16);
         SMR_HIP(ctx, hipGetLastError());
+#if SMR_WAVE_TIMING
+        if (args.dbg) {
+            unsigned long long h[16];
+            SMR_HIP(ctx, hipMemcpyAsync(h, args.dbg, 128, hipMemcpyDeviceToHost, ctx->stream));
+            SMR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            const double w = 1e3 * (double)(h[10] ? h[10] : 1);
+            fprintf(stderr, "k_ingest_wave kcycles per timed wave (%llu waves, %.1f chunks, %.1f tile rows each): prologue %.1f | k-steps %.1f land %.1f last-mfma+ring %.1f pass2-mfma %.1f encode %.1f store+fetch %.1f issue %.1f\n",
+                    h[10], (double)h[8] / (double)(h[10] ? h[10] : 1), (double)h[9] / (double)(h[10] ? h[10] : 1), h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, h[6] / w,
+                    h[7] / w, h[5] / w);
+        }
+#endif
     }
     return SMR_OK;
 }

@@ -67,10 +67,11 @@ struct Band {
     void *meta;
     uint4 *frag;
     int K, nks, n_units;
+    bool k01 = false;
 };
 Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
     Band B;
-    wave_band_geometry(scale, offset, n_dst, n_src, axis, &B.K, &B.nks);
+    wave_band_geometry(scale, offset, n_dst, n_src, axis, &B.K, &B.nks, &B.k01);
     const int n_tiles = (n_dst + 15) / 16;
     B.n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;
     const size_t meta_bytes = ((size_t)B.n_units * (axis == 2 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
@@ -95,7 +96,7 @@ Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
 // (scale, offset) per axis as smr_resample_plan_make gives them for a two-pass, horizontal-first plan.  `pieces`: vertical pieces
 // per column pair (rounded up to a multiple of the workgroup's waves); `specialised` != 0 asks for the <4, 3, 2> build when the
 // job's k-step counts allow it.  Returns 0, or a negative number when the job is outside the kernel's limits:
-// -1 k-steps, -2 specialised build not applicable.  info[0..3] = NKS, KT, KV, workgroups.
+// -1 k-steps, -2 specialised build not applicable.  info[0..3] = NKS, NKS, KV, workgroups.
 extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, int sh, int full_range, int nv12, float scale_h, float off_h, float scale_v,
                                float off_v, u8 *dst, int dw, int dh, int pieces, int specialised, int *info) {
     static float tables[SMR_TABLE_FLOATS];
@@ -111,8 +112,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
     Band bh = build_band(scale_h, off_h, dw, sw, 2), bv = build_band(scale_v, off_v, dh, sh, 3);
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
-    if (bh.K > W_KT_MAX || bh.nks > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
-    const bool cls432 = bh.nks <= 4 && bh.K == 3 && bv.K == 2;
+    if (bh.K > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
+    const bool cls432 = bh.K <= 4 && bv.K == 2;
     if (specialised && !cls432) return -2;
 
     WArgs args;
@@ -124,7 +125,7 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     J.dst.pitch = (u32)(((size_t)dw * 4 + 255) & ~(size_t)255); J.dst.w = dw; J.dst.h = dh;
     J.src_w = sw; J.src_h = sh;
     J.conv = m_conv_constants(full_range != 0);
-    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.KT = bh.K; J.NKS = bh.nks; J.n_pairs = bh.n_units;
+    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.NKS = bh.K; J.n_pairs = bh.n_units;
     J.n_htiles = (dw + 15) / 16;
     J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
     int p = pieces < 1 ? 1 : pieces;
@@ -136,19 +137,22 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
     args.n_jobs = 1;
     const bool spec = specialised && cls432;
-    args.b_bytes = w_band_bytes(spec ? 3 : bh.K);
-    args.raw_bytes = (w_raw_bytes(spec ? 4 : bh.nks) + 15) & ~15;
+    args.b_bytes = w_band_bytes(spec ? 4 : bh.K);
+    args.raw_bytes = (w_raw_bytes(spec ? 4 : bh.K) + 15) & ~15;
     args.direct = nullptr;
     const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
     const int total = args.wg_prefix[1];
     if (info) info[3] = total;
     const unsigned blocks = (unsigned)((total + 7) & ~7);
-    if (spec) {
-        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 3, 2, 4096>(args, tables, lut16); });
-        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 3, 2, 0>(args, tables, lut16); });
+    if (spec && bh.k01) {
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4097>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 1>(args, tables, lut16); });
+    } else if (spec) {
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 0>(args, tables, lut16); });
     } else {
-        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 0, 4096>(args, tables, lut16); });
-        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 0, 0>(args, tables, lut16); });
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 0>(args, tables, lut16); });
     }
     for (int yy = 0; yy < dh; yy++) memcpy(dst + (size_t)yy * dw * 4, J.dst.ptr + (size_t)yy * J.dst.pitch, (size_t)dw * 4);
     return 0;

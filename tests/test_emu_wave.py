@@ -55,17 +55,17 @@ def _p(a):
     return a.ctypes.data_as(P8)
 
 
-# (source, tile, crop or None, pieces, specialised build, white noise, NV12, expected (NKS, KT, KV) or None)
+# (source, tile, crop or None, pieces, specialised build, white noise, NV12, expected (NKS, NKS, KV) or None)
 CASES = [
-    ((96, 60), (64, 40), None, 1, 1, False, False, (4, 3, 2)),      # the benchmark's class: scale 1.5
-    ((96, 60), (64, 40), None, 6, 0, True, False, (4, 3, 2)),       # same through the generic build, more pieces than tile rows
-    ((192, 120), (128, 80), None, 4, 1, True, False, (4, 3, 2)),    # several pairs, pieces that cut between tiles
+    ((96, 60), (64, 40), None, 1, 1, False, False, (4, 4, 2)),      # the benchmark's class: scale 1.5
+    ((96, 60), (64, 40), None, 6, 0, True, False, (4, 4, 2)),       # same through the generic build, more pieces than tile rows
+    ((192, 120), (128, 80), None, 4, 1, True, False, (4, 4, 2)),    # several pairs, pieces that cut between tiles
     ((130, 74), (86, 49), None, 2, 0, False, False, None),           # odd tile sizes: a last pair with one tile, partial tiles
     ((64, 36), (96, 54), None, 2, 0, True, False, None),             # upscale (7 taps, several tiles per chunk)
     ((256, 144), (128, 72), None, 2, 0, True, False, None),          # scale 2
-    ((384, 216), (128, 72), None, 2, 0, True, False, (7, 5, 3)),     # scale 3: the north-star target's class
-    ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1, True, False, (4, 3, 2)),  # crop: windows inside the frame
-    ((96, 60), (64, 40), None, 2, 1, True, True, (4, 3, 2)),        # NV12
+    ((384, 216), (128, 72), None, 2, 0, True, False, (7, 7, 3)),     # scale 3: the north-star target's class
+    ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1, True, False, (4, 4, 2)),  # crop: windows inside the frame
+    ((96, 60), (64, 40), None, 2, 1, True, True, (4, 4, 2)),        # NV12
     ((16, 8), (12, 6), None, 1, 0, True, False, None),               # smaller than a chunk
 ]
 

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --latency-frames 5 $*"
+BENCH=${PROF_CMD:-"python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --latency-frames 5 $*"}  # PROF_CMD: profile another command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 i=0
 MAXG=${PROF_GROUPS:-99}
