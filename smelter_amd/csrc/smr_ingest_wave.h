@@ -311,7 +311,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #else
 #define W_MARK(ph) do { } while (0)
 #endif
-    const int NKS = NKS_T ? NKS_T : J.NKS, KV = KV_T ? KV_T : J.KV;
+    // (the narrow class runs its 4 k-steps unconditionally; a wide class (NKS_T = 8) is unrolled to NKS_T steps but lays its LDS out for the
+    //  job's own count, so that a 7-step job does not pay for an eighth in LDS and conversions)
+    constexpr bool FIXED_NKS = NKS_T > 0 && NKS_T <= 4;
+    const int NKS = FIXED_NKS ? NKS_T : J.NKS, KV = KV_T ? KV_T : J.KV;
     constexpr int NKS_N = NKS_T ? NKS_T : W_NKS_MAX, KV_N = KV_T ? KV_T : W_KV_MAX;
     constexpr bool NV = (FL & 4096) != 0, DIRECT = (FL & 2048) != 0, K01 = (FL & 1) != 0;
     const float *s_thr = (const float *)(smem + W_OFF_THR);
@@ -500,6 +503,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
                     if (K01 && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
+                    if (NKS_T > 4 && (j < klo[i] || j > khi[i])) continue;  // (uniform: wide windows — most (tile, k-step) fragments are zero)
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++)
                         acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][0]), acc[i][ch]);
@@ -513,17 +517,20 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             read_raw(0, cur);
 #pragma unroll
             for (int j = 0; j < NKS_T; j++) {
-                if (j + 1 < NKS_T) read_raw(j + 1, nxt);
-                if (j > 0) read_b(j - 1, bq);
-                if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
-                convert(cur, a);
-                if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
-                if (j > 0) mfmas(j - 1, a_prev, bq);
+                if (FIXED_NKS || j < NKS) {  // (uniform)
+                    if (j + 1 < NKS_T && (FIXED_NKS || j + 1 < NKS)) read_raw(j + 1, nxt);
+                    if (j > 0) read_b(j - 1, bq);
+                    if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
+                    convert(cur, a);
+                    if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
+                    if (j > 0) mfmas(j - 1, a_prev, bq);
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) a_prev[ch] = a[ch];
-                cur = nxt;
+                    for (int ch = 0; ch < 3; ch++) a_prev[ch] = a[ch];
+                    cur = nxt;
+                }
             }
-            read_b(NKS_T - 1, bq);
+            const int j_last = FIXED_NKS ? NKS_T - 1 : NKS - 1;
+            read_b(j_last, bq);
             if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
             W_MARK(1);
             // ---- the next chunk's footprint (issued a whole conversion ago; the one after it goes out now) while the weights arrive
@@ -535,7 +542,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             }
             W_MARK(2);
             if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
-            mfmas(NKS_T - 1, a_prev, bq);
+            mfmas(j_last, a_prev, bq);
         } else {
 #pragma unroll
             for (int j = 0; j < NKS_N; j++) {
@@ -712,7 +719,7 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
     // ---- prologue: the decode LUT ((hi | lo << 16), clamp folded in), the encode tables and the pair's pass-1 band go to LDS.  Every
     //      load is issued before the first store, and the piece's own first loads (its weights, its first chunk) go out in between:
     //      the workgroup pays one memory latency, not four.
-    const int NKS = NKS_T ? NKS_T : J.NKS;
+    const int NKS = (NKS_T > 0 && NKS_T <= 4) ? NKS_T : J.NKS;  // (as in wave_piece)
     const uint4 *src = J.h_frag + (size_t)pair * 2 * J.NKS * 2 * 64;
     uint4 *Bs = (uint4 *)(smem + W_OFF_B);
     constexpr int NL = (M_LUT_ENTRIES + W_THREADS - 1) / W_THREADS, NT = (SMR_TABLE_FLOATS - 256 + W_THREADS - 1) / W_THREADS;
@@ -936,13 +943,14 @@ int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resampl
     return SMR_OK;
 }
 
-// builds: generic | the benchmark scenes' class (pair windows of <= 4 k-steps, pass-2 windows of 2: scales around 1.5) | the class
-//         with its two always-zero weight fragments skipped;  each plain | direct output (2048) | NV12-capable (4096) | both
+// builds: generic | the benchmark scenes' class (pair windows of <= 4 k-steps, pass-2 windows of 2: scales around 1.5) | that class with
+//         its two always-zero weight fragments skipped | the north-star target's class (windows of <= 8 k-steps, pass-2 windows of 3:
+//         scales around 3);  each plain | direct output (2048) | NV12-capable (4096) | both
 typedef void (*WaveKernel)(const WArgs, const float *, const u32 *);
-constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 2, 0>,    k_ingest_wave<4, 2, 1>,
-                                    k_ingest_wave<0, 0, 2048>, k_ingest_wave<4, 2, 2048>, k_ingest_wave<4, 2, 2049>,
-                                    k_ingest_wave<0, 0, 4096>, k_ingest_wave<4, 2, 4096>, k_ingest_wave<4, 2, 4097>,
-                                    k_ingest_wave<0, 0, 6144>, k_ingest_wave<4, 2, 6144>, k_ingest_wave<4, 2, 6145>};
+constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 2, 0>,    k_ingest_wave<4, 2, 1>,    k_ingest_wave<8, 3, 0>,
+                                    k_ingest_wave<0, 0, 2048>, k_ingest_wave<4, 2, 2048>, k_ingest_wave<4, 2, 2049>, k_ingest_wave<8, 3, 2048>,
+                                    k_ingest_wave<0, 0, 4096>, k_ingest_wave<4, 2, 4096>, k_ingest_wave<4, 2, 4097>, k_ingest_wave<8, 3, 4096>,
+                                    k_ingest_wave<0, 0, 6144>, k_ingest_wave<4, 2, 6144>, k_ingest_wave<4, 2, 6145>, k_ingest_wave<8, 3, 6144>};
 constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 
 int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr) {
@@ -962,23 +970,25 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         const size_t nj = jobs.size() - j0 < (size_t)MAX_WJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_WJOBS_PER_LAUNCH;
         WArgs args;
         memset(&args, 0, sizeof(args));
-        bool cls432 = true, any_nv = false, k01 = true;
+        bool cls432 = true, cls83 = true, any_nv = false, k01 = true;
         int nks_max = 1;
         long long tile_rows = 0;  // sum over jobs of pairs x tile rows: the unit of work
         for (size_t j = 0; j < nj; j++) {
             const WJob &J = jobs[j0 + j];
             cls432 = cls432 && J.NKS <= 4 && J.KV == 2;
+            cls83 = cls83 && J.NKS <= 8 && J.KV == 3;
             any_nv = any_nv || J.nv12;
             k01 = k01 && J.k01;
             nks_max = J.NKS > nks_max ? J.NKS : nks_max;
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
-        int ki = cls432 ? (k01 ? 2 : 1) : 0;
-        if (direct) ki += 3;
-        if (any_nv) ki += 6;
+        int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
+        if (direct) ki += 4;
+        if (any_nv) ki += 8;
+        const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
         const WaveKernel kern = W_KERNELS[ki];
-        args.b_bytes = w_band_bytes(cls432 ? 4 : nks_max);
-        args.raw_bytes = (w_raw_bytes(cls432 ? 4 : nks_max) + 15) & ~15;
+        args.b_bytes = w_band_bytes(cls_nks ? cls_nks : nks_max);
+        args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;
         const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
         if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of LDS", lds);
         // as many waves as are resident at once (registers and LDS), one piece each: every wave starts and ends with the launch

@@ -113,8 +113,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     Band bh = build_band(scale_h, off_h, dw, sw, 2), bv = build_band(scale_v, off_v, dh, sh, 3);
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
     if (bh.K > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
-    const bool cls432 = bh.K <= 4 && bv.K == 2;
-    if (specialised && !cls432) return -2;
+    const bool cls432 = bh.K <= 4 && bv.K == 2, cls83 = bh.K <= 8 && bv.K == 3;
+    if (specialised && !cls432 && !cls83) return -2;
 
     WArgs args;
     memset(&args, 0, sizeof(args));
@@ -136,9 +136,10 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     args.wg_prefix[0] = 0;
     args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
     args.n_jobs = 1;
-    const bool spec = specialised && cls432;
-    args.b_bytes = w_band_bytes(spec ? 4 : bh.K);
-    args.raw_bytes = (w_raw_bytes(spec ? 4 : bh.K) + 15) & ~15;
+    const bool spec = specialised && cls432, spec83 = specialised && !cls432 && cls83;
+    const int cls_nks = spec ? 4 : 0;
+    args.b_bytes = w_band_bytes(cls_nks ? cls_nks : bh.K);
+    args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : bh.K) + 15) & ~15;
     args.direct = nullptr;
     const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
     const int total = args.wg_prefix[1];
@@ -147,6 +148,9 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     if (spec && bh.k01) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4097>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 1>(args, tables, lut16); });
+    } else if (spec83) {
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 0>(args, tables, lut16); });
     } else if (spec) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4096>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 0>(args, tables, lut16); });

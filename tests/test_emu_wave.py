@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
+from tests import convert_model
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 EMU = os.path.join(HERE, "emu")
@@ -63,7 +64,8 @@ CASES = [
     ((130, 74), (86, 49), None, 2, 0, False, False, None),           # odd tile sizes: a last pair with one tile, partial tiles
     ((64, 36), (96, 54), None, 2, 0, True, False, None),             # upscale (7 taps, several tiles per chunk)
     ((256, 144), (128, 72), None, 2, 0, True, False, None),          # scale 2
-    ((384, 216), (128, 72), None, 2, 0, True, False, (7, 7, 3)),     # scale 3: the north-star target's class
+    ((384, 216), (128, 72), None, 2, 0, True, False, (7, 7, 3)),     # scale 3: the north-star target's class, generic build
+    ((384, 216), (128, 72), None, 3, 1, True, False, (7, 7, 3)),     # ... and its class build (windows of <= 8 k-steps, pass-2 windows of 3)
     ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1, True, False, (4, 4, 2)),  # crop: windows inside the frame
     ((96, 60), (64, 40), None, 2, 1, True, True, (4, 4, 2)),        # NV12
     ((16, 8), (12, 6), None, 1, 0, True, False, None),               # smaller than a chunk
@@ -95,3 +97,10 @@ def test_emulated_kernel_matches_the_oracle(emu, src, dst, crop, pieces, spec, n
     assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
     assert (d == 0).mean() >= 0.999, (d == 0).mean()
     assert (got[..., 3] == 255).all()
+    # per stage (tests/convert_model.py): against the oracle's resample of the node texture the kernel's own conversion produces
+    node_k = convert_model.node_codes_nv12(y, uu) if nv12 else convert_model.node_codes(y, u, v)
+    dn = np.abs(node_k.astype(np.int16) - node.astype(np.int16))
+    assert dn.max() <= 1 and (dn == 0).mean() >= 0.9998, (dn.max(), (dn == 0).mean())
+    _, want_k = orc.resample(node_k, crop, dw, dh)
+    dk = np.abs(got.astype(np.int16) - want_k.astype(np.int16))
+    assert dk.max() <= 1 and (dk == 0).mean() >= 0.9995, (dk.max(), (dk == 0).mean())
