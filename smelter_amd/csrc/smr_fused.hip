@@ -263,7 +263,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 cm->d_class = nullptr; cm->d_direct = nullptr; cm->d_list = nullptr; cm->n = 0;
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_class, (size_t)b_tiles * sizeof(TileClass)));
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_direct, b_tiles));
-                SMR_HIP(ctx, hipMalloc((void **)&cm->d_list, sizeof(TileList) + (size_t)b_tiles * 4));
+                SMR_HIP(ctx, hipMalloc((void **)&cm->d_list, sizeof(TileList) + (size_t)b_tiles * sizeof(TileFull)));
                 cm->n = b_tiles;
             }
             if (!cm->h_count) {

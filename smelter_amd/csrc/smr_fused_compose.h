@@ -33,7 +33,9 @@ constexpr u32 B_MAX_FIRST = 1024;
 // Measured on configs[2] (kernel incl. ~6 us of stage timer, frames/s one / three in flight): 1 band 41.8 us, 10.1k / 13.9k;
 // 2 bands 29.2 us, 11.7k / 13.3k; 4 bands 30.1 us, 11.5k / 13.0k; 8 bands 33.6 us, 10.2k / 12.6k — every band repeats the
 // workgroup's fixed work (layout list, classification, tables), so two is the default.
-constexpr int B_SLICES = 2;  // ctx->compose_slices (1, 2, 4 or 8: a band holds whole 4x2 output blocks)
+constexpr int B_SLICES = 8;  // ctx->compose_slices (1, 2, 4 or 8: a band holds whole 4x2 output blocks).  Round 3: the bands start from the
+                             // classifier's per-tile record instead of classifying again, so a band's fixed work is small and eight
+                             // one-sweep bands are the fastest (measured: bench.py --inflight 1, SMR_COMPOSE_SLICES)
 struct ComposeOrder {
     u32 n_first;             // workgroups [0, B_SLICES * n_first) take the bands of first[]; workgroup B_SLICES * n_first + t takes tile t unless it is in `taken`
     u16 first[B_MAX_FIRST];  // linear tile indices
@@ -163,9 +165,19 @@ struct alignas(16) TileClass {
     u32 pitch_or_px;
     u32 kind;
 };
+// A tile that needs compositing, with what the classification found out about it (the compositor's workgroups start from this
+// record instead of classifying their band again): the touching layers, the last opaque solid layer, tile_needs' bits.
+struct TileFull {
+    u32 tile;
+    int start;
+    u32 general;
+    u32 pad;
+    u32 touch[MAX_LAYOUT_WORDS];
+};
 struct TileList {
     u32 count;      // zeroed before k_classify_tiles
-    u32 tiles[1];   // really one per tile
+    u32 pad[3];
+    TileFull e[1];  // really one per tile
 };
 // Direct output: direct[tile] = the start layer when the tile is a copy tile of a texture layer in `direct_layers` (the tiles wave A
 // resamples in the same call, at even output positions) — wave A then writes that tile's Y'CbCr itself, the RGBA8 bytes of those
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restri
                                                        int tiles_x, unsigned long long direct_layers, TileClass *__restrict__ tc,
                                                        u8 *__restrict__ direct, TileList *__restrict__ full) {
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
-    __shared__ int s_start, s_general;
+    __shared__ int s_start, s_general, s_slot;
     const int tid = threadIdx.x, tile = blockIdx.x;
     const int tile_y = tile / tiles_x;
     const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H;
@@ -208,12 +220,16 @@ __global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restri
                 }
             }
         }
-        if (c.kind == TC_FULL) {
-            c.pitch_or_px = atomicAdd(&full->count, 1u);
-            full->tiles[c.pitch_or_px] = (u32)tile;
-        }
+        if (c.kind == TC_FULL) c.pitch_or_px = atomicAdd(&full->count, 1u);
+        s_slot = c.kind == TC_FULL ? (int)c.pitch_or_px : -1;
         tc[tile] = c;
         direct[tile] = (u8)d;
+    }
+    __syncthreads();
+    if (s_slot >= 0) {  // (uniform) the record the compositor's bands of this tile start from
+        TileFull &E = full->e[s_slot];
+        if (tid < MAX_LAYOUT_WORDS) E.touch[tid] = tid < ((n + 31) >> 5) ? s_touch[tid] : 0u;
+        if (tid == 0) { E.tile = (u32)tile; E.start = start; E.general = (u32)s_general; E.pad = 0u; }
     }
 }
 
@@ -343,12 +359,15 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
 // Rows [band, band + rh) of tile `tile`, classified and composited by the whole workgroup (uniform call; may be called again).
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV); NV = 2: RGBA8 surface (in `yp`)
 // BIG: the layout list is longer than the LDS copy (B_MAX_LAYOUTS / B_MAX_MASKS) and is read where it lies in memory
+// `pre`: the tile's record from k_classify_tiles — touching layers, start layer and tile_needs' bits of the WHOLE tile, valid for every
+// band of it (a layer solid over the tile is solid over the band; a superset of the band's touching layers composites to the same
+// pixels) — so a band's workgroup does not classify again.
 template <int NV, bool BIG>
-__device__ __forceinline__ void compose_full(int tile, int band, int rh, const SurfView &yp, const SurfView &up, const SurfView &vp, int W, int H,
+__device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, int band, int rh, const SurfView &yp, const SurfView &up, const SurfView &vp, int W, int H,
                                              const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g, int n, int n_masks,
                                              int srgb_and_ablate, const float *__restrict__ tables, int tiles_x, float *s_tab) {
-    __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
-    __shared__ int s_start, s_general;
+    const int tile = (int)pre->tile;
+    __shared__ u32 s_touch[MAX_LAYOUT_WORDS];
     __shared__ u32 s_px[B_TILE_W * B_TILE_H];  // general tiles: composited RGBA8
     // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
     // dependent scalar-memory round trip per field per layer per wave
@@ -374,14 +393,12 @@ __device__ __forceinline__ void compose_full(int tile, int band, int rh, const S
     const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
     if (ablate & 1) return;
     if (ty0 >= H) return;
-    if (tid == 0) s_general = 0;
-    classify_layouts(s_touch, s_solid, &s_start, layouts, masks, n, tx0, ty0, min(tx0 + B_TILE_W, W), min(ty0 + rh, H), tid, 256);
-    const int start = s_start;
-    // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
-    tile_needs(s_touch, start, &s_general, layouts, n, tid, 256);
+    if (tid < MAX_LAYOUT_WORDS) s_touch[tid] = pre->touch[tid];
+    const int start = pre->start;
+    const u32 needs = pre->general;  // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
     __syncthreads();
-    const bool general = (s_general & 1) != 0;
-    const bool sampled = s_general == 2;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)
+    const bool general = (needs & 1u) != 0;
+    const bool sampled = needs == 2u;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)
     if (ablate & 2) return;
     if ((ablate & 16) && general) return;   // profiling: copy tiles only
     if ((ablate & 32) && !general) return;  // profiling: general tiles only
@@ -523,7 +540,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         const u32 gi = blockIdx.x / (u32)slices;
         if (gi >= full->count) return;
         const int rh = B_TILE_H / slices;
-        compose_full<NV, BIG>((int)full->tiles[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
+        compose_full<NV, BIG>(&full->e[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
                          tables, tiles_x, s_tab);
         return;
     }
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
 #pragma unroll 1
     for (int k = 0; k < B_COPY_TILES; k++)
         if (c[k].kind == TC_FULL && (int)c[k].pitch_or_px >= n_banded)
-            compose_full<NV, BIG>(t0 + k, 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+            compose_full<NV, BIG>(&full->e[c[k].pitch_or_px], 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
 }
 
 }  // namespace
