@@ -239,6 +239,12 @@ SMR_API int smr_resample_pass(smr_ctx *ctx, const smr_surface *src, int axis, fl
 SMR_API int smr_downsample(smr_ctx *ctx, const smr_surface *src, uint32_t fx, uint32_t fy, smr_surface *dst);
 /* format/rgba_rescale.wgsl via FramePreProcessor::rescale_node_texture (frame_pre_processor.rs:117-132) */
 SMR_API int smr_rescale_bilinear(smr_ctx *ctx, const smr_surface *src, smr_surface *dst);
+/* a15: FramePreProcessor::process_to_bytes (state/frame_pre_processor.rs:84-107) in one call — the frame (device-resident, any
+ * smr_frame_format) through convert_to_node_texture into an RGBA8 node texture at its own resolution, the optional bilinear rescale
+ * to dst_w x dst_h (0 x 0 = none; filtering in linear light in GpuOptimized mode, as rescale_node_texture does it) and the
+ * read-back as tightly packed rows (host_pitch 0) or rows host_pitch bytes apart.  Blocks until the bytes are in `host`.
+ * The intermediate surfaces belong to the context and are reused while the resolutions repeat (as the reference's instance does). */
+SMR_API int smr_frame_preprocess(smr_ctx *ctx, const smr_frame *in, uint32_t dst_w, uint32_t dst_h, void *host, size_t host_pitch);
 
 /* ---- a9/a10: LayoutShader::render (layout/shader.rs:93-167 + apply_layouts.wgsl) ---
  * Clears target to transparent, draws layouts back to front with premultiplied OVER.

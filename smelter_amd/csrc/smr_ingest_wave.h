@@ -265,7 +265,7 @@ struct WJob {
     int layer, ox, oy;    // direct output: the layer this tile is blitted by (-1 = none) and its (even) position in the output frame
 };
 
-constexpr int MAX_WJOBS_PER_LAUNCH = 12;
+constexpr int MAX_WJOBS_PER_LAUNCH = 16;
 struct WArgs {
     WJob jobs[MAX_WJOBS_PER_LAUNCH];
     int wg_prefix[MAX_WJOBS_PER_LAUNCH + 1];  // workgroups per job = n_pairs * pieces / W_WAVES, piece-group major, pair fastest

@@ -342,4 +342,28 @@ int smr_rescale_bilinear(smr_ctx *ctx, const smr_surface *src, smr_surface *dst)
     return smr_check_hip(ctx, hipGetLastError(), "k_rescale_bilinear");
 }
 
+
+// FramePreProcessor::process_to_bytes (state/frame_pre_processor.rs:84-107): upload_and_convert_to_node_texture, the optional
+// rescale_node_texture, download — the three public passes chained on the context's own scratch surfaces.
+int smr_frame_preprocess(smr_ctx *ctx, const smr_frame *in, uint32_t dst_w, uint32_t dst_h, void *host, size_t host_pitch) {
+    SMR_ENTER(ctx);
+    if (!ctx || !in || !host) return SMR_ERR_INVALID;
+    if ((dst_w == 0) != (dst_h == 0)) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_preprocess: target %ux%u (both zero = no rescale)", dst_w, dst_h);
+    if (int rc = smr_validate_frame(ctx, in, "smr_frame_preprocess")) return rc;
+    constexpr size_t SLOT_PRE_NODE = 3300, SLOT_PRE_SCALED = 3301;
+    smr_surface *node = smr_cached_surface(ctx, SLOT_PRE_NODE, in->width, in->height, SMR_PX_RGBA8);
+    if (!node) return SMR_ERR_OOM;
+    int rc = smr_frame_to_rgba(ctx, in, node);
+    if (rc != SMR_OK) return rc;
+    const smr_surface *out = node;
+    if (dst_w) {
+        smr_surface *scaled = smr_cached_surface(ctx, SLOT_PRE_SCALED, dst_w, dst_h, SMR_PX_RGBA8);
+        if (!scaled) return SMR_ERR_OOM;
+        rc = smr_rescale_bilinear(ctx, node, scaled);
+        if (rc != SMR_OK) return rc;
+        out = scaled;
+    }
+    return smr_surface_download(ctx, out, host, host_pitch);
+}
+
 }  // extern "C"

@@ -340,6 +340,13 @@ class Context:
     def downsample(self, src: Surface, fx: int, fy: int, dst: Surface):
         self._check(self.lib.smr_downsample(self.handle, src.handle, fx, fy, dst.handle))
 
+    def frame_preprocess(self, frame: DeviceFrame, size: Optional[tuple] = None) -> np.ndarray:
+        """FramePreProcessor::process_to_bytes: frame -> RGBA8 node texture -> optional bilinear rescale to `size` = (w, h) -> bytes."""
+        w, h = size if size else (frame.w, frame.h)
+        out = np.empty((h, w, 4), np.uint8)
+        self._check(self.lib.smr_frame_preprocess(self.handle, C.byref(frame.c), (size or (0, 0))[0], (size or (0, 0))[1], out.ctypes.data, 0))
+        return out
+
     def rescale_bilinear(self, src: Surface, dst: Surface):
         self._check(self.lib.smr_rescale_bilinear(self.handle, src.handle, dst.handle))
 

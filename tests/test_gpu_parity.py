@@ -245,6 +245,48 @@ def test_rescale_bilinear(ctx, ctx_cpu, hip, srgb):
     check(d.download(), orc.rescale_bilinear(src, 123, 77, orc.PX_RGBA8_SRGB if srgb else orc.PX_RGBA8_UNORM), TOL, 0.99, "rescale")
 
 
+# ------------------------------------------------------------------ a15 FramePreProcessor::process_to_bytes, chained
+@pytest.mark.parametrize("fmt_name,size", [("420", None), ("420", (123, 77)), ("nv12", (200, 120)), ("j420", (64, 36)), ("uyvy", (96, 54)),
+                                           ("bgra", None), ("bgra", (50, 30)), ("444", (161, 91))])
+def test_frame_preprocess_chain(ctx, hip, fmt_name, size):
+    """smr_frame_preprocess = upload_and_convert_to_node_texture -> rescale_node_texture (optional) -> download
+    (state/frame_pre_processor.rs:84-132) in one call, against the oracle's converter followed by its bilinear rescale."""
+    w, h = 160, 90
+    rng = np.random.default_rng(7)
+    if fmt_name in ("420", "j420", "444"):
+        ov = {"420": orc.YUV420, "j420": orc.YUVJ420, "444": orc.YUV444}[fmt_name]
+        ch, cw = orc.chroma_shape(w, h, ov)
+        y, u, v = (rng.integers(0, 256, s, dtype=np.uint8) for s in ((h, w), (ch, cw), (ch, cw)))
+        f = ctx.frame({"420": hip.FRAME_PLANAR_YUV420, "j420": hip.FRAME_PLANAR_YUVJ420, "444": hip.FRAME_PLANAR_YUV444}[fmt_name], w, h, [y, u, v])
+        node = orc.planar_yuv_to_rgba(y, u, v, w, h, ov)
+    elif fmt_name == "nv12":
+        y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        uv = rng.integers(0, 256, (h // 2, w // 2, 2), dtype=np.uint8)
+        f = ctx.frame(hip.FRAME_NV12, w, h, [y, uv])
+        node = orc.nv12_to_rgba(y, uv, w, h)
+    elif fmt_name == "uyvy":
+        data = rng.integers(0, 256, (h, w // 2, 4), dtype=np.uint8)
+        f = ctx.frame(hip.FRAME_UYVY422, w, h, [data])
+        node = orc.interleaved422_to_rgba(data, w, h, 0)
+    else:
+        data = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        f = ctx.frame(hip.FRAME_BGRA, w, h, [data])
+        node = orc.swizzle_to_rgba(data, w, h, 0)
+    got = ctx.frame_preprocess(f, size)
+    want = node if size is None else orc.rescale_bilinear(node, size[0], size[1], orc.PX_RGBA8_SRGB)
+    assert got.shape == want.shape
+    check(got, want, TOL, 0.99, f"preprocess {fmt_name} -> {size}")
+    # the same bytes as the three public passes one by one
+    n = ctx.frame_to_rgba(f)
+    if size is not None:
+        d = ctx.surface(size[0], size[1])
+        ctx.rescale_bilinear(n, d)
+        n = d
+    assert (n.download() == got).all()
+    with pytest.raises(hip.SmrError):
+        ctx.frame_preprocess(f, (0, 5))
+
+
 # ------------------------------------------------------------------ a9/a10 compositor
 def _layout_zoo(W, H):
     col = lambda c: orc.color_to_shader(c, True)
