@@ -20,6 +20,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define dev_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
 #define dev_udot4(a, b, c) __builtin_amdgcn_udot4((a), (b), (c), false)
 #define dev_fmed3(a, b, c) __builtin_amdgcn_fmed3f((a), (b), (c))
+#define dev_mad24(a, b, c) ((u32)__umul24((a), (b)) + (c))  // a, b < 2^24: v_mad_u32_u24
 #define dev_readfirstlane(x) __builtin_amdgcn_readfirstlane(x)
 #define dev_mfma_16x16x32_f16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16((a), (b), (c), 0, 0, 0)
 #define dev_wait_vmcnt0() __builtin_amdgcn_s_waitcnt(0x0f70)

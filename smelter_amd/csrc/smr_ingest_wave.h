@@ -58,6 +58,14 @@ namespace {
 #ifndef SMR_WAVE_TIMING
 #define SMR_WAVE_TIMING 0  // profiling build (tools/variant.sh): shader cycles per phase of the first wave of every workgroup -> WArgs::dbg
 #endif
+#ifndef SMR_WAVE_ONE_TILE
+#define SMR_WAVE_ONE_TILE 0  // profiling experiment: 1 = every wave works on the first tile of its pair only (half of the output is not written)
+#endif
+#define W_NTI (SMR_WAVE_ONE_TILE ? 1 : 2)
+#ifndef SMR_WAVE_B_REGS
+#define SMR_WAVE_B_REGS 0   // 1: narrow class builds keep the pair's pass-1 weights in registers for the whole piece (no LDS band, no re-reads):
+                            // + 31 VGPRs, 12 LDS reads fewer per chunk, measured neutral (57.5 vs 57.6 us): the kernel is bound by vector-ALU issue
+#endif
 #ifndef SMR_WAVE_PREFETCH_B
 #define SMR_WAVE_PREFETCH_B 0  // 1: a k-step's weight fragments are read from LDS before its block is converted (A/B knob)
 #endif
@@ -292,6 +300,15 @@ __host__ __device__ inline int w_band_bytes(int nks) { return 2 * nks * 2 * 64 *
 // starts in k-step 0 (those two zero fragments are skipped), 2048 direct output, 4096 NV12-capable staging.
 // `finish_prologue`: stores the workgroup's tables into LDS and meets the other waves — called once, after this wave's first global
 // loads are in flight and before its first LDS access.
+// srgb_encode8 (smr_internal.h) with the clamp as one median: the operand is a finite matrix-core sum, never a NaN to be quieted first.
+__device__ __forceinline__ u32 w_encode8(float x, const float *__restrict__ thr) {
+    const u8 *enc = (const u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
+    const float xc = dev_fmed3(x, 1.220703125e-4f, 0.99999994f);
+    u32 c = enc[(__float_as_uint(xc) - 0x39000000u) >> 16];
+    c += thr[c + 1] <= x ? 1u : 0u;
+    return c;
+}
+
 template <int NKS_T, int KV_T, int FL, typename Pro>
 __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restrict__ Dg, int pair, int vt0, int vt1, u8 *smem, u32 b_off, u32 raw_off,
                                            unsigned long long *dbg, Pro finish_prologue) {
@@ -350,6 +367,22 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     const int c_col0c = w_clampi(c_col0, 0, (cw - 1) & ~3);  // ... of the dword actually loaded (clamp-to-edge)
     const bool c_live = c_d < cs;
     const bool c_edge = c_live && (c_col0 < 0 || c_col0 + 3 > cw - 1);
+    // per-lane constants of the loads: luma column offsets; per chroma load the plane base, its pitch and the row within the chunk
+    u32 y_col[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) y_col[cb] = (u32)min(base + 4 * (16 * cb + l16), sw4 - 4);
+    const u8 *c_base[NCL];
+    u32 c_pitch[NCL];
+    int c_row[NCL];
+#pragma unroll
+    for (int k = 0; k < NCL; k++) {
+        const int rt = min(RPLC * k + c_t, 17);  // (plane, row) task; tasks past the 18th repeat the last one
+        const int plane = rt >= 9 ? 1 : 0;
+        c_row[k] = rt - 9 * plane;
+        c_base[k] = plane ? v_ptr : u_ptr;
+        c_pitch[k] = plane ? v_pitch : u_pitch;
+    }
+    const u32 c_colb = nv ? 2u * (u32)c_col0c : (u32)c_col0c;
     auto issue = [&](int c) {
         if (SMR_WAVE_ABL & 256) c = J.v_meta[vt0].x;  // profiling: always the same rows (cache hits)
         if (SMR_WAVE_ABL & 128) {                       // profiling: no global loads
@@ -359,26 +392,20 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             for (int k = 0; k < NCL; k++) pc[k] = 0x80808080u + (u32)c;
             return;
         }
-        const int r0 = 16 * c - 1;
+        // (32-bit offsets from the plane bases: a plane is far below 4 GiB; row * pitch is a 24-bit multiply-add with the lane's column)
+        const int r0 = 16 * c - 1 + lq;
 #pragma unroll
         for (int rb = 0; rb < 4; rb++) {
-            const u8 *rowp = y_ptr + (size_t)w_clampi(r0 + 4 * rb + lq, 0, sh - 1) * y_pitch;
+            const u32 row = (u32)min(max(r0 + 4 * rb, 0), sh - 1);
 #pragma unroll
-            for (int cb = 0; cb < NCB; cb++)
-                py[rb * NCB + cb] = *(const u32 *)(rowp + min(base + 4 * (16 * cb + l16), sw4 - 4));
+            for (int cb = 0; cb < NCB; cb++) py[rb * NCB + cb] = *(const u32 *)(y_ptr + dev_mad24(row, y_pitch, y_col[cb]));
         }
         const int i0 = 8 * c - 1;  // chroma row of the chunk's first row pair
 #pragma unroll
         for (int k = 0; k < NCL; k++) {
-            const int rt = min(RPLC * k + c_t, 17);  // (plane, row) task; tasks past the 18th repeat the last one
-            const int plane = rt >= 9 ? 1 : 0, r = rt - 9 * plane;
-            const u8 *rowp = (plane ? v_ptr : u_ptr) + (size_t)w_clampi(i0 + r, 0, chh - 1) * (plane ? v_pitch : u_pitch);
-            if (nv) {  // four chroma texels = eight interleaved bytes; the plane's four are picked when they land
-                pc[k] = *(const u32 *)(rowp + 2 * (u32)c_col0c);
-                pc_hi[NV ? k : 0] = *(const u32 *)(rowp + 2 * (u32)c_col0c + 4);
-            } else {
-                pc[k] = *(const u32 *)(rowp + (u32)c_col0c);
-            }
+            const u32 off = dev_mad24((u32)min(max(i0 + c_row[k], 0), chh - 1), c_pitch[k], c_colb);
+            pc[k] = *(const u32 *)(c_base[k] + off);
+            if (nv) pc_hi[NV ? k : 0] = *(const u32 *)(c_base[k] + off + 4);  // (four chroma texels = eight interleaved bytes; the plane's four are picked when they land)
         }
     };
     auto land = [&]() {
@@ -425,13 +452,14 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     const u32 w13 = (l16 & 1) ? WB13 : WA13, w31 = (l16 & 1) ? WB31 : WA31;
 
     // ---- pass-2 state: the ring of f16 rows (two chunks per register quad) and the weights of the next tile to finish
-    uint4 ring[2][3][KV_N];
+    //      (one register vector per tile and channel, written at a uniform runtime index: register-indexed moves, not a select per slot)
+    typedef u32 ring_t __attribute__((ext_vector_type(4 * KV_N)));
+    ring_t ring[2][3];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < W_NTI; i++)
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int p = 0; p < KV_N; p++) ring[i][c][p] = make_uint4(0u, 0u, 0u, 0u);
+        for (int c = 0; c < 3; c++) ring[i][c] = (ring_t)(0u);
+    auto ring_quad = [&](int i, int ch, int p) { return make_uint4(ring[i][ch][4 * p], ring[i][ch][4 * p + 1], ring[i][ch][4 * p + 2], ring[i][ch][4 * p + 3]); };
     uint4 bvh[KV_N], bvl[KV_N];
     const uint4 *const v_frag = J.v_frag;
     const bool dj = DIRECT && Dg != nullptr && J.layer >= 0;  // (uniform)
@@ -446,7 +474,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             }
         if (dj) {  // direct output: the class of the 128x16 output tile this lane's four pixels of tile row t fall into
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < W_NTI; i++) {
                 const int x = tx0 + 16 * i + 4 * lq, y = 16 * t + l16;
                 const int X = d_ox + x, Y = d_oy + y;
                 const bool in = y < d_h && x < d_w && X >= 0 && Y >= 0 && X < Dg->yp.w && Y < Dg->yp.h;
@@ -455,6 +483,28 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             }
         }
     };
+
+    // ---- narrow class builds: the pair's pass-1 band (hi / lo fragments of both tiles, every k-step that is not known to be zero) is
+    //      loop-invariant: it lives in registers for the whole piece instead of being re-read from LDS chunk after chunk
+    constexpr bool B_REGS = FIXED_NKS && SMR_WAVE_PIPE && SMR_WAVE_B_REGS;
+    uint4 breg[B_REGS ? 2 : 1][B_REGS ? NKS_N : 1][2];
+    if (B_REGS) {
+        const uint4 *const src = J.h_frag + (size_t)pair * 2 * J.NKS * 2 * 64;
+#pragma unroll
+        for (int i = 0; i < W_NTI; i++)
+#pragma unroll
+            for (int j = 0; j < NKS_N; j++) {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+                const bool skip = K01 && ((i == 0 && j == 3) || (i == 1 && j == 0));  // (known zero: never read)
+                const bool have = !skip && j < J.NKS;  // (uniform: a job of the class with a narrower window meets zero weights beyond it)
+                const int jj = min(j, J.NKS - 1);  // (always a valid address; the value is dropped below: a select of addresses would go through scratch)
+                const uint4 fh = skip ? z : src[((i * J.NKS + jj) * 2) * 64 + lane], fl = skip ? z : src[((i * J.NKS + jj) * 2 + 1) * 64 + lane];
+                breg[B_REGS ? i : 0][B_REGS ? j : 0][0] = make_uint4(have ? fh.x : 0u, have ? fh.y : 0u, have ? fh.z : 0u, have ? fh.w : 0u);
+                breg[B_REGS ? i : 0][B_REGS ? j : 0][1] = make_uint4(have ? fl.x : 0u, have ? fl.y : 0u, have ? fl.z : 0u, have ? fl.w : 0u);
+            }
+    } else {
+        breg[0][0][0] = breg[0][0][1] = make_uint4(0u, 0u, 0u, 0u);
+    }
 
     int vt = vt0;
     int2 vm = J.v_meta[vt0];
@@ -474,7 +524,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         // ---- conversion + pass 1 of chunk c: k-step by k-step, straight into the accumulators of the tiles it feeds
         f32x4 acc[2][3];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < W_NTI; i++)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) acc[i][ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (NKS_T && SMR_WAVE_PIPE) {
@@ -489,7 +539,12 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             };
             auto read_b = [&](int j, uint4 (&bq)[2][2]) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < W_NTI; i++) {
+                    if (B_REGS) {  // (a register rename)
+                        bq[i][0] = breg[B_REGS ? i : 0][B_REGS ? j : 0][0];
+                        bq[i][1] = breg[B_REGS ? i : 0][B_REGS ? j : 0][1];
+                        continue;
+                    }
                     bq[i][0] = Bs[((i * NKS + j) * 2) * 64 + lane];
                     bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
                 }
@@ -501,7 +556,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             };
             auto mfmas = [&](int j, const uint4 (&a)[3], const uint4 (&bq)[2][2]) {
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                for (int i = 0; i < W_NTI; i++) {
                     if (K01 && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
                     if (NKS_T > 4 && (j < klo[i] || j > khi[i])) continue;  // (uniform: wide windows — most (tile, k-step) fragments are zero)
 #pragma unroll
@@ -550,7 +605,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     uint4 bq[2][2];
                     if (SMR_WAVE_PREFETCH_B) {
     #pragma unroll
-                        for (int i = 0; i < 2; i++) {
+                        for (int i = 0; i < W_NTI; i++) {
                             bq[i][0] = Bs[((i * NKS + j) * 2) * 64 + lane];
                             bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
                         }
@@ -572,7 +627,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                         continue;
                     }
     #pragma unroll
-                    for (int i = 0; i < 2; i++) {
+                    for (int i = 0; i < W_NTI; i++) {
                         if (K01 && NKS_T && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
                         if (NKS_T || (j >= klo[i] && j <= khi[i])) {  // (uniform)
                             if (!SMR_WAVE_PREFETCH_B) {
@@ -599,25 +654,38 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
         // ---- the chunk's 16 rows of H, rounded to f16 (resampler.rs:25-28), into ring slot c mod 2 KV: lane holds rows 4 lq .. + 3 of
         //      output column l16 of either tile
+        u32 h16[2][3][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < W_NTI; i++)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
                 const __half2 h0 = __floats2half2_rn(acc[i][ch][0], acc[i][ch][1]), h1 = __floats2half2_rn(acc[i][ch][2], acc[i][ch][3]);
                 const u32 lo = *(const u32 *)&h0, hi = *(const u32 *)&h1;
+                h16[i][ch][0] = lo;
+                h16[i][ch][1] = hi;
+            }
+        // (slot is uniform: one taken branch with twelve moves, not a select per slot and value — the empty asm keeps the compiler from
+        //  turning the branches back into selects)
 #pragma unroll
-                for (int s = 0; s < 2 * KV_N; s++)
-                    if (s == slot) {  // (uniform)
-                        if (s & 1) { ring[i][ch][s >> 1].z = lo; ring[i][ch][s >> 1].w = hi; }
-                        else { ring[i][ch][s >> 1].x = lo; ring[i][ch][s >> 1].y = hi; }
+        for (int s = 0; s < 2 * KV_N; s++)
+            if (s == slot) {
+#pragma unroll
+                for (int i = 0; i < W_NTI; i++)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        ring[i][ch][2 * s] = h16[i][ch][0];
+                        ring[i][ch][2 * s + 1] = h16[i][ch][1];
                     }
+#ifndef SMR_EMU
+                asm volatile("" ::: "memory");
+#endif
             }
         slot = slot + 1 == 2 * KV ? 0 : slot + 1;
         W_MARK(3);
         // ---- pass 2 + encode + store of every output tile whose window ends with chunk c
         while (vt <= vt1 && vm.y == c) {
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < W_NTI; i++) {
                 if (klo[i] == 0xff) continue;  // (uniform: no second tile in the last pair of an odd tile count)
                 f32x4 o[3];
 #pragma unroll
@@ -625,7 +693,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 if (SMR_WAVE_ABL & 8) {
                     const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
                     if (!(SMR_WAVE_ABL & 16) && y < d_h && x + 3 < d_w)
-                        *(uint4 *)(d_ptr + (size_t)y * d_pitch + (size_t)x * 4) = make_uint4(ring[i][0][0].x ^ ring[i][1][0].y, ring[i][2][0].z, ring[i][0][KV_N - 1].w, ring[i][1][KV_N - 1].x);
+                        *(uint4 *)(d_ptr + (size_t)y * d_pitch + (size_t)x * 4) = make_uint4(ring[i][0][0] ^ ring[i][1][1], ring[i][2][2], ring[i][0][4 * KV_N - 1], ring[i][1][4 * KV_N - 4]);
                     continue;
                 }
 #pragma unroll
@@ -633,10 +701,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     if (p < KV) {
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)
-                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring[i][ch][p]), __builtin_bit_cast(f16x8, bvh[p]), o[ch]);
+                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvh[p]), o[ch]);
 #pragma unroll
                         for (int ch = 0; ch < 3; ch++)
-                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring[i][ch][p]), __builtin_bit_cast(f16x8, bvl[p]), o[ch]);
+                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvl[p]), o[ch]);
                     }
                 }
                 W_MARK(4);
@@ -645,7 +713,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 u32 px[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    px[k] = srgb_encode8(o[0][k], s_thr) | (srgb_encode8(o[1][k], s_thr) << 8) | (srgb_encode8(o[2][k], s_thr) << 16) | 0xff000000u;
+                    px[k] = w_encode8(o[0][k], s_thr) | (w_encode8(o[1][k], s_thr) << 8) | (w_encode8(o[2][k], s_thr) << 16) | 0xff000000u;
 #ifndef SMR_EMU
 #pragma unroll
                 for (int k = 0; k < 4; k++) asm volatile("" : "+v"(px[k]));  // (all twelve lookups in flight together: not sunk into the store branches)
@@ -662,7 +730,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     if (direct) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);
                 }
                 if (!direct && y < d_h && x < d_w && (!(SMR_WAVE_ABL & 16) || px[0] == 0x12345678u)) {  // (16: profiling, all work but no store traffic)
-                    u8 *op = d_ptr + (size_t)y * d_pitch + (size_t)x * 4;
+                    u8 *op = d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u);  // (a tile is far below 4 GiB)
                     if (x + 3 < d_w) {
                         *(uint4 *)op = make_uint4(px[0], px[1], px[2], px[3]);
                     } else {
@@ -723,7 +791,8 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
     const uint4 *src = J.h_frag + (size_t)pair * 2 * J.NKS * 2 * 64;
     uint4 *Bs = (uint4 *)(smem + W_OFF_B);
     constexpr int NL = (M_LUT_ENTRIES + W_THREADS - 1) / W_THREADS, NT = (SMR_TABLE_FLOATS - 256 + W_THREADS - 1) / W_THREADS;
-    constexpr int NB = NKS_T ? (2 * NKS_T * 2 * 64 + W_THREADS - 1) / W_THREADS : 1;
+    constexpr bool B_REGS = NKS_T > 0 && NKS_T <= 4 && SMR_WAVE_PIPE && SMR_WAVE_B_REGS;  // (as in wave_piece: no LDS band)
+    constexpr int NB = NKS_T && !B_REGS ? (2 * NKS_T * 2 * 64 + W_THREADS - 1) / W_THREADS : 1;
     u32 r_lut[NL];
     float r_thr[NT];
     uint4 r_b[NB];
@@ -731,7 +800,7 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
     for (int k = 0; k < NL; k++) r_lut[k] = lut[min(max(tid + k * W_THREADS - 256, 0), 255)];
 #pragma unroll
     for (int k = 0; k < NT; k++) r_thr[k] = tables[256 + min(tid + k * W_THREADS, SMR_TABLE_FLOATS - 257)];
-    if (NKS_T) {
+    if (NKS_T && !B_REGS) {
 #pragma unroll
         for (int k = 0; k < NB; k++) {  // (a job of the class with a narrower window: its band in the class's layout, zero beyond)
             const int i = tid + k * W_THREADS, t = i / (NKS * 128), r = i - t * (NKS * 128);
@@ -746,7 +815,8 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
 #pragma unroll
         for (int k = 0; k < NT; k++)
             if (tid + k * W_THREADS < SMR_TABLE_FLOATS - 256) ((float *)(smem + W_OFF_THR))[tid + k * W_THREADS] = r_thr[k];
-        if (NKS_T) {
+        if (B_REGS) {
+        } else if (NKS_T) {
 #pragma unroll
             for (int k = 0; k < NB; k++)
                 if (tid + k * W_THREADS < 2 * NKS * 2 * 64) Bs[tid + k * W_THREADS] = r_b[k];
@@ -987,7 +1057,8 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         if (any_nv) ki += 8;
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
         const WaveKernel kern = W_KERNELS[ki];
-        args.b_bytes = w_band_bytes(cls_nks ? cls_nks : nks_max);
+        // (the narrow class keeps its pass-1 band in registers: no LDS for it)
+        args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);
         args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;
         const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
         if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of LDS", lds);

@@ -40,6 +40,7 @@ static inline unsigned dev_udot4(unsigned a, unsigned b, unsigned c) {
     for (int i = 0; i < 4; i++) c += ((a >> (8 * i)) & 0xffu) * ((b >> (8 * i)) & 0xffu);
     return c;
 }
+static inline uint32_t dev_mad24(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xffffffu) * (b & 0xffffffu) + c; }
 static inline float dev_fmed3(float a, float b, float c) {
     const float lo = a < b ? a : b, hi = a < b ? b : a;
     return c < lo ? lo : (c > hi ? hi : c);
