@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-frames", type=int, default=2000)
-    ap.add_argument("--ingest", choices=["auto", "valu", "mfma"], default="auto",
+    ap.add_argument("--ingest", choices=["auto", "valu", "mfma", "mfma_wg"], default="auto",
                     help="ingest + Lanczos kernel: matrix cores where applicable (auto, default), exact f32 (valu)")
     ap.add_argument("--direct-output", action="store_true",
                     help="SMR_OPT_DIRECT_OUTPUT: the resampling kernel writes Y'CbCr for the compositor's copy tiles (A/B; default off)")
@@ -214,7 +214,7 @@ def main():
     if side is not None:
         torch.cuda.set_stream(side)
     ctx = hip.Context(local_rank, stream=side.cuda_stream if side is not None else None)
-    ingest_impl = {"auto": hip.INGEST_AUTO, "valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_MFMA_F16}[args.ingest]
+    ingest_impl = {"auto": hip.INGEST_AUTO, "valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_MFMA_F16, "mfma_wg": hip.INGEST_MFMA_F16_WG}[args.ingest]
     ctx.set_ingest_impl(ingest_impl)
     ctx.set_direct_output(args.direct_output)
     layouts, res = build_scene()
@@ -405,22 +405,24 @@ def main():
         if dom is not None:
             b = kernel_bytes.get(dom, ALGO_BYTES_PER_FRAME)
             ach = b / (stages[dom]["avg_us"] * 1e-6) / 1e9
-            kname = {"fused_ingest_resample": "k_ingest_resample" if args.ingest == "valu" else "k_ingest_mfma",
+            kname = {"fused_ingest_resample": {"valu": "k_ingest_resample", "mfma_wg": "k_ingest_mfma"}.get(args.ingest, "k_ingest_wave"),
                      "fused_compose_output": "k_compose_output"}.get(dom, dom)
             # HBM bytes per launch from the PMC passes of tools/prof.sh on this same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
             # separate --pmc runs): counters cannot be read from inside the process, so the committed summary is quoted
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
-            if os.path.exists(tpath) and args.config == 2:  # the committed counter passes are of the default workload
+            tname = {2: "r03_traffic.json", 3: "r03_traffic_configs3.json"}.get(args.config)  # the committed counter passes: default workload, target
+            tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+            if tpath and os.path.exists(tpath):
                 t = json.load(open(tpath)).get(kname)
                 if t:
-                    traffic, traffic_src = t["hbm_bytes_per_launch"], "profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                    traffic, traffic_src = t["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
             result["roofline"] = {"bound": "hbm", "kernel": kname,
                                   "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
                                   "bytes_per_launch": b, "avg_launch_us": stages[dom]["avg_us"], "traffic": traffic,
                                   "traffic_source": traffic_src,
-                                  "limiter": "vector ALU issue (colour conversion at ~70 cycles per pixel of half-rate conversions / 3-operand ops) and "
-                                             "LDS gathers (decode / encode tables), not HBM: see DESIGN.md section 3"}
+                                  "limiter": "instruction issue, not HBM: ~580 vector-ALU + 54 matrix-core + ~110 LDS instructions per 1024 source "
+                                             "pixels (25 vector-ALU per pixel of colour conversion, most of them half-rate), saturated at two waves per "
+                                             "SIMD — a third wave per SIMD gains nothing (profiles/r03_occupancy.txt); see DESIGN.md section 3"}
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM
         lat = []

@@ -289,9 +289,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         }
     }
     memcpy((u8 *)packed.extra_host + order_bytes, &direct, sizeof(direct));
-    const MDirect *direct_dev = direct.cls ? (const MDirect *)((const u8 *)packed.extra_dev + order_bytes) : nullptr;
-    rc = smr_pack_commit(ctx, &packed);
+    rc = smr_pack_commit(ctx, &packed);  // (may move the pack's device pointers onto the previous frame's identical copy)
     if (rc != SMR_OK) return rc;
+    const MDirect *direct_dev = direct.cls ? (const MDirect *)((const u8 *)packed.extra_dev + order_bytes) : nullptr;
     if (classify_now) {
         SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_classify_tiles, dim3(b_tiles), dim3(64), 0, ctx->stream, packed.layouts, packed.masks, packed.n, (int)out_w, (int)out_h,

@@ -54,6 +54,7 @@ struct LayoutSlot {
     size_t bytes = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
+    size_t resident_bytes = 0;  // leading bytes of host that the device copy holds (0 = none): smr_pack_commit's reuse
 };
 
 struct StagePending {
@@ -99,6 +100,9 @@ struct smr_ctx {
     // per-call layout parameters travel through a ring of pinned staging slots
     std::vector<LayoutSlot> layout_ring;
     size_t layout_ring_next = 0;
+    int layout_last = -1;           // ring index of the pack committed last (its device copy is reused by an identical pack)
+    bool no_pack_reuse = false;     // SMR_NO_PACK_REUSE (A/B, tests)
+    unsigned long long pack_reused = 0;
     // scratch owned by the ctx (resampler intermediates, fused tiles)
     struct Scratch { void *ptr = nullptr; size_t bytes = 0; };
     std::vector<Scratch> scratch;  // indexed slots, grown on demand

@@ -76,6 +76,10 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         slot.bytes = want;
     }
     if (!slot.done) SMR_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+    // (the slot's device copy no longer matches anything; zeroed so that equal packs are equal byte for byte, padding included)
+    slot.resident_bytes = 0;
+    if (ctx->layout_last == (int)(&slot - ctx->layout_ring.data())) ctx->layout_last = -1;
+    memset(slot.host, 0, bytes);
 
     DevLayout *hl = (DevLayout *)slot.host;
     DevMask *hm = (DevMask *)((u8 *)slot.host + lay_bytes);
@@ -211,8 +215,24 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
 }
 
 // host -> device copy of the packed slot (after the caller filled the extra region)
+// A pack that equals, byte for byte, the one committed last (a scene that does not move between two frames: same layouts, same
+// source surfaces, same parameter block) reuses that pack's device copy: no copy is queued, the frame is its kernels only.  The
+// staging slot just filled goes back to the ring (it is the next one handed out), the reused slot stays busy until this frame is done.
 int smr_pack_commit(smr_ctx *ctx, PackedLayouts *p) {
+    LayoutSlot *prev = ctx->layout_last >= 0 ? &ctx->layout_ring[(size_t)ctx->layout_last] : nullptr;
+    if (prev && prev != p->slot && !ctx->no_pack_reuse && prev->resident_bytes == p->copy_bytes && memcmp(prev->host, p->slot->host, p->copy_bytes) == 0) {
+        const ptrdiff_t d = (const u8 *)prev->dev - (const u8 *)p->slot->dev;
+        p->layouts = (const DevLayout *)((const u8 *)p->layouts + d);
+        p->masks = (const DevMask *)((const u8 *)p->masks + d);
+        p->extra_dev = (u8 *)p->extra_dev + d;
+        ctx->layout_ring_next = (size_t)(p->slot - ctx->layout_ring.data());
+        p->slot = prev;
+        ctx->pack_reused++;
+        return SMR_OK;
+    }
     SMR_HIP(ctx, hipMemcpyAsync(p->slot->dev, p->slot->host, p->copy_bytes, hipMemcpyHostToDevice, ctx->stream));
+    p->slot->resident_bytes = p->copy_bytes;
+    ctx->layout_last = (int)(p->slot - ctx->layout_ring.data());
     return SMR_OK;
 }
 

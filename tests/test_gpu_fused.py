@@ -681,6 +681,51 @@ def test_tile_class_cache_survives_alternating_and_evicted_layout_lists(hip):
         c.close()
 
 
+def test_a_scene_at_rest_reuses_its_parameter_pack_with_new_pixels(hip, monkeypatch):
+    """smr_pack_commit queues no copy when the packed layout list equals the previous frame's byte for byte (a scene that does not
+    move): the device copy of that frame is read again.  The pixels are new every frame — same device frames, new uploads — and a
+    different list in between must not be served from the stale copy.  Every frame equals the frame of a context that never reuses."""
+    iw, ih, W, H = 480, 270, 960, 540
+    lay_a, res_a = scenes.cfg3_scene(iw, ih, W, H, 4)
+    lay_b = [Layout_shift(l, 16, 8) for l in lay_a]
+    frames_px = [[scenes.test_input(i, iw, ih, noise_seed=100 * t + i) for i in range(4)] for t in range(4)]
+    sequence = [(lay_a, 0), (lay_a, 1), (lay_a, 2), (lay_b, 2), (lay_b, 3), (lay_a, 3), (lay_a, 0)]
+
+    def run(c):
+        _, label_host = _label_surfaces(c, 1)
+        lt = c.surface_from(label_host)
+        dev = [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih) for _ in range(4)]
+        outs = []
+        for lay, t in sequence:
+            for i in range(4):
+                dev[i].upload(list(frames_px[t][i]))
+            srcs, k = [], 0
+            for r in res_a:
+                if r == (iw, ih):
+                    srcs.append(dev[k])
+                    k += 1
+                else:
+                    srcs.append(lt)
+            outs.append(_render(c, hip, lay, srcs, W, H))
+        return outs
+
+    c = hip.Context(0)
+    try:
+        got = run(c)
+    finally:
+        c.close()
+    monkeypatch.setenv("SMR_NO_PACK_REUSE", "1")
+    f = hip.Context(0)
+    try:
+        want = run(f)
+    finally:
+        f.close()
+    for step, (g, w_) in enumerate(zip(got, want)):
+        for a, b, pl in zip(g, w_, "YUV"):
+            assert np.array_equal(a, b), f"frame {step} plane {pl}: {int((a != b).sum())} bytes differ"
+    assert not np.array_equal(got[0][0], got[1][0]) and not np.array_equal(got[2][0], got[3][0])  # (the frames do differ)
+
+
 def Layout_shift(l, dx, dy):
     import copy
     m = copy.deepcopy(l)
