@@ -33,9 +33,10 @@ constexpr u32 B_MAX_FIRST = 1024;
 // Measured on configs[2] (kernel incl. ~6 us of stage timer, frames/s one / three in flight): 1 band 41.8 us, 10.1k / 13.9k;
 // 2 bands 29.2 us, 11.7k / 13.3k; 4 bands 30.1 us, 11.5k / 13.0k; 8 bands 33.6 us, 10.2k / 12.6k — every band repeats the
 // workgroup's fixed work (layout list, classification, tables), so two is the default.
-constexpr int B_SLICES = 8;  // ctx->compose_slices (1, 2, 4 or 8: a band holds whole 4x2 output blocks).  Round 3: the bands start from the
-                             // classifier's per-tile record instead of classifying again, so a band's fixed work is small and eight
-                             // one-sweep bands are the fastest (measured: bench.py --inflight 1, SMR_COMPOSE_SLICES)
+constexpr int B_SLICES = 4;  // ctx->compose_slices (1, 2, 4 or 8: a band holds whole 4x2 output blocks).  Round 3: the bands start from the
+                             // classifier's per-tile record instead of classifying again, so a band's fixed work is small; measured with the
+                             // scene's parameter pack resident (profiles/r03_compose_ab.txt): four bands 23.2 us on configs[2] and 48.3 us
+                             // on configs[4], eight bands 25.0 / 57.1 us
 struct ComposeOrder {
     u32 n_first;             // workgroups [0, B_SLICES * n_first) take the bands of first[]; workgroup B_SLICES * n_first + t takes tile t unless it is in `taken`
     u16 first[B_MAX_FIRST];  // linear tile indices
@@ -397,11 +398,11 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
     const int start = pre->start;
     const u32 needs = pre->general;  // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
     __syncthreads();
-    const bool general = (needs & 1u) != 0;
-    const bool sampled = needs == 2u;  // nothing but the start layer, and that one needs filtering (a tile in mid-transition)
+    // (k_classify_tiles lists a tile here only when some layer needs blending arithmetic; copy, colour, clear and sampled tiles have
+    //  their own classes and never reach this function.  The general path is correct for any tile, so it is the only one.)
+    const bool general = true;
     if (ablate & 2) return;
-    if ((ablate & 16) && general) return;   // profiling: copy tiles only
-    if ((ablate & 32) && !general) return;  // profiling: general tiles only
+    if (ablate & 16) return;   // profiling: copy tiles only
     const int words = (n + 31) >> 5;
     const bool no_block = px0 >= W || py0 >= H || 2 * (tid >> 5) >= rh;      // (W, H even: a block has four or two columns, always two rows)
     const int nsweeps = (B_TILE_W * rh) / 256;
@@ -478,42 +479,6 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
             acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
             acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
         }
-    } else if (sampled) {
-        // ---- sampled tiles: the whole tile lies in the solid region of one opaque texture layer that is not a texel-aligned
-        //      blit (a video tile at a fractional position or another scale — every tile of a grid in mid-transition) and
-        //      nothing above touches it.  Per pixel this is exactly what the general path does for such a layer (coverage is
-        //      certain, the fragment is the sample, blended over the cleared target), without the per-pixel start search, the
-        //      LDS-resident running colour and the one-pixel-at-a-time sweeps: the eight pixels of a thread's 4x2 block are
-        //      independent, so their texel fetches overlap.
-        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
-        __syncthreads();
-        const float *dec = s_tab, *thr = s_tab + 256;
-        const DevLayout L = load_uniform(&layouts[start]);
-        if (!no_block) {
-#pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] = composite_layout_solid(0u, L, px0 + (k & 3), py0 + (k >> 2), srgb, dec, thr);
-        }
-    } else {
-        if (!no_block && start >= 0) {
-            const DevLayout &L = layouts[start];
-            if (L.type != 0) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) acc[k] = L.solid_px;
-            } else {
-                // 1:1 blit of an opaque texture: bilinear weights are exactly (1,0), decode -> encode is the identity
-                const u8 *r0 = L.src.ptr + (size_t)(py0 - L.iy) * L.src.pitch + (size_t)(px0 - L.ix) * 4;
-                const u8 *r1 = r0 + L.src.pitch;
-                if ((((uintptr_t)r0) & 15) == 0 && (L.src.pitch & 15) == 0 && px0 + 3 < W) {
-                    const uint4 t0 = *(const uint4 *)r0, t1 = *(const uint4 *)r1;
-                    acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
-                    acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        if (px0 + c < W) { acc[c] = ((const u32 *)r0)[c]; acc[4 + c] = ((const u32 *)r1)[c]; }
-                }
-            }
-        }
     }
 
     if (!no_block) store_yuv_block<NV>(acc, px0, py0, W, yp, up, vp);
@@ -535,15 +500,18 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     // The first `slices * n_banded` workgroups take the tiles that need compositing (TileList; the host sized the grid from the
     // list's length when it knows it, from its own prediction otherwise), band by band — they are latency-bound and would be the
     // tail of the kernel.  Every other workgroup takes B_COPY_TILES consecutive tiles of the row-major order.
+    // (the compositing path is most of the kernel's code: it is instantiated once, at the end, and both ways into it — a band of a
+    //  listed tile; a tile the list had no room for — only choose its arguments)
     const int rest = (int)blockIdx.x - slices * n_banded;
+    const TileFull *full_entry = nullptr;
+    int full_band = 0, full_rows = B_TILE_H;
     if (rest < 0) {
         const u32 gi = blockIdx.x / (u32)slices;
         if (gi >= full->count) return;
-        const int rh = B_TILE_H / slices;
-        compose_full<NV, BIG>(&full->e[gi], (int)(blockIdx.x % (u32)slices) * rh, rh, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate,
-                         tables, tiles_x, s_tab);
-        return;
-    }
+        full_rows = B_TILE_H / slices;
+        full_band = (int)(blockIdx.x % (u32)slices) * full_rows;
+        full_entry = &full->e[gi];
+    } else {
     // ---- copy tiles, straight from their class records (k_classify_tiles): no layout list, no classification, no barrier
     const int t0 = rest * B_COPY_TILES;
     const int bx = 4 * (tid & 31), by = 2 * (tid >> 5);
@@ -614,16 +582,23 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         const int px0 = (tile - ty * tiles_x) * B_TILE_W + bx, py0 = ty * B_TILE_H + by;
         if (px0 < W && py0 < H) {
             u32 a[8];
+            // (four pixels at a time: their texel fetches overlap; the second row reuses the code)
+#ifndef SMR_SAMPLED_ROWS_UNROLLED
+#define SMR_SAMPLED_ROWS_UNROLLED 0  // A/B: 1 = both rows of the block unrolled (eight fetches in flight, 14 KB more code)
+#endif
+#pragma unroll(SMR_SAMPLED_ROWS_UNROLLED ? 2 : 1)
+            for (int r = 0; r < 2; r++)
 #pragma unroll
-            for (int q = 0; q < 8; q++) a[q] = composite_layout_solid(0u, L, px0 + (q & 3), py0 + (q >> 2), srgb_and_ablate & 1, s_tab, s_tab + 256);
+                for (int q = 0; q < 4; q++) a[r * 4 + q] = composite_layout_solid(0u, L, px0 + q, py0 + r, srgb_and_ablate & 1, s_tab, s_tab + 256);
             store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
         }
     }
     // a tile that needs compositing and found no room on the band list (the host's bound was short): here, all sixteen rows
-#pragma unroll 1
-    for (int k = 0; k < B_COPY_TILES; k++)
-        if (c[k].kind == TC_FULL && (int)c[k].pitch_or_px >= n_banded)
-            compose_full<NV, BIG>(&full->e[c[k].pitch_or_px], 0, B_TILE_H, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+    static_assert(B_COPY_TILES == 1, "one tile per workgroup is handed on to the compositing path");
+    if (c[0].kind == TC_FULL && (int)c[0].pitch_or_px >= n_banded) full_entry = &full->e[c[0].pitch_or_px];
+    }
+    if (full_entry)  // (uniform)
+        compose_full<NV, BIG>(full_entry, full_band, full_rows, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
 }
 
 }  // namespace
