@@ -396,7 +396,6 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
     if (ty0 >= H) return;
     if (tid < MAX_LAYOUT_WORDS) s_touch[tid] = pre->touch[tid];
     const int start = pre->start;
-    const u32 needs = pre->general;  // does any layer of this tile need blending arithmetic (and therefore the sRGB tables)?
     __syncthreads();
     // (k_classify_tiles lists a tile here only when some layer needs blending arithmetic; copy, colour, clear and sampled tiles have
     //  their own classes and never reach this function.  The general path is correct for any tile, so it is the only one.)
@@ -583,10 +582,8 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
         if (px0 < W && py0 < H) {
             u32 a[8];
             // (four pixels at a time: their texel fetches overlap; the second row reuses the code)
-#ifndef SMR_SAMPLED_ROWS_UNROLLED
-#define SMR_SAMPLED_ROWS_UNROLLED 0  // A/B: 1 = both rows of the block unrolled (eight fetches in flight, 14 KB more code)
-#endif
-#pragma unroll(SMR_SAMPLED_ROWS_UNROLLED ? 2 : 1)
+            // (both rows unrolled: 14 KB more code, same time — profiles/r03_compose_ab.txt, variant s8)
+#pragma unroll 1
             for (int r = 0; r < 2; r++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) a[r * 4 + q] = composite_layout_solid(0u, L, px0 + q, py0 + r, srgb_and_ablate & 1, s_tab, s_tab + 256);
