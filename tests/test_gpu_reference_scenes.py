@@ -13,7 +13,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from tests import refpipe, scenes
+from oracle import scene as S
+from tests import refpipe, scene_json, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +35,17 @@ def ctxs(hip):
     yield c
     for x in c.values():
         x.close()
+
+
+independent = [0]  # snapshots whose oracle picture came from oracle/scene.py's layouts
+
+
+def _convertible(update):
+    try:
+        scene_json.to_oracle(update)
+        return True
+    except scene_json.Unsupported:
+        return False
 
 
 def _input_planes(inp):
@@ -69,11 +81,18 @@ def test_reference_scene(ctxs, hip, case):
         nodes_o[inp["id"]] = orc.planar_yuv_to_rgba(*planes[inp["id"]], inp["width"], inp["height"], omp=True)
     graph = None
     snaps = 0
+    # static = no update of this test carries a transition (a later update of a moving scene would start from an animated state)
+    static = all(_convertible(s["update"]) for s in case["steps"] if "update" in s)
+    oracle_root, oracle_inputs = None, None
     try:
         for step in case["steps"]:
             if "update" in step:
                 renderer.update_scene(OUTPUT_ID, W, H, step["update"])
                 graph = engine.update(step["update"], W, H)
+                try:
+                    oracle_root, oracle_inputs = scene_json.to_oracle(step["update"]) if static else (None, None)
+                except scene_json.Unsupported:
+                    oracle_root, oracle_inputs = None, None
                 continue
             pts_ms = step.get("snapshot_ms", step.get("render_ms"))
             got = renderer.render(pts_ms / 1e3, frames)[OUTPUT_ID].download()
@@ -85,6 +104,14 @@ def test_reference_scene(ctxs, hip, case):
             layouts = engine.layouts(0, int(pts_ms * 1e6), res, hip.MODE_GPU_OPTIMIZED if srgb else hip.MODE_CPU_OPTIMIZED)
             if "snapshot_ms" not in step:
                 continue
+            if oracle_root is not None:
+                # a scene at rest: the picture the product is compared with is rendered from layouts that never saw the product's
+                # scene engine — oracle/scene.py over tests/scene_json.py's reading of the JSON (88 of the 110 scenes; scenes in
+                # transition keep the engine's list: the oracle has no transition state machine.  tests/test_reference_scene_layouts.py
+                # pins both against hand-computed answers)
+                assert [k.ref_id for k in kids] == oracle_inputs
+                layouts = S.scene_layouts(oracle_root, W, H, res, srgb=srgb)
+                independent[0] += 1
             want, _ = refpipe.render_yuv420(layouts, [nodes_o.get(k.ref_id) for k in kids], W, H, srgb=srgb, omp=True)
             for g, w_, pl in zip(got, want, "YUV"):
                 d, ex = refpipe.max_diff(g, w_), refpipe.exact_fraction(g, w_)
@@ -96,3 +123,8 @@ def test_reference_scene(ctxs, hip, case):
         for f in frames.values():
             f.destroy()
     assert snaps >= 1
+
+
+def test_most_snapshots_were_checked_against_independent_layouts():
+    """(runs after the scenes: pytest keeps file order)"""
+    assert independent[0] >= 70
