@@ -186,6 +186,20 @@ SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, r
 SMR_API int smr_profile_enable(smr_ctx *ctx, int enable);
 SMR_API int smr_profile_read(smr_ctx *ctx, int stage, float *total_ms, uint32_t *launches);
 SMR_API int smr_profile_reset(smr_ctx *ctx);
+/* Which kernels a context has launched since it was created (always counted, no events): the tests assert the path a resample plan x
+ * input format takes; a host can watch for scenes that leave the fast paths. */
+typedef enum smr_kernel_id {
+    SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave: fused conversion + Lanczos on the matrix cores (planar 4:2:0, NV12) */
+    SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an opaque RGBA8 node texture (every other format after smr_frame_to_rgba; opaque surfaces) */
+    SMR_KERNEL_INGEST_MFMA_WG = 2,   /* k_ingest_mfma (SMR_INGEST_MFMA_F16_WG) */
+    SMR_KERNEL_INGEST_VALU = 3,      /* k_ingest_resample: fused conversion + Lanczos, every pass in f32 */
+    SMR_KERNEL_RESAMPLE_GENERAL = 4, /* smr_resample on a node texture: box pre-reduction and one or two Lanczos pass kernels */
+    SMR_KERNEL_FRAME_TO_RGBA = 5,    /* the stand-alone converters (InputTexture::convert_to_node_texture) */
+    SMR_KERNEL_COMPOSE_OUTPUT = 6,   /* k_compose_output: layout shader + output conversion */
+    SMR_KERNEL_APPLY_LAYOUTS = 7,    /* k_apply_layouts: the general compositor */
+    SMR_KERNEL_COUNT_ = 8
+} smr_kernel_id;
+SMR_API int smr_debug_kernel_launches(const smr_ctx *ctx, uint32_t kernel, uint64_t *count);
 
 /* ---- surfaces (NodeTexture / wgpu::Texture; state/node_texture.rs:11-163) -------- */
 SMR_API int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, smr_surface **out);

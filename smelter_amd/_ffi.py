@@ -33,7 +33,7 @@ EXPORTS = [
     "smr_host_alloc", "smr_host_free", "smr_frame_upload_async", "smr_frame_download_async",
     "smr_frame_to_rgba", "smr_add_premultiplied_alpha", "smr_remove_premultiplied_alpha",
     "smr_rgba_to_frame", "smr_frame_fill_black",
-    "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear", "smr_frame_preprocess",
+    "smr_resample_plan_make", "smr_resample", "smr_resample_pass", "smr_downsample", "smr_rescale_bilinear", "smr_frame_preprocess", "smr_debug_kernel_launches",
     "smr_apply_layouts", "smr_render_layouts", "smr_ingest_resample", "smr_ingest_resample_batch", "smr_blit_glyphs", "smr_builtin_shader",
     "smr_scene_create", "smr_scene_destroy", "smr_scene_last_error", "smr_scene_register_image", "smr_scene_set_text_measurer", "smr_scene_update",
     "smr_scene_parse",
@@ -200,6 +200,7 @@ def load():
         "smr_ctx_mode": ([P], U),
         "smr_ctx_set_option": ([P, U, C.c_int32], I),
         "smr_frame_preprocess": ([P, P, U, U, P, C.c_size_t], I),
+        "smr_debug_kernel_launches": ([P, U, C.POINTER(C.c_uint64)], I),
         "smr_comm_create_local": ([PP, U, PP], I),
         "smr_comm_unique_id": ([C.POINTER(C.c_uint8)], I),
         "smr_comm_create_rank": ([P, U, U, C.POINTER(C.c_uint8), PP], I),

@@ -192,6 +192,7 @@ int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
     if (int rc = smr_validate_frame(ctx, in, "smr_frame_to_rgba")) return rc;
     StageScope scope(ctx, SMR_STAGE_INGEST);
+    ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
     SurfView dst = view_of(node);
     const int w = (int)in->width, h = (int)in->height;
     switch (in->format) {

@@ -280,6 +280,12 @@ int smr_profile_read(smr_ctx *ctx, int stage, float *total_ms, uint32_t *launche
     return SMR_OK;
 }
 
+int smr_debug_kernel_launches(const smr_ctx *ctx, uint32_t kernel, uint64_t *count) {
+    if (!ctx || !count || kernel >= SMR_KERNEL_COUNT_) return SMR_ERR_INVALID;
+    *count = ctx->kernel_launches[kernel];
+    return SMR_OK;
+}
+
 int smr_profile_reset(smr_ctx *ctx) {
     SMR_ENTER(ctx);
     if (!ctx) return SMR_ERR_INVALID;

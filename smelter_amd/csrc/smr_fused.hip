@@ -109,7 +109,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
-    std::vector<WJob> wjobs;
+    std::vector<WJob> wjobs, wjobs_rgba;
     std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
@@ -158,6 +158,26 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     int rc = make_mfma_job_transposed(ctx, sources[si].frame, plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
                     if (rc != SMR_OK) return rc;
                     if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); transposed.push_back(back); }
+                }
+                // an opaque source the fused conversion does not read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB frames after the exact
+                // converter; opaque surfaces): the same matrix-core kernel on its RGBA8 node texture
+                if (!on_mfma && fused && kinds[si] == 2) {
+                    if (is_frame && !node_ready[si]) {
+                        // (only convert when the kernel will take the job: the geometry test needs the node's size, not its pixels)
+                        SurfView probe;
+                        probe.ptr = nullptr; probe.pitch = ((u32)src_w[si] * 4u + 255u) & ~255u; probe.w = src_w[si]; probe.h = src_h[si];
+                        if (can_fuse_wave_rgba(ctx, probe, plan, tile)) {
+                            int rc = ensure_node(si);
+                            if (rc != SMR_OK) return rc;
+                        }
+                    }
+                    if (node_ready[si] && can_fuse_wave_rgba(ctx, views[si], plan, tile)) {
+                        WJob J;
+                        int rc = make_wave_job_rgba(ctx, views[si], plan, tile, &J);
+                        if (rc != SMR_OK) return rc;
+                        wjobs_rgba.push_back(J);
+                        on_mfma = true;
+                    }
                 }
                 if (on_mfma) {
                 } else if (fused && is_frame && can_fuse_ingest(sources[si].frame, plan)) {
@@ -318,6 +338,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         rc = launch_wave(ctx, wjobs, direct_dev);
         if (rc != SMR_OK) return rc;
     }
+    if (!wjobs_rgba.empty()) {
+        rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
+        if (rc != SMR_OK) return rc;
+    }
     if (!mjobs.empty()) {
         rc = launch_mfma(ctx, mjobs, direct_dev);
         if (rc != SMR_OK) return rc;
@@ -334,6 +358,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- wave B (or the general compositor + output converters)
     if (fuse_out) {
         StageScope scope(ctx, SMR_STAGE_FUSED_COMPOSE);
+        ctx->kernel_launches[SMR_KERNEL_COMPOSE_OUTPUT]++;
         // 1-D grid: bands of the tiles that need the (latency-bound) general path first — as many as the class list holds when its
         // length is known, as many as the host's own prediction says otherwise — then every tile in order
         u32 n_banded = cm->count_known ? *cm->h_count : (n_first <= B_MAX_FIRST ? n_first : B_MAX_FIRST);

@@ -668,6 +668,7 @@ int launch_ingest(smr_ctx *ctx, std::vector<IngestJob> &jobs) {
         ctx->valu_attr_set = true;
     }
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
+    ctx->kernel_launches[SMR_KERNEL_INGEST_VALU]++;
     for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_JOBS_PER_LAUNCH) {
         const size_t nj = jobs.size() - j0 < (size_t)MAX_JOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_JOBS_PER_LAUNCH;
         IngestArgs args;

@@ -870,6 +870,7 @@ int launch_mfma(smr_ctx *ctx, std::vector<MJob> &jobs, const MDirect *direct = n
     }
     if (int rc = flush_mfma_builds(ctx)) return rc;
     StageScope scope(ctx, SMR_STAGE_FUSED_INGEST);
+    ctx->kernel_launches[SMR_KERNEL_INGEST_MFMA_WG]++;
     for (size_t j0 = 0; j0 < jobs.size(); j0 += MAX_MJOBS_PER_LAUNCH) {
         const size_t nj = jobs.size() - j0 < (size_t)MAX_MJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_MJOBS_PER_LAUNCH;
         MArgs args;

@@ -334,6 +334,12 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     const int NKS = FIXED_NKS ? NKS_T : J.NKS, KV = KV_T ? KV_T : J.KV;
     constexpr int NKS_N = NKS_T ? NKS_T : W_NKS_MAX, KV_N = KV_T ? KV_T : W_KV_MAX;
     constexpr bool NV = (FL & 4096) != 0, DIRECT = (FL & 2048) != 0, K01 = (FL & 1) != 0;
+    // 8192: the source is an RGBA8 node texture with alpha == 1 (a frame of any other format after the exact converter, or an opaque
+    // surface): the block of a k-step is one 16-byte load per lane, already in the conversion's layout (lane (m, q): row m, texels
+    // 4 q .. 4 q + 3), held in registers — no LDS staging — and its "conversion" is the decode table alone.
+    constexpr bool RG = (FL & 8192) != 0;
+    constexpr int RG_N = RG ? NKS_N : 1;
+    uint4 rg[RG_N];  // block j of the chunk at hand; refilled with the next chunk's block j as soon as it has been converted
     const float *s_thr = (const float *)(smem + W_OFF_THR);
     const uint4 *Bs = (const uint4 *)(smem + b_off);
 
@@ -384,6 +390,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     }
     const u32 c_colb = nv ? 2u * (u32)c_col0c : (u32)c_col0c;
     auto issue = [&](int c) {
+        if (RG) return;  // (rg_load, block by block)
         if (SMR_WAVE_ABL & 256) c = J.v_meta[vt0].x;  // profiling: always the same rows (cache hits)
         if (SMR_WAVE_ABL & 128) {                       // profiling: no global loads
 #pragma unroll
@@ -409,6 +416,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
     };
     auto land = [&]() {
+        if (RG) return;
         if (SMR_WAVE_ABL & 64) {  // profiling: no LDS writes (one keeps the loads alive)
             u32 x = 0;
 #pragma unroll
@@ -450,6 +458,26 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // Row 0 of a chunk is an odd luma row: 3/4 of chroma row p = row / 2 (weights A); odd chunk rows take 3/4 of row p + 1 (B).
     constexpr u32 WA13 = 0x03010903u, WA31 = 0x01030309u, WB13 = 0x09030301u, WB31 = 0x03090103u;
     const u32 w13 = (l16 & 1) ? WB13 : WA13, w31 = (l16 & 1) ? WB31 : WA31;
+
+    // RGBA source: block j of chunk c (texels past the row's end or rows outside the frame only ever meet zero weights: any readable
+    // address will do) ...
+    auto rg_load = [&](int c, int j) {
+        const u32 row = (u32)min(max(16 * c - 1 + l16, 0), sh - 1);
+        return *(const uint4 *)(y_ptr + dev_mad24(row, y_pitch, 4u * (u32)min(base + 16 * j + 4 * lq, sw4 - 4)));
+    };
+    // ... and its texel bytes -> decode table (entries 256 .. 511 of the LUT are the codes themselves)
+    auto convert_rgba = [&](const uint4 &t, uint4 (&a)[3]) {
+        const u32 px[4] = {t.x, t.y, t.z, t.w};
+        u32 o[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            o[0][k] = dev_lds_u32(((px[k] << 2) & 0x3fcu) + 1024u);
+            o[1][k] = dev_lds_u32(((px[k] >> 6) & 0x3fcu) + 1024u);
+            o[2][k] = dev_lds_u32(((px[k] >> 14) & 0x3fcu) + 1024u);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
+    };
 
     // ---- pass-2 state: the ring of f16 rows (two chunks per register quad) and the weights of the next tile to finish
     //      (one register vector per tile and channel, written at a uniform runtime index: register-indexed moves, not a select per slot)
@@ -511,6 +539,11 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     int2 vm_next = J.v_meta[min(vt0 + 1, vt1)];  // (read a tile ahead: a scalar load the loop never waits for)
     const int c_first = vm.x, c_last = J.v_meta[vt1].y;
     fetch_bv(vt0);
+    if (RG) {
+#pragma unroll
+        for (int j = 0; j < RG_N; j++)
+            if (j < NKS) rg[j] = rg_load(c_first, j);
+    }
     issue(c_first);
     finish_prologue();
     dev_wait_vmcnt0();
@@ -533,6 +566,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             //      operands arrived long ago, and the tail of block j's gathers lands behind them.
             struct Raw { u32 yy, u0, u1, u2, u3, v0, v1, v2, v3; };
             auto read_raw = [&](int j, Raw &r) {
+                if (RG) return;
                 r.yy = yrow[4 * j];
                 r.u0 = urow[2 * j]; r.u1 = urow[2 * j + 1]; r.u2 = urow[cs + 2 * j]; r.u3 = urow[cs + 2 * j + 1];
                 r.v0 = vrow[2 * j]; r.v1 = vrow[2 * j + 1]; r.v2 = vrow[cs + 2 * j]; r.v3 = vrow[cs + 2 * j + 1];
@@ -549,7 +583,12 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
                 }
             };
-            auto convert = [&](const Raw &r, uint4 (&a)[3]) {
+            auto convert = [&](int j, const Raw &r, uint4 (&a)[3]) {
+                if (RG) {
+                    convert_rgba(rg[RG ? j : 0], a);
+                    if (c < c_last) rg[RG ? j : 0] = rg_load(c + 1, j);
+                    return;
+                }
                 const u32 ua = dev_alignbyte(r.u1, r.u0, shb), ub = dev_alignbyte(r.u3, r.u2, shb);
                 const u32 va = dev_alignbyte(r.v1, r.v0, shb), vb = dev_alignbyte(r.v3, r.v2, shb);
                 m_convert_px<false>(K, r.yy, ua, ub, va, vb, w13, w31, a);
@@ -576,7 +615,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     if (j + 1 < NKS_T && (FIXED_NKS || j + 1 < NKS)) read_raw(j + 1, nxt);
                     if (j > 0) read_b(j - 1, bq);
                     if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
-                    convert(cur, a);
+                    convert(j, cur, a);
                     if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
                     if (j > 0) mfmas(j - 1, a_prev, bq);
 #pragma unroll
@@ -610,11 +649,17 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                             bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
                         }
                     }
-                    const u32 yy = yrow[4 * j];
-                    const u32 ua = dev_alignbyte(urow[2 * j + 1], urow[2 * j], shb), ub = dev_alignbyte(urow[cs + 2 * j + 1], urow[cs + 2 * j], shb);
-                    const u32 va = dev_alignbyte(vrow[2 * j + 1], vrow[2 * j], shb), vb = dev_alignbyte(vrow[cs + 2 * j + 1], vrow[cs + 2 * j], shb);
+                    u32 yy = 0u, ua = 0u, ub = 0u, va = 0u, vb = 0u;
+                    if (!RG) {
+                        yy = yrow[4 * j];
+                        ua = dev_alignbyte(urow[2 * j + 1], urow[2 * j], shb); ub = dev_alignbyte(urow[cs + 2 * j + 1], urow[cs + 2 * j], shb);
+                        va = dev_alignbyte(vrow[2 * j + 1], vrow[2 * j], shb); vb = dev_alignbyte(vrow[cs + 2 * j + 1], vrow[cs + 2 * j], shb);
+                    }
                     uint4 a[3];
-                    if (SMR_WAVE_ABL & 4) {
+                    if (RG) {
+                        convert_rgba(rg[RG ? j : 0], a);
+                        if (c < c_last) rg[RG ? j : 0] = rg_load(c + 1, j);
+                    } else if (SMR_WAVE_ABL & 4) {
                         a[0] = make_uint4(yy, ua, ub, va); a[1] = make_uint4(vb, yy, ua, ub); a[2] = make_uint4(va, vb, yy, ua);
                     } else {
                         m_convert_px<(SMR_WAVE_ABL & 1) != 0>(K, yy, ua, ub, va, vb, w13, w31, a);
@@ -977,6 +1022,43 @@ int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     return SMR_OK;
 }
 
+// An RGBA8 node texture with alpha == 1 as the source (k_ingest_wave's 8192 builds): a frame of a format the fused conversion does not
+// read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB) after the exact converter, or an opaque surface.  Horizontal-first Lanczos plans with
+// the kernel's window limits (shrink factors up to ~3.5).
+bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile) {
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return false;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
+    if (src.w < 8 || src.h < 2 || (((uintptr_t)src.ptr) % 16) || (src.pitch % 16) || src.pitch < (((size_t)src.w + 3u) & ~(size_t)3u) * 4u) return false;
+    if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
+    int NKS, KV, unused;
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, 2)) NKS = t->K;
+    else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, src.w, 2, &NKS, &unused);
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, src.h, 3)) KV = t->K;
+    else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, src.h, 3, &KV, &unused);
+    return NKS <= W_NKS_MAX && KV <= W_KV_MAX;
+}
+
+int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, WJob *out) {
+    WaveBand bh, bv;
+    int rc = get_wave_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, 2, &bh);
+    if (rc != SMR_OK) return rc;
+    rc = get_wave_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, src.h, 3, &bv);
+    if (rc != SMR_OK) return rc;
+    WJob &J = *out;
+    memset(&J, 0, sizeof(J));
+    J.yp = src; J.up = src; J.vp = src;
+    J.dst = view_of(tile);
+    J.src_w = src.w; J.src_h = src.h;
+    J.conv = m_conv_constants(true);
+    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.NKS = bh.K; J.n_pairs = bh.n_units;
+    J.k01 = bh.k01 ? 1 : 0;
+    J.n_htiles = ((int)tile->w + 15) / 16;
+    J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
+    J.pieces = W_WAVES;
+    J.layer = -1;
+    return SMR_OK;
+}
+
 // A job for a vertical-first plan: the same kernel on the transposed frame (see make_mfma_job_transposed).
 int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, WJob *out, bool *ok,
                              MTransposeBack *back) {
@@ -1022,10 +1104,14 @@ constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 
                                     k_ingest_wave<0, 0, 4096>, k_ingest_wave<4, 2, 4096>, k_ingest_wave<4, 2, 4097>, k_ingest_wave<8, 3, 4096>,
                                     k_ingest_wave<0, 0, 6144>, k_ingest_wave<4, 2, 6144>, k_ingest_wave<4, 2, 6145>, k_ingest_wave<8, 3, 6144>};
 constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
+// RGBA8 node textures as the source: the same four classes
+constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
 
-int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr) {
+int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
-        for (WaveKernel k : W_KERNELS) {
+        std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
+        all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
+        for (WaveKernel k : all) {
             SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipFuncAttributes fa;
             SMR_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)k));
@@ -1053,10 +1139,14 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
         int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
-        if (direct) ki += 4;
-        if (any_nv) ki += 8;
+        if (!rgba) {
+            if (direct) ki += 4;
+            if (any_nv) ki += 8;
+        }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
-        const WaveKernel kern = W_KERNELS[ki];
+        const WaveKernel kern = rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
+        if (rgba) ki += 100;  // (occupancy cache key)
+        ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);
         args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;

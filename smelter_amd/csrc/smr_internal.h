@@ -103,6 +103,7 @@ struct smr_ctx {
     int layout_last = -1;           // ring index of the pack committed last (its device copy is reused by an identical pack)
     bool no_pack_reuse = false;     // SMR_NO_PACK_REUSE (A/B, tests)
     unsigned long long pack_reused = 0;
+    unsigned long long kernel_launches[SMR_KERNEL_COUNT_] = {};  // smr_debug_kernel_launches
     // scratch owned by the ctx (resampler intermediates, fused tiles)
     struct Scratch { void *ptr = nullptr; size_t bytes = 0; };
     std::vector<Scratch> scratch;  // indexed slots, grown on demand

@@ -268,6 +268,7 @@ extern "C" int smr_apply_layouts(smr_ctx *ctx, smr_surface *target, const smr_la
 
 int smr_launch_apply_layouts(smr_ctx *ctx, smr_surface *target, const PackedLayouts *p) {
     StageScope scope(ctx, SMR_STAGE_LAYOUT);
+    ctx->kernel_launches[SMR_KERNEL_APPLY_LAYOUTS]++;
     dim3 grid((target->w + LAYOUT_TILE_W - 1) / LAYOUT_TILE_W, (target->h + LAYOUT_TILE_H - 1) / LAYOUT_TILE_H, 1);
     hipLaunchKernelGGL(k_apply_layouts, grid, dim3(LAYOUT_TILE_W * LAYOUT_TILE_H), 0, ctx->stream, view_of(target), p->layouts,
                        p->masks, p->n, ctx->srgb() ? 1 : 0, ctx->d_tables);

@@ -298,6 +298,7 @@ int smr_resample(smr_ctx *ctx, const smr_surface *src, const float crop[4], smr_
     int kind = smr_resample_plan_make(src->w, src->h, crop, dst->w, dst->h, &plan);
     if (kind < 0) return smr_fail(ctx, kind, "smr_resample: box reduction left no residual scale");
     if (kind == 0) return 0;
+    ctx->kernel_launches[SMR_KERNEL_RESAMPLE_GENERAL]++;
     StageScope scope(ctx, SMR_STAGE_RESAMPLE);
     const smr_surface *cur = src;
     smr_surface reduced, mid;

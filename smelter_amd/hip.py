@@ -140,6 +140,7 @@ def pack_layouts(layouts) -> "C.Array":
 
 
 INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_WG = 0, 1, 2, 3
+KERNEL_NAMES = ("ingest_wave", "ingest_wave_rgba", "ingest_mfma_wg", "ingest_valu", "resample_general", "frame_to_rgba", "compose_output", "apply_layouts")
 COMM_ID_BYTES = 128
 
 
@@ -268,6 +269,15 @@ class Context:
 
     def profile_reset(self):
         self._check(self.lib.smr_profile_reset(self.handle))
+
+    def kernel_launches(self) -> dict:
+        """Launch counts per kernel since the context was created (smr_debug_kernel_launches; names of smr_kernel_id)."""
+        out = {}
+        for k, name in enumerate(KERNEL_NAMES):
+            n = C.c_uint64()
+            self._check(self.lib.smr_debug_kernel_launches(self.handle, k, C.byref(n)))
+            out[name] = n.value
+        return out
 
     def profile_read(self):
         out = {}

@@ -106,9 +106,11 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         if (!smr_build_tables(tables, lut16)) return -9;
         have_tables = true;
     }
-    Plane py = make_plane(y, sw, sh, 1);
-    Plane pu = nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1);
-    Plane pv = nv12 ? pu : make_plane(v, sw / 2, sh / 2, 1);
+    const bool rgba = nv12 == 2;  // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
+    if (rgba) nv12 = 0;
+    Plane py = make_plane(y, sw, sh, rgba ? 4 : 1);
+    Plane pu = rgba ? py : (nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1));
+    Plane pv = (nv12 || rgba) ? pu : make_plane(v, sw / 2, sh / 2, 1);
     std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
     Band bh = build_band(scale_h, off_h, dw, sw, 2), bv = build_band(scale_v, off_v, dh, sh, 3);
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
@@ -145,7 +147,12 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     const int total = args.wg_prefix[1];
     if (info) info[3] = total;
     const unsigned blocks = (unsigned)((total + 7) & ~7);
-    if (spec && bh.k01) {
+    if (rgba) {
+        if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193>(args, tables, lut16); });
+        else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192>(args, tables, lut16); });
+        else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192>(args, tables, lut16); });
+    } else if (spec && bh.k01) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4097>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 1>(args, tables, lut16); });
     } else if (spec83) {

@@ -104,3 +104,39 @@ def test_emulated_kernel_matches_the_oracle(emu, src, dst, crop, pieces, spec, n
     _, want_k = orc.resample(node_k, crop, dw, dh)
     dk = np.abs(got.astype(np.int16) - want_k.astype(np.int16))
     assert dk.max() <= 1 and (dk == 0).mean() >= 0.9995, (dk.max(), (dk == 0).mean())
+
+
+# (source, tile, crop, pieces, specialised build)
+RGBA_CASES = [
+    ((96, 60), (64, 40), None, 2, 1),          # the benchmark's class, zero fragments skipped
+    ((96, 60), (64, 40), None, 3, 0),          # generic build
+    ((130, 74), (86, 49), None, 2, 0),         # odd sizes: partial tiles, a width that is not a multiple of 4
+    ((64, 36), (96, 54), None, 2, 0),          # upscale
+    ((256, 144), (128, 72), None, 2, 0),       # scale 2
+    ((384, 216), (128, 72), None, 3, 1),       # scale 3: the wide class build
+    ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1),  # crop
+]
+
+
+@pytest.mark.parametrize("src,dst,crop,pieces,spec", RGBA_CASES)
+def test_emulated_kernel_on_an_rgba_node_texture(emu, src, dst, crop, pieces, spec):
+    """The 8192 builds: the source is the RGBA8 node texture itself (what the exact converter wrote for a 4:2:2 / 4:4:4 / packed / BGRA
+    frame), so the only arithmetic between the bytes and the oracle's resample is the matrix-core Lanczos: <= 1 LSB, no conversion term."""
+    (sw, sh), (dw, dh) = src, dst
+    rng = np.random.default_rng(sw * 7 + dh)
+    node = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+    node[..., 3] = 255
+    crop = crop or (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 2 and plan.levels == (0, 0) and tuple(plan.axis[:2]) == (0, 1)
+    _, want = orc.resample(node, crop, dw, dh)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    flat = np.ascontiguousarray(node)
+    rc = emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 2, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh, pieces,
+                             spec, info)
+    assert rc == 0, (rc, list(info))
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
+    assert (d == 0).mean() >= 0.9995, (d == 0).mean()
+    assert (got[..., 3] == 255).all()

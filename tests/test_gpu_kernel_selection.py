@@ -1,0 +1,127 @@
+"""Which kernel a (resample plan x input format) combination runs on, asserted from smr_debug_kernel_launches, and its parity with
+the oracle on that path.  The table below is the map of the fast paths and of what is still outside them:
+
+* `wave`       k_ingest_wave with the fused conversion (planar 4:2:0 limited / full range, NV12): two-pass Lanczos plans, either pass
+               order (a vertical-first plan runs on the transposed frame), up- and down-scaling
+* `wave_rgba`  the same kernel on the RGBA8 node texture the exact converter wrote (4:2:2, 4:4:4, packed UYVY / YUYV) or on an
+               opaque surface: horizontal-first two-pass plans
+* `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32): every source with an alpha channel
+               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — single-axis plans, box-pre-reduced plans
+               (shrink factors from 4) and the vertical-first plans of the RGBA route.  Nothing falls to the one-launch f32 kernel
+               (k_ingest_resample) any more unless SMR_INGEST_VALU_F32 asks for it.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle.oracle import Layout
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from smelter_amd import hip as h
+    return h
+
+
+# name -> (source size, tile size): the plan smr_resample_plan_make gives for the full-frame crop
+PLANS = {
+    "two_pass_h_first": ((640, 360), (426, 240)),
+    "two_pass_v_first": ((640, 360), (427, 239)),
+    "upscale": ((320, 180), (480, 270)),
+    "scale_2": ((640, 360), (320, 180)),
+    "single_axis_h": ((640, 360), (426, 360)),
+    "single_axis_v": ((640, 360), (640, 240)),
+    "box_prereduced": ((1280, 720), (160, 90)),
+}
+FORMATS = ["yuv420", "yuvj420", "nv12", "yuv422", "yuv444", "uyvy", "yuyv", "bgra", "opaque_surface", "alpha_surface"]
+FUSED_YUV = {"yuv420", "yuvj420", "nv12"}
+OPAQUE_RGBA_ROUTE = {"yuv422", "yuv444", "uyvy", "yuyv", "opaque_surface"}
+
+
+def expected_path(fmt, plan):
+    if fmt in ("bgra", "alpha_surface"):
+        return "general"
+    if plan in ("single_axis_h", "single_axis_v", "box_prereduced"):
+        return "general"
+    if fmt in FUSED_YUV:
+        return "wave"
+    return "general" if plan == "two_pass_v_first" else "wave_rgba"
+
+
+def _smooth(rng, shape, lo=16, hi=235):
+    """Camera-like bytes: smooth structure plus a little sensor noise (white noise is the per-stage tests' business)."""
+    h, w = shape[:2]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    c = shape[2] if len(shape) == 3 else 1
+    out = np.empty((h, w, c), np.float32)
+    for k in range(c):
+        fx, fy, ph = rng.uniform(0.01, 0.06), rng.uniform(0.01, 0.06), rng.uniform(0, 6.28)
+        out[..., k] = (lo + hi) / 2 + (hi - lo) / 2.2 * np.sin(fx * xx + ph) * np.cos(fy * yy - ph) + rng.normal(0, 1.5, (h, w))
+    out = np.clip(np.rint(out), lo, hi).astype(np.uint8)
+    return out if len(shape) == 3 else out[..., 0]
+
+
+def _source(ctx, hip, fmt, w, h, rng):
+    """-> (device source, the oracle's node texture for it)"""
+    y = _smooth(rng, (h, w))
+    if fmt in ("yuv420", "yuvj420", "yuv422", "yuv444"):
+        variant = {"yuv420": orc.YUV420, "yuvj420": orc.YUVJ420, "yuv422": orc.YUV422, "yuv444": orc.YUV444}[fmt]
+        ch, cw = orc.chroma_shape(w, h, variant)
+        u, v = _smooth(rng, (ch, cw), 40, 220), _smooth(rng, (ch, cw), 40, 220)
+        f = {"yuv420": hip.FRAME_PLANAR_YUV420, "yuvj420": hip.FRAME_PLANAR_YUVJ420, "yuv422": hip.FRAME_PLANAR_YUV422, "yuv444": hip.FRAME_PLANAR_YUV444}[fmt]
+        return ctx.frame(f, w, h, [y, u, v]), orc.planar_yuv_to_rgba(y, u, v, w, h, variant)
+    if fmt == "nv12":
+        uv = _smooth(rng, (h // 2, w // 2, 2), 40, 220)
+        return ctx.frame(hip.FRAME_NV12, w, h, [y, uv]), orc.nv12_to_rgba(y, uv, w, h)
+    if fmt in ("uyvy", "yuyv"):
+        data = _smooth(rng, (h, w // 2, 4), 30, 225)
+        order = 0 if fmt == "uyvy" else 1
+        return ctx.frame(hip.FRAME_UYVY422 if order == 0 else hip.FRAME_YUYV422, w, h, [data]), orc.interleaved422_to_rgba(data, w, h, order)
+    data = _smooth(rng, (h, w, 4), 0, 255)
+    if fmt == "bgra":
+        return ctx.frame(hip.FRAME_BGRA, w, h, [data]), orc.swizzle_to_rgba(data, w, h, 0)
+    if fmt == "opaque_surface":
+        data[..., 3] = 255
+        surf = ctx.surface_from(data)
+        surf.opaque = True  # SMR_SOURCE_OPAQUE_SURFACE
+        return surf, data
+    # premultiplied translucent texture
+    a = data[..., 3:4].astype(np.uint16)
+    data[..., :3] = (data[..., :3].astype(np.uint16) * a // 255).astype(np.uint8)
+    return ctx.surface_from(data), data
+
+
+@pytest.mark.parametrize("plan", sorted(PLANS))
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_path_and_parity(hip, fmt, plan):
+    (sw, sh), (dw, dh) = PLANS[plan]
+    ctx = hip.Context(0)
+    try:
+        rng = np.random.default_rng(FORMATS.index(fmt) * 100 + sorted(PLANS).index(plan))
+        src, node = _source(ctx, hip, fmt, sw, sh, rng)
+        out = ctx.surface(dw, dh)
+        layouts = [Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=(0, 0, sw, sh))]
+        before = ctx.kernel_launches()
+        ctx.render_layouts(layouts, [src], dw, dh, out_rgba=out)
+        got = out.download()
+        ran = {k: v - before[k] for k, v in ctx.kernel_launches().items()}
+        want_path = expected_path(fmt, plan)
+        fast = {"wave": "ingest_wave", "wave_rgba": "ingest_wave_rgba", "valu": "ingest_valu", "general": "resample_general"}[want_path]
+        assert ran[fast] == 1, (fmt, plan, want_path, ran)
+        for other in ("ingest_wave", "ingest_wave_rgba", "ingest_valu", "resample_general", "ingest_mfma_wg"):
+            if other != fast:
+                assert ran[other] == 0, (fmt, plan, want_path, ran)
+        # the converter runs exactly when the path needs a node texture of a frame
+        needs_node = want_path in ("wave_rgba", "general") and fmt not in ("opaque_surface", "alpha_surface")
+        assert ran["frame_to_rgba"] == (1 if needs_node else 0), (fmt, plan, ran)
+        assert ran["compose_output"] + ran["apply_layouts"] == 1
+        # parity: the oracle's resample of the oracle's node texture, composited 1:1 (the source covers the output)
+        _, tile = orc.resample(node, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+        want = orc.apply_layouts(dw, dh, [Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=(0, 0, dw, dh))], [tile])
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, (fmt, plan, int(d.max()))
+        assert (d == 0).mean() >= 0.985, (fmt, plan, float((d == 0).mean()))
+    finally:
+        ctx.close()
