@@ -178,6 +178,17 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         wjobs_rgba.push_back(J);
                         on_mfma = true;
                     }
+                    if (!on_mfma && plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1) {  // vertical-first
+                        if (is_frame) {
+                            int rc = ensure_node(si);
+                            if (rc != SMR_OK) return rc;
+                        }
+                        WJob J;
+                        MTransposeBack back;
+                        int rc = make_wave_job_rgba_transposed(ctx, views[si], plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
+                        if (rc != SMR_OK) return rc;
+                        if (on_mfma) { wjobs_rgba.push_back(J); transposed.push_back(back); }
+                    }
                 }
                 if (on_mfma) {
                 } else if (fused && is_frame && can_fuse_ingest(sources[si].frame, plan)) {

@@ -1095,6 +1095,28 @@ int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resampl
     return SMR_OK;
 }
 
+// ... and a vertical-first plan on an RGBA8 node texture: the node transposed in, the tile transposed back
+int make_wave_job_rgba_transposed(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, WJob *out, bool *ok,
+                                  MTransposeBack *back) {
+    *ok = false;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return SMR_OK;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
+    smr_surface *node_t = smr_cached_surface(ctx, slot0, (u32)src.h, (u32)src.w, SMR_PX_RGBA8);
+    smr_surface *tile_t = smr_cached_surface(ctx, slot0 + 3, tile->h, tile->w, SMR_PX_RGBA8);
+    if (!node_t || !tile_t) return SMR_ERR_OOM;
+    smr_resample_plan pt = plan;
+    pt.axis[0] = 0; pt.axis[1] = 1;
+    if (!can_fuse_wave_rgba(ctx, view_of(node_t), pt, tile_t)) return SMR_OK;
+    if (int rc = make_wave_job_rgba(ctx, view_of(node_t), pt, tile_t, out)) return rc;
+    smr_surface node;  // non-owning alias of the node view
+    node.ptr = src.ptr; node.pitch = src.pitch; node.w = (u32)src.w; node.h = (u32)src.h; node.fmt = SMR_PX_RGBA8;
+    if (int rc = launch_transpose<u32>(ctx, &node, node_t)) return rc;
+    back->tile_t = tile_t;
+    back->tile = tile;
+    *ok = true;
+    return SMR_OK;
+}
+
 // builds: generic | the benchmark scenes' class (pair windows of <= 4 k-steps, pass-2 windows of 2: scales around 1.5) | that class with
 //         its two always-zero weight fragments skipped | the north-star target's class (windows of <= 8 k-steps, pass-2 windows of 3:
 //         scales around 3);  each plain | direct output (2048) | NV12-capable (4096) | both

@@ -4,10 +4,10 @@ the oracle on that path.  The table below is the map of the fast paths and of wh
 * `wave`       k_ingest_wave with the fused conversion (planar 4:2:0 limited / full range, NV12): two-pass Lanczos plans, either pass
                order (a vertical-first plan runs on the transposed frame), up- and down-scaling
 * `wave_rgba`  the same kernel on the RGBA8 node texture the exact converter wrote (4:2:2, 4:4:4, packed UYVY / YUYV) or on an
-               opaque surface: horizontal-first two-pass plans
+               opaque surface: two-pass plans, either pass order
 * `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32): every source with an alpha channel
-               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — single-axis plans, box-pre-reduced plans
-               (shrink factors from 4) and the vertical-first plans of the RGBA route.  Nothing falls to the one-launch f32 kernel
+               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — single-axis plans and box-pre-reduced
+               plans (shrink factors from 4).  Nothing falls to the one-launch f32 kernel
                (k_ingest_resample) any more unless SMR_INGEST_VALU_F32 asks for it.
 """
 import numpy as np
@@ -47,7 +47,7 @@ def expected_path(fmt, plan):
         return "general"
     if fmt in FUSED_YUV:
         return "wave"
-    return "general" if plan == "two_pass_v_first" else "wave_rgba"
+    return "wave_rgba"
 
 
 def _smooth(rng, shape, lo=16, hi=235):
