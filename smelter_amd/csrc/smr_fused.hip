@@ -49,6 +49,7 @@ constexpr size_t SLOT_NODE0 = 16;     // + source index
 constexpr size_t SLOT_TILE0 = 2048;   // + layout index
 constexpr size_t SLOT_TRANSPOSED0 = 4096;  // + 4 * layout index: transposed planes and tile of a vertical-first plan
 constexpr size_t SLOT_TRANSPOSED_SINGLE = 3200;  // smr_ingest_resample's own four
+constexpr size_t SLOT_REDUCED0 = 12288;   // + layout index: the box-reduced RGBA16F node of a plan with shrink factors from 4
 
 }  // namespace
 
@@ -109,7 +110,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
-    std::vector<WJob> wjobs, wjobs_rgba;
+    std::vector<WJob> wjobs, wjobs_rgba, wjobs_f16;
     std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
@@ -177,6 +178,28 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         if (rc != SMR_OK) return rc;
                         wjobs_rgba.push_back(J);
                         on_mfma = true;
+                    }
+                    if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 0 && plan.axis[1] == 1) {
+                        // box-pre-reduced plan (shrink factors from 4): downsample.wgsl's pass as it is, then the residual Lanczos
+                        // (scales below 2) on the matrix cores, reading the RGBA16F texels as they are
+                        smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
+                        if (!reduced) return SMR_ERR_OOM;
+                        if (can_fuse_wave_rgba(ctx, view_of(reduced), plan, tile, 8)) {
+                            if (is_frame) {
+                                int rc = ensure_node(si);
+                                if (rc != SMR_OK) return rc;
+                            }
+                            smr_surface node;  // non-owning alias of the node view
+                            node.ptr = views[si].ptr; node.pitch = views[si].pitch; node.w = (u32)views[si].w; node.h = (u32)views[si].h;
+                            node.fmt = SMR_PX_RGBA8;
+                            int rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
+                            if (rc != SMR_OK) return rc;
+                            WJob J;
+                            rc = make_wave_job_rgba(ctx, view_of(reduced), plan, tile, &J);
+                            if (rc != SMR_OK) return rc;
+                            wjobs_f16.push_back(J);
+                            on_mfma = true;
+                        }
                     }
                     if (!on_mfma && plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1) {  // vertical-first
                         if (is_frame) {
@@ -351,6 +374,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
     if (!wjobs_rgba.empty()) {
         rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_f16.empty()) {
+        rc = launch_wave(ctx, wjobs_f16, nullptr, true, true);
         if (rc != SMR_OK) return rc;
     }
     if (!mjobs.empty()) {

@@ -337,9 +337,12 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // 8192: the source is an RGBA8 node texture with alpha == 1 (a frame of any other format after the exact converter, or an opaque
     // surface): the block of a k-step is one 16-byte load per lane, already in the conversion's layout (lane (m, q): row m, texels
     // 4 q .. 4 q + 3), held in registers — no LDS staging — and its "conversion" is the decode table alone.
-    constexpr bool RG = (FL & 8192) != 0;
+    // 16384 (with 8192): that node texture is RGBA16F in linear light — what the box pre-reduction of a plan with shrink factors from 4
+    // leaves (resampler.rs: downsample.wgsl into an Rgba16Float texture): the f16 texels ARE the operand's hi halves, lo = 0.
+    constexpr bool RG = (FL & 8192) != 0, RH = RG && (FL & 16384) != 0;
     constexpr int RG_N = RG ? NKS_N : 1;
     uint4 rg[RG_N];  // block j of the chunk at hand; refilled with the next chunk's block j as soon as it has been converted
+    uint4 rg2[RH ? RG_N : 1];  // (RGBA16F: texels 2, 3 of the block; rg holds 0, 1)
     const float *s_thr = (const float *)(smem + W_OFF_THR);
     const uint4 *Bs = (const uint4 *)(smem + b_off);
 
@@ -463,10 +466,24 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // address will do) ...
     auto rg_load = [&](int c, int j) {
         const u32 row = (u32)min(max(16 * c - 1 + l16, 0), sh - 1);
-        return *(const uint4 *)(y_ptr + dev_mad24(row, y_pitch, 4u * (u32)min(base + 16 * j + 4 * lq, sw4 - 4)));
+        const u32 col = (u32)min(base + 16 * j + 4 * lq, sw4 - 4);
+        if (RH) {
+            const u8 *p = y_ptr + dev_mad24(row, y_pitch, 8u * col);
+            rg2[RH ? (j < RG_N ? j : 0) : 0] = *(const uint4 *)(p + 16);
+            return *(const uint4 *)p;
+        }
+        return *(const uint4 *)(y_ptr + dev_mad24(row, y_pitch, 4u * col));
     };
     // ... and its texel bytes -> decode table (entries 256 .. 511 of the LUT are the codes themselves)
-    auto convert_rgba = [&](const uint4 &t, uint4 (&a)[3]) {
+    auto convert_rgba = [&](int j, uint4 (&a)[3]) {
+        const uint4 t = rg[RG ? (j < RG_N ? j : 0) : 0];
+        if (RH) {  // texel = (r | g << 16, b | a << 16): hi = the f16 itself, lo = 0
+            const uint4 t2 = rg2[RH ? (j < RG_N ? j : 0) : 0];
+            a[0] = make_uint4(t.x & 0xffffu, t.z & 0xffffu, t2.x & 0xffffu, t2.z & 0xffffu);
+            a[1] = make_uint4(t.x >> 16, t.z >> 16, t2.x >> 16, t2.z >> 16);
+            a[2] = make_uint4(t.y & 0xffffu, t.w & 0xffffu, t2.y & 0xffffu, t2.w & 0xffffu);
+            return;
+        }
         const u32 px[4] = {t.x, t.y, t.z, t.w};
         u32 o[3][4];
 #pragma unroll
@@ -585,8 +602,8 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             };
             auto convert = [&](int j, const Raw &r, uint4 (&a)[3]) {
                 if (RG) {
-                    convert_rgba(rg[RG ? j : 0], a);
-                    if (c < c_last) rg[RG ? j : 0] = rg_load(c + 1, j);
+                    convert_rgba(j, a);
+                    if (c < c_last) rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(c + 1, j);
                     return;
                 }
                 const u32 ua = dev_alignbyte(r.u1, r.u0, shb), ub = dev_alignbyte(r.u3, r.u2, shb);
@@ -657,8 +674,8 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     }
                     uint4 a[3];
                     if (RG) {
-                        convert_rgba(rg[RG ? j : 0], a);
-                        if (c < c_last) rg[RG ? j : 0] = rg_load(c + 1, j);
+                        convert_rgba(j, a);
+                        if (c < c_last) rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(c + 1, j);
                     } else if (SMR_WAVE_ABL & 4) {
                         a[0] = make_uint4(yy, ua, ub, va); a[1] = make_uint4(vb, yy, ua, ub); a[2] = make_uint4(va, vb, yy, ua);
                     } else {
@@ -1025,10 +1042,11 @@ int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
 // An RGBA8 node texture with alpha == 1 as the source (k_ingest_wave's 8192 builds): a frame of a format the fused conversion does not
 // read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB) after the exact converter, or an opaque surface.  Horizontal-first Lanczos plans with
 // the kernel's window limits (shrink factors up to ~3.5).
-bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile) {
+// (bpp 8: an RGBA16F surface that is already box-reduced — the plan's levels then describe what was done to get it)
+bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, int bpp = 4) {
     if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return false;
-    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
-    if (src.w < 8 || src.h < 2 || (((uintptr_t)src.ptr) % 16) || (src.pitch % 16) || src.pitch < (((size_t)src.w + 3u) & ~(size_t)3u) * 4u) return false;
+    if (!(plan.kind == 2 && (bpp == 8 || (plan.levels[0] == 0 && plan.levels[1] == 0)) && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
+    if (src.w < 8 || src.h < 2 || (((uintptr_t)src.ptr) % 16) || (src.pitch % 16) || src.pitch < (((size_t)src.w + 3u) & ~(size_t)3u) * (size_t)bpp) return false;
     if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
     int NKS, KV, unused;
     if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, 2)) NKS = t->K;
@@ -1128,11 +1146,14 @@ constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 
 constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 // RGBA8 node textures as the source: the same four classes
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
+// ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; the windows the generic build holds reach ~3.2)
+constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>;
 
-int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false) {
+int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
         std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
+        all.push_back(W_KERNEL_RGBA16F);
         for (WaveKernel k : all) {
             SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipFuncAttributes fa;
@@ -1160,14 +1181,15 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             nks_max = J.NKS > nks_max ? J.NKS : nks_max;
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
+        if (f16) cls432 = cls83 = false;  // (one generic build)
         int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
         if (!rgba) {
             if (direct) ki += 4;
             if (any_nv) ki += 8;
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
-        const WaveKernel kern = rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
-        if (rgba) ki += 100;  // (occupancy cache key)
+        const WaveKernel kern = f16 ? W_KERNEL_RGBA16F : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
+        if (rgba) ki += f16 ? 200 : 100;  // (occupancy cache key)
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);

@@ -106,9 +106,10 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         if (!smr_build_tables(tables, lut16)) return -9;
         have_tables = true;
     }
-    const bool rgba = nv12 == 2;  // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
+    const bool f16 = nv12 == 3;           // y = an RGBA16F node texture (linear light): the 8192 + 16384 build
+    const bool rgba = nv12 == 2 || f16;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
     if (rgba) nv12 = 0;
-    Plane py = make_plane(y, sw, sh, rgba ? 4 : 1);
+    Plane py = make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1);
     Plane pu = rgba ? py : (nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1));
     Plane pv = (nv12 || rgba) ? pu : make_plane(v, sw / 2, sh / 2, 1);
     std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
@@ -147,7 +148,9 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     const int total = args.wg_prefix[1];
     if (info) info[3] = total;
     const unsigned blocks = (unsigned)((total + 7) & ~7);
-    if (rgba) {
+    if (f16) {
+        run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 16384>(args, tables, lut16); });
+    } else if (rgba) {
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193>(args, tables, lut16); });
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192>(args, tables, lut16); });
         else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192>(args, tables, lut16); });

@@ -140,3 +140,29 @@ def test_emulated_kernel_on_an_rgba_node_texture(emu, src, dst, crop, pieces, sp
     assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
     assert (d == 0).mean() >= 0.9995, (d == 0).mean()
     assert (got[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("src,dst,pieces", [((96, 60), (64, 40), 2), ((130, 74), (69, 40), 3), ((100, 56), (64, 36), 1)])
+def test_emulated_kernel_on_a_box_reduced_rgba16f_texture(emu, src, dst, pieces):
+    """The 8192 + 16384 build: the source is the RGBA16F texture downsample.wgsl leaves (linear light, alpha 1); its f16 texels are
+    the matrix cores' operands as they are, so the only difference from the oracle's two passes is the f16-pair weights."""
+    (sw, sh), (dw, dh) = src, dst
+    rng = np.random.default_rng(sw + 3 * dh)
+    lin = rng.random((sh, sw, 4), dtype=np.float32) ** 2.2
+    lin[..., 3] = 1.0
+    tex = lin.astype(np.float16).view(np.uint16)
+    crop = (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 2 and plan.levels == (0, 0) and tuple(plan.axis[:2]) == (0, 1)
+    mid = orc.resample_pass(tex, orc.PX_RGBA16F, plan.axis[0], plan.scale[0], plan.offset[0], plan.perp_offset[0], orc.PX_RGBA16F, plan.mid[0], plan.mid[1])
+    want = orc.resample_pass(mid, orc.PX_RGBA16F, plan.axis[1], plan.scale[1], plan.offset[1], plan.perp_offset[1], orc.PX_RGBA8_SRGB, dw, dh)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    flat = np.ascontiguousarray(tex).view(np.uint8)
+    rc = emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 3, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh, pieces, 0,
+                             info)
+    assert rc == 0, (rc, list(info))
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
+    assert (d == 0).mean() >= 0.9995, (d == 0).mean()
+    assert (got[..., 3] == 255).all()

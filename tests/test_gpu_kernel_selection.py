@@ -5,9 +5,13 @@ the oracle on that path.  The table below is the map of the fast paths and of wh
                order (a vertical-first plan runs on the transposed frame), up- and down-scaling
 * `wave_rgba`  the same kernel on the RGBA8 node texture the exact converter wrote (4:2:2, 4:4:4, packed UYVY / YUYV) or on an
                opaque surface: two-pass plans, either pass order
+* `wave_box`   box-pre-reduced plans (shrink factors above 4) of every opaque source, horizontal-first, residual scales up to ~3.2:
+               the exact converter, downsample.wgsl's pass as it is (RGBA16F, linear light), then the residual Lanczos on the matrix
+               cores reading the f16 texels as they are
 * `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32): every source with an alpha channel
-               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — single-axis plans and box-pre-reduced
-               plans (shrink factors from 4).  Nothing falls to the one-launch f32 kernel
+               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — single-axis plans (one pass whose f32 sums
+               are encoded directly: the two-pass kernel would round them to f16 first), box-pre-reduced plans whose residual scale
+               exceeds ~3.2 or that filter vertically first.  Nothing falls to the one-launch f32 kernel
                (k_ingest_resample) any more unless SMR_INGEST_VALU_F32 asks for it.
 """
 import numpy as np
@@ -33,7 +37,8 @@ PLANS = {
     "scale_2": ((640, 360), (320, 180)),
     "single_axis_h": ((640, 360), (426, 360)),
     "single_axis_v": ((640, 360), (640, 240)),
-    "box_prereduced": ((1280, 720), (160, 90)),
+    "box_prereduced": ((1920, 1080), (400, 225)),    # 2x box, residual 2.4 both ways
+    "box_prereduced_8": ((1280, 720), (160, 90)),      # 2x box, residual 4: windows wider than the kernel holds
 }
 FORMATS = ["yuv420", "yuvj420", "nv12", "yuv422", "yuv444", "uyvy", "yuyv", "bgra", "opaque_surface", "alpha_surface"]
 FUSED_YUV = {"yuv420", "yuvj420", "nv12"}
@@ -43,7 +48,11 @@ OPAQUE_RGBA_ROUTE = {"yuv422", "yuv444", "uyvy", "yuyv", "opaque_surface"}
 def expected_path(fmt, plan):
     if fmt in ("bgra", "alpha_surface"):
         return "general"
-    if plan in ("single_axis_h", "single_axis_v", "box_prereduced"):
+    if plan in ("single_axis_h", "single_axis_v"):
+        return "general"
+    if plan == "box_prereduced":
+        return "wave_box"
+    if plan == "box_prereduced_8":
         return "general"
     if fmt in FUSED_YUV:
         return "wave"
@@ -108,13 +117,14 @@ def test_path_and_parity(hip, fmt, plan):
         got = out.download()
         ran = {k: v - before[k] for k, v in ctx.kernel_launches().items()}
         want_path = expected_path(fmt, plan)
-        fast = {"wave": "ingest_wave", "wave_rgba": "ingest_wave_rgba", "valu": "ingest_valu", "general": "resample_general"}[want_path]
+        fast = {"wave": "ingest_wave", "wave_rgba": "ingest_wave_rgba", "wave_box": "ingest_wave_rgba", "valu": "ingest_valu",
+                "general": "resample_general"}[want_path]
         assert ran[fast] == 1, (fmt, plan, want_path, ran)
         for other in ("ingest_wave", "ingest_wave_rgba", "ingest_valu", "resample_general", "ingest_mfma_wg"):
             if other != fast:
                 assert ran[other] == 0, (fmt, plan, want_path, ran)
         # the converter runs exactly when the path needs a node texture of a frame
-        needs_node = want_path in ("wave_rgba", "general") and fmt not in ("opaque_surface", "alpha_surface")
+        needs_node = want_path in ("wave_rgba", "wave_box", "general") and fmt not in ("opaque_surface", "alpha_surface")
         assert ran["frame_to_rgba"] == (1 if needs_node else 0), (fmt, plan, ran)
         assert ran["compose_output"] + ran["apply_layouts"] == 1
         # parity: the oracle's resample of the oracle's node texture, composited 1:1 (the source covers the output)
