@@ -161,19 +161,26 @@ SMR_API uint32_t smr_ctx_mode(const smr_ctx *ctx);  /* smr_mode the context was 
 SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — render_loop.rs:177-183 */
 /* Context options (RendererOptions has no counterpart: these select between equivalent implementations).
  *   SMR_OPT_INGEST_IMPL         arithmetic of the fused ingest + Lanczos kernel (wave A of smr_render_layouts / smr_ingest_resample*):
- *       SMR_INGEST_AUTO      matrix cores where the frame format / plan allow it, the f32 kernel elsewhere (default)
+ *       SMR_INGEST_AUTO      matrix cores where the source / plan allow it (every opaque source, two-pass and box-pre-reduced plans:
+ *                            smr_debug_kernel_launches tells), the general pass kernels elsewhere (default)
  *       SMR_INGEST_VALU_F32  exact f32 everywhere: bit-identical to the pass-per-launch kernels (smr_frame_to_rgba + smr_resample)
  *       SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
  *       SMR_INGEST_MFMA_F16_WG  the first matrix-core kernel (k_ingest_mfma: a workgroup pipeline of convert and filter waves
  *                            around LDS) instead of the wave-autonomous one (k_ingest_wave) AUTO prefers; same arithmetic
  *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
  *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated
- *     in f32: it deviates from the f32 sequence of resample.wgsl:64-87 by at most 1 LSB on every content class (tests).
+ *     in f32.  Its deviation is bounded per stage: the fused colour conversion is within one code of planar_yuv_to_rgba.wgsl
+ *     (~2e-5 of the bytes differ), and the resample is within 1 LSB — on every byte of every content class — of resample.wgsl's
+ *     passes applied to that node texture.  End to end that is within 1 LSB on camera-like content; on white noise a flipped
+ *     bright texel seen through the linear-light filter at a dark output can show as 2..4 codes (3 bytes in 7.4 million,
+ *     tests/test_gpu_fused.py).  Sources that need no fused conversion (RGBA8 / RGBA16F node textures: 4:2:2, 4:4:4, packed YUV,
+ *     opaque surfaces, box-pre-reduced plans) are within 1 LSB end to end.  A host that needs the f32 sequence bit for bit
+ *     (snapshot tests) selects SMR_INGEST_VALU_F32.
  *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling)
  *   SMR_OPT_DIRECT_OUTPUT       1: when smr_render_layouts sees the same layout list again (a scene at rest), the pixels the
  *                               compositor would only copy from a freshly resampled input are converted to Y'CbCr by the resampling
- *                               kernel itself and their RGBA8 form is never stored (HBM traffic per frame 1.2x instead of 2.7x the
- *                               algorithmic bytes, at the price of vector-ALU time in that kernel: DESIGN.md); 0 (default): always through
+ *                               kernel itself and their RGBA8 form is never stored (HBM traffic per frame 1.5x instead of 2.9x the
+ *                               algorithmic bytes, at the price of vector-ALU time in a kernel that is instruction-bound: DESIGN.md); 0 (default): always through
  *                               the RGBA8 tile.  Same output bytes either way. */
 typedef enum smr_ingest_impl { SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, SMR_INGEST_MFMA_F16_WG = 3 } smr_ingest_impl;
 typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2 } smr_option;
