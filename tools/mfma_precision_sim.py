@@ -1,4 +1,5 @@
-"""CPU model of k_ingest_mfma's arithmetic (smelter_amd/csrc/smr_ingest_mfma.h) against the oracle: where the matrix-core formulation
+"""CPU model of the matrix-core resamplers' arithmetic (k_ingest_mfma, round 2: T pair, Wh pair, Wv feedback — the default below;
+k_ingest_wave, round 3: pairs for all three) against the oracle: where the matrix-core formulation
 of the two Lanczos passes spends the resampler's 1-LSB budget, variant by variant.  numpy only — the f32 accumulation order of the
 matrix cores is not modelled (np.matmul's is used), so the counts are close to, not equal to, what tools/mfma_ab.py measures on
 the device.
