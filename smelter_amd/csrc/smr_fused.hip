@@ -110,7 +110,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
-    std::vector<WJob> wjobs, wjobs_rgba, wjobs_f16;
+    std::vector<WJob> wjobs, wjobs_rgba, wjobs_f16, wjobs_sa, wjobs_sa_rgba;
     std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
@@ -159,6 +159,53 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     int rc = make_mfma_job_transposed(ctx, sources[si].frame, plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
                     if (rc != SMR_OK) return rc;
                     if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); transposed.push_back(back); }
+                }
+                // a single-axis plan (only one of width / height changes) of an opaque source: the one pass on the matrix cores, its f32
+                // sums encoded directly (k_ingest_wave's 32768 builds); a height-only plan runs on the transposed frame / node
+                if (!on_mfma && fused && kinds[si] == 2 && plan.kind == 1 && plan.levels[0] == 0 && plan.levels[1] == 0) {
+                    const smr_resample_plan p2 = single_axis_as_two_pass(plan);
+                    const int perp = plan.perp_offset[0];
+                    WJob J;
+                    MTransposeBack back;
+                    bool rgba_job = false, took = false;
+                    if (is_frame && can_fuse_wave(ctx, sources[si].frame, p2, tile)) {
+                        int rc = make_wave_job(ctx, sources[si].frame, p2, tile, &J);
+                        if (rc != SMR_OK) return rc;
+                        took = true;
+                    }
+                    if (!took && is_frame) {
+                        int rc = make_wave_job_transposed(ctx, sources[si].frame, p2, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &took, &back);
+                        if (rc != SMR_OK) return rc;
+                        if (took) transposed.push_back(back);
+                    }
+                    if (!took) {  // the RGBA route
+                        SurfView probe = views[si];
+                        if (is_frame && !node_ready[si]) { probe.ptr = nullptr; probe.pitch = ((u32)src_w[si] * 4u + 255u) & ~255u; probe.w = src_w[si]; probe.h = src_h[si]; }
+                        const bool h_only = p2.axis[0] == 0;
+                        if (!h_only || can_fuse_wave_rgba(ctx, probe, p2, tile)) {
+                            if (is_frame) {
+                                int rc = ensure_node(si);
+                                if (rc != SMR_OK) return rc;
+                            }
+                            if (h_only) {
+                                if (can_fuse_wave_rgba(ctx, views[si], p2, tile)) {
+                                    int rc = make_wave_job_rgba(ctx, views[si], p2, tile, &J);
+                                    if (rc != SMR_OK) return rc;
+                                    took = true;
+                                }
+                            } else {
+                                int rc = make_wave_job_rgba_transposed(ctx, views[si], p2, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &took, &back);
+                                if (rc != SMR_OK) return rc;
+                                if (took) transposed.push_back(back);
+                            }
+                            rgba_job = took;
+                        }
+                    }
+                    if (took) {
+                        J.perp = perp;
+                        (rgba_job ? wjobs_sa_rgba : wjobs_sa).push_back(J);
+                        on_mfma = true;
+                    }
                 }
                 // an opaque source the fused conversion does not read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB frames after the exact
                 // converter; opaque surfaces): the same matrix-core kernel on its RGBA8 node texture
@@ -378,6 +425,14 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
     if (!wjobs_f16.empty()) {
         rc = launch_wave(ctx, wjobs_f16, nullptr, true, true);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_sa.empty()) {
+        rc = launch_wave(ctx, wjobs_sa, nullptr, false, false, true);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_sa_rgba.empty()) {
+        rc = launch_wave(ctx, wjobs_sa_rgba, nullptr, true, false, true);
         if (rc != SMR_OK) return rc;
     }
     if (!mjobs.empty()) {

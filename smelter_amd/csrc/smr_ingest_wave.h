@@ -271,6 +271,7 @@ struct WJob {
     int pieces;           // vertical pieces per column pair (a multiple of W_WAVES)
     int nv12;
     int layer, ox, oy;    // direct output: the layer this tile is blitted by (-1 = none) and its (even) position in the output frame
+    int perp;             // single-axis builds (FL & 32768): output row y shows source row y + perp
 };
 
 constexpr int MAX_WJOBS_PER_LAUNCH = 16;
@@ -340,6 +341,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // 16384 (with 8192): that node texture is RGBA16F in linear light — what the box pre-reduction of a plan with shrink factors from 4
     // leaves (resampler.rs: downsample.wgsl into an Rgba16Float texture): the f16 texels ARE the operand's hi halves, lo = 0.
     constexpr bool RG = (FL & 8192) != 0, RH = RG && (FL & 16384) != 0;
+    // 32768: a single-axis plan (ResampledChild with one pass, resampler.rs:123-145 — only the width changes): pass 1's f32 sums are
+    // encoded and stored as they are, row for row; there is no f16 rounding and no pass 2.  The job's vertical band (scale 1) only
+    // supplies the chunk ranges of the pieces.  (Height-only plans run on the transposed frame.)
+    constexpr bool SA = (FL & 32768) != 0;
     constexpr int RG_N = RG ? NKS_N : 1;
     uint4 rg[RG_N];  // block j of the chunk at hand; refilled with the next chunk's block j as soon as it has been converted
     uint4 rg2[RH ? RG_N : 1];  // (RGBA16F: texels 2, 3 of the block; rg holds 0, 1)
@@ -555,7 +560,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     int2 vm = J.v_meta[vt0];
     int2 vm_next = J.v_meta[min(vt0 + 1, vt1)];  // (read a tile ahead: a scalar load the loop never waits for)
     const int c_first = vm.x, c_last = J.v_meta[vt1].y;
-    fetch_bv(vt0);
+    if (!SA) fetch_bv(vt0);
     if (RG) {
 #pragma unroll
         for (int j = 0; j < RG_N; j++)
@@ -713,6 +718,27 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 land();
                 dev_wave_lds_sync();
             }
+        }
+        if (SA) {
+            // ---- single-axis plan: the chunk's rows are output rows (lane holds rows 4 lq .. + 3 of output column l16 of either tile)
+            const int y_lo = 16 * vt0, y_hi = min(16 * vt1 + 15, d_h - 1), perp = J.perp;
+#pragma unroll
+            for (int i = 0; i < W_NTI; i++) {
+                if (klo[i] == 0xff) continue;
+                const int x = tx0 + 16 * i + l16;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int y = 16 * c - 1 + 4 * lq + k - perp;
+                    const u32 px = w_encode8(acc[i][0][k], s_thr) | (w_encode8(acc[i][1][k], s_thr) << 8) | (w_encode8(acc[i][2][k], s_thr) << 16) | 0xff000000u;
+                    if (y >= y_lo && y <= y_hi && x < d_w) *(u32 *)(d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u)) = px;
+                }
+            }
+            while (vt <= vt1 && vm.y == c) {
+                vt++;
+                if (vt <= vt1) { vm = vm_next; vm_next = J.v_meta[min(vt + 1, vt1)]; }
+            }
+            if (c + 1 < c_last) issue(c + 2);
+            continue;
         }
         // ---- the chunk's 16 rows of H, rounded to f16 (resampler.rs:25-28), into ring slot c mod 2 KV: lane holds rows 4 lq .. + 3 of
         //      output column l16 of either tile
@@ -1039,6 +1065,19 @@ int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     return SMR_OK;
 }
 
+// A single-axis plan written as the two-pass plan the job builders understand: the scaled axis first, then a scale-1 "pass" along the
+// other axis that only carries the perpendicular crop offset (its band gives the pieces their chunk ranges; the 32768 builds do not
+// run it).  The caller sets WJob::perp and launches the single-axis build.
+inline smr_resample_plan single_axis_as_two_pass(const smr_resample_plan &plan) {
+    smr_resample_plan p = plan;
+    p.kind = 2;
+    p.axis[1] = 1 - plan.axis[0];
+    p.scale[1] = 1.0f;
+    p.offset[1] = (float)plan.perp_offset[0];
+    p.perp_offset[0] = p.perp_offset[1] = 0;
+    return p;
+}
+
 // An RGBA8 node texture with alpha == 1 as the source (k_ingest_wave's 8192 builds): a frame of a format the fused conversion does not
 // read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB) after the exact converter, or an opaque surface.  Horizontal-first Lanczos plans with
 // the kernel's window limits (shrink factors up to ~3.5).
@@ -1148,12 +1187,15 @@ constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
 // ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; the windows the generic build holds reach ~3.2)
 constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>;
+// ... and single-axis plans (generic build): planar | NV12-capable | RGBA8 node texture
+constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>};
 
-int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false) {
+int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
         std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
         all.push_back(W_KERNEL_RGBA16F);
+        all.insert(all.end(), W_KERNELS_SA, W_KERNELS_SA + 3);
         for (WaveKernel k : all) {
             SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipFuncAttributes fa;
@@ -1181,15 +1223,16 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             nks_max = J.NKS > nks_max ? J.NKS : nks_max;
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
-        if (f16) cls432 = cls83 = false;  // (one generic build)
+        if (f16 || sa) cls432 = cls83 = false;  // (one generic build)
         int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
-        if (!rgba) {
+        if (!rgba && !sa) {
             if (direct) ki += 4;
             if (any_nv) ki += 8;
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
-        const WaveKernel kern = f16 ? W_KERNEL_RGBA16F : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
-        if (rgba) ki += f16 ? 200 : 100;  // (occupancy cache key)
+        const WaveKernel kern = sa ? W_KERNELS_SA[rgba ? 2 : (any_nv ? 1 : 0)] : f16 ? W_KERNEL_RGBA16F : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
+        if (sa) ki = 300 + (rgba ? 2 : (any_nv ? 1 : 0));  // (occupancy cache key)
+        else if (rgba) ki += f16 ? 200 : 100;
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);

@@ -117,6 +117,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
     if (bh.K > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
     const bool cls432 = bh.K <= 4 && bv.K == 2, cls83 = bh.K <= 8 && bv.K == 3;
+    const bool sa = specialised == 2;  // single-axis plan: scale_v = 1, off_v = the perpendicular crop offset; the 32768 builds
+    if (sa) specialised = 0;
     if (specialised && !cls432 && !cls83) return -2;
 
     WArgs args;
@@ -139,6 +141,7 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     args.wg_prefix[0] = 0;
     args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
     args.n_jobs = 1;
+    if (sa) J.perp = (int)off_v;
     const bool spec = specialised && cls432, spec83 = specialised && !cls432 && cls83;
     const int cls_nks = spec ? 4 : 0;
     args.b_bytes = w_band_bytes(cls_nks ? cls_nks : bh.K);
@@ -148,7 +151,11 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     const int total = args.wg_prefix[1];
     if (info) info[3] = total;
     const unsigned blocks = (unsigned)((total + 7) & ~7);
-    if (f16) {
+    if (sa) {
+        if (rgba) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 8192>(args, tables, lut16); });
+        else if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768>(args, tables, lut16); });
+    } else if (f16) {
         run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 16384>(args, tables, lut16); });
     } else if (rgba) {
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193>(args, tables, lut16); });

@@ -166,3 +166,49 @@ def test_emulated_kernel_on_a_box_reduced_rgba16f_texture(emu, src, dst, pieces)
     assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
     assert (d == 0).mean() >= 0.9995, (d == 0).mean()
     assert (got[..., 3] == 255).all()
+
+
+# (source, tile width, crop (top, left, width, height) or None, pieces, source kind: 0 planar, 1 NV12, 2 RGBA8 node)
+SA_CASES = [
+    ((96, 60), 64, None, 2, 0),
+    ((96, 60), 64, None, 3, 1),
+    ((130, 74), 200, None, 2, 0),                      # upscale of the width only
+    ((200, 120), 64, (20.0, 10.0, 96.0, 60.0), 2, 0),  # crop: the rows start at 20 (the perpendicular offset)
+    ((96, 60), 64, None, 2, 2),
+    ((256, 144), 100, (8.0, 0.0, 256.0, 100.0), 3, 2),
+]
+
+
+@pytest.mark.parametrize("src,dw,crop,pieces,kind", SA_CASES)
+def test_emulated_single_axis_plan(emu, src, dw, crop, pieces, kind):
+    """The 32768 builds: a plan with one pass (only the width changes).  Pass 1's f32 sums are encoded directly — no f16 rounding, no
+    pass 2 — so the tile is the oracle's single resample pass within 1 LSB."""
+    sw, sh = src
+    crop = crop or (0.0, 0.0, float(sw), float(sh))
+    dh = int(crop[3])
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 1 and plan.axis[0] == 0 and plan.levels == (0, 0), plan
+    if kind == 2:
+        rng = np.random.default_rng(sw + dw)
+        node = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+        node[..., 3] = 255
+        a = b = c_ = np.ascontiguousarray(node)
+        node_k = node
+    else:
+        y, u, v = _planes(sw, sh, True, seed=sw * 3 + dw)
+        if kind == 1:
+            uu = np.ascontiguousarray(np.stack([u, v], axis=-1))
+            node, node_k = orc.nv12_to_rgba(y, uu, sw, sh), convert_model.node_codes_nv12(y, uu)
+        else:
+            uu = u
+            node, node_k = orc.planar_yuv_to_rgba(y, u, v, sw, sh), convert_model.node_codes(y, u, v)
+        a, b, c_ = y, uu, v
+    want = orc.resample_pass(node_k, orc.PX_RGBA8_SRGB, 0, plan.scale[0], plan.offset[0], plan.perp_offset[0], orc.PX_RGBA8_SRGB, dw, dh)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    rc = emu.emu_ingest_wave(_p(a), _p(b), _p(c_), sw, sh, 0, kind, plan.scale[0], plan.offset[0], 1.0, float(plan.perp_offset[0]), _p(got), dw, dh, pieces, 2, info)
+    assert rc == 0, (rc, list(info))
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
+    assert (d == 0).mean() >= 0.9995, (d == 0).mean()
+    assert (got[..., 3] == 255).all()

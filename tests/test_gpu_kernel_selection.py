@@ -8,10 +8,11 @@ the oracle on that path.  The table below is the map of the fast paths and of wh
 * `wave_box`   box-pre-reduced plans (shrink factors above 4) of every opaque source, horizontal-first, residual scales up to ~3.2:
                the exact converter, downsample.wgsl's pass as it is (RGBA16F, linear light), then the residual Lanczos on the matrix
                cores reading the f16 texels as they are
+               Single-axis plans (only the width or only the height changes) take `wave` / `wave_rgba` too: one pass on the matrix
+               cores whose f32 sums are encoded directly (the 32768 builds), height-only plans on the transposed frame / node.
 * `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32): every source with an alpha channel
-               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — single-axis plans (one pass whose f32 sums
-               are encoded directly: the two-pass kernel would round them to f16 first), box-pre-reduced plans whose residual scale
-               exceeds ~3.2 or that filter vertically first.  Nothing falls to the one-launch f32 kernel
+               (BGRA / ARGB frames, translucent surfaces), and — the holes that are left — box-pre-reduced plans whose residual
+               scale exceeds ~3.2 or that filter vertically first.  Nothing falls to the one-launch f32 kernel
                (k_ingest_resample) any more unless SMR_INGEST_VALU_F32 asks for it.
 """
 import numpy as np
@@ -49,7 +50,7 @@ def expected_path(fmt, plan):
     if fmt in ("bgra", "alpha_surface"):
         return "general"
     if plan in ("single_axis_h", "single_axis_v"):
-        return "general"
+        return "wave" if fmt in FUSED_YUV else "wave_rgba"
     if plan == "box_prereduced":
         return "wave_box"
     if plan == "box_prereduced_8":
@@ -131,7 +132,13 @@ def test_path_and_parity(hip, fmt, plan):
         _, tile = orc.resample(node, (0.0, 0.0, float(sw), float(sh)), dw, dh)
         want = orc.apply_layouts(dw, dh, [Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=(0, 0, dw, dh))], [tile])
         d = np.abs(got.astype(np.int16) - want.astype(np.int16))
-        assert d.max() <= 1, (fmt, plan, int(d.max()))
+        if want_path == "wave":
+            # the fused colour conversion differs from planar_yuv_to_rgba.wgsl by one code in ~2e-5 of the node's bytes; where the
+            # output is dark a linear-light filter can show such a flip as 2..4 codes (include/smr.h, tests/test_convert_model.py):
+            # the resample stage itself is pinned within 1 LSB on every byte by tests/test_gpu_fused.py and tests/test_emu_wave.py
+            assert d.max() <= 4 and (d > 1).mean() <= 1e-5, (fmt, plan, int(d.max()), float((d > 1).mean()))
+        else:
+            assert d.max() <= 1, (fmt, plan, int(d.max()))
         assert (d == 0).mean() >= 0.985, (fmt, plan, float((d == 0).mean()))
     finally:
         ctx.close()
