@@ -226,6 +226,36 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         wjobs_rgba.push_back(J);
                         on_mfma = true;
                     }
+                    if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 1 && plan.axis[1] == 0) {
+                        // the same for a vertical-first residual: the box-reduced node transposed in, the tile transposed back
+                        smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
+                        smr_surface *reduced_t = smr_cached_surface(ctx, SLOT_TRANSPOSED0 + 4 * (size_t)li, (u32)plan.reduced_h, (u32)plan.reduced_w, SMR_PX_RGBA16F);
+                        smr_surface *tile_t = smr_cached_surface(ctx, SLOT_TRANSPOSED0 + 4 * (size_t)li + 3, tile->h, tile->w, SMR_PX_RGBA8);
+                        if (!reduced || !reduced_t || !tile_t) return SMR_ERR_OOM;
+                        smr_resample_plan pt = plan;
+                        pt.axis[0] = 0; pt.axis[1] = 1;
+                        if (can_fuse_wave_rgba(ctx, view_of(reduced_t), pt, tile_t, 8)) {
+                            if (is_frame) {
+                                int rc = ensure_node(si);
+                                if (rc != SMR_OK) return rc;
+                            }
+                            smr_surface node;  // non-owning alias of the node view
+                            node.ptr = views[si].ptr; node.pitch = views[si].pitch; node.w = (u32)views[si].w; node.h = (u32)views[si].h;
+                            node.fmt = SMR_PX_RGBA8;
+                            int rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
+                            if (rc != SMR_OK) return rc;
+                            rc = launch_transpose<uint2>(ctx, reduced, reduced_t);
+                            if (rc != SMR_OK) return rc;
+                            WJob J;
+                            rc = make_wave_job_rgba(ctx, view_of(reduced_t), pt, tile_t, &J);
+                            if (rc != SMR_OK) return rc;
+                            wjobs_f16.push_back(J);
+                            MTransposeBack back;
+                            back.tile_t = tile_t; back.tile = tile;
+                            transposed.push_back(back);
+                            on_mfma = true;
+                        }
+                    }
                     if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 0 && plan.axis[1] == 1) {
                         // box-pre-reduced plan (shrink factors from 4): downsample.wgsl's pass as it is, then the residual Lanczos
                         // (scales below 2) on the matrix cores, reading the RGBA16F texels as they are
