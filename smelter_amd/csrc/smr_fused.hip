@@ -110,7 +110,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
-    std::vector<WJob> wjobs, wjobs_rgba, wjobs_f16, wjobs_sa, wjobs_sa_rgba;
+    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_sa, wjobs_sa_rgba;
     std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
@@ -209,7 +209,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 }
                 // an opaque source the fused conversion does not read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB frames after the exact
                 // converter; opaque surfaces): the same matrix-core kernel on its RGBA8 node texture
-                if (!on_mfma && fused && kinds[si] == 2) {
+                if (!on_mfma && fused && (kinds[si] == 2 || (kinds[si] == 1 && plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0))) {
+                    // (kinds 1: the node has an alpha channel — the four-channel builds, two-pass plans)
+                    std::vector<WJob> &rgba_jobs = kinds[si] == 2 ? wjobs_rgba : wjobs_rgba_alpha;
                     if (is_frame && !node_ready[si]) {
                         // (only convert when the kernel will take the job: the geometry test needs the node's size, not its pixels)
                         SurfView probe;
@@ -223,10 +225,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         WJob J;
                         int rc = make_wave_job_rgba(ctx, views[si], plan, tile, &J);
                         if (rc != SMR_OK) return rc;
-                        wjobs_rgba.push_back(J);
+                        rgba_jobs.push_back(J);
                         on_mfma = true;
                     }
-                    if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 1 && plan.axis[1] == 0) {
+                    if (!on_mfma && kinds[si] == 2 && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 1 && plan.axis[1] == 0) {
                         // the same for a vertical-first residual: the box-reduced node transposed in, the tile transposed back
                         smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
                         smr_surface *reduced_t = smr_cached_surface(ctx, SLOT_TRANSPOSED0 + 4 * (size_t)li, (u32)plan.reduced_h, (u32)plan.reduced_w, SMR_PX_RGBA16F);
@@ -256,7 +258,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             on_mfma = true;
                         }
                     }
-                    if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 0 && plan.axis[1] == 1) {
+                    if (!on_mfma && kinds[si] == 2 && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 0 && plan.axis[1] == 1) {
                         // box-pre-reduced plan (shrink factors from 4): downsample.wgsl's pass as it is, then the residual Lanczos
                         // (scales below 2) on the matrix cores, reading the RGBA16F texels as they are
                         smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
@@ -287,7 +289,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         MTransposeBack back;
                         int rc = make_wave_job_rgba_transposed(ctx, views[si], plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
                         if (rc != SMR_OK) return rc;
-                        if (on_mfma) { wjobs_rgba.push_back(J); transposed.push_back(back); }
+                        if (on_mfma) { rgba_jobs.push_back(J); transposed.push_back(back); }
                     }
                 }
                 if (on_mfma) {
@@ -451,6 +453,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
     if (!wjobs_rgba.empty()) {
         rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_rgba_alpha.empty()) {
+        rc = launch_wave(ctx, wjobs_rgba_alpha, nullptr, true, false, false, true);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_f16.empty()) {

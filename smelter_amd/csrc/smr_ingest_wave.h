@@ -312,7 +312,7 @@ __device__ __forceinline__ u32 w_encode8(float x, const float *__restrict__ thr)
 
 template <int NKS_T, int KV_T, int FL, typename Pro>
 __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restrict__ Dg, int pair, int vt0, int vt1, u8 *smem, u32 b_off, u32 raw_off,
-                                           unsigned long long *dbg, Pro finish_prologue) {
+                                           unsigned long long *dbg, Pro finish_prologue, int J_b_bytes) {
     const int lane = threadIdx.x & 63, l16 = lane & 15, lq = lane >> 4;
 #if SMR_WAVE_TIMING
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
@@ -345,6 +345,12 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // encoded and stored as they are, row for row; there is no f16 rounding and no pass 2.  The job's vertical band (scale 1) only
     // supplies the chunk ranges of the pieces.  (Height-only plans run on the transposed frame.)
     constexpr bool SA = (FL & 32768) != 0;
+    // 65536 (with 8192): the RGBA8 node texture has an alpha channel (premultiplied: a text run, an image, a nested layout node, a
+    // BGRA / ARGB frame): alpha is a fourth channel through both passes — linear, not sRGB: a / 255 as an f16 pair from its own 256-entry
+    // table, unorm8 on the way out (resample.wgsl filters all four channels of the premultiplied texel).
+    constexpr bool AL = RG && !RH && (FL & 65536) != 0;
+    constexpr int NCH = AL ? 4 : 3;
+    const u32 alpha_tab = b_off + (u32)J_b_bytes;  // LDS: behind the pass-1 band (the raw staging area of the other builds)
     constexpr int RG_N = RG ? NKS_N : 1;
     uint4 rg[RG_N];  // block j of the chunk at hand; refilled with the next chunk's block j as soon as it has been converted
     uint4 rg2[RH ? RG_N : 1];  // (RGBA16F: texels 2, 3 of the block; rg holds 0, 1)
@@ -473,14 +479,21 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         const u32 row = (u32)min(max(16 * c - 1 + l16, 0), sh - 1);
         const u32 col = (u32)min(base + 16 * j + 4 * lq, sw4 - 4);
         if (RH) {
+            // (texels past the row's end are the surface's padding — arbitrary bits, possibly an f16 NaN or infinity, and 0 x NaN is
+            //  not 0: they are replaced by zero.  The byte builds need no such care: every byte decodes to a finite value.)
             const u8 *p = y_ptr + dev_mad24(row, y_pitch, 8u * col);
-            rg2[RH ? (j < RG_N ? j : 0) : 0] = *(const uint4 *)(p + 16);
-            return *(const uint4 *)p;
+            uint4 t = *(const uint4 *)p, t2 = *(const uint4 *)(p + 16);
+            const int nvalid = sw - (int)col;  // >= 1
+            if (nvalid < 2) { t.z = 0u; t.w = 0u; }
+            if (nvalid < 3) { t2.x = 0u; t2.y = 0u; }
+            if (nvalid < 4) { t2.z = 0u; t2.w = 0u; }
+            rg2[RH ? (j < RG_N ? j : 0) : 0] = t2;
+            return t;
         }
         return *(const uint4 *)(y_ptr + dev_mad24(row, y_pitch, 4u * col));
     };
     // ... and its texel bytes -> decode table (entries 256 .. 511 of the LUT are the codes themselves)
-    auto convert_rgba = [&](int j, uint4 (&a)[3]) {
+    auto convert_rgba = [&](int j, uint4 (&a)[4]) {
         const uint4 t = rg[RG ? (j < RG_N ? j : 0) : 0];
         if (RH) {  // texel = (r | g << 16, b | a << 16): hi = the f16 itself, lo = 0
             const uint4 t2 = rg2[RH ? (j < RG_N ? j : 0) : 0];
@@ -490,25 +503,26 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             return;
         }
         const u32 px[4] = {t.x, t.y, t.z, t.w};
-        u32 o[3][4];
+        u32 o[4][4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             o[0][k] = dev_lds_u32(((px[k] << 2) & 0x3fcu) + 1024u);
             o[1][k] = dev_lds_u32(((px[k] >> 6) & 0x3fcu) + 1024u);
             o[2][k] = dev_lds_u32(((px[k] >> 14) & 0x3fcu) + 1024u);
+            if (AL) o[3][k] = dev_lds_u32(((px[k] >> 22) & 0x3fcu) + alpha_tab);
         }
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
+        for (int ch = 0; ch < NCH; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
     };
 
     // ---- pass-2 state: the ring of f16 rows (two chunks per register quad) and the weights of the next tile to finish
     //      (one register vector per tile and channel, written at a uniform runtime index: register-indexed moves, not a select per slot)
     typedef u32 ring_t __attribute__((ext_vector_type(4 * KV_N)));
-    ring_t ring[2][3];
+    ring_t ring[2][4];
 #pragma unroll
     for (int i = 0; i < W_NTI; i++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) ring[i][c] = (ring_t)(0u);
+        for (int c = 0; c < NCH; c++) ring[i][c] = (ring_t)(0u);
     auto ring_quad = [&](int i, int ch, int p) { return make_uint4(ring[i][ch][4 * p], ring[i][ch][4 * p + 1], ring[i][ch][4 * p + 2], ring[i][ch][4 * p + 3]); };
     uint4 bvh[KV_N], bvl[KV_N];
     const uint4 *const v_frag = J.v_frag;
@@ -577,11 +591,11 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     W_MARK(0);
     for (int c = c_first; c <= c_last; c++) {
         // ---- conversion + pass 1 of chunk c: k-step by k-step, straight into the accumulators of the tiles it feeds
-        f32x4 acc[2][3];
+        f32x4 acc[2][4];
 #pragma unroll
         for (int i = 0; i < W_NTI; i++)
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) acc[i][ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ch = 0; ch < NCH; ch++) acc[i][ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (NKS_T && SMR_WAVE_PIPE) {
             // ---- class build: software pipeline over the k-steps.  Step j: the LDS reads of block j + 1 and of the weights of step
             //      j - 1 go out, block j is converted (vector ALU + table gathers), then the MFMAs of step j - 1 are issued — their
@@ -605,7 +619,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
                 }
             };
-            auto convert = [&](int j, const Raw &r, uint4 (&a)[3]) {
+            auto convert = [&](int j, const Raw &r, uint4 (&a)[4]) {
                 if (RG) {
                     convert_rgba(j, a);
                     if (c < c_last) rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(c + 1, j);
@@ -615,21 +629,21 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 const u32 va = dev_alignbyte(r.v1, r.v0, shb), vb = dev_alignbyte(r.v3, r.v2, shb);
                 m_convert_px<false>(K, r.yy, ua, ub, va, vb, w13, w31, a);
             };
-            auto mfmas = [&](int j, const uint4 (&a)[3], const uint4 (&bq)[2][2]) {
+            auto mfmas = [&](int j, const uint4 (&a)[4], const uint4 (&bq)[2][2]) {
 #pragma unroll
                 for (int i = 0; i < W_NTI; i++) {
                     if (K01 && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
                     if (NKS_T > 4 && (j < klo[i] || j > khi[i])) continue;  // (uniform: wide windows — most (tile, k-step) fragments are zero)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
+                    for (int ch = 0; ch < NCH; ch++)
                         acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][0]), acc[i][ch]);
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++)
+                    for (int ch = 0; ch < NCH; ch++)
                         acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][1]), acc[i][ch]);
                 }
             };
             Raw cur, nxt;
-            uint4 a[3], a_prev[3], bq[2][2];
+            uint4 a[4], a_prev[4], bq[2][2];
             read_raw(0, cur);
 #pragma unroll
             for (int j = 0; j < NKS_T; j++) {
@@ -641,7 +655,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     if (SMR_WAVE_PIPE_FENCE) dev_sched_barrier();
                     if (j > 0) mfmas(j - 1, a_prev, bq);
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) a_prev[ch] = a[ch];
+                    for (int ch = 0; ch < NCH; ch++) a_prev[ch] = a[ch];
                     cur = nxt;
                 }
             }
@@ -677,7 +691,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                         ua = dev_alignbyte(urow[2 * j + 1], urow[2 * j], shb); ub = dev_alignbyte(urow[cs + 2 * j + 1], urow[cs + 2 * j], shb);
                         va = dev_alignbyte(vrow[2 * j + 1], vrow[2 * j], shb); vb = dev_alignbyte(vrow[cs + 2 * j + 1], vrow[cs + 2 * j], shb);
                     }
-                    uint4 a[3];
+                    uint4 a[4];
                     if (RG) {
                         convert_rgba(j, a);
                         if (c < c_last) rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(c + 1, j);
@@ -702,10 +716,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                                 bq[i][1] = Bs[((i * NKS + j) * 2 + 1) * 64 + lane];
                             }
     #pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
+                            for (int ch = 0; ch < NCH; ch++)
                                 acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][0]), acc[i][ch]);
     #pragma unroll
-                            for (int ch = 0; ch < 3; ch++)
+                            for (int ch = 0; ch < NCH; ch++)
                                 acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][1]), acc[i][ch]);
                         }
                     }
@@ -742,11 +756,11 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
         // ---- the chunk's 16 rows of H, rounded to f16 (resampler.rs:25-28), into ring slot c mod 2 KV: lane holds rows 4 lq .. + 3 of
         //      output column l16 of either tile
-        u32 h16[2][3][2];
+        u32 h16[2][4][2];
 #pragma unroll
         for (int i = 0; i < W_NTI; i++)
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
+            for (int ch = 0; ch < NCH; ch++) {
                 const __half2 h0 = __floats2half2_rn(acc[i][ch][0], acc[i][ch][1]), h1 = __floats2half2_rn(acc[i][ch][2], acc[i][ch][3]);
                 const u32 lo = *(const u32 *)&h0, hi = *(const u32 *)&h1;
                 h16[i][ch][0] = lo;
@@ -760,7 +774,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #pragma unroll
                 for (int i = 0; i < W_NTI; i++)
 #pragma unroll
-                    for (int ch = 0; ch < 3; ch++) {
+                    for (int ch = 0; ch < NCH; ch++) {
                         ring[i][ch][2 * s] = h16[i][ch][0];
                         ring[i][ch][2 * s + 1] = h16[i][ch][1];
                     }
@@ -775,9 +789,9 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #pragma unroll
             for (int i = 0; i < W_NTI; i++) {
                 if (klo[i] == 0xff) continue;  // (uniform: no second tile in the last pair of an odd tile count)
-                f32x4 o[3];
+                f32x4 o[4];
 #pragma unroll
-                for (int ch = 0; ch < 3; ch++) o[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int ch = 0; ch < NCH; ch++) o[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (SMR_WAVE_ABL & 8) {
                     const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
                     if (!(SMR_WAVE_ABL & 16) && y < d_h && x + 3 < d_w)
@@ -788,10 +802,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 for (int p = 0; p < KV_N; p++) {
                     if (p < KV) {
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
+                        for (int ch = 0; ch < NCH; ch++)
                             o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvh[p]), o[ch]);
 #pragma unroll
-                        for (int ch = 0; ch < 3; ch++)
+                        for (int ch = 0; ch < NCH; ch++)
                             o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvl[p]), o[ch]);
                     }
                 }
@@ -801,7 +815,8 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 u32 px[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    px[k] = w_encode8(o[0][k], s_thr) | (w_encode8(o[1][k], s_thr) << 8) | (w_encode8(o[2][k], s_thr) << 16) | 0xff000000u;
+                    px[k] = w_encode8(o[0][k], s_thr) | (w_encode8(o[1][k], s_thr) << 8) | (w_encode8(o[2][k], s_thr) << 16) |
+                            (AL ? unorm8(o[AL ? 3 : 0][k]) << 24 : 0xff000000u);
 #ifndef SMR_EMU
 #pragma unroll
                 for (int k = 0; k < 4; k++) asm volatile("" : "+v"(px[k]));  // (all twelve lookups in flight together: not sunk into the store branches)
@@ -911,6 +926,14 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
         } else {
             for (int i = tid; i < 2 * NKS * 2 * 64; i += W_THREADS) Bs[i] = src[i];
         }
+        if ((FL & 8192) && !(FL & 16384) && (FL & 65536)) {  // alpha builds: a / 255 (correctly rounded, as unorm_of_byte) as (hi | lo << 16)
+            for (int i = tid; i < 256; i += W_THREADS) {
+                const float v = unorm_of_byte((u32)i);
+                const __half2 h = __floats2half2_rn(v, 0.0f);                       // hi
+                const __half2 l = __floats2half2_rn(v - __half22float2(h).x, 0.0f);  // lo = v - hi
+                ((u32 *)(smem + W_OFF_B + args.b_bytes))[i] = ((*(const u32 *)&h) & 0xffffu) | ((*(const u32 *)&l) << 16);
+            }
+        }
         __syncthreads();
     };
     if (SMR_WAVE_ABL & 1024) {  // profiling: launch + prologue only
@@ -922,7 +945,7 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
     const int vt0 = (int)(((long long)piece * J.n_vtiles) / J.pieces), vt1 = (int)(((long long)(piece + 1) * J.n_vtiles) / J.pieces) - 1;
     if (vt0 <= vt1)
         wave_piece<NKS_T, KV_T, FL>(J, args.direct, pair, vt0, vt1, smem, (u32)W_OFF_B, (u32)(W_OFF_B + args.b_bytes + wave * args.raw_bytes), args.dbg,
-                                    finish_prologue);
+                                    finish_prologue, args.b_bytes);
     else
         finish_prologue();
 }
@@ -1185,15 +1208,20 @@ constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 
 constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 // RGBA8 node textures as the source: the same four classes
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
+// ... with an alpha channel (premultiplied RGBA8: text, images, nested layout nodes, BGRA / ARGB frames): four channels
+constexpr WaveKernel W_KERNELS_RGBA_ALPHA[] = {k_ingest_wave<0, 0, 8192 + 65536>, k_ingest_wave<4, 2, 8192 + 65536>, k_ingest_wave<4, 2, 8193 + 65536>,
+                                               k_ingest_wave<8, 3, 8192 + 65536>};
 // ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; the windows the generic build holds reach ~3.2)
 constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>;
 // ... and single-axis plans (generic build): planar | NV12-capable | RGBA8 node texture
 constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>};
 
-int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false) {
+int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false,
+                bool alpha = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
         std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
+        all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
         all.push_back(W_KERNEL_RGBA16F);
         all.insert(all.end(), W_KERNELS_SA, W_KERNELS_SA + 3);
         for (WaveKernel k : all) {
@@ -1230,9 +1258,10 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             if (any_nv) ki += 8;
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
-        const WaveKernel kern = sa ? W_KERNELS_SA[rgba ? 2 : (any_nv ? 1 : 0)] : f16 ? W_KERNEL_RGBA16F : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
+        const WaveKernel kern = sa ? W_KERNELS_SA[rgba ? 2 : (any_nv ? 1 : 0)]
+                                   : f16 ? W_KERNEL_RGBA16F : alpha ? W_KERNELS_RGBA_ALPHA[ki] : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
         if (sa) ki = 300 + (rgba ? 2 : (any_nv ? 1 : 0));  // (occupancy cache key)
-        else if (rgba) ki += f16 ? 200 : 100;
+        else if (rgba) ki += f16 ? 200 : alpha ? 400 : 100;
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);

@@ -56,7 +56,7 @@ struct Plane {
 Plane make_plane(const u8 *tight, int w, int h, int bpp) {
     Plane p;
     const u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
-    p.buf.assign((size_t)pitch * h + 64, 0xcd);
+    p.buf.assign((size_t)pitch * h + 64, bpp == 8 ? 0xff : 0xcd);  // (row padding: arbitrary bytes; as f16 texels 0xffff is a NaN)
     for (int y = 0; y < h; y++) memcpy(p.buf.data() + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
     p.view.ptr = p.buf.data(); p.view.pitch = pitch; p.view.w = w; p.view.h = h;
     return p;
@@ -107,7 +107,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         have_tables = true;
     }
     const bool f16 = nv12 == 3;           // y = an RGBA16F node texture (linear light): the 8192 + 16384 build
-    const bool rgba = nv12 == 2 || f16;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
+    const bool alpha = nv12 == 4;         // y = a premultiplied RGBA8 node texture with an alpha channel: the 8192 + 65536 builds
+    const bool rgba = nv12 == 2 || f16 || alpha;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
     if (rgba) nv12 = 0;
     Plane py = make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1);
     Plane pu = rgba ? py : (nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1));
@@ -157,6 +158,11 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768>(args, tables, lut16); });
     } else if (f16) {
         run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 16384>(args, tables, lut16); });
+    } else if (alpha) {
+        if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193 + 65536>(args, tables, lut16); });
+        else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192 + 65536>(args, tables, lut16); });
+        else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192 + 65536>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 65536>(args, tables, lut16); });
     } else if (rgba) {
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193>(args, tables, lut16); });
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192>(args, tables, lut16); });

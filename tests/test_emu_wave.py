@@ -212,3 +212,28 @@ def test_emulated_single_axis_plan(emu, src, dw, crop, pieces, kind):
     assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
     assert (d == 0).mean() >= 0.9995, (d == 0).mean()
     assert (got[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("src,dst,crop,pieces,spec", RGBA_CASES)
+def test_emulated_kernel_on_a_node_texture_with_alpha(emu, src, dst, crop, pieces, spec):
+    """The 8192 + 65536 builds: a premultiplied RGBA8 node texture with an alpha channel (text, image, nested layout node, BGRA / ARGB
+    frame): alpha is a fourth channel through both passes, linear, unorm8 on the way out — resample.wgsl on all four channels."""
+    (sw, sh), (dw, dh) = src, dst
+    rng = np.random.default_rng(sw * 11 + dh)
+    node = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+    a = node[..., 3:4].astype(np.uint16)
+    node[..., :3] = (node[..., :3].astype(np.uint16) * a // 255).astype(np.uint8)  # premultiplied
+    crop = crop or (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 2 and plan.levels == (0, 0) and tuple(plan.axis[:2]) == (0, 1)
+    _, want = orc.resample(node, crop, dw, dh)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    flat = np.ascontiguousarray(node)
+    rc = emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 4, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh, pieces,
+                             spec, info)
+    assert rc == 0, (rc, list(info))
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
+    assert (d == 0).mean() >= 0.9995, (d == 0).mean()
+    assert not (got[..., 3] == 255).all()

@@ -251,7 +251,17 @@ def test_random_geometries_fused_equals_unfused(ctx, ctx_unfused, hip, seed):
         ctx.set_strip_width(0)
     ref = _render(ctx_unfused, hip, layouts, frames(ctx_unfused), W, H)
     _assert_matches_unfused(ctx, got, ref, (seed, iw, ih, W, H, scene), identical=0.98, noise=True)
-    nodes = [_node(ctx, y, u, v, iw, ih) for y, u, v in planes]
+    # which node texture a layout's tile was resampled from: the fused conversion's (two-pass and single-axis plans), or — for a
+    # box-pre-reduced plan, whose first step is downsample.wgsl on the node — the exact converter's
+    nodes = []
+    for i, (y, u, v) in enumerate(planes):
+        tex = [l for l in layouts if l.type == 0 and l.source_index == i]
+        boxed = False
+        for l in tex:
+            dw, dh = max(int(np.floor(l.width + 0.5)), 1), max(int(np.floor(l.height + 0.5)), 1)
+            plan = orc.resample_plan(iw, ih, tuple(l.crop), dw, dh)
+            boxed = boxed or (plan.kind > 0 and plan.levels != (0, 0))
+        nodes.append(orc.planar_yuv_to_rgba(y, u, v, iw, ih) if boxed else _node(ctx, y, u, v, iw, ih))
     want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
     for g, w_, pl in zip(got, want, "YUV"):
         assert _within_one_lsb(g, w_), (seed, pl, iw, ih, W, H, refpipe.max_diff(g, w_))

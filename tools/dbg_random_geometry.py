@@ -1,0 +1,54 @@
+import sys, numpy as np
+sys.path.insert(0, '.')
+from oracle import oracle as orc
+from tests import scenes, refpipe, convert_model
+from smelter_amd import hip
+from smelter_amd.scene import Scene
+for seed in (34, 41, 48):
+    rng = np.random.default_rng(1000 + seed)
+    iw, ih = int(rng.integers(8, 700)), int(rng.integers(8, 500))
+    ih = int(np.clip(ih, iw // 3, iw * 3))
+    if seed % 3:
+        iw, ih = iw & ~1, ih & ~1
+    iw, ih = max(iw, 2), max(ih, 2)
+    W, H = int(rng.integers(8, 300)) * 4, int(rng.integers(8, 250)) * 2
+    n = int(rng.integers(1, 4))
+    kids = []
+    for i in range(n):
+        w, h = float(rng.integers(4, W)), float(rng.integers(4, H))
+        kids.append({"type": "rescaler", "mode": str(rng.choice(["fit", "fill"])), "width": w, "height": h,
+                     "top": float(rng.integers(0, max(1, H - int(h)))), "left": float(rng.integers(0, max(1, W - int(w)))),
+                     "horizontal_align": str(rng.choice(["left", "center", "right"])), "vertical_align": str(rng.choice(["top", "center", "bottom"])),
+                     "child": {"type": "input_stream", "input_id": f"in{i}"}})
+    scene = {"type": "view", "background_color": "#102030FF", "children": kids}
+    sc = Scene(); sc.update(scene, W, H)
+    layouts = sc.layouts(0, 0, [(iw, ih)] * n)
+    planes = [scenes.random_yuv420(iw, ih, 77 + seed * 10 + i) for i in range(n)]
+    planes = [(y, u[: ih // 2, : iw // 2], v[: ih // 2, : iw // 2]) for y, u, v in planes]
+    c = hip.Context(0)
+    before = c.kernel_launches()
+    out = c.frame(hip.FRAME_PLANAR_YUV420, W, H)
+    c.render_layouts(layouts, [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes], W, H, out=out)
+    got = out.download()
+    ran = {k: v - before[k] for k, v in c.kernel_launches().items() if v - before[k]}
+    print("seed", seed, (iw, ih), (W, H), ran)
+    for l in layouts:
+        if l.type == 0:
+            dw, dh = max(int(np.floor(l.width + 0.5)), 1), max(int(np.floor(l.height + 0.5)), 1)
+            print("   layout src", l.source_index, "crop", [round(x, 2) for x in l.crop], "->", (dw, dh), orc.resample_plan(iw, ih, tuple(l.crop), dw, dh))
+    for name, mk in (("exact", lambda y, u, v: orc.planar_yuv_to_rgba(y, u, v, iw, ih)), ("model", lambda y, u, v: convert_model.node_codes(y, u, v) if iw % 2 == 0 and ih % 2 == 0 else orc.planar_yuv_to_rgba(y, u, v, iw, ih))):
+        nodes = [mk(*p) for p in planes]
+        want, _ = refpipe.render_yuv420(layouts, nodes, W, H)
+        print("   vs", name, [(refpipe.max_diff(g, w_), int((np.abs(g.astype(int) - w_.astype(int)) > 1).sum())) for g, w_ in zip(got, want)])
+    # each texture layout alone
+    for li, l in enumerate(layouts):
+        if l.type != 0:
+            continue
+        only = [x for x in layouts if x.type != 0 or x is l]
+        out2 = c.frame(hip.FRAME_PLANAR_YUV420, W, H)
+        c.render_layouts(only, [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes], W, H, out=out2)
+        g2 = out2.download()
+        nodes = [orc.planar_yuv_to_rgba(*p, iw, ih) for p in planes]
+        w2, _ = refpipe.render_yuv420(only, nodes, W, H)
+        print("   layout", li, "alone:", [(refpipe.max_diff(g, w_), int((np.abs(g.astype(int) - w_.astype(int)) > 1).sum())) for g, w_ in zip(g2, w2)])
+    c.close()
