@@ -425,15 +425,19 @@ def main():
                                              "SIMD — a third wave per SIMD gains nothing (profiles/r03_occupancy.txt); see DESIGN.md section 3"}
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM
-        lat = []
+        lat, enq = [], []
         for s in range(args.latency_frames):
             t1 = time.perf_counter()
             step_fn(s, ctx)
+            t2 = time.perf_counter()
             ctx.sync()
             lat.append(time.perf_counter() - t1)
-        lat = np.array(lat) * 1e3
+            enq.append(t2 - t1)
+        lat, enq = np.array(lat) * 1e3, np.array(enq) * 1e3
         result["latency_ms"] = {"p50": round(float(np.percentile(lat, 50)), 4), "p99": round(float(np.percentile(lat, 99)), 4),
-                                "frames": args.latency_frames, "definition": "host enqueue -> output planes resident in HBM, 1 frame in flight"}
+                                "frames": args.latency_frames, "definition": "host enqueue -> output planes resident in HBM, 1 frame in flight",
+                                "host_call_p50": round(float(np.percentile(enq, 50)), 4),
+                                "host_call": "the smr_renderer_render call alone (layout maths, parameter pack, two launches) on an idle device"}
         # ... and to host-visible: the same plus the stream-ordered read-back of the output planes into pinned host memory
         from smelter_amd.renderer import BorrowedFrame
         lat, host_out = [], None

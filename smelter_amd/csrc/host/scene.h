@@ -224,6 +224,15 @@ struct GraphNode {
     int parent = -1;
     std::vector<int> children;
     Size forced_size; bool has_forced_size = false;
+    // node_layouts' result while nothing under the node is in transition: the list does not depend on pts then, and a scene at rest
+    // is the common case (the layout + flatten maths is ~8 us of the renderer thread per frame, in front of the first launch)
+    struct LayoutCache {
+        bool valid = false, srgb = false;
+        int64_t pts_ns = 0;
+        uint32_t w = 0, h = 0;
+        std::vector<std::optional<Size>> resolutions;
+        std::vector<smr_layout> layouts;
+    } cache;
 };
 
 class Scene {

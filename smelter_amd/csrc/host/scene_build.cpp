@@ -720,6 +720,14 @@ bool Scene::parse(const std::string &json, std::string &out, std::string &err) c
     return true;
 }
 
+// Is any component under `s` still moving at pts?  (TransitionState::is_finished, scene/transition.rs:79-81)
+static bool in_transition(const Stateful &s, int64_t pts_ns) {
+    if (s.transition && !s.transition->is_finished(pts_ns)) return true;
+    for (const std::unique_ptr<Stateful> &c : s.children)
+        if (c && in_transition(*c, pts_ns)) return true;
+    return false;
+}
+
 bool Scene::node_layouts(int node, int64_t pts_ns, const std::vector<std::optional<Size>> &child_resolutions, bool srgb,
                          std::vector<smr_layout> &out, uint32_t &w, uint32_t &h, std::string &err) {
     if (node < 0 || node >= (int)nodes_.size() || !nodes_[node].component->is_layout()) { err = "node_layouts: not a layout node"; return false; }
@@ -733,6 +741,19 @@ bool Scene::node_layouts(int node, int64_t pts_ns, const std::vector<std::option
         else input_resolutions_.erase(k.component->ref_id);
     }
     Stateful &root = *g.component;
+    if (g.cache.valid && g.cache.srgb == srgb && pts_ns >= g.cache.pts_ns && g.cache.resolutions.size() == child_resolutions.size()) {
+        bool same = true;
+        for (size_t i = 0; i < child_resolutions.size() && same; i++) {
+            const std::optional<Size> &a = g.cache.resolutions[i], &b = child_resolutions[i];
+            same = a.has_value() == b.has_value() && (!a || (a->width == b->width && a->height == b->height));
+        }
+        if (same) {
+            out = g.cache.layouts;
+            w = g.cache.w; h = g.cache.h;
+            return true;
+        }
+    }
+    g.cache.valid = false;
     // SizedLayoutComponent::resolution (scene/layout.rs:245-257)
     Position p = root.position(pts_ns);
     w = (uint32_t)(size_t)(p.width ? *p.width : g.forced_size.width);
@@ -772,6 +793,11 @@ bool Scene::node_layouts(int node, int64_t pts_ns, const std::vector<std::option
             o.masks[m].top = mk.top; o.masks[m].left = mk.left; o.masks[m].width = mk.width; o.masks[m].height = mk.height;
         }
         out.push_back(o);
+    }
+    if (!in_transition(root, pts_ns)) {  // (transitions only ever end between two scene updates: a later pts is at rest too)
+        g.cache.valid = true; g.cache.srgb = srgb; g.cache.pts_ns = pts_ns; g.cache.w = w; g.cache.h = h;
+        g.cache.resolutions = child_resolutions;
+        g.cache.layouts = out;
     }
     return true;
 }

@@ -303,6 +303,33 @@ def test_view_transition_linear():
     assert _box(sc2, 1).width == 300.0
 
 
+def test_layouts_of_a_scene_at_rest_are_served_from_the_cache_and_never_stale():
+    """node_layouts keeps its result while nothing under the node is in transition (smr_host::Scene::node_layouts): the list must
+    still follow a transition frame by frame, settle when it ends, change with the input resolutions and with the next update."""
+    sc = Scene()
+    scene = {"type": "view", "children": [{"type": "rescaler", "id": "r", "width": 400.0, "height": 300.0, "top": 10.0, "left": 10.0,
+                                           "child": {"type": "input_stream", "input_id": "a"}}]}
+    sc.update(scene, 1280, 720)
+
+    def first(pts_ns, res):
+        arr, n, _, _ = sc.node_layouts(0, pts_ns, [res])
+        assert n == 1
+        return (arr[0].top, arr[0].left, arr[0].width, arr[0].height)
+
+    at_rest = first(0, (640, 360))
+    assert first(1_000_000_000, (640, 360)) == at_rest            # cached
+    other_input = first(2_000_000_000, (360, 640))                  # another resolution: not the cached list
+    assert other_input != at_rest
+    assert first(3_000_000_000, (640, 360)) == at_rest
+    moved = dict(scene["children"][0], width=800.0, transition={"duration_ms": 1000})
+    sc.update({"type": "view", "children": [moved]}, 1280, 720)     # starts at the last rendered pts (3 s)
+    seen = [first(int(t * 1e9), (640, 360)) for t in (3.0, 3.25, 3.5, 3.75, 4.0, 5.0, 6.0)]
+    assert seen[0] == at_rest and len(set(seen[:5])) == 5           # every frame of the transition is its own list
+    assert seen[4] == seen[5] == seen[6] != at_rest                 # settled: served from the cache from here on
+    sc.update(scene, 1280, 720)                                     # no transition on the new scene: jumps back
+    assert first(7_000_000_000, (640, 360)) == at_rest
+
+
 def test_view_transition_easing_and_offsets():
     tr = {"duration_ms": 1000, "easing_function": {"function_name": "cubic_bezier", "points": [0.25, 0.1, 0.25, 1.0]}}
     sc = Scene()
