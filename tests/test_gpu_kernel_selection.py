@@ -145,3 +145,45 @@ def test_path_and_parity(hip, fmt, plan):
         assert (d == 0).mean() >= 0.985, (fmt, plan, float((d == 0).mean()))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("fmt", ["yuv444", "uyvy", "opaque_surface", "alpha_surface", "nv12"])
+@pytest.mark.parametrize("seed", range(16))
+def test_random_geometries_on_every_route(hip, fmt, seed):
+    """Random source sizes, tile sizes and crops (two-pass, single-axis, box-pre-reduced, direct — whatever the planner makes of them)
+    through whichever route the source takes: within 1 LSB of the oracle's plan on the oracle's node texture, and the same bytes on a
+    second run (uninitialised padding must never reach a sum)."""
+    rng = np.random.default_rng(5000 + 97 * FORMATS.index(fmt) + seed)
+    sw, sh = int(rng.integers(12, 400)) * 2, int(rng.integers(8, 260)) * 2
+    if seed % 4 == 0:
+        dw, dh = int(rng.integers(4, 60)), int(rng.integers(4, 60))              # strong shrink: box levels
+    elif seed % 4 == 1:
+        dw, dh = int(rng.integers(8, 2 * sw)), sh                               # width only
+    else:
+        dw, dh = int(rng.integers(8, 2 * sw)), int(rng.integers(8, 2 * sh))
+    crop = (0.0, 0.0, float(sw), float(sh))
+    if seed % 3 == 0:  # a crop with integer and fractional offsets
+        cl, ct = float(rng.integers(0, sw // 4)), float(rng.integers(0, sh // 4)) + (0.5 if seed % 2 else 0.0)
+        crop = (ct, cl, float(rng.integers(sw // 2, sw - int(cl))), float(rng.integers(sh // 2, sh - int(ct) - 1)))
+    ctx = hip.Context(0)
+    try:
+        src, node = _source(ctx, hip, fmt, sw, sh, rng)
+        layouts = [Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=crop)]
+        outs = []
+        for _ in range(2):
+            out = ctx.surface(dw, dh)
+            ctx.render_layouts(layouts, [src], dw, dh, out_rgba=out)
+            outs.append(out.download())
+        assert np.array_equal(outs[0], outs[1])
+        kind, tile = orc.resample(node, crop, dw, dh)
+        srcs = [tile] if kind > 0 else [node]
+        lay = [Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=(0, 0, dw, dh) if kind > 0 else crop)]
+        want = orc.apply_layouts(dw, dh, lay, srcs)
+        d = np.abs(outs[0].astype(np.int16) - want.astype(np.int16))
+        if fmt == "nv12":  # the fused conversion's one-code flips (see test_path_and_parity)
+            assert d.max() <= 4 and (d > 1).mean() <= 2e-5, (fmt, seed, (sw, sh), (dw, dh), crop, int(d.max()))
+        else:
+            assert d.max() <= 1, (fmt, seed, (sw, sh), (dw, dh), crop, int(d.max()), int((d > 1).sum()))
+        assert (d == 0).mean() >= 0.98, (fmt, seed, float((d == 0).mean()))
+    finally:
+        ctx.close()
