@@ -58,6 +58,9 @@ namespace {
 #ifndef SMR_WAVE_TIMING
 #define SMR_WAVE_TIMING 0  // profiling build (tools/variant.sh): shader cycles per phase of the first wave of every workgroup -> WArgs::dbg
 #endif
+#ifndef SMR_WAVE_SETPRIO
+#define SMR_WAVE_SETPRIO 0   // A/B: s_setprio level around the pass-1 MFMAs of the pipelined builds (measured: see profiles/r03_setprio.txt)
+#endif
 #ifndef SMR_WAVE_ONE_TILE
 #define SMR_WAVE_ONE_TILE 0  // profiling experiment: 1 = every wave works on the first tile of its pair only (half of the output is not written)
 #endif
@@ -630,6 +633,9 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 m_convert_px<false>(K, r.yy, ua, ub, va, vb, w13, w31, a);
             };
             auto mfmas = [&](int j, const uint4 (&a)[4], const uint4 (&bq)[2][2]) {
+#if SMR_WAVE_SETPRIO
+                __builtin_amdgcn_s_setprio(SMR_WAVE_SETPRIO);
+#endif
 #pragma unroll
                 for (int i = 0; i < W_NTI; i++) {
                     if (K01 && ((i == 0 && j == 3) || (i == 1 && j == 0))) continue;
@@ -641,6 +647,9 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     for (int ch = 0; ch < NCH; ch++)
                         acc[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, a[ch]), __builtin_bit_cast(f16x8, bq[i][1]), acc[i][ch]);
                 }
+#if SMR_WAVE_SETPRIO
+                __builtin_amdgcn_s_setprio(0);
+#endif
             };
             Raw cur, nxt;
             uint4 a[4], a_prev[4], bq[2][2];
