@@ -630,7 +630,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 }
                 const u32 ua = dev_alignbyte(r.u1, r.u0, shb), ub = dev_alignbyte(r.u3, r.u2, shb);
                 const u32 va = dev_alignbyte(r.v1, r.v0, shb), vb = dev_alignbyte(r.v3, r.v2, shb);
-                m_convert_px<false>(K, r.yy, ua, ub, va, vb, w13, w31, a);
+                m_convert_px<(SMR_WAVE_ABL & 1) != 0>(K, r.yy, ua, ub, va, vb, w13, w31, a);  // (ABL & 1: profiling, no table gathers)
             };
             auto mfmas = [&](int j, const uint4 (&a)[4], const uint4 (&bq)[2][2]) {
 #if SMR_WAVE_SETPRIO
