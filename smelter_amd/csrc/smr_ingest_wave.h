@@ -19,9 +19,16 @@
 //     made of chunks (c0, c1) is row 4 q + e of c0 for e < 4 and row 4 q + e - 4 of c1 for e >= 4.  A tile's window is the 2 KV
 //     chunks that end with the chunk of its last row; chunk c lives in ring slot c mod 2 KV (an absolute grid, so one band per
 //     tile serves every piece), the ring is 2 KV register pairs per channel and tile.  No f16 intermediate in LDS either.
-//   * Pass-2 weights are f16 pairs too (w_hi + w_lo, two MFMAs on the same A operand): with single-f16 weights a dark output that is
-//     a cancelling sum of bright rows was off by up to 4 LSB on white noise (round 2); with pairs every content class is within 1.
+//   * Pass-2 weights are f16 pairs too (w_hi + w_lo, two MFMAs on the same A operand): against the reference's two passes applied to
+//     the node texture this kernel's conversion produces, every byte of every content class is within 1 LSB (single-f16 pass-2
+//     weights are not, on white noise: tools/mfma_precision_sim.py).
 //   * The reference's own quantisation points are kept: u8 node texture, f16 (RTNE) between the passes, u8 sRGB tile.
+//
+// Builds (template <NKS_T, KV_T, FL>): the k-step class (generic, or fixed counts with the loops unrolled / software-pipelined) and,
+// in FL: 1 two always-zero fragments skipped | 2048 direct output | 4096 NV12-capable staging | 8192 the source is an RGBA8 node
+// texture (16-byte loads straight into the conversion layout, decode table only: 4:2:2 / 4:4:4 / packed YUV after the exact
+// converter, opaque surfaces) | + 16384 that texture is RGBA16F, linear light (box-pre-reduced plans) | + 65536 it has an alpha
+// channel (four channels) | 32768 single-axis plan: pass 1's f32 sums are encoded and stored directly (no f16 rounding, no pass 2).
 //
 // Work split: a workgroup = W_WAVES waves on the same column pair (they share its pass-1 band in LDS), each with its own vertical
 // piece; workgroups are ordered pair-fastest within a band of rows, so neighbouring pairs read the same source lines at the same
