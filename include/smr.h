@@ -197,7 +197,7 @@ SMR_API int smr_profile_reset(smr_ctx *ctx);
  * input format takes; a host can watch for scenes that leave the fast paths. */
 typedef enum smr_kernel_id {
     SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave: fused conversion + Lanczos on the matrix cores (planar 4:2:0, NV12) */
-    SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an opaque RGBA8 node texture (every other format after smr_frame_to_rgba; opaque surfaces) */
+    SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an RGBA8 / box-reduced RGBA16F node texture (every other format after smr_frame_to_rgba; surfaces) */
     SMR_KERNEL_INGEST_MFMA_WG = 2,   /* k_ingest_mfma (SMR_INGEST_MFMA_F16_WG) */
     SMR_KERNEL_INGEST_VALU = 3,      /* k_ingest_resample: fused conversion + Lanczos, every pass in f32 */
     SMR_KERNEL_RESAMPLE_GENERAL = 4, /* smr_resample on a node texture: box pre-reduction and one or two Lanczos pass kernels */

@@ -110,7 +110,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<IngestJob> jobs;
     std::vector<MJob> mjobs;
     std::vector<u32> mjob_layout;
-    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_sa, wjobs_sa_rgba;
+    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_f16_alpha, wjobs_sa, wjobs_sa_rgba, wjobs_sa_rgba_alpha;
     std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
@@ -162,7 +162,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 }
                 // a single-axis plan (only one of width / height changes) of an opaque source: the one pass on the matrix cores, its f32
                 // sums encoded directly (k_ingest_wave's 32768 builds); a height-only plan runs on the transposed frame / node
-                if (!on_mfma && fused && kinds[si] == 2 && plan.kind == 1 && plan.levels[0] == 0 && plan.levels[1] == 0) {
+                if (!on_mfma && fused && kinds[si] != 0 && plan.kind == 1 && plan.levels[0] == 0 && plan.levels[1] == 0) {
                     const smr_resample_plan p2 = single_axis_as_two_pass(plan);
                     const int perp = plan.perp_offset[0];
                     WJob J;
@@ -203,15 +203,16 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     }
                     if (took) {
                         J.perp = perp;
-                        (rgba_job ? wjobs_sa_rgba : wjobs_sa).push_back(J);
+                        (rgba_job ? (kinds[si] == 2 ? wjobs_sa_rgba : wjobs_sa_rgba_alpha) : wjobs_sa).push_back(J);
                         on_mfma = true;
                     }
                 }
                 // an opaque source the fused conversion does not read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB frames after the exact
                 // converter; opaque surfaces): the same matrix-core kernel on its RGBA8 node texture
-                if (!on_mfma && fused && (kinds[si] == 2 || (kinds[si] == 1 && plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0))) {
-                    // (kinds 1: the node has an alpha channel — the four-channel builds, two-pass plans)
+                if (!on_mfma && fused && kinds[si] != 0) {
+                    // (kinds 1: the node has an alpha channel — the four-channel builds)
                     std::vector<WJob> &rgba_jobs = kinds[si] == 2 ? wjobs_rgba : wjobs_rgba_alpha;
+                    std::vector<WJob> &f16_jobs = kinds[si] == 2 ? wjobs_f16 : wjobs_f16_alpha;
                     if (is_frame && !node_ready[si]) {
                         // (only convert when the kernel will take the job: the geometry test needs the node's size, not its pixels)
                         SurfView probe;
@@ -228,7 +229,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         rgba_jobs.push_back(J);
                         on_mfma = true;
                     }
-                    if (!on_mfma && kinds[si] == 2 && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 1 && plan.axis[1] == 0) {
+                    if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 1 && plan.axis[1] == 0) {
                         // the same for a vertical-first residual: the box-reduced node transposed in, the tile transposed back
                         smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
                         smr_surface *reduced_t = smr_cached_surface(ctx, SLOT_TRANSPOSED0 + 4 * (size_t)li, (u32)plan.reduced_h, (u32)plan.reduced_w, SMR_PX_RGBA16F);
@@ -251,14 +252,14 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             WJob J;
                             rc = make_wave_job_rgba(ctx, view_of(reduced_t), pt, tile_t, &J);
                             if (rc != SMR_OK) return rc;
-                            wjobs_f16.push_back(J);
+                            f16_jobs.push_back(J);
                             MTransposeBack back;
                             back.tile_t = tile_t; back.tile = tile;
                             transposed.push_back(back);
                             on_mfma = true;
                         }
                     }
-                    if (!on_mfma && kinds[si] == 2 && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 0 && plan.axis[1] == 1) {
+                    if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 0 && plan.axis[1] == 1) {
                         // box-pre-reduced plan (shrink factors from 4): downsample.wgsl's pass as it is, then the residual Lanczos
                         // (scales below 2) on the matrix cores, reading the RGBA16F texels as they are
                         smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
@@ -276,7 +277,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             WJob J;
                             rc = make_wave_job_rgba(ctx, view_of(reduced), plan, tile, &J);
                             if (rc != SMR_OK) return rc;
-                            wjobs_f16.push_back(J);
+                            f16_jobs.push_back(J);
                             on_mfma = true;
                         }
                     }
@@ -461,6 +462,14 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     }
     if (!wjobs_f16.empty()) {
         rc = launch_wave(ctx, wjobs_f16, nullptr, true, true);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_f16_alpha.empty()) {
+        rc = launch_wave(ctx, wjobs_f16_alpha, nullptr, true, true, false, true);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_sa_rgba_alpha.empty()) {
+        rc = launch_wave(ctx, wjobs_sa_rgba_alpha, nullptr, true, false, true, true);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_sa.empty()) {

@@ -358,7 +358,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // 65536 (with 8192): the RGBA8 node texture has an alpha channel (premultiplied: a text run, an image, a nested layout node, a
     // BGRA / ARGB frame): alpha is a fourth channel through both passes — linear, not sRGB: a / 255 as an f16 pair from its own 256-entry
     // table, unorm8 on the way out (resample.wgsl filters all four channels of the premultiplied texel).
-    constexpr bool AL = RG && !RH && (FL & 65536) != 0;
+    constexpr bool AL = RG && (FL & 65536) != 0;
     constexpr int NCH = AL ? 4 : 3;
     const u32 alpha_tab = b_off + (u32)J_b_bytes;  // LDS: behind the pass-1 band (the raw staging area of the other builds)
     constexpr int RG_N = RG ? NKS_N : 1;
@@ -510,6 +510,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             a[0] = make_uint4(t.x & 0xffffu, t.z & 0xffffu, t2.x & 0xffffu, t2.z & 0xffffu);
             a[1] = make_uint4(t.x >> 16, t.z >> 16, t2.x >> 16, t2.z >> 16);
             a[2] = make_uint4(t.y & 0xffffu, t.w & 0xffffu, t2.y & 0xffffu, t2.w & 0xffffu);
+            if (AL) a[3] = make_uint4(t.y >> 16, t.w >> 16, t2.y >> 16, t2.w >> 16);
             return;
         }
         const u32 px[4] = {t.x, t.y, t.z, t.w};
@@ -759,7 +760,8 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int y = 16 * c - 1 + 4 * lq + k - perp;
-                    const u32 px = w_encode8(acc[i][0][k], s_thr) | (w_encode8(acc[i][1][k], s_thr) << 8) | (w_encode8(acc[i][2][k], s_thr) << 16) | 0xff000000u;
+                    const u32 px = w_encode8(acc[i][0][k], s_thr) | (w_encode8(acc[i][1][k], s_thr) << 8) | (w_encode8(acc[i][2][k], s_thr) << 16) |
+                                   (AL ? unorm8(acc[i][AL ? 3 : 0][k]) << 24 : 0xff000000u);
                     if (y >= y_lo && y <= y_hi && x < d_w) *(u32 *)(d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u)) = px;
                 }
             }
@@ -1228,9 +1230,10 @@ constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wav
 constexpr WaveKernel W_KERNELS_RGBA_ALPHA[] = {k_ingest_wave<0, 0, 8192 + 65536>, k_ingest_wave<4, 2, 8192 + 65536>, k_ingest_wave<4, 2, 8193 + 65536>,
                                                k_ingest_wave<8, 3, 8192 + 65536>};
 // ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; the windows the generic build holds reach ~3.2)
-constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>;
+constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>, W_KERNEL_RGBA16F_ALPHA = k_ingest_wave<0, 0, 8192 + 16384 + 65536>;
 // ... and single-axis plans (generic build): planar | NV12-capable | RGBA8 node texture
-constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>};
+constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>,
+                                       k_ingest_wave<0, 0, 32768 + 8192 + 65536>};
 
 int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false,
                 bool alpha = false) {
@@ -1239,7 +1242,8 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
         all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
         all.push_back(W_KERNEL_RGBA16F);
-        all.insert(all.end(), W_KERNELS_SA, W_KERNELS_SA + 3);
+        all.push_back(W_KERNEL_RGBA16F_ALPHA);
+        all.insert(all.end(), W_KERNELS_SA, W_KERNELS_SA + 4);
         for (WaveKernel k : all) {
             SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipFuncAttributes fa;
@@ -1274,10 +1278,12 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             if (any_nv) ki += 8;
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
-        const WaveKernel kern = sa ? W_KERNELS_SA[rgba ? 2 : (any_nv ? 1 : 0)]
-                                   : f16 ? W_KERNEL_RGBA16F : alpha ? W_KERNELS_RGBA_ALPHA[ki] : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
-        if (sa) ki = 300 + (rgba ? 2 : (any_nv ? 1 : 0));  // (occupancy cache key)
-        else if (rgba) ki += f16 ? 200 : alpha ? 400 : 100;
+        const int sa_i = rgba ? (alpha ? 3 : 2) : (any_nv ? 1 : 0);
+        const WaveKernel kern = sa ? W_KERNELS_SA[sa_i]
+                                   : f16 ? (alpha ? W_KERNEL_RGBA16F_ALPHA : W_KERNEL_RGBA16F)
+                                         : alpha ? W_KERNELS_RGBA_ALPHA[ki] : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
+        if (sa) ki = 300 + sa_i;  // (occupancy cache key)
+        else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : 100;
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);

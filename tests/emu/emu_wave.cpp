@@ -106,8 +106,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         if (!smr_build_tables(tables, lut16)) return -9;
         have_tables = true;
     }
-    const bool f16 = nv12 == 3;           // y = an RGBA16F node texture (linear light): the 8192 + 16384 build
-    const bool alpha = nv12 == 4;         // y = a premultiplied RGBA8 node texture with an alpha channel: the 8192 + 65536 builds
+    const bool f16 = nv12 == 3 || nv12 == 5;   // y = an RGBA16F node texture (linear light): the 8192 + 16384 build (5: with an alpha channel)
+    const bool alpha = nv12 == 4 || nv12 == 5; // y = a premultiplied node texture with an alpha channel: the + 65536 builds
     const bool rgba = nv12 == 2 || f16 || alpha;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
     if (rgba) nv12 = 0;
     Plane py = make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1);
@@ -153,11 +153,13 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     if (info) info[3] = total;
     const unsigned blocks = (unsigned)((total + 7) & ~7);
     if (sa) {
-        if (rgba) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 8192>(args, tables, lut16); });
+        if (alpha) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 8192 + 65536>(args, tables, lut16); });
+        else if (rgba) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 8192>(args, tables, lut16); });
         else if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 4096>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768>(args, tables, lut16); });
     } else if (f16) {
-        run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 16384>(args, tables, lut16); });
+        if (alpha) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 16384 + 65536>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 16384>(args, tables, lut16); });
     } else if (alpha) {
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193 + 65536>(args, tables, lut16); });
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192 + 65536>(args, tables, lut16); });

@@ -237,3 +237,35 @@ def test_emulated_kernel_on_a_node_texture_with_alpha(emu, src, dst, crop, piece
     assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
     assert (d == 0).mean() >= 0.9995, (d == 0).mean()
     assert not (got[..., 3] == 255).all()
+
+
+def test_emulated_alpha_builds_of_the_single_axis_and_box_routes(emu):
+    """+ 65536 on the 32768 (single-axis) and 16384 (RGBA16F) builds: alpha as a fourth channel there too."""
+    # single-axis, premultiplied RGBA8 with alpha
+    sw, sh, dw = 130, 74, 90
+    rng = np.random.default_rng(5)
+    node = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+    node[..., :3] = (node[..., :3].astype(np.uint16) * node[..., 3:4].astype(np.uint16) // 255).astype(np.uint8)
+    plan = orc.resample_plan(sw, sh, (0.0, 0.0, float(sw), float(sh)), dw, sh)
+    assert plan.kind == 1 and plan.axis[0] == 0
+    want = orc.resample_pass(node, orc.PX_RGBA8_SRGB, 0, plan.scale[0], plan.offset[0], plan.perp_offset[0], orc.PX_RGBA8_SRGB, dw, sh)
+    got = np.zeros((sh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    flat = np.ascontiguousarray(node)
+    assert emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 4, plan.scale[0], plan.offset[0], 1.0, 0.0, _p(got), dw, sh, 2, 2, info) == 0
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.9995 and not (got[..., 3] == 255).all(), (d.max(), (d == 0).mean())
+    # RGBA16F (linear light, premultiplied) with alpha, two passes
+    sw, sh, dw, dh = 130, 74, 69, 40
+    lin = rng.random((sh, sw, 4), dtype=np.float32)
+    lin[..., :3] *= lin[..., 3:4]
+    tex = lin.astype(np.float16).view(np.uint16)
+    plan = orc.resample_plan(sw, sh, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+    assert plan.kind == 2 and tuple(plan.axis[:2]) == (0, 1)
+    mid = orc.resample_pass(tex, orc.PX_RGBA16F, 0, plan.scale[0], plan.offset[0], 0, orc.PX_RGBA16F, plan.mid[0], plan.mid[1])
+    want = orc.resample_pass(mid, orc.PX_RGBA16F, 1, plan.scale[1], plan.offset[1], 0, orc.PX_RGBA8_SRGB, dw, dh)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    flat = np.ascontiguousarray(tex).view(np.uint8)
+    assert emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 5, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh, 2, 0, info) == 0
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.9995 and not (got[..., 3] == 255).all(), (d.max(), (d == 0).mean())

@@ -10,11 +10,10 @@ the oracle on that path.  The table below is the map of the fast paths and of wh
                cores reading the f16 texels as they are
                Single-axis plans (only the width or only the height changes) take `wave` / `wave_rgba` too: one pass on the matrix
                cores whose f32 sums are encoded directly (the 32768 builds), height-only plans on the transposed frame / node.
-               Sources with an alpha channel (BGRA / ARGB frames, translucent surfaces: premultiplied RGBA8) take `wave_rgba` for
-               two-pass plans: alpha is a fourth channel through both passes (the 65536 builds).
-* `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32) — the holes that are left:
-               single-axis and box-pre-reduced plans of sources with an alpha channel, box-pre-reduced plans whose residual scale
-               exceeds ~3.2.  Nothing falls to the one-launch f32 kernel
+               Sources with an alpha channel (BGRA / ARGB frames, translucent surfaces: premultiplied RGBA8) take the same routes
+               with alpha as a fourth channel (the 65536 builds).
+* `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32) — the hole that is left:
+               box-pre-reduced plans whose residual scale exceeds ~3.2.  Nothing falls to the one-launch f32 kernel
                (k_ingest_resample) any more unless SMR_INGEST_VALU_F32 asks for it.
 """
 import numpy as np
@@ -50,8 +49,10 @@ OPAQUE_RGBA_ROUTE = {"yuv422", "yuv444", "uyvy", "yuyv", "opaque_surface"}
 
 
 def expected_path(fmt, plan):
-    if fmt in ("bgra", "alpha_surface"):  # an alpha channel: the four-channel builds take the two-pass plans
-        return "wave_rgba" if plan in ("two_pass_h_first", "two_pass_v_first", "upscale", "scale_2") else "general"
+    if fmt in ("bgra", "alpha_surface"):  # an alpha channel: the four-channel builds
+        if plan == "box_prereduced_8":
+            return "general"
+        return "wave_box" if plan.startswith("box_prereduced") else "wave_rgba"
     if plan in ("single_axis_h", "single_axis_v"):
         return "wave" if fmt in FUSED_YUV else "wave_rgba"
     if plan in ("box_prereduced", "box_prereduced_v_first"):
