@@ -1224,6 +1224,9 @@ constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 
                                     k_ingest_wave<0, 0, 4096>, k_ingest_wave<4, 2, 4096>, k_ingest_wave<4, 2, 4097>, k_ingest_wave<8, 3, 4096>,
                                     k_ingest_wave<0, 0, 6144>, k_ingest_wave<4, 2, 6144>, k_ingest_wave<4, 2, 6145>, k_ingest_wave<8, 3, 6144>};
 constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
+// scales around 2 (windows of 5 .. 8 k-steps, pass-2 windows of 2: what the narrow class and the 4K class leave between them —
+// a 4x4 grid of 1080p inputs on a 4K output, tiles in mid-transition): plain | direct output | NV12-capable | both
+constexpr WaveKernel W_KERNELS_82[] = {k_ingest_wave<8, 2, 0>, k_ingest_wave<8, 2, 2048>, k_ingest_wave<8, 2, 4096>, k_ingest_wave<8, 2, 6144>};
 // RGBA8 node textures as the source: the same four classes
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
 // ... with an alpha channel (premultiplied RGBA8: text, images, nested layout nodes, BGRA / ARGB frames): four channels
@@ -1239,6 +1242,7 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
                 bool alpha = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
         std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
+        all.insert(all.end(), W_KERNELS_82, W_KERNELS_82 + 4);
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
         all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
         all.push_back(W_KERNEL_RGBA16F);
@@ -1259,19 +1263,21 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         const size_t nj = jobs.size() - j0 < (size_t)MAX_WJOBS_PER_LAUNCH ? jobs.size() - j0 : (size_t)MAX_WJOBS_PER_LAUNCH;
         WArgs args;
         memset(&args, 0, sizeof(args));
-        bool cls432 = true, cls83 = true, any_nv = false, k01 = true;
+        bool cls432 = true, cls83 = true, cls82 = true, any_nv = false, k01 = true;
         int nks_max = 1;
         long long tile_rows = 0;  // sum over jobs of pairs x tile rows: the unit of work
         for (size_t j = 0; j < nj; j++) {
             const WJob &J = jobs[j0 + j];
             cls432 = cls432 && J.NKS <= 4 && J.KV == 2;
             cls83 = cls83 && J.NKS <= 8 && J.KV == 3;
+            cls82 = cls82 && J.NKS <= 8 && J.KV == 2;
             any_nv = any_nv || J.nv12;
             k01 = k01 && J.k01;
             nks_max = J.NKS > nks_max ? J.NKS : nks_max;
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
-        if (f16 || sa) cls432 = cls83 = false;  // (one generic build)
+        if (f16 || sa) cls432 = cls83 = cls82 = false;  // (one generic build)
+        if (rgba || cls432) cls82 = false;
         int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
         if (!rgba && !sa) {
             if (direct) ki += 4;
@@ -1279,10 +1285,12 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
         const int sa_i = rgba ? (alpha ? 3 : 2) : (any_nv ? 1 : 0);
-        const WaveKernel kern = sa ? W_KERNELS_SA[sa_i]
+        const WaveKernel kern = cls82 ? W_KERNELS_82[(direct ? 1 : 0) + (any_nv ? 2 : 0)]
+                                : sa ? W_KERNELS_SA[sa_i]
                                    : f16 ? (alpha ? W_KERNEL_RGBA16F_ALPHA : W_KERNEL_RGBA16F)
                                          : alpha ? W_KERNELS_RGBA_ALPHA[ki] : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
-        if (sa) ki = 300 + sa_i;  // (occupancy cache key)
+        if (cls82) ki = 500 + (direct ? 1 : 0) + (any_nv ? 2 : 0);  // (occupancy cache key)
+        else if (sa) ki = 300 + sa_i;
         else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : 100;
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)

@@ -117,10 +117,10 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     Band bh = build_band(scale_h, off_h, dw, sw, 2), bv = build_band(scale_v, off_v, dh, sh, 3);
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
     if (bh.K > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
-    const bool cls432 = bh.K <= 4 && bv.K == 2, cls83 = bh.K <= 8 && bv.K == 3;
+    const bool cls432 = bh.K <= 4 && bv.K == 2, cls83 = bh.K <= 8 && bv.K == 3, cls82 = !cls432 && bh.K <= 8 && bv.K == 2;
     const bool sa = specialised == 2;  // single-axis plan: scale_v = 1, off_v = the perpendicular crop offset; the 32768 builds
     if (sa) specialised = 0;
-    if (specialised && !cls432 && !cls83) return -2;
+    if (specialised && !cls432 && !cls83 && !cls82) return -2;
 
     WArgs args;
     memset(&args, 0, sizeof(args));
@@ -173,6 +173,9 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     } else if (spec && bh.k01) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4097>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 1>(args, tables, lut16); });
+    } else if (specialised && cls82 && !rgba) {
+        if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 4096>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 0>(args, tables, lut16); });
     } else if (spec83) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 4096>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 0>(args, tables, lut16); });

@@ -64,6 +64,8 @@ CASES = [
     ((130, 74), (86, 49), None, 2, 0, False, False, None),           # odd tile sizes: a last pair with one tile, partial tiles
     ((64, 36), (96, 54), None, 2, 0, True, False, None),             # upscale (7 taps, several tiles per chunk)
     ((256, 144), (128, 72), None, 2, 0, True, False, None),          # scale 2
+    ((256, 144), (128, 72), None, 3, 1, True, False, (5, 5, 2)),     # ... and its class build (windows of 5 .. 8 k-steps, pass-2 windows of 2)
+    ((256, 144), (128, 72), None, 2, 1, True, True, (5, 5, 2)),      # ... NV12
     ((384, 216), (128, 72), None, 2, 0, True, False, (7, 7, 3)),     # scale 3: the north-star target's class, generic build
     ((384, 216), (128, 72), None, 3, 1, True, False, (7, 7, 3)),     # ... and its class build (windows of <= 8 k-steps, pass-2 windows of 3)
     ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1, True, False, (4, 4, 2)),  # crop: windows inside the frame
