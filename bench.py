@@ -335,6 +335,12 @@ def main():
             c.sync()
         torch.cuda.synchronize()
 
+    # one-time set-up, not a step: every lane renders two frames so that its weight bands, tile classes, scratch surfaces and kernel
+    # attributes exist before the W warm-up steps and the K timed ones (a context's first frame costs ~1 ms; `config.prime_frames`)
+    PRIME = 2 * max(1, n_lanes)
+    for s in range(PRIME):
+        step_fn(s)
+    barrier()
     for s in range(args.warmup):
         step_fn(s)
     barrier()
@@ -372,7 +378,7 @@ def main():
                                     4: "configs[4] on ONE GPU: 16x1080p YUV420 inputs in an animated Tiles grid (scene update every 45 frames, "
                                        "500 ms cubic-bezier transitions) + one 960x540 layer through the gaussian-blur shader -> 3840x2160 YUV420"}[args.config],
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
-                       "layouts": len(layouts), "input_ring": RING, "frames_in_flight": len(lanes),
+                       "layouts": len(layouts), "prime_frames": PRIME, "input_ring": RING, "frames_in_flight": len(lanes),
                        "frames_per_s_one_in_flight": round(serial_fps, 2) if serial_fps else None,
                        "per_frame_host_work": "smr_renderer_render: frame set -> layout maths at pts (C++ scene engine) -> parameter pack -> 2 kernels"
                        if single else ("layout maths at pts on every rank (C++ scene engine) -> ingest per shard -> gather -> blur layer + compose on the root"
