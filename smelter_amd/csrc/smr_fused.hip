@@ -217,14 +217,16 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         // (only convert when the kernel will take the job: the geometry test needs the node's size, not its pixels)
                         SurfView probe;
                         probe.ptr = nullptr; probe.pitch = ((u32)src_w[si] * 4u + 255u) & ~255u; probe.w = src_w[si]; probe.h = src_h[si];
-                        if (can_fuse_wave_rgba(ctx, probe, plan, tile)) {
+                        bool probe_single = false;
+                        if (can_fuse_wave_rgba(ctx, probe, plan, tile, 4, &probe_single)) {
                             int rc = ensure_node(si);
                             if (rc != SMR_OK) return rc;
                         }
                     }
-                    if (node_ready[si] && can_fuse_wave_rgba(ctx, views[si], plan, tile)) {
+                    bool single = false;
+                    if (node_ready[si] && can_fuse_wave_rgba(ctx, views[si], plan, tile, 4, &single)) {
                         WJob J;
-                        int rc = make_wave_job_rgba(ctx, views[si], plan, tile, &J);
+                        int rc = make_wave_job_rgba(ctx, views[si], plan, tile, &J, single);
                         if (rc != SMR_OK) return rc;
                         rgba_jobs.push_back(J);
                         on_mfma = true;
@@ -237,7 +239,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         if (!reduced || !reduced_t || !tile_t) return SMR_ERR_OOM;
                         smr_resample_plan pt = plan;
                         pt.axis[0] = 0; pt.axis[1] = 1;
-                        if (can_fuse_wave_rgba(ctx, view_of(reduced_t), pt, tile_t, 8)) {
+                        bool single = false;
+                        if (can_fuse_wave_rgba(ctx, view_of(reduced_t), pt, tile_t, 8, &single)) {
                             if (is_frame) {
                                 int rc = ensure_node(si);
                                 if (rc != SMR_OK) return rc;
@@ -250,7 +253,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             rc = launch_transpose<uint2>(ctx, reduced, reduced_t);
                             if (rc != SMR_OK) return rc;
                             WJob J;
-                            rc = make_wave_job_rgba(ctx, view_of(reduced_t), pt, tile_t, &J);
+                            rc = make_wave_job_rgba(ctx, view_of(reduced_t), pt, tile_t, &J, single);
                             if (rc != SMR_OK) return rc;
                             f16_jobs.push_back(J);
                             MTransposeBack back;
@@ -264,7 +267,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         // (scales below 2) on the matrix cores, reading the RGBA16F texels as they are
                         smr_surface *reduced = smr_cached_surface(ctx, SLOT_REDUCED0 + li, (u32)plan.reduced_w, (u32)plan.reduced_h, SMR_PX_RGBA16F);
                         if (!reduced) return SMR_ERR_OOM;
-                        if (can_fuse_wave_rgba(ctx, view_of(reduced), plan, tile, 8)) {
+                        bool single = false;
+                        if (can_fuse_wave_rgba(ctx, view_of(reduced), plan, tile, 8, &single)) {
                             if (is_frame) {
                                 int rc = ensure_node(si);
                                 if (rc != SMR_OK) return rc;
@@ -275,7 +279,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             int rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
                             if (rc != SMR_OK) return rc;
                             WJob J;
-                            rc = make_wave_job_rgba(ctx, view_of(reduced), plan, tile, &J);
+                            rc = make_wave_job_rgba(ctx, view_of(reduced), plan, tile, &J, single);
                             if (rc != SMR_OK) return rc;
                             f16_jobs.push_back(J);
                             on_mfma = true;

@@ -106,14 +106,15 @@ __host__ __device__ inline void w_span(int o0, int o1, float scale, float offset
 struct WPairGeom {
     int base, klo[2], kt[2], last, nks;
 };
-__host__ __device__ inline WPairGeom w_pair_geometry(int pair, float scale, float offset, int taps, int n_dst, int n_src) {
+// (single: axis 4 — one tile per unit, for windows too wide for a pair: the unit's second tile does not exist)
+__host__ __device__ inline WPairGeom w_pair_geometry(int pair, float scale, float offset, int taps, int n_dst, int n_src, bool single = false) {
     WPairGeom g;
     const int n_tiles = (n_dst + 15) >> 4;
     g.base = 0; g.last = 0;
     for (int i = 0; i < 2; i++) {
-        const int t = 2 * pair + i;
+        const int t = single ? pair : 2 * pair + i;
         g.klo[i] = -1; g.kt[i] = 0;
-        if (t >= n_tiles) continue;
+        if (t >= n_tiles || (single && i == 1)) continue;
         const int o0 = 16 * t, o1 = o0 + 15 < n_dst - 1 ? o0 + 15 : n_dst - 1;
         int lo, hi;
         w_span(o0, o1, scale, offset, taps, n_src, &lo, &hi);
@@ -143,14 +144,16 @@ inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, 
     const int n_tiles = (n_dst + 15) / 16;
     int k = 1, n = 1;
     bool pat = true;
-    if (axis == 2) {
-        for (int p = 0; p < (n_tiles + 1) / 2; p++) {
-            const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src);
+    if (axis == 2 || axis == 4) {
+        const bool single = axis == 4;
+        const int units = single ? n_tiles : (n_tiles + 1) / 2;
+        for (int p = 0; p < units; p++) {
+            const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src, single);
             for (int i = 0; i < 2; i++) k = g.kt[i] > k ? g.kt[i] : k;
             n = g.nks > n ? g.nks : n;
         }
-        for (int p = 0; p < (n_tiles + 1) / 2; p++) {  // (against the job's k-step count n: the class build runs min(n, 4) .. 4 steps)
-            const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src);
+        for (int p = 0; p < units; p++) {  // (against the job's k-step count n: the class build runs min(n, 4) .. 4 steps)
+            const WPairGeom g = w_pair_geometry(p, scale, offset, taps, n_dst, n_src, single);
             if (g.klo[0] + g.kt[0] - 1 > 2) pat = false;          // tile 0 reaches k-step 3
             if (g.klo[1] >= 0 && g.klo[1] < 1) pat = false;       // tile 1 starts in k-step 0
         }
@@ -163,7 +166,7 @@ inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, 
             k = need > k ? need : k;
         }
     }
-    *K = axis == 2 ? n : k;  // (axis 2: the band is dense over the pair's window)
+    *K = axis != 3 ? n : k;  // (axis 2 / 4: the band is dense over the unit's window)
     *nks = n;
 }
 
@@ -199,17 +202,18 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
     const int taps = B.taps, n_dst = B.n_dst, n_src = B.n_src, K = B.K;
     const int u = (int)blockIdx.x - B.unit0, lane = threadIdx.x;
     const int n16 = lane & 15, q = lane >> 4;
-    const int n_sub = B.axis == 2 ? 2 : 1;
+    const bool horiz = B.axis != 3, single = B.axis == 4;
+    const int n_sub = horiz ? 2 : 1;
     WPairGeom G;
     int v_cs = 0, v_ce = 0;
-    if (B.axis == 2) G = w_pair_geometry(u, scale, offset, taps, n_dst, n_src);
+    if (horiz) G = w_pair_geometry(u, scale, offset, taps, n_dst, n_src, single);
     else w_vtile_chunks(u, scale, offset, taps, n_dst, n_src, &v_cs, &v_ce);
     for (int sub = 0; sub < n_sub; sub++) {
-        const int tile = B.axis == 2 ? 2 * u + sub : u;
+        const int tile = horiz && !single ? 2 * u + sub : u;
         // origin of the window in source texels / rows, and its length
         const int wlo = v_ce - 2 * K + 1;  // (axis 3) first chunk of the window; may be negative: those chunks do not exist
-        const int origin = B.axis == 2 ? G.base : 16 * wlo - 1;
-        const int span = B.axis == 2 ? 16 * K : 32 * K;
+        const int origin = horiz ? G.base : 16 * wlo - 1;
+        const int span = horiz ? 16 * K : 32 * K;
         for (int i = lane; i < 16 * W_WSPAN; i += 64) {
             (&s_w[0][0])[i] = 0.0f;
             (&s_q[0][0])[i] = (_Float16)0.0f;
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
             f16x8 v, r;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                if (B.axis == 2) {
+                if (horiz) {
                     const int kk = 32 * j + 8 * q + e;
                     v[e] = s_q[n16][kk >> 1];
                     r[e] = (kk & 1) ? (_Float16)0.0f : s_r[n16][kk >> 1];
@@ -249,14 +253,14 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
                     r[e] = s_r[n16][idx];
                 }
             }
-            const size_t f = B.axis == 2 ? (((size_t)u * 2 + sub) * K + j) * 2 : ((size_t)u * K + j) * 2;
+            const size_t f = horiz ? (((size_t)u * 2 + sub) * K + j) * 2 : ((size_t)u * K + j) * 2;
             B.frag[f * 64 + lane] = __builtin_bit_cast(uint4, v);
             B.frag[(f + 1) * 64 + lane] = __builtin_bit_cast(uint4, r);
         }
         __syncthreads();
     }
     if (lane == 0) {
-        if (B.axis == 2) {
+        if (horiz) {
             int r[2];
             for (int i = 0; i < 2; i++) r[i] = G.klo[i] < 0 ? 0xffff : (G.klo[i] | ((G.klo[i] + G.kt[i] - 1) << 8));
             ((int4 *)B.meta)[u] = make_int4(G.base, G.last, r[0], r[1]);
@@ -282,6 +286,7 @@ struct WJob {
     int nv12;
     int layer, ox, oy;    // direct output: the layer this tile is blitted by (-1 = none) and its (even) position in the output frame
     int perp;             // single-axis builds (FL & 32768): output row y shows source row y + perp
+    int single;           // the pass-1 band has one tile per unit (axis 4: windows too wide for a pair): unit u = output columns 16 u ..
 };
 
 constexpr int MAX_WJOBS_PER_LAUNCH = 16;
@@ -372,7 +377,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     const int base = hm.x;
     const int nks = min(((hm.y - base) >> 4) + 1, NKS);  // k-steps of this pair's window
     const int klo[2] = {hm.z & 0xff, hm.w & 0xff}, khi[2] = {(hm.z >> 8) & 0xff, (hm.w >> 8) & 0xff};  // (0xff / 0xff: no such tile)
-    const int tx0 = 32 * pair;
+    const int tx0 = (J.single ? 16 : 32) * pair;
     const int d_w = J.dst.w, d_h = J.dst.h;
     u8 *const d_ptr = J.dst.ptr;
     const u32 d_pitch = J.dst.pitch;
@@ -987,7 +992,7 @@ struct WaveBand {
 
 int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis, WaveBand *out) {
     const int n_tiles = (n_dst + 15) / 16;
-    const int n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;
+    const int n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;  // (axis 4: one tile per unit)
     smr_ctx::MfmaTable *hit = find_mfma_table(ctx, scale, offset, n_dst, n_src, axis), *victim = nullptr;
     if (!hit) {
         int K, nks;
@@ -999,8 +1004,8 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
             ctx->mfma_tables.emplace_back();
             victim = &ctx->mfma_tables.back();
         }
-        const size_t meta_bytes = ((size_t)n_units * (axis == 2 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
-        const size_t frags = axis == 2 ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;  // (axis 2: K = k-steps of the widest window)
+        const size_t meta_bytes = ((size_t)n_units * (axis != 3 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
+        const size_t frags = axis != 3 ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;  // (axis 2 / 4: K = k-steps of the widest window)
         const size_t need = meta_bytes + frags * 64 * sizeof(uint4);
         for (size_t i = ctx->pending_bands.size(); i-- > 0;)
             if (victim->dev && ctx->pending_bands[i].meta == victim->dev) ctx->pending_bands.erase(ctx->pending_bands.begin() + (long)i);
@@ -1103,6 +1108,7 @@ int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
     if (J.nv12) J.vp = J.up;
     J.layer = -1; J.ox = 0; J.oy = 0;
+    J.perp = 0; J.single = 0;
     return SMR_OK;
 }
 
@@ -1123,7 +1129,9 @@ inline smr_resample_plan single_axis_as_two_pass(const smr_resample_plan &plan) 
 // read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB) after the exact converter, or an opaque surface.  Horizontal-first Lanczos plans with
 // the kernel's window limits (shrink factors up to ~3.5).
 // (bpp 8: an RGBA16F surface that is already box-reduced — the plan's levels then describe what was done to get it)
-bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, int bpp = 4) {
+// *single (may be null): the pair windows are too wide but one tile per unit fits (axis 4 bands) — make_wave_job_rgba's `single`
+bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, int bpp = 4, bool *single = nullptr) {
+    if (single) *single = false;
     if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return false;
     if (!(plan.kind == 2 && (bpp == 8 || (plan.levels[0] == 0 && plan.levels[1] == 0)) && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
     if (src.w < 8 || src.h < 2 || (((uintptr_t)src.ptr) % 16) || (src.pitch % 16) || src.pitch < (((size_t)src.w + 3u) & ~(size_t)3u) * (size_t)bpp) return false;
@@ -1133,12 +1141,18 @@ bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_pl
     else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, src.w, 2, &NKS, &unused);
     if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, src.h, 3)) KV = t->K;
     else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, src.h, 3, &KV, &unused);
+    if (NKS > W_NKS_MAX && single && KV <= W_KV_MAX) {
+        if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, 4)) NKS = t->K;
+        else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, src.w, 4, &NKS, &unused);
+        *single = NKS <= W_NKS_MAX;
+        return *single;
+    }
     return NKS <= W_NKS_MAX && KV <= W_KV_MAX;
 }
 
-int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, WJob *out) {
+int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, WJob *out, bool single = false) {
     WaveBand bh, bv;
-    int rc = get_wave_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, 2, &bh);
+    int rc = get_wave_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, single ? 4 : 2, &bh);
     if (rc != SMR_OK) return rc;
     rc = get_wave_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, src.h, 3, &bv);
     if (rc != SMR_OK) return rc;
@@ -1154,6 +1168,8 @@ int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_pla
     J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
     J.pieces = W_WAVES;
     J.layer = -1;
+    J.single = single ? 1 : 0;
+    if (single) J.k01 = 0;
     return SMR_OK;
 }
 
@@ -1204,8 +1220,9 @@ int make_wave_job_rgba_transposed(smr_ctx *ctx, const SurfView &src, const smr_r
     if (!node_t || !tile_t) return SMR_ERR_OOM;
     smr_resample_plan pt = plan;
     pt.axis[0] = 0; pt.axis[1] = 1;
-    if (!can_fuse_wave_rgba(ctx, view_of(node_t), pt, tile_t)) return SMR_OK;
-    if (int rc = make_wave_job_rgba(ctx, view_of(node_t), pt, tile_t, out)) return rc;
+    bool single = false;
+    if (!can_fuse_wave_rgba(ctx, view_of(node_t), pt, tile_t, 4, &single)) return SMR_OK;
+    if (int rc = make_wave_job_rgba(ctx, view_of(node_t), pt, tile_t, out, single)) return rc;
     smr_surface node;  // non-owning alias of the node view
     node.ptr = src.ptr; node.pitch = src.pitch; node.w = (u32)src.w; node.h = (u32)src.h; node.fmt = SMR_PX_RGBA8;
     if (int rc = launch_transpose<u32>(ctx, &node, node_t)) return rc;
@@ -1232,7 +1249,7 @@ constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wav
 // ... with an alpha channel (premultiplied RGBA8: text, images, nested layout nodes, BGRA / ARGB frames): four channels
 constexpr WaveKernel W_KERNELS_RGBA_ALPHA[] = {k_ingest_wave<0, 0, 8192 + 65536>, k_ingest_wave<4, 2, 8192 + 65536>, k_ingest_wave<4, 2, 8193 + 65536>,
                                                k_ingest_wave<8, 3, 8192 + 65536>};
-// ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; the windows the generic build holds reach ~3.2)
+// ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; above ~3.2 as one-tile units, WJob::single)
 constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>, W_KERNEL_RGBA16F_ALPHA = k_ingest_wave<0, 0, 8192 + 16384 + 65536>;
 // ... and single-axis plans (generic build): planar | NV12-capable | RGBA8 node texture
 constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>,

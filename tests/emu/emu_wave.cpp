@@ -74,8 +74,8 @@ Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
     wave_band_geometry(scale, offset, n_dst, n_src, axis, &B.K, &B.nks, &B.k01);
     const int n_tiles = (n_dst + 15) / 16;
     B.n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;
-    const size_t meta_bytes = ((size_t)B.n_units * (axis == 2 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
-    const size_t frags = axis == 2 ? (size_t)B.n_units * 2 * B.K * 2 : (size_t)B.n_units * B.K * 2;
+    const size_t meta_bytes = ((size_t)B.n_units * (axis != 3 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
+    const size_t frags = axis != 3 ? (size_t)B.n_units * 2 * B.K * 2 : (size_t)B.n_units * B.K * 2;
     B.mem.assign(meta_bytes + frags * 64 * sizeof(uint4) + 32, 0);
     u8 *base = (u8 *)(((uintptr_t)B.mem.data() + 15) & ~(uintptr_t)15);
     B.meta = base;
@@ -114,7 +114,9 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     Plane pu = rgba ? py : (nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1));
     Plane pv = (nv12 || rgba) ? pu : make_plane(v, sw / 2, sh / 2, 1);
     std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
-    Band bh = build_band(scale_h, off_h, dw, sw, 2), bv = build_band(scale_v, off_v, dh, sh, 3);
+    const bool single = specialised == 3;  // one tile per unit (axis 4 bands): windows too wide for a pair; generic builds
+    if (single) specialised = 0;
+    Band bh = build_band(scale_h, off_h, dw, sw, single ? 4 : 2), bv = build_band(scale_v, off_v, dh, sh, 3);
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
     if (bh.K > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
     const bool cls432 = bh.K <= 4 && bv.K == 2, cls83 = bh.K <= 8 && bv.K == 3, cls82 = !cls432 && bh.K <= 8 && bv.K == 2;
@@ -139,6 +141,7 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     J.pieces = p;
     J.nv12 = nv12;
     J.layer = -1;
+    J.single = single ? 1 : 0;
     args.wg_prefix[0] = 0;
     args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
     args.n_jobs = 1;

@@ -271,3 +271,33 @@ def test_emulated_alpha_builds_of_the_single_axis_and_box_routes(emu):
     assert emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 5, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh, 2, 0, info) == 0
     d = np.abs(got.astype(np.int16) - want.astype(np.int16))
     assert d.max() <= 1 and (d == 0).mean() >= 0.9995 and not (got[..., 3] == 255).all(), (d.max(), (d == 0).mean())
+
+
+@pytest.mark.parametrize("kind", [2, 3])
+def test_emulated_single_tile_units_for_wide_windows(emu, kind):
+    """A residual scale of 3.9 (what a box-pre-reduced plan can leave): a column pair's window would need 10 k-steps, more than the
+    kernel holds, so the pass-1 band is built with one tile per unit (axis 4) and a wave works on one 16-column tile."""
+    sw, sh, dw, dh = 500, 96, 128, 48
+    rng = np.random.default_rng(77 + kind)
+    crop = (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 2 and plan.levels == (0, 0) and tuple(plan.axis[:2]) == (0, 1) and plan.scale[0] > 3.8
+    if kind == 2:
+        node = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+        node[..., 3] = 255
+        _, want = orc.resample(node, crop, dw, dh)
+        flat = np.ascontiguousarray(node)
+    else:
+        lin = rng.random((sh, sw, 4), dtype=np.float32) ** 2.2
+        lin[..., 3] = 1.0
+        tex = lin.astype(np.float16).view(np.uint16)
+        mid = orc.resample_pass(tex, orc.PX_RGBA16F, 0, plan.scale[0], plan.offset[0], 0, orc.PX_RGBA16F, plan.mid[0], plan.mid[1])
+        want = orc.resample_pass(mid, orc.PX_RGBA16F, 1, plan.scale[1], plan.offset[1], 0, orc.PX_RGBA8_SRGB, dw, dh)
+        flat = np.ascontiguousarray(tex).view(np.uint8)
+    got = np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    rc = emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, kind, plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1], _p(got), dw, dh, 2, 3, info)
+    assert rc == 0, (rc, list(info))
+    assert info[1] <= 8, list(info)
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.9995, (d.max(), (d == 0).mean())

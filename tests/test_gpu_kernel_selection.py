@@ -5,15 +5,17 @@ the oracle on that path.  The table below is the map of the fast paths and of wh
                order (a vertical-first plan runs on the transposed frame), up- and down-scaling
 * `wave_rgba`  the same kernel on the RGBA8 node texture the exact converter wrote (4:2:2, 4:4:4, packed UYVY / YUYV) or on an
                opaque surface: two-pass plans, either pass order
-* `wave_box`   box-pre-reduced plans (shrink factors above 4) of every opaque source, either pass order, residual scales up to ~3.2:
+* `wave_box`   box-pre-reduced plans (shrink factors above 4) of every source, either pass order:
                the exact converter, downsample.wgsl's pass as it is (RGBA16F, linear light), then the residual Lanczos on the matrix
                cores reading the f16 texels as they are
                Single-axis plans (only the width or only the height changes) take `wave` / `wave_rgba` too: one pass on the matrix
                cores whose f32 sums are encoded directly (the 32768 builds), height-only plans on the transposed frame / node.
                Sources with an alpha channel (BGRA / ARGB frames, translucent surfaces: premultiplied RGBA8) take the same routes
                with alpha as a fourth channel (the 65536 builds).
-* `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32) — the hole that is left:
-               box-pre-reduced plans whose residual scale exceeds ~3.2.  Nothing falls to the one-launch f32 kernel
+               Windows too wide for a column pair (scales above ~3.2: 9 or 10 k-steps) are worked one 16-column tile per wave
+               (axis 4 bands) on the node-texture routes.
+* `general`    smr_frame_to_rgba + smr_resample (box pre-reduction and Lanczos pass kernels, f32): nothing of this table any more —
+               what still takes it are resample targets smaller than the kernel's minimum source (8 x 2) and degenerate plans.  Nothing falls to the one-launch f32 kernel
                (k_ingest_resample) any more unless SMR_INGEST_VALU_F32 asks for it.
 """
 import numpy as np
@@ -41,7 +43,8 @@ PLANS = {
     "single_axis_v": ((640, 360), (640, 240)),
     "box_prereduced": ((1920, 1080), (400, 225)),    # 2x box, residual 2.4 both ways
     "box_prereduced_v_first": ((1280, 720), (250, 140)),   # 2x box, residual 2.57 vertically > 2.56 horizontally
-    "box_prereduced_8": ((1280, 720), (160, 90)),      # 2x box, residual 4: windows wider than the kernel holds
+    "box_prereduced_8": ((1280, 720), (160, 90)),      # 2x box, residual 4: windows too wide for a column pair — one tile per unit
+    "two_pass_wide": ((1280, 720), (340, 190)),         # no box, scale 3.8: the same for a plain two-pass plan
 }
 FORMATS = ["yuv420", "yuvj420", "nv12", "yuv422", "yuv444", "uyvy", "yuyv", "bgra", "opaque_surface", "alpha_surface"]
 FUSED_YUV = {"yuv420", "yuvj420", "nv12"}
@@ -50,15 +53,15 @@ OPAQUE_RGBA_ROUTE = {"yuv422", "yuv444", "uyvy", "yuyv", "opaque_surface"}
 
 def expected_path(fmt, plan):
     if fmt in ("bgra", "alpha_surface"):  # an alpha channel: the four-channel builds
-        if plan == "box_prereduced_8":
-            return "general"
         return "wave_box" if plan.startswith("box_prereduced") else "wave_rgba"
     if plan in ("single_axis_h", "single_axis_v"):
         return "wave" if fmt in FUSED_YUV else "wave_rgba"
     if plan in ("box_prereduced", "box_prereduced_v_first"):
         return "wave_box"
     if plan == "box_prereduced_8":
-        return "general"
+        return "wave_box"
+    if plan == "two_pass_wide":  # (the fused conversion keeps to column pairs: such a plan takes the node-texture route)
+        return "wave_rgba"
     if fmt in FUSED_YUV:
         return "wave"
     return "wave_rgba"
