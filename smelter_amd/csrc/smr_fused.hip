@@ -332,11 +332,11 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- parameters -> device (one pinned staging slot, one copy)
     const u32 b_tiles_x = (out_w + B_TILE_W - 1) / B_TILE_W, b_tiles_y = (out_h + B_TILE_H - 1) / B_TILE_H;
     const u32 b_tiles = b_tiles_x * b_tiles_y;
-    const size_t order_bytes = (sizeof(ComposeOrder) + (size_t)((b_tiles + 31) / 32) * 4 + 15) & ~(size_t)15;
+    const size_t order_bytes = 0;
     PackedLayouts packed;
     int rc = smr_pack_layouts(ctx, eff.data(), n, views.data(), kinds.data(), next_view, (int)out_w, (int)out_h, order_bytes + sizeof(MDirect), &packed);
     if (rc != SMR_OK) return rc;
-    const u32 n_first = compose_order(packed, (int)b_tiles_x, (int)b_tiles_y, (ComposeOrder *)packed.extra_host);
+    const u32 n_first = compose_predict(packed, (int)b_tiles_x, (int)b_tiles_y, ctx->compose_bitmap);
     const bool fits_b = fused && (out_w % 2 == 0) && (out_h % 2 == 0) && packed.n <= MAX_LAYOUT_WORDS * 32;
     const bool big_list = packed.n > B_MAX_LAYOUTS || packed.n_masks > B_MAX_MASKS;  // read in place instead of from an LDS copy
     const bool fuse_yuv = fits_b && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
@@ -503,8 +503,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         ctx->kernel_launches[SMR_KERNEL_COMPOSE_OUTPUT]++;
         // 1-D grid: bands of the tiles that need the (latency-bound) general path first — as many as the class list holds when its
         // length is known, as many as the host's own prediction says otherwise — then every tile in order
-        u32 n_banded = cm->count_known ? *cm->h_count : (n_first <= B_MAX_FIRST ? n_first : B_MAX_FIRST);
+        u32 n_banded = cm->count_known ? *cm->h_count : n_first;
         if (n_banded > b_tiles) n_banded = b_tiles;
+        if (ctx->debug_ingest)
+            fprintf(stderr, "k_compose_output: %u tiles, band list %u (%s; predicted %u, last read back %u)\n", b_tiles, n_banded, cm->count_known ? "known" : "predicted", n_first, *cm->h_count);
         dim3 grid(ctx->compose_slices * n_banded + (b_tiles + B_COPY_TILES - 1) / B_COPY_TILES, 1, 1);
         const TileList *full = (const TileList *)cm->d_list;
         const TileClass *tc = (const TileClass *)cm->d_class;

@@ -23,35 +23,33 @@ constexpr int B_MAX_LAYOUTS = 48;             // LDS-resident layout list (large
 constexpr int B_MAX_MASKS = 96;
 static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS copies move 16 B words");
 
-// Launch order of the tiles (rides behind the layout list in the parameter slot).  The few tiles that take the general path
-// are latency-bound (one wave per SIMD, ~25 us each); started last they are the tail of the kernel, started first they
-// overlap the copy tiles.  The host predicts them from the layout geometry — only the order depends on the prediction,
-// every workgroup still classifies its tile itself.
-constexpr u32 B_MAX_FIRST = 1024;
-// A tile that needs compositing is rendered by B_SLICES workgroups, each taking a band of B_TILE_H / B_SLICES rows of it (classified
-// on its own, like a small tile): the general path is one pixel per thread and pure latency, so a band costs one sweep instead of eight.
-// Measured on configs[2] (kernel incl. ~6 us of stage timer, frames/s one / three in flight): 1 band 41.8 us, 10.1k / 13.9k;
-// 2 bands 29.2 us, 11.7k / 13.3k; 4 bands 30.1 us, 11.5k / 13.0k; 8 bands 33.6 us, 10.2k / 12.6k — every band repeats the
-// workgroup's fixed work (layout list, classification, tables), so two is the default.
-constexpr int B_SLICES = 4;  // ctx->compose_slices (1, 2, 4 or 8: a band holds whole 4x2 output blocks).  Round 3: the bands start from the
-                             // classifier's per-tile record instead of classifying again, so a band's fixed work is small; measured with the
-                             // scene's parameter pack resident (profiles/r03_compose_ab.txt): four bands 23.2 us on configs[2] and 48.3 us
-                             // on configs[4], eight bands 25.0 / 57.1 us
-struct ComposeOrder {
-    u32 n_first;             // workgroups [0, B_SLICES * n_first) take the bands of first[]; workgroup B_SLICES * n_first + t takes tile t unless it is in `taken`
-    u16 first[B_MAX_FIRST];  // linear tile indices
-    u32 taken[1];            // bitmap over all tiles (really (tiles + 31) / 32 words)
-};
+// How many workgroups the compositor's band list gets.  The tiles that need compositing are latency-bound (layer records through
+// scalar registers, one pixel per thread); started last they would be the tail of the kernel, so the first workgroups of the grid
+// take them band by band from the classifier's list (TileList).  The host sizes that part of the grid from the list's length once
+// it has come back from the device; for a list that is new this frame (a scene in transition) from this prediction — an upper
+// bound: a workgroup beyond the list's end returns at once, a listed tile beyond the prediction is composited by the workgroup that
+// owns it, four bands one after the other.
+// A tile that needs compositing is rendered by B_SLICES workgroups, each taking a band of B_TILE_H / B_SLICES rows of it, starting from
+// the classifier's per-tile record (touching layers, start layer) instead of classifying again.  Measured with the scene's parameter
+// pack resident (profiles/r03_compose_ab.txt): four bands 23.2 us on configs[2] and 48.3 us on configs[4], eight bands 25.0 / 57.1 us.
+constexpr int B_SLICES = 4;          // ctx->compose_slices: 4 or 8 (a band holds whole 4x2 output blocks)
+#ifndef SMR_COMPOSE_MIN_WAVES
+#define SMR_COMPOSE_MIN_WAVES 2
+#endif
+// waves per SIMD the register allocation must leave room for.  The kernel needs ~106 VGPRs: four workgroups per CU fit anyway (24 KB of
+// LDS each would allow six).  Asking for 5 / 6 costs spills (96 / 80 VGPRs, 48 / 80 B of scratch) and is slower on configs[2]
+// (23.5 -> 24.8 / 25.8 us) though faster on configs[4] (47.8 -> 44.0 / 43.1 us): profiles/r03_compose_occupancy.txt.
+constexpr int B_MIN_WAVES = SMR_COMPOSE_MIN_WAVES;
+constexpr int B_BAND_ROWS = 4;       // rows of the workgroup's LDS pixel state: a band is at most this tall
+static_assert(B_TILE_H % B_BAND_ROWS == 0 && B_TILE_H / B_SLICES <= B_BAND_ROWS, "a band fits the LDS pixel state");
 
-// Host: tiles likely to need the general path.  A layer that can never be a tile's copy layer (translucent colour, texture
-// that is not an aligned opaque blit, rotated quad) marks its whole pixel box; a copy-capable layer marks the corner squares
-// of its rounded rect and of its masks, and the bands along its edges where border / blur / fractional coordinates keep the
-// fragment from being the base value.
-inline u32 compose_order(const PackedLayouts &p, int tiles_x, int tiles_y, ComposeOrder *out) {
+// Host: tiles likely to need compositing -> their number.  A layer that can never be solid over a tile (translucent colour, texture
+// with an alpha channel, rotated quad) marks its whole pixel box; every other layer marks the corner squares of its rounded rect and
+// of its masks, and the bands along its edges where border / blur / fractional coordinates keep the fragment from being the base
+// value.  `bitmap`: scratch, one bit per tile.
+inline u32 compose_predict(const PackedLayouts &p, int tiles_x, int tiles_y, std::vector<u32> &bitmap) {
     const int tiles = tiles_x * tiles_y, words = (tiles + 31) / 32;
-    out->n_first = 0;
-    for (int i = 0; i < words; i++) out->taken[i] = 0u;
-    if (tiles > 65535) return 0;
+    bitmap.assign((size_t)words, 0u);
     auto mark = [&](float x0, float y0, float x1, float y1) {  // pixel-space box, clipped to the tile grid
         int tx0 = (int)floorf(x0 / (float)B_TILE_W), tx1 = (int)floorf(x1 / (float)B_TILE_W);
         int ty0 = (int)floorf(y0 / (float)B_TILE_H), ty1 = (int)floorf(y1 / (float)B_TILE_H);
@@ -60,7 +58,7 @@ inline u32 compose_order(const PackedLayouts &p, int tiles_x, int tiles_y, Compo
         for (int ty = ty0; ty <= ty1; ty++)
             for (int tx = tx0; tx <= tx1; tx++) {
                 const int t = ty * tiles_x + tx;
-                out->taken[t >> 5] |= 1u << (t & 31);
+                bitmap[t >> 5] |= 1u << (t & 31);
             }
     };
     auto corners = [&](float left, float top, float w, float h, float c, const DevLayout &L) {
@@ -76,8 +74,9 @@ inline u32 compose_order(const PackedLayouts &p, int tiles_x, int tiles_y, Compo
     for (int i = 0; i < p.n; i++) {
         const DevLayout &L = p.host_layouts[i];
         if (L.bx1 <= L.bx0 || L.by1 <= L.by0) continue;
-        const bool copy_capable = (L.flags & DL_UNROTATED) && (L.type == 0 ? ((L.flags & DL_ALIGNED) && L.src_kind == 2) : (L.flags & DL_COLOR_OPAQUE) != 0);
-        if (!copy_capable) {
+        // (an opaque texture at a fractional position or another scale is sampled, not copied — TC_SAMPLED — but solid all the same)
+        const bool solid_capable = (L.flags & DL_UNROTATED) && (L.type == 0 ? L.src_kind == 2 : (L.flags & DL_COLOR_OPAQUE) != 0);
+        if (!solid_capable) {
             mark((float)L.bx0, (float)L.by0, (float)L.bx1 - 1.0f, (float)L.by1 - 1.0f);
             continue;
         }
@@ -97,21 +96,7 @@ inline u32 compose_order(const PackedLayouts &p, int tiles_x, int tiles_y, Compo
         }
     }
     u32 nf = 0;
-    for (int w = 0; w < words && nf <= B_MAX_FIRST; w++) {
-        u32 bits = out->taken[w];
-        while (bits) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            if (nf < B_MAX_FIRST) out->first[nf] = (u16)(w * 32 + b);
-            nf++;
-        }
-    }
-    if (nf > B_MAX_FIRST) {  // too many to list
-        for (int i = 0; i < words; i++) out->taken[i] = 0u;
-        out->n_first = 0;
-        return B_MAX_FIRST + 1;
-    }
-    out->n_first = nf;
+    for (int w = 0; w < words; w++) nf += (u32)__builtin_popcount(bitmap[w]);
     return nf;
 }
 
@@ -369,7 +354,7 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
                                              int srgb_and_ablate, const float *__restrict__ tables, int tiles_x, float *s_tab) {
     const int tile = (int)pre->tile;
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS];
-    __shared__ u32 s_px[B_TILE_W * B_TILE_H];  // general tiles: composited RGBA8
+    __shared__ u32 s_px[B_TILE_W * B_BAND_ROWS];  // the band's composited RGBA8
     // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
     // dependent scalar-memory round trip per field per layer per wave
     __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
@@ -380,13 +365,32 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
     const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H + band;
     const int px0 = tx0 + 4 * (tid & 31), py0 = ty0 + 2 * (tid >> 5);  // this thread's 4x2 output block
     __syncthreads();  // (a previous call's readers of the shared tile are done)
-    if (!BIG) {
-        const uint4 *gl = (const uint4 *)layouts_g;
-        uint4 *ll = (uint4 *)s_lay;
-        for (int i = tid; i < n * (int)(sizeof(DevLayout) / 16); i += 256) ll[i] = gl[i];
-        const uint4 *gm = (const uint4 *)masks_g;
-        uint4 *lm = (uint4 *)s_mask;
-        for (int i = tid; i < n_masks * (int)(sizeof(DevMask) / 16); i += 256) lm[i] = gm[i];
+    // (one round trip: every load of the list, the masks and the tables is issued before the first store — as loops with a load and a
+    //  store per trip they were eight dependent trips to the L2)
+    {
+        static_assert(SMR_TABLE_FLOATS % 4 == 0 && SMR_TABLE_FLOATS / 4 <= 256, "one 16 B word of the tables per thread");
+        constexpr int LW = (B_MAX_LAYOUTS * (int)(sizeof(DevLayout) / 16) + 255) / 256, MW = (B_MAX_MASKS * (int)(sizeof(DevMask) / 16) + 255) / 256;
+        const uint4 *gl = (const uint4 *)layouts_g, *gm = (const uint4 *)masks_g, *gt = (const uint4 *)tables;
+        const int nl = BIG ? 0 : n * (int)(sizeof(DevLayout) / 16), nm = BIG ? 0 : n_masks * (int)(sizeof(DevMask) / 16);
+        uint4 wl[LW], wm[MW], wt = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < LW; k++) {
+            wl[k] = wt;
+            if (tid + 256 * k < nl) wl[k] = gl[tid + 256 * k];
+        }
+#pragma unroll
+        for (int k = 0; k < MW; k++) {
+            wm[k] = wt;
+            if (tid + 256 * k < nm) wm[k] = gm[tid + 256 * k];
+        }
+        if (tid < SMR_TABLE_FLOATS / 4) wt = gt[tid];
+#pragma unroll
+        for (int k = 0; k < LW; k++)
+            if (tid + 256 * k < nl) ((uint4 *)s_lay)[tid + 256 * k] = wl[k];
+#pragma unroll
+        for (int k = 0; k < MW; k++)
+            if (tid + 256 * k < nm) ((uint4 *)s_mask)[tid + 256 * k] = wm[k];
+        if (tid < SMR_TABLE_FLOATS / 4) ((uint4 *)s_tab)[tid] = wt;
     }
     const DevLayout *layouts = BIG ? layouts_g : s_lay;
     const DevMask *masks = BIG ? masks_g : s_mask;
@@ -407,15 +411,13 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
     const int nsweeps = (B_TILE_W * rh) / 256;
 
     if (general) {
-        for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
-        __syncthreads();
         const float *dec = s_tab, *thr = s_tab + 256;
         // ---- one pixel per thread and sweep (a wave covers 64 consecutive pixels of one row); layers are the OUTER loop:
         //      a layer's record is pulled into scalar registers once per wave and then applied to the wave's 8 sweeps.
         //      Per-pixel state lives in LDS: s_px = running RGBA8, s_sp = per-pixel start layer.
-        constexpr int SWEEPS = (B_TILE_W * B_TILE_H) / 256;
-        __shared__ short s_sp[B_TILE_W * B_TILE_H];
-        __shared__ u32 s_raw[B_TILE_W * B_TILE_H];  // prefetched texels of the aligned texture layer being applied
+        constexpr int SWEEPS = (B_TILE_W * B_BAND_ROWS) / 256;
+        __shared__ short s_sp[B_TILE_W * B_BAND_ROWS];
+        __shared__ u32 s_raw[B_TILE_W * B_BAND_ROWS];  // prefetched texels of the aligned texture layer being applied
 #pragma unroll 1
         for (int sweep = 0; sweep < nsweeps; sweep++) {
             s_px[sweep * 256 + tid] = 0u;
@@ -423,7 +425,7 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
         }
         // (each thread only ever touches its own 8 pixels of s_px / s_sp: no barrier needed until the conversion phase)
         // -- per-pixel start: the topmost touched layer above the tile's start whose solid region holds the pixel
-        for (int wi = words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {
+        for (int wi = (ablate & 4) ? -1 : words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {  // (4: profiling, no per-pixel start)
             u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
             if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
             while (bits) {
@@ -489,13 +491,13 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
 constexpr int B_COPY_TILES = 1;
 
 template <int NV, bool BIG>
-__global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
+__global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
                                                         const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
                                                         int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
                                                         int tiles_x, int tiles, const TileClass *__restrict__ tc, const TileList *__restrict__ full,
                                                         int n_banded, int slices) {
     const int tid = threadIdx.x;
-    __shared__ float s_tab[SMR_TABLE_FLOATS];  // decode / encode tables (whoever needs them loads them)
+    __shared__ __attribute__((aligned(16))) float s_tab[SMR_TABLE_FLOATS];  // decode / encode tables (whoever needs them loads them)
     // The first `slices * n_banded` workgroups take the tiles that need compositing (TileList; the host sized the grid from the
     // list's length when it knows it, from its own prediction otherwise), band by band — they are latency-bound and would be the
     // tail of the kernel.  Every other workgroup takes B_COPY_TILES consecutive tiles of the row-major order.
@@ -503,12 +505,13 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     //  listed tile; a tile the list had no room for — only choose its arguments)
     const int rest = (int)blockIdx.x - slices * n_banded;
     const TileFull *full_entry = nullptr;
-    int full_band = 0, full_rows = B_TILE_H;
+    int full_band = 0, full_end = B_TILE_H, full_rows = B_BAND_ROWS;
     if (rest < 0) {
         const u32 gi = blockIdx.x / (u32)slices;
         if (gi >= full->count) return;
         full_rows = B_TILE_H / slices;
         full_band = (int)(blockIdx.x % (u32)slices) * full_rows;
+        full_end = full_band + full_rows;
         full_entry = &full->e[gi];
     } else {
     // ---- copy tiles, straight from their class records (k_classify_tiles): no layout list, no classification, no barrier
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
     // sampled tiles: one layer's record straight from the list in memory, eight independent pixels per thread
 #pragma unroll 1
     for (int k = 0; k < B_COPY_TILES; k++) {
-        if (c[k].kind != TC_SAMPLED) continue;
+        if (c[k].kind != TC_SAMPLED || ((srgb_and_ablate >> 8) & 32)) continue;  // (32: profiling, no sampled tiles)
         __syncthreads();
         for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
         __syncthreads();
@@ -590,12 +593,14 @@ __global__ __launch_bounds__(256) void k_compose_output(SurfView yp, SurfView up
             store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
         }
     }
-    // a tile that needs compositing and found no room on the band list (the host's bound was short): here, all sixteen rows
+    // a tile that needs compositing and found no room on the band list (the host's bound was short): here, band after band
     static_assert(B_COPY_TILES == 1, "one tile per workgroup is handed on to the compositing path");
     if (c[0].kind == TC_FULL && (int)c[0].pitch_or_px >= n_banded) full_entry = &full->e[c[0].pitch_or_px];
     }
-    if (full_entry)  // (uniform)
-        compose_full<NV, BIG>(full_entry, full_band, full_rows, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+    if (full_entry)  // (uniform; one band of a listed tile, or the four bands of a tile the list's bound left out)
+#pragma unroll 1
+        for (int band = full_band; band < full_end; band += full_rows)
+            compose_full<NV, BIG>(full_entry, band, full_rows, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
 }
 
 }  // namespace

@@ -147,7 +147,8 @@ struct smr_ctx {
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
-    int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (1, 2, 4, 8)
+    int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
+    std::vector<u32> compose_bitmap;  // compose_predict's scratch
     bool direct_output = false;  // SMR_OPT_DIRECT_OUTPUT: wave A writes Y'CbCr for the compositor's copy tiles of a scene at rest
     std::vector<uint8_t> class_key_scratch;
     std::vector<TileClassMap> class_maps;  // tile classes of the last few layout lists (smr_fused.hip)
