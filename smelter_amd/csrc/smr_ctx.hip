@@ -164,6 +164,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
     if (const char *e = getenv("SMR_NO_PACK_REUSE")) ctx->no_pack_reuse = atoi(e) != 0;
+    if (const char *e = getenv("SMR_INGEST_MIN_ROWS")) ctx->ingest_min_rows = atoi(e);
     ctx->debug_ingest = getenv("SMR_DEBUG_INGEST") != nullptr;
     if (const char *e = getenv("SMR_COMPOSE_SLICES")) {
         const int v = atoi(e);

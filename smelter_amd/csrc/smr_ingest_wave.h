@@ -1329,7 +1329,11 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         const long long slots = (long long)(per_cu > wg_cap ? wg_cap : per_cu) * (ctx->cu_count - reserve) * W_WAVES;  // resident waves
         // pieces per column pair: the same number of tile rows per wave for every job, rounded so that the launch fits the resident set
         double rows_per_wave = (double)tile_rows / (double)slots;
-        if (rows_per_wave < 2.0) rows_per_wave = 2.0;  // (a piece re-converts its window's head: not below two tile rows)
+        // (a piece re-converts its window's head, so short pieces cost conversions — but a launch that cannot fill the chip is bound by
+        //  the length of a wave's chain, not by throughput: configs[4]'s single-input node 34 -> 24 us with one tile row per wave
+        //  instead of two, profiles/r03_min_rows.txt)
+        const double min_rows = ctx->ingest_min_rows > 0 ? (double)ctx->ingest_min_rows : 1.0;
+        if (rows_per_wave < min_rows) rows_per_wave = min_rows;
         int total = 0;
         for (int pass = 0; pass < 8; pass++) {
             total = 0;

@@ -149,6 +149,7 @@ struct smr_ctx {
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
     int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
     std::vector<u32> compose_bitmap;  // compose_predict's scratch
+    int ingest_min_rows = 0;     // SMR_INGEST_MIN_ROWS (profiling): least tile rows per wave of k_ingest_wave (0: the default, 1)
     bool direct_output = false;  // SMR_OPT_DIRECT_OUTPUT: wave A writes Y'CbCr for the compositor's copy tiles of a scene at rest
     std::vector<uint8_t> class_key_scratch;
     std::vector<TileClassMap> class_maps;  // tile classes of the last few layout lists (smr_fused.hip)
