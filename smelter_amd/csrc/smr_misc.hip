@@ -54,23 +54,54 @@ __global__ __launch_bounds__(256) void k_blit_glyphs(SurfView target, float4 bg,
     *(u32 *)(target.ptr + (size_t)y * target.pitch + (size_t)x * 4) = r | (g << 8) | (b << 16) | (a << 24);
 }
 
-// Separable gaussian: one axis per launch, RGBA8 (node encoding) between the passes.
-__global__ __launch_bounds__(256) void k_gauss_axis(SurfView src, SurfView dst, float sigma, int radius, int axis, int pxi,
-                                                    const float *__restrict__ tables) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+// Separable gaussian: one axis per launch, RGBA8 (node encoding) between the passes.  A workgroup owns a BW x BH block of the target:
+// the taps' weights (one expf each) and the block's source footprint — BH rows of BW + 2 r texels, or BH + 2 r rows of BW — are
+// computed / fetched and decoded once into LDS, then every pixel sums its 2 r + 1 taps from there in tap order (the order, the
+// running weight sum and the final division are those of the one-thread-per-pixel loop this replaces: 22 -> 5 us per axis on
+// configs[4]'s 960x540 layer, profiles/r03_gauss.txt).
+constexpr int G_MAX_RADIUS = 192;  // ceil(3 * 64)
+template <int BW, int BH, int AXIS>
+__global__ __launch_bounds__(256) void k_gauss_axis(SurfView src, SurfView dst, float sigma, int radius, int pxi, const float *__restrict__ tables) {
+    static_assert(BW * BH == 256, "one thread per pixel of the block");
+    extern __shared__ __attribute__((aligned(16))) float4 s_tex[];
+    __shared__ float s_w[2 * G_MAX_RADIUS + 1];
+    __shared__ float s_tab[SMR_TABLE_FLOATS];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BW, y0 = blockIdx.y * BH;
+    for (int i = tid; i <= 2 * radius; i += 256) {
+        const int k = i - radius;
+        s_w[i] = sigma > 0.0f ? expf(-((float)k * (float)k) / (2.0f * sigma * sigma)) : (k == 0 ? 1.0f : 0.0f);
+    }
+    for (int i = tid; i < SMR_TABLE_FLOATS; i += 256) s_tab[i] = tables[i];
+    __syncthreads();
+    const int SW = AXIS == 0 ? BW + 2 * radius : BW, SH = AXIS == 0 ? BH : BH + 2 * radius;
+    for (int i = tid; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int sx = clampi(x0 + lx - (AXIS == 0 ? radius : 0), 0, src.w - 1), sy = clampi(y0 + ly - (AXIS == 1 ? radius : 0), 0, src.h - 1);
+        s_tex[i] = load_texel(src, pxi, sx, sy, s_tab);
+    }
+    __syncthreads();
+    const int ly = tid / BW, lx = tid - ly * BW;
+    const int x = x0 + lx, y = y0 + ly;
     if (x >= dst.w || y >= dst.h) return;
     float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
     float ws = 0.0f;
-    for (int k = -radius; k <= radius; k++) {
-        float wt = sigma > 0.0f ? expf(-((float)k * (float)k) / (2.0f * sigma * sigma)) : (k == 0 ? 1.0f : 0.0f);
-        int sx = axis == 0 ? clampi(x + k, 0, src.w - 1) : x;
-        int sy = axis == 1 ? clampi(y + k, 0, src.h - 1) : y;
-        float4 t = load_texel(src, pxi, sx, sy, tables);
+    const float4 *t0 = &s_tex[ly * SW + lx];  // tap 0 of this pixel: radius texels to the left / above
+    const int step = AXIS == 0 ? 1 : SW;
+    for (int i = 0; i <= 2 * radius; i++) {
+        const float wt = s_w[i];
+        const float4 t = t0[i * step];
         sum.x = sum.x + t.x * wt; sum.y = sum.y + t.y * wt; sum.z = sum.z + t.z * wt; sum.w = sum.w + t.w * wt;
         ws = ws + wt;
     }
-    store_texel(dst, pxi, x, y, make_float4(sum.x / ws, sum.y / ws, sum.z / ws, sum.w / ws), tables + 256);
+    store_texel(dst, pxi, x, y, make_float4(sum.x / ws, sum.y / ws, sum.z / ws, sum.w / ws), s_tab + 256);
+}
+
+template <int BW, int BH, int AXIS>
+void launch_gauss_axis(smr_ctx *ctx, const SurfView &src, const SurfView &dst, float sigma, int radius, int pxi) {
+    const size_t lds = (size_t)(AXIS == 0 ? (BW + 2 * radius) * BH : BW * (BH + 2 * radius)) * sizeof(float4);
+    dim3 grid((dst.w + BW - 1) / BW, (dst.h + BH - 1) / BH, 1);
+    hipLaunchKernelGGL((k_gauss_axis<BW, BH, AXIS>), grid, dim3(256), lds, ctx->stream, src, dst, sigma, radius, pxi, ctx->d_tables);
 }
 
 double srgb_to_linear_f64(double c) {
@@ -142,10 +173,12 @@ int smr_builtin_shader(smr_ctx *ctx, uint32_t id, const void *params, size_t par
         tmp.ptr = smr_scratch(ctx, 3, tmp.pitch * tmp.h);
         if (!tmp.ptr) return SMR_ERR_OOM;
         const int pxi = ctx->srgb() ? PXI_RGBA8_SRGB : PXI_RGBA8_UNORM;
-        dim3 grid((dst->w + 63) / 64, (dst->h + 3) / 4, 1);
         StageScope scope(ctx, SMR_STAGE_LAYOUT);
-        hipLaunchKernelGGL(k_gauss_axis, grid, dim3(256), 0, ctx->stream, view_of(s), view_of(&tmp), sigma, radius, 0, pxi, ctx->d_tables);
-        hipLaunchKernelGGL(k_gauss_axis, grid, dim3(256), 0, ctx->stream, view_of(&tmp), view_of(dst), sigma, radius, 1, pxi, ctx->d_tables);
+        // rows: 64 x 4 blocks (28.7 KB of staged texels at the largest radius); columns: the widest block whose footprint stays small
+        launch_gauss_axis<64, 4, 0>(ctx, view_of(s), view_of(&tmp), sigma, radius, pxi);
+        if (radius <= 28) launch_gauss_axis<32, 8, 1>(ctx, view_of(&tmp), view_of(dst), sigma, radius, pxi);
+        else if (radius <= 56) launch_gauss_axis<16, 16, 1>(ctx, view_of(&tmp), view_of(dst), sigma, radius, pxi);
+        else launch_gauss_axis<8, 32, 1>(ctx, view_of(&tmp), view_of(dst), sigma, radius, pxi);  // (<= 53 KB at radius 192)
         SMR_HIP(ctx, hipGetLastError());
         return SMR_OK;
     }

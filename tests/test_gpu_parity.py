@@ -375,7 +375,7 @@ def test_blit_glyphs(ctx, hip):
     check(t.download(), orc.blit_glyphs(40, 30, bg, g2, atlas, srgb=True), TOL, 0.995, "glyph blit overlap")
 
 
-@pytest.mark.parametrize("sigma", [0.0, 1.5, 4.0])
+@pytest.mark.parametrize("sigma", [0.0, 1.5, 4.0, 10.0, 20.0, 64.0])  # (radius 30 / 60 / 192: the other block shapes of the column pass)
 def test_gaussian_blur(ctx, hip, sigma):
     src = np.random.default_rng(15).integers(0, 256, (70, 130, 4), dtype=np.uint8)
     got = ctx.gaussian_blur(ctx.surface_from(src), sigma).download()
