@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
 #pragma unroll 1
             for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) a[r * 4 + q] = composite_layout_solid(0u, L, px0 + q, py0 + r, srgb_and_ablate & 1, s_tab, s_tab + 256);
+                for (int q = 0; q < 4; q++) a[r * 4 + q] = composite_sampled_opaque(L, px0 + q, py0 + r, srgb_and_ablate & 1, s_tab, s_tab + 256);
             store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
         }
     }

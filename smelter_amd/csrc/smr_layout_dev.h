@@ -287,4 +287,38 @@ __device__ __forceinline__ u32 composite_layout_solid(u32 acc, const DevLayout &
     return blend_store(acc, frag, srgb, dec, thr);
 }
 
+// composite_layout_solid for the one case k_classify_tiles calls TC_SAMPLED: an opaque (src_kind 2) unrotated texture layer that is not
+// a 1:1 blit, onto a cleared pixel, in the layer's solid region.  Every texel's alpha is 1, the bilinear weights of a sample sum to 1
+// exactly (8-bit sub-texel fractions: 1 - f is exact), so the fragment's alpha is exactly 1, the blend keeps nothing of the
+// destination (dst * 0) and the stored alpha is 255: only the three colour channels are fetched, filtered — the operations of
+// sample_rgba_bilinear in their order — and encoded.
+__device__ __forceinline__ u32 composite_sampled_opaque(const DevLayout &L, int px, int py, int srgb, const float *__restrict__ dec,
+                                                        const float *__restrict__ thr) {
+    float fx_, fy_, lx, ly;
+    layout_covers(L, px, py, fx_, fy_, lx, ly);
+    const float u01 = div_cr(lx, L.qw, L.rqw) + 0.5f, v01 = 0.5f - div_cr(ly, L.qh, L.rqh);
+    const float tu = div_cr(L.crop[1] + u01 * L.crop[2], (float)L.tex_w, L.rtw);
+    const float tv = div_cr(L.crop[0] + v01 * L.crop[3], (float)L.tex_h, L.rth);
+    const SurfView &s = L.src;
+    const float sx = tu * (float)s.w - 0.5f, sy = tv * (float)s.h - 0.5f;
+    const float fx0 = floorf(sx), fy0 = floorf(sy);
+    const float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
+    const int x0 = clampi((int)fx0, 0, s.w - 1), x1 = clampi((int)fx0 + 1, 0, s.w - 1);
+    const int y0 = clampi((int)fy0, 0, s.h - 1), y1 = clampi((int)fy0 + 1, 0, s.h - 1);
+    const u8 *r0 = s.ptr + (size_t)y0 * s.pitch, *r1 = s.ptr + (size_t)y1 * s.pitch;
+    const u32 ta = ((const u32 *)r0)[x0], tb = ((const u32 *)r0)[x1], tc = ((const u32 *)r1)[x0], td = ((const u32 *)r1)[x1];
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    u32 out = 0xff000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const u32 ba = (ta >> (8 * ch)) & 0xffu, bb = (tb >> (8 * ch)) & 0xffu, bc = (tc >> (8 * ch)) & 0xffu, bd = (td >> (8 * ch)) & 0xffu;
+        float a, b, c, d;
+        if (srgb) { a = dec[ba]; b = dec[bb]; c = dec[bc]; d = dec[bd]; }
+        else { a = (float)ba / 255.0f; b = (float)bb / 255.0f; c = (float)bc / 255.0f; d = (float)bd / 255.0f; }
+        const float o = (a * gx + b * fx) * gy + (c * gx + d * fx) * fy;
+        out |= (srgb ? srgb_encode8(o, thr) : unorm8(o)) << (8 * ch);
+    }
+    return out;
+}
+
 #endif  // __HIPCC__
