@@ -169,12 +169,22 @@ struct TileList {
 // resamples in the same call, at even output positions) — wave A then writes that tile's Y'CbCr itself, the RGBA8 bytes of those
 // pixels never exist in memory — else 0xff.
 constexpr u32 B_CLASS_NONE = 0xffu;
-__global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks, int n, int W, int H,
-                                                       int tiles_x, unsigned long long direct_layers, TileClass *__restrict__ tc,
-                                                       u8 *__restrict__ direct, TileList *__restrict__ full) {
-    __shared__ u32 s_touch[MAX_LAYOUT_WORDS], s_solid[MAX_LAYOUT_WORDS];
-    __shared__ int s_start, s_general, s_slot;
-    const int tid = threadIdx.x, tile = blockIdx.x;
+constexpr int B_CLASSIFY_TILES = 16;  // tiles per workgroup of k_classify_tiles, one wave each: the tiles that need compositing take their
+                                      // list slots with ONE atomic per workgroup (a thousand atomics on one counter were most of the
+                                      // kernel: 15.3 -> 7.7 us for a 4K output in transition)
+__global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks, int n,
+                                                                          int W, int H, int tiles_x, int tiles, unsigned long long direct_layers,
+                                                                          TileClass *__restrict__ tc, u8 *__restrict__ direct, TileList *__restrict__ full) {
+    __shared__ u32 s_touch_w[B_CLASSIFY_TILES][MAX_LAYOUT_WORDS], s_solid_w[B_CLASSIFY_TILES][MAX_LAYOUT_WORDS];
+    __shared__ int s_start_w[B_CLASSIFY_TILES], s_general_w[B_CLASSIFY_TILES], s_slot_w[B_CLASSIFY_TILES];
+    __shared__ TileClass s_class_w[B_CLASSIFY_TILES];
+    __shared__ u32 s_direct_w[B_CLASSIFY_TILES];
+    // (every wave runs the same barriers: a wave past the last tile classifies the last tile again and writes nothing)
+    const int wave = threadIdx.x >> 6, tid = threadIdx.x & 63;
+    const bool live = (int)blockIdx.x * B_CLASSIFY_TILES + wave < tiles;
+    const int tile = min((int)blockIdx.x * B_CLASSIFY_TILES + wave, tiles - 1);
+    u32 *s_touch = s_touch_w[wave], *s_solid = s_solid_w[wave];
+    int &s_start = s_start_w[wave], &s_general = s_general_w[wave], &s_slot = s_slot_w[wave];
     const int tile_y = tile / tiles_x;
     const int tx0 = (tile - tile_y * tiles_x) * B_TILE_W, ty0 = tile_y * B_TILE_H;
     if (tid == 0) s_general = 0;
@@ -206,13 +216,30 @@ __global__ __launch_bounds__(64) void k_classify_tiles(const DevLayout *__restri
                 }
             }
         }
-        if (c.kind == TC_FULL) c.pitch_or_px = atomicAdd(&full->count, 1u);
-        s_slot = c.kind == TC_FULL ? (int)c.pitch_or_px : -1;
-        tc[tile] = c;
-        direct[tile] = (u8)d;
+        s_slot = (live && c.kind == TC_FULL) ? 1 : 0;  // (a request; the slot itself below)
+        s_class_w[wave] = c;
+        s_direct_w[wave] = d;
     }
     __syncthreads();
-    if (s_slot >= 0) {  // (uniform) the record the compositor's bands of this tile start from
+    if (threadIdx.x == 0) {
+        int want = 0;
+        for (int w = 0; w < B_CLASSIFY_TILES; w++) want += s_slot_w[w];
+        const u32 base = want ? atomicAdd(&full->count, (u32)want) : 0u;
+        int at = 0;
+        for (int w = 0; w < B_CLASSIFY_TILES; w++) {
+            const int mine = s_slot_w[w] ? (int)base + at : -1;
+            at += s_slot_w[w];
+            s_slot_w[w] = mine;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && live) {
+        TileClass c = s_class_w[wave];
+        if (c.kind == TC_FULL) c.pitch_or_px = (u32)s_slot;
+        tc[tile] = c;
+        direct[tile] = (u8)s_direct_w[wave];
+    }
+    if (s_slot >= 0) {  // (uniform per wave) the record the compositor's bands of this tile start from
         TileFull &E = full->e[s_slot];
         if (tid < MAX_LAYOUT_WORDS) E.touch[tid] = tid < ((n + 31) >> 5) ? s_touch[tid] : 0u;
         if (tid == 0) { E.tile = (u32)tile; E.start = start; E.general = (u32)s_general; E.pad = 0u; }
