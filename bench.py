@@ -162,7 +162,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency-frames", type=int, default=2000)
-    ap.add_argument("--ingest", choices=["auto", "valu", "mfma", "mfma_wg"], default="auto",
+    ap.add_argument("--ingest", choices=["auto", "valu", "mfma", "mfma_wg", "mfma_node"], default="auto",
                     help="ingest + Lanczos kernel: matrix cores where applicable (auto, default), exact f32 (valu)")
     ap.add_argument("--direct-output", action="store_true",
                     help="SMR_OPT_DIRECT_OUTPUT: the resampling kernel writes Y'CbCr for the compositor's copy tiles (A/B; default off)")
@@ -214,7 +214,8 @@ def main():
     if side is not None:
         torch.cuda.set_stream(side)
     ctx = hip.Context(local_rank, stream=side.cuda_stream if side is not None else None)
-    ingest_impl = {"auto": hip.INGEST_AUTO, "valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_MFMA_F16, "mfma_wg": hip.INGEST_MFMA_F16_WG}[args.ingest]
+    ingest_impl = {"auto": hip.INGEST_AUTO, "valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_MFMA_F16, "mfma_wg": hip.INGEST_MFMA_F16_WG,
+                   "mfma_node": hip.INGEST_MFMA_F16_NODE}[args.ingest]
     ctx.set_ingest_impl(ingest_impl)
     ctx.set_direct_output(args.direct_output)
     layouts, res = build_scene()

@@ -167,6 +167,11 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *       SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
  *       SMR_INGEST_MFMA_F16_WG  the first matrix-core kernel (k_ingest_mfma: a workgroup pipeline of convert and filter waves
  *                            around LDS) instead of the wave-autonomous one (k_ingest_wave) AUTO prefers; same arithmetic
+ *       SMR_INGEST_MFMA_F16_NODE  no fused colour conversion: every frame goes through the exact converter (smr_frame_to_rgba's
+ *                            kernels, the WGSL operation sequence) into its RGBA8 node texture, as the reference does, and the
+ *                            matrix-core kernel resamples that — within 1 LSB of the reference END TO END on every content class,
+ *                            for one more pass over the inputs (configs[2]: 18.0k -> 12.5k frames/s, latency p50 83 -> 98 us; the f32
+ *                            kernel: 7.4k frames/s — profiles/r03_ingest_node.txt)
  *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
  *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated
  *     in f32.  Its deviation is bounded per stage: the fused colour conversion is within one code of planar_yuv_to_rgba.wgsl
@@ -174,15 +179,17 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *     passes applied to that node texture.  End to end that is within 1 LSB on camera-like content; on white noise a flipped
  *     bright texel seen through the linear-light filter at a dark output can show as 2..4 codes (3 bytes in 7.4 million,
  *     tests/test_gpu_fused.py).  Sources that need no fused conversion (RGBA8 / RGBA16F node textures: 4:2:2, 4:4:4, packed YUV,
- *     opaque surfaces, box-pre-reduced plans) are within 1 LSB end to end.  A host that needs the f32 sequence bit for bit
- *     (snapshot tests) selects SMR_INGEST_VALU_F32.
+ *     opaque surfaces, box-pre-reduced plans) are within 1 LSB end to end.  A host that needs <= 1 LSB end to end on adversarial content
+ *     selects SMR_INGEST_MFMA_F16_NODE; one that needs the f32 sequence bit for bit (snapshot tests) SMR_INGEST_VALU_F32.
  *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling)
  *   SMR_OPT_DIRECT_OUTPUT       1: when smr_render_layouts sees the same layout list again (a scene at rest), the pixels the
  *                               compositor would only copy from a freshly resampled input are converted to Y'CbCr by the resampling
  *                               kernel itself and their RGBA8 form is never stored (HBM traffic per frame 1.5x instead of 2.9x the
  *                               algorithmic bytes, at the price of vector-ALU time in a kernel that is instruction-bound: DESIGN.md); 0 (default): always through
  *                               the RGBA8 tile.  Same output bytes either way. */
-typedef enum smr_ingest_impl { SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, SMR_INGEST_MFMA_F16_WG = 3 } smr_ingest_impl;
+typedef enum smr_ingest_impl {
+    SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, SMR_INGEST_MFMA_F16_WG = 3, SMR_INGEST_MFMA_F16_NODE = 4
+} smr_ingest_impl;
 typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */

@@ -49,6 +49,113 @@ __global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba(SurfView yp, SurfView up,
     }
 }
 
+// The same pass for 4:2:0 frames of even size (planar, limited or full range; NV12), several frames per launch: what k_yuv_to_rgba
+// computes, value for value, without its per-pixel coordinate arithmetic and divisions.  For a w x h frame with (w / 2) x (h / 2) chroma
+// the sample position of luma column x in chroma texels is x / 2 - 0.25: the float evaluation ((x + .5) / w) * (w / 2) - .5 is off by
+// less than 1e-3 for w <= 16384, so floor() and the 8-bit sub-texel fraction (subtexel(): a multiple of 1 / 256) come out as
+// floor(x / 2 - .25) and exactly .75 (x even) / .25 (x odd); rows likewise.  A thread converts a 4 x 2 pixel block (columns 4 g .. + 3,
+// rows 2 p, 2 p + 1) from chroma columns 2 g - 1 .. 2 g + 2 and rows p - 1 .. p + 1 (clamped like the sampler clamps), with
+// sample_plane_bilinear's products and sums in its order, byte / 255 as unorm_of_byte (the IEEE quotient for every byte) and the
+// matrix + store of yuv_to_rgb_px.  tests/test_gpu_parity.py holds it to the general kernel bit for bit.
+struct ConvJob {
+    SurfView yp, up, vp, dst;
+    int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
+};
+constexpr int MAX_CONV_JOBS = 16;
+struct ConvBatch {
+    ConvJob j[MAX_CONV_JOBS];
+};
+__global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba_batch(const ConvBatch B) {
+    const ConvJob &J = B.j[blockIdx.z];
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), p = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int w = J.dst.w, h = J.dst.h, cw = w >> 1, ch = h >> 1;
+    if (4 * g >= w || 2 * p >= h) return;
+    // chroma neighbourhood as unorm values: t[plane][row j = p - 1 + j][column 2 g - 1 + k], columns and rows clamped like the sampler
+    // clamps.  The four bytes of a row come from two aligned dwords (three for NV12's interleaved pairs) starting at the window's first
+    // existing column; the clamped columns are then byte moves: at the left edge (g = 0) the window is columns 0, 0, 1, 2, at the right
+    // edge the last existing column repeats.  Planes whose rows are not dword-aligned or too tight take the bytes one by one.
+    float t[2][3][4];
+    const int first = 2 * g - 1;                              // leftmost chroma column of the window (-1 for g = 0)
+    const int first_ld = first < 0 ? 0 : first;               // ... that exists
+    const int byte0 = J.nv ? 2 * first_ld : first_ld;         // its byte offset in the row
+    const int base = byte0 & ~3;
+    const u32 sh = (u32)(byte0 - base);
+    const bool dwords = (J.up.pitch & 3u) == 0 && (((uintptr_t)J.up.ptr) & 3) == 0 && (J.vp.pitch & 3u) == 0 && (((uintptr_t)J.vp.ptr) & 3) == 0 &&
+                        (u32)base + (J.nv ? 12u : 8u) <= J.up.pitch && (J.nv || (u32)base + 8u <= J.vp.pitch);
+    const int nvalid = cw - first;                            // window columns 0 .. nvalid - 1 are at or left of the last column (>= 2)
+    const u32 right_fix = nvalid >= 4 ? 0x03020100u : nvalid == 3 ? 0x02020100u : 0x01010100u;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int cy = clampi(p - 1 + j, 0, ch - 1);
+        const u8 *ur = J.up.ptr + (u32)cy * J.up.pitch, *vr = J.vp.ptr + (u32)cy * J.vp.pitch;  // (a plane is far below 4 GiB)
+        if (dwords) {  // (uniform)
+            u32 uw, vw;
+            if (J.nv) {
+                const u32 d0 = *(const u32 *)(ur + base), d1 = *(const u32 *)(ur + base + 4), d2 = *(const u32 *)(ur + base + 8);
+                const u32 w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);  // U V U V of two columns each
+                uw = __builtin_amdgcn_perm(w1, w0, 0x06040200u);
+                vw = __builtin_amdgcn_perm(w1, w0, 0x07050301u);
+            } else {
+                uw = __builtin_amdgcn_alignbyte(*(const u32 *)(ur + base + 4), *(const u32 *)(ur + base), sh);
+                vw = __builtin_amdgcn_alignbyte(*(const u32 *)(vr + base + 4), *(const u32 *)(vr + base), sh);
+            }
+            if (first < 0) {  // columns 0 1 2 3 -> 0 0 1 2
+                uw = (uw << 8) | (uw & 0xffu);
+                vw = (vw << 8) | (vw & 0xffu);
+            }
+            uw = __builtin_amdgcn_perm(0u, uw, right_fix);
+            vw = __builtin_amdgcn_perm(0u, vw, right_fix);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                t[0][j][k] = unorm_of_byte((uw >> (8 * k)) & 0xffu);
+                t[1][j][k] = unorm_of_byte((vw >> (8 * k)) & 0xffu);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int cx = clampi(first + k, 0, cw - 1);
+                t[0][j][k] = unorm_of_byte(J.nv ? ur[2 * cx] : ur[cx]);
+                t[1][j][k] = unorm_of_byte(J.nv ? ur[2 * cx + 1] : vr[cx]);
+            }
+        }
+    }
+    // horizontal lerps of the three chroma rows at the four luma columns: a * (1 - fx) + b * fx with fx = .75, .25, .75, .25
+    float H[2][3][4];
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            H[c][j][0] = t[c][j][0] * 0.25f + t[c][j][1] * 0.75f;
+            H[c][j][1] = t[c][j][1] * 0.75f + t[c][j][2] * 0.25f;
+            H[c][j][2] = t[c][j][1] * 0.25f + t[c][j][2] * 0.75f;
+            H[c][j][3] = t[c][j][2] * 0.75f + t[c][j][3] * 0.25f;
+        }
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = 2 * p + r;
+        if (y >= h) break;
+        const u8 *yr = J.yp.ptr + ((u32)y * J.yp.pitch + 4u * (u32)g);
+        const bool whole = 4 * g + 3 < w && (((uintptr_t)yr) & 3) == 0;
+        const u32 y4 = whole ? *(const u32 *)yr : 0u;
+        u32 px[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (4 * g + i >= w) { px[i] = 0u; continue; }
+            const float yy = unorm_of_byte(whole ? (y4 >> (8 * i)) & 0xffu : (u32)yr[i]);
+            // row 2 p: chroma rows (p - 1, p), fy = .75; row 2 p + 1: rows (p, p + 1), fy = .25 — top * (1 - fy) + bot * fy
+            const float uu = r == 0 ? H[0][0][i] * 0.25f + H[0][1][i] * 0.75f : H[0][1][i] * 0.75f + H[0][2][i] * 0.25f;
+            const float vv = r == 0 ? H[1][0][i] * 0.25f + H[1][1][i] * 0.75f : H[1][1][i] * 0.75f + H[1][2][i] * 0.25f;
+            px[i] = yuv_to_rgb_px_cr(yy, uu, vv, J.full != 0);
+        }
+        u8 *row = J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g);
+        if (4 * g + 3 < w) {
+            *(uint4 *)row = make_uint4(px[0], px[1], px[2], px[3]);
+        } else {
+            for (int i = 0; i < 4 && 4 * g + i < w; i++) ((u32 *)row)[i] = px[i];
+        }
+    }
+}
+
 // interleaved_{uyvy,yuyv}_to_rgba.wgsl:24-62. src is the (w/2) x h RGBA8 packed texture.
 __global__ __launch_bounds__(BLOCK) void k_interleaved422_to_rgba(SurfView src, SurfView dst, int order) {
     const int x = blockIdx.x * BLOCK + threadIdx.x;
@@ -183,6 +290,53 @@ u32 host_unorm8(float x) {
 
 }  // namespace
 
+
+// k_yuv420_to_rgba_batch's frames: 4:2:0 with even luma size (chroma planes exactly half), within the width the coordinate argument holds for
+static bool conv_batchable(const smr_frame *in) {
+    if (in->format != SMR_FRAME_PLANAR_YUV420 && in->format != SMR_FRAME_PLANAR_YUVJ420 && in->format != SMR_FRAME_NV12) return false;
+    if (in->width % 2 || in->height % 2 || in->width < 2 || in->height < 2 || in->width > 16384 || in->height > 16384) return false;
+    if (!in->planes[0] || !in->planes[1] || (in->format != SMR_FRAME_NV12 && !in->planes[2])) return false;
+    return getenv("SMR_CONVERT_GENERAL") == nullptr;  // (tests: the one-thread-per-four-pixels kernel as the reference)
+}
+
+// smr_frame_to_rgba for several frames: one launch for every 16 frames k_yuv420_to_rgba_batch takes, the others one by one
+int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n) {
+    if (!ctx || (n && (!in || !nodes))) return SMR_ERR_INVALID;
+    ConvBatch B;
+    u32 nb = 0;
+    int mw = 0, mh = 0;
+    auto flush = [&]() -> int {
+        if (!nb) return SMR_OK;
+        StageScope scope(ctx, SMR_STAGE_INGEST);
+        hipLaunchKernelGGL(k_yuv420_to_rgba_batch, dim3((unsigned)((mw + 255) / 256), (unsigned)((mh + 7) / 8), nb), dim3(BLOCK), 0, ctx->stream, B);
+        SMR_HIP(ctx, hipGetLastError());
+        nb = 0; mw = 0; mh = 0;
+        return SMR_OK;
+    };
+    for (u32 i = 0; i < n; i++) {
+        if (!in[i] || !nodes[i]) return SMR_ERR_INVALID;
+        if (!conv_batchable(in[i])) {
+            if (int rc = smr_frame_to_rgba(ctx, in[i], nodes[i])) return rc;
+            continue;
+        }
+        if (nodes[i]->fmt != SMR_PX_RGBA8 || nodes[i]->w != in[i]->width || nodes[i]->h != in[i]->height)
+            return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in[i]->width, in[i]->height);
+        if (int rc = smr_validate_frame(ctx, in[i], "smr_frame_to_rgba")) return rc;
+        ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
+        ConvJob &J = B.j[nb++];
+        const bool nv = in[i]->format == SMR_FRAME_NV12;
+        J.yp = view_of(in[i]->planes[0]); J.up = view_of(in[i]->planes[1]); J.vp = nv ? J.up : view_of(in[i]->planes[2]);
+        J.dst = view_of(nodes[i]);
+        J.full = in[i]->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
+        J.nv = nv ? 1 : 0;
+        mw = (int)in[i]->width > mw ? (int)in[i]->width : mw;
+        mh = (int)in[i]->height > mh ? (int)in[i]->height : mh;
+        if (nb == MAX_CONV_JOBS)
+            if (int rc = flush()) return rc;
+    }
+    return flush();
+}
+
 extern "C" {
 
 int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
@@ -191,6 +345,7 @@ int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
     if (node->fmt != SMR_PX_RGBA8 || node->w != in->width || node->h != in->height)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
     if (int rc = smr_validate_frame(ctx, in, "smr_frame_to_rgba")) return rc;
+    if (conv_batchable(in)) return smr_frames_to_rgba_batch(ctx, &in, &node, 1);
     StageScope scope(ctx, SMR_STAGE_INGEST);
     ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
     SurfView dst = view_of(node);

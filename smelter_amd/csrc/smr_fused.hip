@@ -93,16 +93,27 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: bad source kind %u", s.kind);
         }
     }
+    // (the conversions are queued and go out together — one launch for the 4:2:0 frames of a call, smr_frames_to_rgba_batch — before
+    //  the first kernel that reads a node texture: flush_nodes)
+    std::vector<const smr_frame *> conv_in;
+    std::vector<smr_surface *> conv_node;
     auto ensure_node = [&](u32 i) -> int {
         if (node_ready[i]) return SMR_OK;
         const smr_frame *f = sources[i].frame;
         smr_surface *node = smr_cached_surface(ctx, SLOT_NODE0 + i, f->width, f->height, SMR_PX_RGBA8);
         if (!node) return SMR_ERR_OOM;
-        int rc = smr_frame_to_rgba(ctx, f, node);
-        if (rc != SMR_OK) return rc;
+        conv_in.push_back(f);
+        conv_node.push_back(node);
         views[i] = view_of(node);
         node_ready[i] = 1;
         return SMR_OK;
+    };
+    auto flush_nodes = [&]() -> int {
+        if (conv_in.empty()) return SMR_OK;
+        int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size());
+        conv_in.clear();
+        conv_node.clear();
+        return rc;
     };
 
     // ---- resample_scaled_children (layout.rs:238-278): per texture layout decide direct / general / fused
@@ -194,7 +205,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                                     took = true;
                                 }
                             } else {
-                                int rc = make_wave_job_rgba_transposed(ctx, views[si], p2, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &took, &back);
+                                int rc = flush_nodes();
+                                if (rc != SMR_OK) return rc;
+                                rc = make_wave_job_rgba_transposed(ctx, views[si], p2, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &took, &back);
                                 if (rc != SMR_OK) return rc;
                                 if (took) transposed.push_back(back);
                             }
@@ -248,7 +261,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             smr_surface node;  // non-owning alias of the node view
                             node.ptr = views[si].ptr; node.pitch = views[si].pitch; node.w = (u32)views[si].w; node.h = (u32)views[si].h;
                             node.fmt = SMR_PX_RGBA8;
-                            int rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
+                            int rc = flush_nodes();
+                            if (rc != SMR_OK) return rc;
+                            rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
                             if (rc != SMR_OK) return rc;
                             rc = launch_transpose<uint2>(ctx, reduced, reduced_t);
                             if (rc != SMR_OK) return rc;
@@ -276,7 +291,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                             smr_surface node;  // non-owning alias of the node view
                             node.ptr = views[si].ptr; node.pitch = views[si].pitch; node.w = (u32)views[si].w; node.h = (u32)views[si].h;
                             node.fmt = SMR_PX_RGBA8;
-                            int rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
+                            int rc = flush_nodes();
+                            if (rc != SMR_OK) return rc;
+                            rc = smr_downsample(ctx, &node, 1u << plan.levels[0], 1u << plan.levels[1], reduced);
                             if (rc != SMR_OK) return rc;
                             WJob J;
                             rc = make_wave_job_rgba(ctx, view_of(reduced), plan, tile, &J, single);
@@ -292,7 +309,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         }
                         WJob J;
                         MTransposeBack back;
-                        int rc = make_wave_job_rgba_transposed(ctx, views[si], plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
+                        int rc = flush_nodes();
+                        if (rc != SMR_OK) return rc;
+                        rc = make_wave_job_rgba_transposed(ctx, views[si], plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
                         if (rc != SMR_OK) return rc;
                         if (on_mfma) { rgba_jobs.push_back(J); transposed.push_back(back); }
                     }
@@ -311,7 +330,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     smr_surface node;  // non-owning alias of the node view for the general resampler
                     node.ptr = views[si].ptr; node.pitch = views[si].pitch; node.w = (u32)views[si].w; node.h = (u32)views[si].h;
                     node.fmt = SMR_PX_RGBA8;
-                    int rc = smr_resample(ctx, &node, L.crop, tile);
+                    int rc = flush_nodes();
+                    if (rc != SMR_OK) return rc;
+                    rc = smr_resample(ctx, &node, L.crop, tile);
                     if (rc < 0) return rc;
                 }
                 // ResampledChild::output_crop (resampler.rs:292-299)
@@ -328,6 +349,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             if (rc != SMR_OK) return rc;
         }
     }
+    if (int rc = flush_nodes()) return rc;  // (the queued conversions: everything below may read a node texture)
 
     // ---- parameters -> device (one pinned staging slot, one copy)
     const u32 b_tiles_x = (out_w + B_TILE_W - 1) / B_TILE_W, b_tiles_y = (out_h + B_TILE_H - 1) / B_TILE_H;
@@ -558,6 +580,22 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
     if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample: degenerate plan");
     if (kind == 0) return 0;
     if (new_call) ctx->weight_call++;
+    // SMR_INGEST_MFMA_F16_NODE: the exact converter into the node texture, then the matrix-core kernel on it (opaque formats, plans
+    // the kernel holds with the horizontal pass first; anything else below)
+    if (!fused_disabled(ctx) && ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE && in->format <= SMR_FRAME_NV12) {
+        smr_surface *node = smr_cached_surface(ctx, SLOT_INGEST_NODE, in->width, in->height, SMR_PX_RGBA8);
+        if (!node) return SMR_ERR_OOM;
+        bool single = false;
+        if (can_fuse_wave_rgba(ctx, view_of(node), plan, dst, 4, &single)) {
+            int rc = smr_frame_to_rgba(ctx, in, node);
+            if (rc != SMR_OK) return rc;
+            std::vector<WJob> wjobs(1);
+            rc = make_wave_job_rgba(ctx, view_of(node), plan, dst, &wjobs[0], single);
+            if (rc != SMR_OK) return rc;
+            rc = launch_wave(ctx, wjobs, nullptr, true);
+            return rc == SMR_OK ? kind : rc;
+        }
+    }
     if (!fused_disabled(ctx) && can_fuse_wave(ctx, in, plan, dst)) {
         std::vector<WJob> wjobs(1);
         int rc = make_wave_job(ctx, in, plan, dst, &wjobs[0]);
@@ -639,6 +677,11 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         if (kinds) kinds[i] = kind;
         if (kind == 0) continue;
         bool on_mfma = false;
+        if (ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) {  // (one by one: each input has its own node texture pass)
+            int rc = ingest_resample_one(ctx, in[i], crop, dst[i], false);
+            if (rc < 0) return rc;
+            continue;
+        }
         if (!fused_disabled(ctx) && can_fuse_wave(ctx, in[i], plan, dst[i])) {
             WJob J;
             int rc = make_wave_job(ctx, in[i], plan, dst[i], &J);

@@ -688,7 +688,7 @@ bool mfma_plane_ok(const SurfView &p, u32 bytes) { return (p.pitch % 4) == 0 && 
 // What k_ingest_mfma covers: planar 4:2:0 (limited or full range) with even luma size and dword-aligned planes, separable
 // plan, horizontal pass first, no box pre-reduction, 16-byte aligned tile rows, footprints that fit the LDS.
 bool can_fuse_mfma(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32) return false;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) return false;
     const bool nv12 = f && f->format == SMR_FRAME_NV12;
     if (!f || !f->planes[0] || !f->planes[1] || (!nv12 && !f->planes[2])) return false;
 #ifdef SMR_ABLATION_BUILDS
@@ -805,7 +805,7 @@ int make_mfma_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
 int make_mfma_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, MJob *out, bool *ok,
                              MTransposeBack *back) {
     *ok = false;
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || !f || !f->planes[0] || !f->planes[1]) return SMR_OK;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE || !f || !f->planes[0] || !f->planes[1]) return SMR_OK;
     if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
     const bool nv12 = f->format == SMR_FRAME_NV12;
     if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return SMR_OK;

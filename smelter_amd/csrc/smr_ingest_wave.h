@@ -1067,7 +1067,7 @@ int flush_wave_builds(smr_ctx *ctx) {
 // two-pass plan with the horizontal pass first and no box pre-reduction (vertical-first plans come back on the transposed frame,
 // as for k_ingest_mfma), 16-byte aligned tile rows, k-step counts within the kernel's limits.
 bool can_fuse_wave(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return false;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG || ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) return false;
     const bool nv12 = f && f->format == SMR_FRAME_NV12;
     if (!f || !f->planes[0] || !f->planes[1] || (!nv12 && !f->planes[2])) return false;
     if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return false;
@@ -1177,7 +1177,8 @@ int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_pla
 int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, WJob *out, bool *ok,
                              MTransposeBack *back) {
     *ok = false;
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG || !f || !f->planes[0] || !f->planes[1]) return SMR_OK;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG || ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) return SMR_OK;
+    if (!f || !f->planes[0] || !f->planes[1]) return SMR_OK;
     if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
     const bool nv12 = f->format == SMR_FRAME_NV12;
     if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return SMR_OK;

@@ -139,7 +139,7 @@ def pack_layouts(layouts) -> "C.Array":
     return arr
 
 
-INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_WG = 0, 1, 2, 3
+INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_WG, INGEST_MFMA_F16_NODE = 0, 1, 2, 3, 4
 KERNEL_NAMES = ("ingest_wave", "ingest_wave_rgba", "ingest_mfma_wg", "ingest_valu", "resample_general", "frame_to_rgba", "compose_output", "apply_layouts")
 COMM_ID_BYTES = 128
 
@@ -245,7 +245,8 @@ class Context:
 
     def set_ingest_impl(self, impl: int):
         """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (matrix cores, wave-autonomous
-        kernel where it applies) / INGEST_MFMA_F16_WG (the workgroup-pipelined matrix-core kernel) — SMR_OPT_INGEST_IMPL."""
+        kernel where it applies) / INGEST_MFMA_F16_WG (the workgroup-pipelined matrix-core kernel) / INGEST_MFMA_F16_NODE (exact converter into the node texture,
+        matrix cores for the resample only: within 1 LSB end to end on every content) — SMR_OPT_INGEST_IMPL."""
         self.set_option(OPT_INGEST_IMPL, impl)
 
     def set_direct_output(self, on: bool):

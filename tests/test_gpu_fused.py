@@ -632,7 +632,8 @@ def test_full_size_white_noise_within_one_lsb(hip):
     c = hip.Context(0)
     try:
         f = c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, [y, u, v])
-        for impl, want, ident in ((hip.INGEST_VALU_F32, want_o, 0.9999), (hip.INGEST_MFMA_F16, want_k, 0.9995)):
+        # (INGEST_MFMA_F16_NODE: exact converter + matrix-core resampler — within 1 LSB of the oracle END TO END on this content too)
+        for impl, want, ident in ((hip.INGEST_VALU_F32, want_o, 0.9999), (hip.INGEST_MFMA_F16, want_k, 0.9995), (hip.INGEST_MFMA_F16_NODE, want_o, 0.9995)):
             c.set_ingest_impl(impl)
             t = c.surface(dw, dh)
             c.ingest_resample(f, crop, t)

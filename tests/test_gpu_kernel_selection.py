@@ -191,3 +191,39 @@ def test_random_geometries_on_every_route(hip, fmt, seed):
         assert (d == 0).mean() >= 0.98, (fmt, seed, float((d == 0).mean()))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("fmt", ["yuv420", "yuvj420", "nv12"])
+@pytest.mark.parametrize("plan", ["two_pass_h_first", "two_pass_v_first", "scale_2", "single_axis_h", "box_prereduced"])
+def test_node_texture_option_is_within_one_lsb_end_to_end(hip, fmt, plan):
+    """SMR_INGEST_MFMA_F16_NODE: no fused conversion — the frame goes through the exact converter into its node texture and the
+    matrix-core kernel resamples that.  White-noise planes (the content on which the fused conversion's one-code flips show as 2..4
+    codes end to end): every byte within 1 LSB of the oracle's converter + resampler."""
+    (sw, sh), (dw, dh) = PLANS[plan]
+    ctx = hip.Context(0)
+    try:
+        ctx.set_ingest_impl(hip.INGEST_MFMA_F16_NODE)
+        rng = np.random.default_rng(7 + sorted(PLANS).index(plan))
+        y = rng.integers(0, 256, (sh, sw), dtype=np.uint8)
+        if fmt == "nv12":
+            uv = rng.integers(0, 256, (sh // 2, sw // 2, 2), dtype=np.uint8)
+            src, node = ctx.frame(hip.FRAME_NV12, sw, sh, [y, uv]), orc.nv12_to_rgba(y, uv, sw, sh)
+        else:
+            u = rng.integers(0, 256, (sh // 2, sw // 2), dtype=np.uint8)
+            v = rng.integers(0, 256, (sh // 2, sw // 2), dtype=np.uint8)
+            variant = orc.YUV420 if fmt == "yuv420" else orc.YUVJ420
+            src = ctx.frame(hip.FRAME_PLANAR_YUV420 if fmt == "yuv420" else hip.FRAME_PLANAR_YUVJ420, sw, sh, [y, u, v])
+            node = orc.planar_yuv_to_rgba(y, u, v, sw, sh, variant)
+        out = ctx.surface(dw, dh)
+        before = ctx.kernel_launches()
+        ctx.render_layouts([Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=(0, 0, sw, sh))], [src], dw, dh, out_rgba=out)
+        got = out.download()
+        ran = {k: v - before[k] for k, v in ctx.kernel_launches().items()}
+        assert ran["frame_to_rgba"] == 1 and ran["ingest_wave_rgba"] == 1 and ran["ingest_wave"] == 0 and ran["resample_general"] == 0, (fmt, plan, ran)
+        _, tile = orc.resample(node, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+        want = orc.apply_layouts(dw, dh, [Layout(top=0, left=0, width=dw, height=dh, type=0, source_index=0, crop=(0, 0, dw, dh))], [tile])
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, (fmt, plan, int(d.max()), int((d > 1).sum()))
+        assert (d == 0).mean() >= 0.97, (fmt, plan, float((d == 0).mean()))
+    finally:
+        ctx.close()

@@ -62,6 +62,34 @@ def test_planar_yuv_to_rgba(ctx, hip, w, h, variant):
     assert (got[..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("w,h", [(64, 36), (66, 38), (2, 2), (6, 4), (258, 10), (1920, 1080), (1922, 1082)])
+@pytest.mark.parametrize("variant", ["420", "j420", "nv12"])
+def test_batched_420_converter_equals_the_general_kernel(ctx, hip, w, h, variant):
+    """k_yuv420_to_rgba_batch (4:2:0 frames of even size: structure-aware, several frames per launch) against k_yuv_to_rgba (the WGSL
+    pass as it is written, SMR_CONVERT_GENERAL=1): every byte equal, on white noise and on the extremes."""
+    import os
+    rng = np.random.default_rng(hash((w, h, variant)) % 2**32)
+    for content in ("noise", "extremes"):
+        if content == "noise":
+            y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            c = rng.integers(0, 256, (h // 2, w // 2, 2), dtype=np.uint8)
+        else:
+            y = rng.choice(np.array([0, 1, 15, 16, 17, 234, 235, 236, 254, 255], np.uint8), (h, w))
+            c = rng.choice(np.array([0, 15, 16, 17, 127, 128, 129, 239, 240, 241, 255], np.uint8), (h // 2, w // 2, 2))
+        if variant == "nv12":
+            f = ctx.frame(hip.FRAME_NV12, w, h, [y, c])
+        else:
+            f = ctx.frame(hip.FRAME_PLANAR_YUV420 if variant == "420" else hip.FRAME_PLANAR_YUVJ420, w, h,
+                          [y, np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])])
+        fast = ctx.frame_to_rgba(f).download()
+        os.environ["SMR_CONVERT_GENERAL"] = "1"
+        try:
+            general = ctx.frame_to_rgba(f).download()
+        finally:
+            del os.environ["SMR_CONVERT_GENERAL"]
+        assert np.array_equal(fast, general), (variant, w, h, content, int((fast != general).sum()))
+
+
 def test_nv12_to_rgba(ctx, hip):
     w, h = 642, 362
     rng = np.random.default_rng(5)

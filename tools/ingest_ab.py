@@ -54,7 +54,7 @@ def stats(a, b):
     return {"max_lsb": int(d.max()), "identical_pct": round(100.0 * float((d == 0).mean()), 4), "bytes_off_by_more_than_1": int((d > 1).sum())}
 
 
-IMPLS = {"f32_valu": hip.INGEST_VALU_F32, "mfma_wg": hip.INGEST_MFMA_F16_WG, "wave": hip.INGEST_MFMA_F16}
+IMPLS = {"f32_valu": hip.INGEST_VALU_F32, "mfma_wg": hip.INGEST_MFMA_F16_WG, "wave": hip.INGEST_MFMA_F16, "wave_node": hip.INGEST_MFMA_F16_NODE}
 
 
 def main():
