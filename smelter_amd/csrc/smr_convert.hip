@@ -49,7 +49,7 @@ __global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba(SurfView yp, SurfView up,
     }
 }
 
-// The same pass for 4:2:0 frames of even size (planar, limited or full range; NV12), several frames per launch: what k_yuv_to_rgba
+// The same pass for planar 4:2:0 (limited or full range), 4:2:2, 4:4:4 and NV12 frames, several frames per launch: what k_yuv_to_rgba
 // computes, value for value, without its per-pixel coordinate arithmetic and divisions.  For a w x h frame with (w / 2) x (h / 2) chroma
 // the sample position of luma column x in chroma texels is x / 2 - 0.25: the float evaluation ((x + .5) / w) * (w / 2) - .5 is off by
 // less than 1e-3 for w <= 16384, so floor() and the 8-bit sub-texel fraction (subtexel(): a multiple of 1 / 256) come out as
@@ -60,22 +60,53 @@ __global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba(SurfView yp, SurfView up,
 struct ConvJob {
     SurfView yp, up, vp, dst;
     int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
+    int sx, sy;    // chroma subsampling: 4:2:0 = (1, 1), 4:2:2 = (1, 0), 4:4:4 = (0, 0)
+    int packed;    // 0 planar / NV12 | 1 UYVY | 2 YUYV: `yp` is the (w / 2) x h plane of U Y0 V Y1 / Y0 U Y1 V groups
 };
 constexpr int MAX_CONV_JOBS = 16;
 struct ConvBatch {
     ConvJob j[MAX_CONV_JOBS];
 };
-__global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba_batch(const ConvBatch B) {
+__global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba_batch(const ConvBatch B) {
     const ConvJob &J = B.j[blockIdx.z];
     const int g = blockIdx.x * 64 + (threadIdx.x & 63), p = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int w = J.dst.w, h = J.dst.h, cw = w >> 1, ch = h >> 1;
+    const int w = J.dst.w, h = J.dst.h, cw = J.sx ? w >> 1 : w, ch = J.sy ? h >> 1 : h;
     if (4 * g >= w || 2 * p >= h) return;
+    if (J.packed) {
+        // interleaved_{uyvy,yuyv}_to_rgba.wgsl:24-62 (k_interleaved422_to_rgba): pixel x takes the luma of its own half of group x / 2 and
+        // the group's chroma, no interpolation — x_pos = floor(x + .5 - 2 / w + .0002) is x for every width from 8 up
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = 2 * p + r;
+            if (y >= h) break;
+            const u8 *sr = J.yp.ptr + ((u32)y * J.yp.pitch + 8u * (u32)g);
+            u32 px[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (4 * g + i >= w) { px[i] = 0u; continue; }
+                const u32 d = *(const u32 *)(sr + 4 * (i >> 1));
+                const u32 c0 = d & 0xffu, c1 = (d >> 8) & 0xffu, c2 = (d >> 16) & 0xffu, c3 = d >> 24;
+                const u32 ub = J.packed == 1 ? c0 : c1, vb = J.packed == 1 ? c2 : c3;
+                const u32 yb = J.packed == 1 ? ((i & 1) ? c3 : c1) : ((i & 1) ? c2 : c0);
+                px[i] = yuv_to_rgb_px_cr(unorm_of_byte(yb), unorm_of_byte(ub), unorm_of_byte(vb), false);
+            }
+            u8 *row = J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g);
+            if (4 * g + 3 < w) {
+                *(uint4 *)row = make_uint4(px[0], px[1], px[2], px[3]);
+            } else {
+                for (int i = 0; i < 4 && 4 * g + i < w; i++) ((u32 *)row)[i] = px[i];
+            }
+        }
+        return;
+    }
     // chroma neighbourhood as unorm values: t[plane][row j = p - 1 + j][column 2 g - 1 + k], columns and rows clamped like the sampler
     // clamps.  The four bytes of a row come from two aligned dwords (three for NV12's interleaved pairs) starting at the window's first
     // existing column; the clamped columns are then byte moves: at the left edge (g = 0) the window is columns 0, 0, 1, 2, at the right
     // edge the last existing column repeats.  Planes whose rows are not dword-aligned or too tight take the bytes one by one.
     float t[2][3][4];
-    const int first = 2 * g - 1;                              // leftmost chroma column of the window (-1 for g = 0)
+    // (a plane that is not subsampled along an axis is sampled at its texel centres: fraction 0 or, an ulp short of the centre, 1 with
+    //  the window one texel earlier — a * 1 + b * 0 or a * 0 + b * 1: the texel itself either way, bit for bit)
+    const int first = J.sx ? 2 * g - 1 : 4 * g;               // leftmost chroma column of the window (-1 for g = 0 of a subsampled row)
     const int first_ld = first < 0 ? 0 : first;               // ... that exists
     const int byte0 = J.nv ? 2 * first_ld : first_ld;         // its byte offset in the row
     const int base = byte0 & ~3;
@@ -83,10 +114,10 @@ __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba_batch(const ConvBatch 
     const bool dwords = (J.up.pitch & 3u) == 0 && (((uintptr_t)J.up.ptr) & 3) == 0 && (J.vp.pitch & 3u) == 0 && (((uintptr_t)J.vp.ptr) & 3) == 0 &&
                         (u32)base + (J.nv ? 12u : 8u) <= J.up.pitch && (J.nv || (u32)base + 8u <= J.vp.pitch);
     const int nvalid = cw - first;                            // window columns 0 .. nvalid - 1 are at or left of the last column (>= 2)
-    const u32 right_fix = nvalid >= 4 ? 0x03020100u : nvalid == 3 ? 0x02020100u : 0x01010100u;
+    const u32 right_fix = nvalid >= 4 || !J.sx ? 0x03020100u : nvalid == 3 ? 0x02020100u : 0x01010100u;
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-        const int cy = clampi(p - 1 + j, 0, ch - 1);
+        const int cy = clampi(J.sy ? p - 1 + j : 2 * p + j, 0, ch - 1);  // (full-height chroma: rows 2 p, 2 p + 1; the third is not used)
         const u8 *ur = J.up.ptr + (u32)cy * J.up.pitch, *vr = J.vp.ptr + (u32)cy * J.vp.pitch;  // (a plane is far below 4 GiB)
         if (dwords) {  // (uniform)
             u32 uw, vw;
@@ -125,10 +156,10 @@ __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba_batch(const ConvBatch 
     for (int c = 0; c < 2; c++)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            H[c][j][0] = t[c][j][0] * 0.25f + t[c][j][1] * 0.75f;
-            H[c][j][1] = t[c][j][1] * 0.75f + t[c][j][2] * 0.25f;
-            H[c][j][2] = t[c][j][1] * 0.25f + t[c][j][2] * 0.75f;
-            H[c][j][3] = t[c][j][2] * 0.75f + t[c][j][3] * 0.25f;
+            H[c][j][0] = J.sx ? t[c][j][0] * 0.25f + t[c][j][1] * 0.75f : t[c][j][0];
+            H[c][j][1] = J.sx ? t[c][j][1] * 0.75f + t[c][j][2] * 0.25f : t[c][j][1];
+            H[c][j][2] = J.sx ? t[c][j][1] * 0.25f + t[c][j][2] * 0.75f : t[c][j][2];
+            H[c][j][3] = J.sx ? t[c][j][2] * 0.75f + t[c][j][3] * 0.25f : t[c][j][3];
         }
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -143,8 +174,9 @@ __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba_batch(const ConvBatch 
             if (4 * g + i >= w) { px[i] = 0u; continue; }
             const float yy = unorm_of_byte(whole ? (y4 >> (8 * i)) & 0xffu : (u32)yr[i]);
             // row 2 p: chroma rows (p - 1, p), fy = .75; row 2 p + 1: rows (p, p + 1), fy = .25 — top * (1 - fy) + bot * fy
-            const float uu = r == 0 ? H[0][0][i] * 0.25f + H[0][1][i] * 0.75f : H[0][1][i] * 0.75f + H[0][2][i] * 0.25f;
-            const float vv = r == 0 ? H[1][0][i] * 0.25f + H[1][1][i] * 0.75f : H[1][1][i] * 0.75f + H[1][2][i] * 0.25f;
+            float uu = r == 0 ? H[0][0][i] * 0.25f + H[0][1][i] * 0.75f : H[0][1][i] * 0.75f + H[0][2][i] * 0.25f;
+            float vv = r == 0 ? H[1][0][i] * 0.25f + H[1][1][i] * 0.75f : H[1][1][i] * 0.75f + H[1][2][i] * 0.25f;
+            if (!J.sy) { uu = H[0][r][i]; vv = H[1][r][i]; }
             px[i] = yuv_to_rgb_px_cr(yy, uu, vv, J.full != 0);
         }
         u8 *row = J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g);
@@ -291,15 +323,20 @@ u32 host_unorm8(float x) {
 }  // namespace
 
 
-// k_yuv420_to_rgba_batch's frames: 4:2:0 with even luma size (chroma planes exactly half), within the width the coordinate argument holds for
+// k_yuv_to_rgba_batch's frames: planar 4:2:0 / 4:2:2 / 4:4:4 and NV12 whose subsampled axes are even (chroma planes exactly half), within the
+// size the coordinate argument holds for
 static bool conv_batchable(const smr_frame *in) {
-    if (in->format != SMR_FRAME_PLANAR_YUV420 && in->format != SMR_FRAME_PLANAR_YUVJ420 && in->format != SMR_FRAME_NV12) return false;
-    if (in->width % 2 || in->height % 2 || in->width < 2 || in->height < 2 || in->width > 16384 || in->height > 16384) return false;
-    if (!in->planes[0] || !in->planes[1] || (in->format != SMR_FRAME_NV12 && !in->planes[2])) return false;
-    return getenv("SMR_CONVERT_GENERAL") == nullptr;  // (tests: the one-thread-per-four-pixels kernel as the reference)
+    if (in->width < 2 || in->height < 2 || in->width > 16384 || in->height > 16384 || getenv("SMR_CONVERT_GENERAL")) return false;  // (the env: tests)
+    if (in->format == SMR_FRAME_UYVY422 || in->format == SMR_FRAME_YUYV422)
+        return in->width % 2 == 0 && in->width >= 8 && in->planes[0] && (in->planes[0]->pitch & 3u) == 0 && (((uintptr_t)in->planes[0]->ptr) & 3) == 0;
+    const bool nv = in->format == SMR_FRAME_NV12;
+    const bool sx = in->format != SMR_FRAME_PLANAR_YUV444, sy = in->format == SMR_FRAME_PLANAR_YUV420 || in->format == SMR_FRAME_PLANAR_YUVJ420 || nv;
+    if (in->format > SMR_FRAME_PLANAR_YUVJ420 && !nv) return false;  // (BGRA / ARGB / RGBA: byte permutes of their own)
+    if ((sx && in->width % 2) || (sy && in->height % 2)) return false;
+    return in->planes[0] && in->planes[1] && (nv || in->planes[2]);
 }
 
-// smr_frame_to_rgba for several frames: one launch for every 16 frames k_yuv420_to_rgba_batch takes, the others one by one
+// smr_frame_to_rgba for several frames: one launch for every 16 frames k_yuv_to_rgba_batch takes, the others one by one
 int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n) {
     if (!ctx || (n && (!in || !nodes))) return SMR_ERR_INVALID;
     ConvBatch B;
@@ -308,7 +345,7 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
     auto flush = [&]() -> int {
         if (!nb) return SMR_OK;
         StageScope scope(ctx, SMR_STAGE_INGEST);
-        hipLaunchKernelGGL(k_yuv420_to_rgba_batch, dim3((unsigned)((mw + 255) / 256), (unsigned)((mh + 7) / 8), nb), dim3(BLOCK), 0, ctx->stream, B);
+        hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((mw + 255) / 256), (unsigned)((mh + 7) / 8), nb), dim3(BLOCK), 0, ctx->stream, B);
         SMR_HIP(ctx, hipGetLastError());
         nb = 0; mw = 0; mh = 0;
         return SMR_OK;
@@ -325,10 +362,16 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
         ConvJob &J = B.j[nb++];
         const bool nv = in[i]->format == SMR_FRAME_NV12;
-        J.yp = view_of(in[i]->planes[0]); J.up = view_of(in[i]->planes[1]); J.vp = nv ? J.up : view_of(in[i]->planes[2]);
+        const bool packed = in[i]->format == SMR_FRAME_UYVY422 || in[i]->format == SMR_FRAME_YUYV422;
+        J.yp = view_of(in[i]->planes[0]);
+        J.up = packed ? J.yp : view_of(in[i]->planes[1]);
+        J.vp = packed || nv ? J.up : view_of(in[i]->planes[2]);
+        J.packed = in[i]->format == SMR_FRAME_UYVY422 ? 1 : in[i]->format == SMR_FRAME_YUYV422 ? 2 : 0;
         J.dst = view_of(nodes[i]);
         J.full = in[i]->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
         J.nv = nv ? 1 : 0;
+        J.sx = in[i]->format != SMR_FRAME_PLANAR_YUV444 ? 1 : 0;
+        J.sy = (in[i]->format == SMR_FRAME_PLANAR_YUV420 || in[i]->format == SMR_FRAME_PLANAR_YUVJ420 || nv) ? 1 : 0;
         mw = (int)in[i]->width > mw ? (int)in[i]->width : mw;
         mh = (int)in[i]->height > mh ? (int)in[i]->height : mh;
         if (nb == MAX_CONV_JOBS)

@@ -22,7 +22,7 @@ __device__ __forceinline__ u32 yuv_to_rgb_px(float y, float u, float v, bool ful
 // (Markstein's correction step; neither divisor's significand is all ones) — checked against the division on 2 x 10^8 random operands
 // per divisor and on every byte, and on the GPU against k_yuv_to_rgba frame by frame (tests/test_gpu_parity.py).
 // The clamps are one v_med3_f32 each (operands are finite; a -0 where clampf gives +0 is absorbed by the sums that follow).
-#ifndef SMR_EMU  // (k_yuv420_to_rgba_batch only: not part of the kernels the lane emulator compiles)
+#ifndef SMR_EMU  // (k_yuv_to_rgba_batch only: not part of the kernels the lane emulator compiles)
 __device__ __forceinline__ u32 yuv_to_rgb_px_cr(float y, float u, float v, bool full) {
     if (!full) {
         constexpr float ky = 0.85882352941f, kc = 0.87843137254f;

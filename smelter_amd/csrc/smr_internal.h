@@ -166,7 +166,7 @@ int smr_fail(smr_ctx *ctx, int code, const char *fmt, ...);
 int smr_check_hip(smr_ctx *ctx, hipError_t e, const char *what);
 void *smr_scratch(smr_ctx *ctx, int slot, size_t bytes);  // nullptr on OOM (error set)
 extern "C" int smr_validate_frame(smr_ctx *ctx, const smr_frame *f, const char *what);  // plane geometry / formats against the frame's format
-// smr_frame_to_rgba for several frames at once (smr_convert.hip): 4:2:0 frames of even size share one launch per 16
+// smr_frame_to_rgba for several frames at once (smr_convert.hip): planar 4:2:0 / 4:2:2 / 4:4:4 and NV12 frames share one launch per 16
 int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n);
 
 // stage-timing helper: brackets kernel launches of one class with HIP events when profiling.

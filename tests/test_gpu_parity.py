@@ -62,25 +62,28 @@ def test_planar_yuv_to_rgba(ctx, hip, w, h, variant):
     assert (got[..., 3] == 255).all()
 
 
-@pytest.mark.parametrize("w,h", [(64, 36), (66, 38), (2, 2), (6, 4), (258, 10), (1920, 1080), (1922, 1082)])
-@pytest.mark.parametrize("variant", ["420", "j420", "nv12"])
-def test_batched_420_converter_equals_the_general_kernel(ctx, hip, w, h, variant):
-    """k_yuv420_to_rgba_batch (4:2:0 frames of even size: structure-aware, several frames per launch) against k_yuv_to_rgba (the WGSL
+@pytest.mark.parametrize("w,h", [(64, 36), (66, 38), (2, 2), (6, 4), (258, 10), (1920, 1080), (1922, 1082), (38, 21), (37, 21)])
+@pytest.mark.parametrize("variant", ["420", "j420", "nv12", "422", "444"])
+def test_batched_converter_equals_the_general_kernel(ctx, hip, w, h, variant):
+    """k_yuv_to_rgba_batch (planar 4:2:0 / 4:2:2 / 4:4:4 and NV12: structure-aware, several frames per launch) against k_yuv_to_rgba (the WGSL
     pass as it is written, SMR_CONVERT_GENERAL=1): every byte equal, on white noise and on the extremes."""
     import os
     rng = np.random.default_rng(hash((w, h, variant)) % 2**32)
+    if (variant in ("420", "j420", "nv12") and (w % 2 or h % 2)) or (variant == "422" and w % 2):
+        pytest.skip("odd size along a subsampled axis: the general kernel's case")
+    cw, ch = (w if variant == "444" else w // 2), (h if variant in ("422", "444") else h // 2)
     for content in ("noise", "extremes"):
         if content == "noise":
             y = rng.integers(0, 256, (h, w), dtype=np.uint8)
-            c = rng.integers(0, 256, (h // 2, w // 2, 2), dtype=np.uint8)
+            c = rng.integers(0, 256, (ch, cw, 2), dtype=np.uint8)
         else:
             y = rng.choice(np.array([0, 1, 15, 16, 17, 234, 235, 236, 254, 255], np.uint8), (h, w))
-            c = rng.choice(np.array([0, 15, 16, 17, 127, 128, 129, 239, 240, 241, 255], np.uint8), (h // 2, w // 2, 2))
+            c = rng.choice(np.array([0, 15, 16, 17, 127, 128, 129, 239, 240, 241, 255], np.uint8), (ch, cw, 2))
         if variant == "nv12":
             f = ctx.frame(hip.FRAME_NV12, w, h, [y, c])
         else:
-            f = ctx.frame(hip.FRAME_PLANAR_YUV420 if variant == "420" else hip.FRAME_PLANAR_YUVJ420, w, h,
-                          [y, np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])])
+            fmt = {"420": hip.FRAME_PLANAR_YUV420, "j420": hip.FRAME_PLANAR_YUVJ420, "422": hip.FRAME_PLANAR_YUV422, "444": hip.FRAME_PLANAR_YUV444}[variant]
+            f = ctx.frame(fmt, w, h, [y, np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])])
         fast = ctx.frame_to_rgba(f).download()
         os.environ["SMR_CONVERT_GENERAL"] = "1"
         try:
@@ -106,6 +109,24 @@ def test_interleaved422_to_rgba(ctx, hip, order):
     fmt = hip.FRAME_UYVY422 if order == 0 else hip.FRAME_YUYV422
     got = ctx.frame_to_rgba(ctx.frame(fmt, w, h, [data])).download()
     check(got, orc.interleaved422_to_rgba(data, w, h, order), TOL, 0.999, "interleaved422")
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("w,h", [(8, 2), (10, 3), (640, 48), (1920, 1080), (1922, 1081), (6, 4)])
+def test_batched_packed422_converter_equals_the_general_kernel(ctx, hip, order, w, h):
+    """UYVY / YUYV through k_yuv_to_rgba_batch's packed mode against k_interleaved422_to_rgba (SMR_CONVERT_GENERAL=1): every byte equal
+    (widths below 8 stay on the general kernel: there both runs are the same kernel)."""
+    import os
+    data = np.random.default_rng(60 + order + w).integers(0, 256, (h, w // 2, 4), dtype=np.uint8)
+    f = ctx.frame(hip.FRAME_UYVY422 if order == 0 else hip.FRAME_YUYV422, w, h, [data])
+    fast = ctx.frame_to_rgba(f).download()
+    os.environ["SMR_CONVERT_GENERAL"] = "1"
+    try:
+        general = ctx.frame_to_rgba(f).download()
+    finally:
+        del os.environ["SMR_CONVERT_GENERAL"]
+    assert np.array_equal(fast, general), (order, w, h, int((fast != general).sum()))
+    check(fast, orc.interleaved422_to_rgba(data, w, h, order), TOL, 0.999, "interleaved422")
 
 
 @pytest.mark.parametrize("kind", [0, 1])
