@@ -363,7 +363,14 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     const bool big_list = packed.n > B_MAX_LAYOUTS || packed.n_masks > B_MAX_MASKS;  // read in place instead of from an LDS copy
     const bool fuse_yuv = fits_b && out && !out_rgba && (out->format == SMR_FRAME_PLANAR_YUV420 || out->format == SMR_FRAME_NV12) &&
                           out->planes[0] && out->planes[1] && (out->format == SMR_FRAME_NV12 || out->planes[2]);
-    const bool fuse_rgba = fits_b && out_rgba && !out && (((uintptr_t)out_rgba->ptr) % 16 == 0) && (out_rgba->pitch % 16 == 0);  // a node's RGBA8 texture
+    // an RGBA8 target: a node's texture (out_rgba), or — for the output formats wave B does not write itself (4:2:2, 4:4:4, full-range
+    // 4:2:0, RGBA) — a scratch surface the output converter then reads (smr_rgba_to_frame): the same compositor kernel either way
+    smr_surface *rgba_target = out_rgba;
+    if (!rgba_target && fits_b && !fuse_yuv) {
+        rgba_target = smr_cached_surface(ctx, SLOT_TARGET, out_w, out_h, SMR_PX_RGBA8);
+        if (!rgba_target) return SMR_ERR_OOM;
+    }
+    const bool fuse_rgba = fits_b && !fuse_yuv && rgba_target && (((uintptr_t)rgba_target->ptr) % 16 == 0) && (rgba_target->pitch % 16 == 0);
     const bool fuse_out = fuse_yuv || fuse_rgba;
 
     // ---- tile classes (k_classify_tiles): kept while a layout list repeats (a scene at rest; a few lists per context, so a
@@ -536,7 +543,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         SurfView p0, p1, p2;
         int nv;
         if (fuse_rgba) {
-            p0 = p1 = p2 = view_of(out_rgba);
+            p0 = p1 = p2 = view_of(rgba_target);
             nv = 2;
         } else {
             p0 = view_of(out->planes[0]); p1 = view_of(out->planes[1]);
@@ -551,7 +558,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         hipLaunchKernelGGL(kernels[nv][big_list ? 1 : 0], grid, dim3(256), 0, ctx->stream, p0, p1, p2, (int)out_w, (int)out_h, packed.layouts, packed.masks,
                            packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
         SMR_HIP(ctx, hipGetLastError());
-        return smr_pack_done(ctx, &packed);
+        rc = smr_pack_done(ctx, &packed);
+        if (rc != SMR_OK) return rc;
+        if (fuse_rgba && out) return smr_rgba_to_frame(ctx, rgba_target, out);
+        return SMR_OK;
     }
 
     smr_surface *target = out_rgba ? out_rgba : smr_cached_surface(ctx, SLOT_TARGET, out_w, out_h, SMR_PX_RGBA8);

@@ -164,9 +164,14 @@ def test_nv12_and_rgba_outputs(ctx, ctx_unfused, hip):
     t = ctx.surface(640, 360)
     ctx.render_layouts(layouts, frames, 640, 360, out_rgba=t)
     assert refpipe.max_diff(t.download(), rgba_want) <= 1
+    # the formats wave B does not write itself (4:2:2, 4:4:4; an RGBA frame likewise): the same compositor kernel onto an RGBA8 scratch target, then the output converter —
+    # not the pass-per-launch compositor (k_apply_layouts)
     for fmt, ov in ((hip.FRAME_PLANAR_YUV422, orc.YUV422), (hip.FRAME_PLANAR_YUV444, orc.YUV444)):
         o = ctx.frame(fmt, 640, 360)
+        before = ctx.kernel_launches()
         ctx.render_layouts(layouts, frames, 640, 360, out=o)
+        ran = {k: v - before[k] for k, v in ctx.kernel_launches().items()}
+        assert ran["compose_output"] == 1 and ran["apply_layouts"] == 0, ran
         for g, w_ in zip(o.download(), orc.rgba_to_planar_yuv(rgba_want, ov)):
             assert refpipe.max_diff(g, w_) <= 1
 
