@@ -303,6 +303,80 @@ __global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView
     }
 }
 
+// rgba_to_yuv.wgsl's three passes (k_rgba_to_y + k_rgba_to_chroma) in one launch for even-sized frames: a thread owns a 4 x 2 pixel block,
+// reads its eight texels once and writes the luma dwords and its share of the chroma planes.  Same values bit for bit: channels are
+// byte / 255 (unorm_of_byte), a chroma sample of a subsampled axis sits exactly between two texels (sub-texel fraction 128 / 256 for
+// sizes up to 8192: a * .5 + b * .5, then rows likewise), one of a full-resolution axis on a texel (x * 1 + y * 0), and the plane
+// formulas + store are yuv_byte (smr_convert_dev.h: yuv_component + unorm8 without the clamps that cannot act on values in [0, 1]).
+// sx / sy: chroma subsampling (4:2:0 = 1, 1; 4:2:2 = 1, 0; 4:4:4 = 0, 0); nv: interleaved chroma in `up` (NV12).
+__global__ __launch_bounds__(BLOCK) void k_rgba_to_planes(SurfView src, SurfView yp, SurfView up, SurfView vp, int sx, int sy, int nv) {
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), p = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int w = src.w, h = src.h;
+    if (4 * g >= w || 2 * p >= h) return;
+    const int nx = min(4, w - 4 * g), ny = min(2, h - 2 * p);
+    float c[2][4][3];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int y = min(2 * p + r, h - 1);
+        const u8 *row = src.ptr + ((u32)y * src.pitch + 16u * (u32)g);
+        u32 t[4];
+        if (nx == 4) {
+            const uint4 q = *(const uint4 *)row;
+            t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = ((const u32 *)row)[min(i, nx - 1)];
+        }
+        u32 yq = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            c[r][i][0] = unorm_of_byte(t[i] & 0xffu); c[r][i][1] = unorm_of_byte((t[i] >> 8) & 0xffu); c[r][i][2] = unorm_of_byte((t[i] >> 16) & 0xffu);
+            yq |= yuv_byte(c[r][i][0], c[r][i][1], c[r][i][2], 0) << (8 * i);
+        }
+        if (r < ny) {
+            u8 *d = yp.ptr + ((u32)(2 * p + r) * yp.pitch + 4u * (u32)g);
+            if (nx == 4) *(u32 *)d = yq;
+            else for (int i = 0; i < nx; i++) d[i] = (u8)(yq >> (8 * i));
+        }
+    }
+    // chroma samples of this block: (sx ? 2 : 4) columns x (sy ? 1 : 2) rows
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if (sy && r == 1) break;
+        if (r >= ny) break;
+        u32 uq = 0, vq = 0;
+        const int n = sx ? 2 : 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= n) break;
+            float m[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                if (sx) {
+                    const float top = c[r][2 * k][ch] * 0.5f + c[r][2 * k + 1][ch] * 0.5f;
+                    m[ch] = sy ? top * 0.5f + (c[1][2 * k][ch] * 0.5f + c[1][2 * k + 1][ch] * 0.5f) * 0.5f : top;
+                } else {
+                    m[ch] = c[r][k][ch];
+                }
+            }
+            uq |= yuv_byte(m[0], m[1], m[2], 1) << (8 * k);
+            vq |= yuv_byte(m[0], m[1], m[2], 2) << (8 * k);
+        }
+        const int cy = sy ? p : 2 * p + r, cx0 = sx ? 2 * g : 4 * g, cn = sx ? (nx + 1) / 2 : nx;  // chroma row, first column, columns of this block
+        if (nv) {
+            u8 *d = up.ptr + ((u32)cy * up.pitch + 2u * (u32)cx0);
+            const u32 uv = (uq & 0xffu) | ((vq & 0xffu) << 8) | ((uq & 0xff00u) << 8) | ((vq & 0xff00u) << 16);
+            if (cn == 2) *(u32 *)d = uv;
+            else *(u16 *)d = (u16)uv;
+        } else {
+            u8 *du = up.ptr + ((u32)cy * up.pitch + (u32)cx0), *dv = vp.ptr + ((u32)cy * vp.pitch + (u32)cx0);
+            if (cn == 4) { *(u32 *)du = uq; *(u32 *)dv = vq; }
+            else if (cn == 2 && sx) { *(u16 *)du = (u16)uq; *(u16 *)dv = (u16)vq; }
+            else for (int i = 0; i < cn; i++) { du[i] = (u8)(uq >> (8 * i)); dv[i] = (u8)(vq >> (8 * i)); }
+        }
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_fill_bytes(SurfView p, int row_bytes, u32 value4) {
     const int x = (blockIdx.x * BLOCK + threadIdx.x) * 4;
     const int y = blockIdx.y;
@@ -473,6 +547,20 @@ int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *ou
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: unsupported output frame format %u", out->format);
     }
     if (!out->planes[0] || !out->planes[1]) return smr_fail(ctx, SMR_ERR_INVALID, "smr_rgba_to_frame: missing planes");
+    {
+        // one launch for frames whose subsampled axes are even and whose planes take dword / word stores (every surface this library allocates)
+        const bool nv = out->format == SMR_FRAME_NV12;
+        const int sx = out->format != SMR_FRAME_PLANAR_YUV444, sy = out->format == SMR_FRAME_PLANAR_YUV420 || nv;
+        const smr_surface *pu = out->planes[1], *pv = nv ? out->planes[1] : out->planes[2];
+        auto aligned = [](const smr_surface *s) { return s && (s->pitch & 3u) == 0 && (((uintptr_t)s->ptr) & 3) == 0; };
+        if (pv && (!sx || w % 2 == 0) && (!sy || h % 2 == 0) && w >= 2 && h >= 2 && w <= 8192 && h <= 8192 && aligned(out->planes[0]) && aligned(pu) && aligned(pv) &&
+            (((uintptr_t)src.ptr) & 15) == 0 && (src.pitch & 15u) == 0 && !getenv("SMR_CONVERT_GENERAL")) {
+            hipLaunchKernelGGL(k_rgba_to_planes, dim3((unsigned)((w + 255) / 256), (unsigned)((h + 7) / 8), 1), dim3(BLOCK), 0, ctx->stream, src,
+                               view_of(out->planes[0]), view_of(pu), view_of(pv), sx, sy, nv ? 1 : 0);
+            SMR_HIP(ctx, hipGetLastError());
+            return SMR_OK;
+        }
+    }
     hipLaunchKernelGGL(k_rgba_to_y, grid_px((w + 3) / 4, h), dim3(BLOCK), 0, ctx->stream, src, view_of(out->planes[0]));
     if (cw > 0 && ch > 0) {
         if (out->format == SMR_FRAME_NV12) {

@@ -193,6 +193,29 @@ def test_rgba_to_frame(ctx, hip, w, h, variant):
         check(g, w_, TOL, 0.999, f"rgba->{variant}")
 
 
+@pytest.mark.parametrize("w,h", [(64, 36), (66, 38), (2, 2), (6, 4), (258, 11), (37, 21), (1920, 1080), (3840, 2160)])
+@pytest.mark.parametrize("variant", ["420", "422", "444", "nv12"])
+def test_one_launch_output_converter_equals_the_three_passes(ctx, hip, w, h, variant):
+    """k_rgba_to_planes (one launch, a 4 x 2 pixel block per thread) against k_rgba_to_y + k_rgba_to_chroma (rgba_to_yuv.wgsl's passes as
+    they are written, SMR_CONVERT_GENERAL=1): every byte of every plane equal."""
+    import os
+    if (variant in ("420", "nv12") and (w % 2 or h % 2)) or (variant == "422" and w % 2):
+        pytest.skip("odd size along a subsampled axis: the three-pass kernels' case")
+    rng = np.random.default_rng(hash((w, h, variant)) % 2**32)
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgba[: h // 2, :, :3] = rng.choice(np.array([0, 1, 127, 128, 254, 255], np.uint8), (h // 2, w, 3))
+    node = ctx.surface_from(rgba)
+    fmt = {"420": hip.FRAME_PLANAR_YUV420, "422": hip.FRAME_PLANAR_YUV422, "444": hip.FRAME_PLANAR_YUV444, "nv12": hip.FRAME_NV12}[variant]
+    fast = ctx.rgba_to_frame(node, fmt).download()
+    os.environ["SMR_CONVERT_GENERAL"] = "1"
+    try:
+        general = ctx.rgba_to_frame(node, fmt).download()
+    finally:
+        del os.environ["SMR_CONVERT_GENERAL"]
+    for a, b, pl in zip(fast, general, "YUV"):
+        assert np.array_equal(a, b), (variant, w, h, pl, int((a != b).sum()))
+
+
 def test_black_fallback(ctx, hip):
     out = ctx.frame(hip.FRAME_PLANAR_YUV420, 66, 34)
     ctx.fill_black(out)
