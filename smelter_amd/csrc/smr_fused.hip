@@ -590,21 +590,29 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
     if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample: degenerate plan");
     if (kind == 0) return 0;
     if (new_call) ctx->weight_call++;
-    // SMR_INGEST_MFMA_F16_NODE: the exact converter into the node texture, then the matrix-core kernel on it (opaque formats, plans
-    // the kernel holds with the horizontal pass first; anything else below)
-    if (!fused_disabled(ctx) && ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE && in->format <= SMR_FRAME_NV12) {
+    // the exact converter into the node texture, then the matrix-core kernel on it (every Y'CbCr format; plans the kernel holds with the
+    // horizontal pass first): first choice with SMR_INGEST_MFMA_F16_NODE, and what 4:2:2 / 4:4:4 / packed frames take in any case
+    auto node_route = [&](int *done) -> int {
+        *done = 0;
+        if (fused_disabled(ctx) || in->format > SMR_FRAME_NV12) return SMR_OK;
         smr_surface *node = smr_cached_surface(ctx, SLOT_INGEST_NODE, in->width, in->height, SMR_PX_RGBA8);
         if (!node) return SMR_ERR_OOM;
         bool single = false;
-        if (can_fuse_wave_rgba(ctx, view_of(node), plan, dst, 4, &single)) {
-            int rc = smr_frame_to_rgba(ctx, in, node);
-            if (rc != SMR_OK) return rc;
-            std::vector<WJob> wjobs(1);
-            rc = make_wave_job_rgba(ctx, view_of(node), plan, dst, &wjobs[0], single);
-            if (rc != SMR_OK) return rc;
-            rc = launch_wave(ctx, wjobs, nullptr, true);
-            return rc == SMR_OK ? kind : rc;
-        }
+        if (!can_fuse_wave_rgba(ctx, view_of(node), plan, dst, 4, &single)) return SMR_OK;
+        int rc = smr_frame_to_rgba(ctx, in, node);
+        if (rc != SMR_OK) return rc;
+        std::vector<WJob> wjobs(1);
+        rc = make_wave_job_rgba(ctx, view_of(node), plan, dst, &wjobs[0], single);
+        if (rc != SMR_OK) return rc;
+        rc = launch_wave(ctx, wjobs, nullptr, true);
+        if (rc == SMR_OK) *done = 1;
+        return rc;
+    };
+    if (ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) {
+        int done = 0;
+        int rc = node_route(&done);
+        if (rc != SMR_OK) return rc;
+        if (done) return kind;
     }
     if (!fused_disabled(ctx) && can_fuse_wave(ctx, in, plan, dst)) {
         std::vector<WJob> wjobs(1);
@@ -646,6 +654,12 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
             if (rc == SMR_OK) rc = launch_transpose<u32>(ctx, back.tile_t, back.tile);
             return rc == SMR_OK ? kind : rc;
         }
+    }
+    if (ctx->ingest_impl != SMR_INGEST_MFMA_F16_NODE) {  // (4:2:2, 4:4:4, packed frames: no fused conversion reads them)
+        int done = 0;
+        int rc = node_route(&done);
+        if (rc != SMR_OK) return rc;
+        if (done) return kind;
     }
     if (!fused_disabled(ctx) && can_fuse_ingest(in, plan)) {
         std::vector<IngestJob> jobs(1);

@@ -227,3 +227,24 @@ def test_node_texture_option_is_within_one_lsb_end_to_end(hip, fmt, plan):
         assert (d == 0).mean() >= 0.97, (fmt, plan, float((d == 0).mean()))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("fmt", ["yuv422", "yuv444", "uyvy"])
+def test_shard_entry_point_takes_the_node_texture_route_too(hip, fmt):
+    """smr_ingest_resample (the per-shard step of the multi-GPU path) on a frame no fused conversion reads: exact converter + matrix-core
+    kernel, not the pass-per-launch resampler."""
+    (sw, sh), (dw, dh) = PLANS["two_pass_h_first"]
+    ctx = hip.Context(0)
+    try:
+        rng = np.random.default_rng(77)
+        src, node = _source(ctx, hip, fmt, sw, sh, rng)
+        tile = ctx.surface(dw, dh)
+        before = ctx.kernel_launches()
+        ctx.ingest_resample(src, (0.0, 0.0, float(sw), float(sh)), tile)
+        ran = {k: v - before[k] for k, v in ctx.kernel_launches().items()}
+        assert ran["frame_to_rgba"] == 1 and ran["ingest_wave_rgba"] == 1 and ran["resample_general"] == 0 and ran["ingest_valu"] == 0, (fmt, ran)
+        _, want = orc.resample(node, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+        d = np.abs(tile.download().astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, (fmt, int(d.max()))
+    finally:
+        ctx.close()
