@@ -175,7 +175,7 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
  *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated
  *     in f32.  Its deviation is bounded per stage: the fused colour conversion is within one code of planar_yuv_to_rgba.wgsl
- *     (~2e-5 of the bytes differ), and the resample is within 1 LSB — on every byte of every content class — of resample.wgsl's
+ *     (2e-5 of the bytes differ on limited-range content, up to 3e-4 on full-range), and the resample is within 1 LSB — on every byte of every content class — of resample.wgsl's
  *     passes applied to that node texture.  End to end that is within 1 LSB on camera-like content; on white noise a flipped
  *     bright texel seen through the linear-light filter at a dark output can show as 2..4 codes (3 bytes in 7.4 million,
  *     tests/test_gpu_fused.py).  Sources that need no fused conversion (RGBA8 / RGBA16F node textures: 4:2:2, 4:4:4, packed YUV,
