@@ -61,7 +61,7 @@ struct ConvJob {
     SurfView yp, up, vp, dst;
     int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
     int sx, sy;    // chroma subsampling: 4:2:0 = (1, 1), 4:2:2 = (1, 0), 4:4:4 = (0, 0)
-    int packed;    // 0 planar / NV12 | 1 UYVY | 2 YUYV: `yp` is the (w / 2) x h plane of U Y0 V Y1 / Y0 U Y1 V groups
+    int packed;    // 0 planar / NV12 | 1 UYVY | 2 YUYV: `yp` is the (w / 2) x h plane of U Y0 V Y1 / Y0 U Y1 V groups | 3 BGRA | 4 ARGB: `yp` is the w x h plane, bytes permuted (bgra_to_rgba.wgsl / argb_to_rgba.wgsl:24-28)
 };
 constexpr int MAX_CONV_JOBS = 16;
 struct ConvBatch {
@@ -72,6 +72,31 @@ __global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba_batch(const ConvBatch B) 
     const int g = blockIdx.x * 64 + (threadIdx.x & 63), p = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int w = J.dst.w, h = J.dst.h, cw = J.sx ? w >> 1 : w, ch = J.sy ? h >> 1 : h;
     if (4 * g >= w || 2 * p >= h) return;
+    if (J.packed >= 3) {  // k_swizzle's byte permutes, 16 B per row and thread (rows are 16 B aligned: smr_frames_to_rgba_batch checks)
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int y = 2 * p + r;
+            if (y >= h) break;
+            const u8 *sr = J.yp.ptr + ((u32)y * J.yp.pitch + 16u * (u32)g);
+            u8 *row = J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g);
+            u32 t[4];
+            if (4 * g + 3 < w) {
+                const uint4 q = *(const uint4 *)sr;
+                t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) t[i] = 4 * g + i < w ? ((const u32 *)sr)[i] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) t[i] = J.packed == 3 ? (t[i] & 0xff00ff00u) | ((t[i] & 0xffu) << 16) | ((t[i] >> 16) & 0xffu) : (t[i] >> 24) | (t[i] << 8);
+            if (4 * g + 3 < w) {
+                *(uint4 *)row = make_uint4(t[0], t[1], t[2], t[3]);
+            } else {
+                for (int i = 0; i < 4 && 4 * g + i < w; i++) ((u32 *)row)[i] = t[i];
+            }
+        }
+        return;
+    }
     if (J.packed) {
         // interleaved_{uyvy,yuyv}_to_rgba.wgsl:24-62 (k_interleaved422_to_rgba): pixel x takes the luma of its own half of group x / 2 and
         // the group's chroma, no interpolation — x_pos = floor(x + .5 - 2 / w + .0002) is x for every width from 8 up
@@ -397,12 +422,16 @@ u32 host_unorm8(float x) {
 }  // namespace
 
 
+static int smr_frame_to_rgba_general(smr_ctx *ctx, const smr_frame *in, smr_surface *node);  // one launch per frame, any geometry
+
 // k_yuv_to_rgba_batch's frames: planar 4:2:0 / 4:2:2 / 4:4:4 and NV12 whose subsampled axes are even (chroma planes exactly half), within the
 // size the coordinate argument holds for
 static bool conv_batchable(const smr_frame *in) {
     if (in->width < 2 || in->height < 2 || in->width > 16384 || in->height > 16384 || getenv("SMR_CONVERT_GENERAL")) return false;  // (the env: tests)
     if (in->format == SMR_FRAME_UYVY422 || in->format == SMR_FRAME_YUYV422)
         return in->width % 2 == 0 && in->width >= 8 && in->planes[0] && (in->planes[0]->pitch & 3u) == 0 && (((uintptr_t)in->planes[0]->ptr) & 3) == 0;
+    if (in->format == SMR_FRAME_BGRA || in->format == SMR_FRAME_ARGB)
+        return in->planes[0] && (in->planes[0]->pitch & 15u) == 0 && (((uintptr_t)in->planes[0]->ptr) & 15) == 0;
     const bool nv = in->format == SMR_FRAME_NV12;
     const bool sx = in->format != SMR_FRAME_PLANAR_YUV444, sy = in->format == SMR_FRAME_PLANAR_YUV420 || in->format == SMR_FRAME_PLANAR_YUVJ420 || nv;
     if (in->format > SMR_FRAME_PLANAR_YUVJ420 && !nv) return false;  // (BGRA / ARGB / RGBA: byte permutes of their own)
@@ -426,21 +455,21 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
     };
     for (u32 i = 0; i < n; i++) {
         if (!in[i] || !nodes[i]) return SMR_ERR_INVALID;
-        if (!conv_batchable(in[i])) {
-            if (int rc = smr_frame_to_rgba(ctx, in[i], nodes[i])) return rc;
-            continue;
-        }
         if (nodes[i]->fmt != SMR_PX_RGBA8 || nodes[i]->w != in[i]->width || nodes[i]->h != in[i]->height)
             return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in[i]->width, in[i]->height);
         if (int rc = smr_validate_frame(ctx, in[i], "smr_frame_to_rgba")) return rc;
+        if (!conv_batchable(in[i]) || (((uintptr_t)nodes[i]->ptr) & 15) != 0 || (nodes[i]->pitch & 15u) != 0) {  // (the batch kernel stores 16 B)
+            if (int rc = smr_frame_to_rgba_general(ctx, in[i], nodes[i])) return rc;
+            continue;
+        }
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
         ConvJob &J = B.j[nb++];
         const bool nv = in[i]->format == SMR_FRAME_NV12;
-        const bool packed = in[i]->format == SMR_FRAME_UYVY422 || in[i]->format == SMR_FRAME_YUYV422;
+        const bool packed = in[i]->format == SMR_FRAME_UYVY422 || in[i]->format == SMR_FRAME_YUYV422 || in[i]->format == SMR_FRAME_BGRA || in[i]->format == SMR_FRAME_ARGB;
         J.yp = view_of(in[i]->planes[0]);
         J.up = packed ? J.yp : view_of(in[i]->planes[1]);
         J.vp = packed || nv ? J.up : view_of(in[i]->planes[2]);
-        J.packed = in[i]->format == SMR_FRAME_UYVY422 ? 1 : in[i]->format == SMR_FRAME_YUYV422 ? 2 : 0;
+        J.packed = in[i]->format == SMR_FRAME_UYVY422 ? 1 : in[i]->format == SMR_FRAME_YUYV422 ? 2 : in[i]->format == SMR_FRAME_BGRA ? 3 : in[i]->format == SMR_FRAME_ARGB ? 4 : 0;
         J.dst = view_of(nodes[i]);
         J.full = in[i]->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
         J.nv = nv ? 1 : 0;
@@ -462,7 +491,12 @@ int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
     if (node->fmt != SMR_PX_RGBA8 || node->w != in->width || node->h != in->height)
         return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
     if (int rc = smr_validate_frame(ctx, in, "smr_frame_to_rgba")) return rc;
-    if (conv_batchable(in)) return smr_frames_to_rgba_batch(ctx, &in, &node, 1);
+    return smr_frames_to_rgba_batch(ctx, &in, &node, 1);  // (one frame: the batch kernel where it applies, the general kernels elsewhere)
+}
+
+}  // extern "C"
+
+static int smr_frame_to_rgba_general(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
     StageScope scope(ctx, SMR_STAGE_INGEST);
     ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
     SurfView dst = view_of(node);
@@ -506,6 +540,8 @@ int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
     SMR_HIP(ctx, hipGetLastError());
     return SMR_OK;
 }
+
+extern "C" {
 
 static int premult_common(smr_ctx *ctx, const smr_surface *src, smr_surface *dst, int mode) {
     SMR_ENTER(ctx);
