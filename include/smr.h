@@ -190,7 +190,14 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
 typedef enum smr_ingest_impl {
     SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, SMR_INGEST_MFMA_F16_WG = 3, SMR_INGEST_MFMA_F16_NODE = 4
 } smr_ingest_impl;
-typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2 } smr_option;
+/*   SMR_OPT_CONVERT_IMPL        which kernels smr_frame_to_rgba (InputTexture::convert_to_node_texture) runs — all of them produce the same bytes:
+ *       SMR_CONVERT_AUTO       the block converters: k_yuv420_to_rgba (4:2:0 planar / NV12: a thread per 4 x 4 block, shared chroma work) and
+ *                              k_yuv_to_rgba_batch (4:2:2, 4:4:4, packed YUV, BGRA / ARGB), the pass kernels for what those leave (default)
+ *       SMR_CONVERT_GENERAL    one kernel per WGSL pass, one launch per frame, coordinates and divisions as the shader writes them (tests: the
+ *                              block converters are held to these bit for bit; SMR_CONVERT_GENERAL=1 in the environment selects it at creation)
+ *       SMR_CONVERT_BLOCK_4X2  k_yuv_to_rgba_batch for 4:2:0 frames too (round 3's converter; A/B) */
+typedef enum smr_convert_impl { SMR_CONVERT_AUTO = 0, SMR_CONVERT_GENERAL = 1, SMR_CONVERT_BLOCK_4X2 = 2 } smr_convert_impl;
+typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
 SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */

@@ -10,6 +10,7 @@
 // 4 B (luma) and stores 16 B per lane; rows are pitched to 256 B so every row starts
 // on a fresh cache line.
 #include "smr_convert_dev.h"
+#include "smr_convert_420.h"
 
 namespace {
 
@@ -57,16 +58,7 @@ __global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba(SurfView yp, SurfView up,
 // rows 2 p, 2 p + 1) from chroma columns 2 g - 1 .. 2 g + 2 and rows p - 1 .. p + 1 (clamped like the sampler clamps), with
 // sample_plane_bilinear's products and sums in its order, byte / 255 as unorm_of_byte (the IEEE quotient for every byte) and the
 // matrix + store of yuv_to_rgb_px.  tests/test_gpu_parity.py holds it to the general kernel bit for bit.
-struct ConvJob {
-    SurfView yp, up, vp, dst;
-    int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
-    int sx, sy;    // chroma subsampling: 4:2:0 = (1, 1), 4:2:2 = (1, 0), 4:4:4 = (0, 0)
-    int packed;    // 0 planar / NV12 | 1 UYVY | 2 YUYV: `yp` is the (w / 2) x h plane of U Y0 V Y1 / Y0 U Y1 V groups | 3 BGRA | 4 ARGB: `yp` is the w x h plane, bytes permuted (bgra_to_rgba.wgsl / argb_to_rgba.wgsl:24-28)
-};
-constexpr int MAX_CONV_JOBS = 16;
-struct ConvBatch {
-    ConvJob j[MAX_CONV_JOBS];
-};
+// (ConvJob / ConvBatch: smr_convert_420.h)
 __global__ __launch_bounds__(BLOCK) void k_yuv_to_rgba_batch(const ConvBatch B) {
     const ConvJob &J = B.j[blockIdx.z];
     const int g = blockIdx.x * 64 + (threadIdx.x & 63), p = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -328,6 +320,19 @@ __global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView
     }
 }
 
+// 4:2:0 frames (planar or NV12, limited or full range) the 4 x 4 block converter takes (smr_convert_420.h): one launch for up to 16 frames,
+// a 64 x 4 thread block per 256 x 16 pixels; the workgroup's first 256 threads build the luma table of the job's range in LDS.
+template <bool NV>
+__global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
+    __shared__ float s_ylut[256];
+    const ConvJob &J = B.j[blockIdx.z];
+    s_ylut[threadIdx.x & 255] = cv420_luma_of_byte(threadIdx.x & 255u, J.full != 0);
+    __syncthreads();
+    const int g = blockIdx.x * 64 + (threadIdx.x & 63), P = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (4 * g >= J.dst.w || 4 * P >= J.dst.h) return;
+    cv420_block<NV>(J, g, P, s_ylut);
+}
+
 // rgba_to_yuv.wgsl's three passes (k_rgba_to_y + k_rgba_to_chroma) in one launch for even-sized frames: a thread owns a 4 x 2 pixel block,
 // reads its eight texels once and writes the luma dwords and its share of the chroma planes.  Same values bit for bit: channels are
 // byte / 255 (unorm_of_byte), a chroma sample of a subsampled axis sits exactly between two texels (sub-texel fraction 128 / 256 for
@@ -426,8 +431,8 @@ static int smr_frame_to_rgba_general(smr_ctx *ctx, const smr_frame *in, smr_surf
 
 // k_yuv_to_rgba_batch's frames: planar 4:2:0 / 4:2:2 / 4:4:4 and NV12 whose subsampled axes are even (chroma planes exactly half), within the
 // size the coordinate argument holds for
-static bool conv_batchable(const smr_frame *in) {
-    if (in->width < 2 || in->height < 2 || in->width > 16384 || in->height > 16384 || getenv("SMR_CONVERT_GENERAL")) return false;  // (the env: tests)
+static bool conv_batchable(const smr_ctx *ctx, const smr_frame *in) {
+    if (in->width < 2 || in->height < 2 || in->width > 16384 || in->height > 16384 || ctx->convert_impl == SMR_CONVERT_GENERAL) return false;
     if (in->format == SMR_FRAME_UYVY422 || in->format == SMR_FRAME_YUYV422)
         return in->width % 2 == 0 && in->width >= 8 && in->planes[0] && (in->planes[0]->pitch & 3u) == 0 && (((uintptr_t)in->planes[0]->ptr) & 3) == 0;
     if (in->format == SMR_FRAME_BGRA || in->format == SMR_FRAME_ARGB)
@@ -439,32 +444,70 @@ static bool conv_batchable(const smr_frame *in) {
     return in->planes[0] && in->planes[1] && (nv || in->planes[2]);
 }
 
-// smr_frame_to_rgba for several frames: one launch for every 16 frames k_yuv_to_rgba_batch takes, the others one by one
+// k_yuv420_to_rgba's frames (cv420_block, smr_convert_420.h): 4:2:0 planar / NV12, width a multiple of 4 from 8, even height, every plane
+// dword-aligned with rows that can be read one dword past a block's chroma window (every surface this library allocates: 256-byte pitch)
+static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) {
+    if (ctx->convert_impl != SMR_CONVERT_AUTO) return false;
+    const bool nv = in->format == SMR_FRAME_NV12;
+    if (in->format != SMR_FRAME_PLANAR_YUV420 && in->format != SMR_FRAME_PLANAR_YUVJ420 && !nv) return false;
+    if (in->width % 4 || in->width < 8 || in->height % 2 || in->height < 2 || in->width > 16384 || in->height > 16384) return false;
+    auto dwords = [](const smr_surface *s) { return s && (s->pitch & 3u) == 0 && (((uintptr_t)s->ptr) & 3) == 0; };
+    if (!dwords(in->planes[0]) || !dwords(in->planes[1]) || (!nv && !dwords(in->planes[2]))) return false;
+    const u32 cw = in->width / 2;
+    // the last block's window starts at chroma column cw - 3: its bytes begin in the dword at ((cw - 3) [* 2]) & ~3 and the loads reach 8 (12) bytes from there
+    const u32 need = nv ? ((2u * (cw - 3u)) & ~3u) + 12u : ((cw - 3u) & ~3u) + 8u;
+    if (in->planes[1]->pitch < need || (!nv && in->planes[2]->pitch < need)) return false;
+    return in->planes[0]->pitch >= in->width;
+}
+
+// smr_frame_to_rgba for several frames: one launch for every 16 frames of a kind (k_yuv420_to_rgba planar / NV12, k_yuv_to_rgba_batch), the
+// others one by one.  Everything queued is launched before the call returns, errors included.
 int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n) {
     if (!ctx || (n && (!in || !nodes))) return SMR_ERR_INVALID;
-    ConvBatch B;
-    u32 nb = 0;
-    int mw = 0, mh = 0;
-    auto flush = [&]() -> int {
-        if (!nb) return SMR_OK;
-        StageScope scope(ctx, SMR_STAGE_INGEST);
-        hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((mw + 255) / 256), (unsigned)((mh + 7) / 8), nb), dim3(BLOCK), 0, ctx->stream, B);
-        SMR_HIP(ctx, hipGetLastError());
-        nb = 0; mw = 0; mh = 0;
-        return SMR_OK;
-    };
+    // validate first, enqueue afterwards: no frame is left half-queued by a bad one behind it
     for (u32 i = 0; i < n; i++) {
         if (!in[i] || !nodes[i]) return SMR_ERR_INVALID;
         if (nodes[i]->fmt != SMR_PX_RGBA8 || nodes[i]->w != in[i]->width || nodes[i]->h != in[i]->height)
             return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in[i]->width, in[i]->height);
         if (int rc = smr_validate_frame(ctx, in[i], "smr_frame_to_rgba")) return rc;
-        if (!conv_batchable(in[i]) || (((uintptr_t)nodes[i]->ptr) & 15) != 0 || (nodes[i]->pitch & 15u) != 0) {  // (the batch kernel stores 16 B)
-            if (int rc = smr_frame_to_rgba_general(ctx, in[i], nodes[i])) return rc;
+    }
+    struct Queue {
+        ConvBatch B;
+        u32 nb = 0;
+        int mw = 0, mh = 0;
+    };
+    Queue q[3];  // 0: k_yuv_to_rgba_batch | 1: k_yuv420_to_rgba planar | 2: ... NV12
+    auto flush = [&](int k) -> int {
+        Queue &Q = q[k];
+        if (!Q.nb) return SMR_OK;
+        StageScope scope(ctx, SMR_STAGE_INGEST);
+        ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;  // (per launch)
+        if (k == 0) hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 7) / 8), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
+        else if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
+        else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
+        Q.nb = 0; Q.mw = 0; Q.mh = 0;
+        SMR_HIP(ctx, hipGetLastError());
+        return SMR_OK;
+    };
+    auto flush_all = [&]() -> int {
+        int rc = SMR_OK;
+        for (int k = 0; k < 3; k++)
+            if (int r = flush(k)) rc = rc ? rc : r;
+        return rc;
+    };
+    for (u32 i = 0; i < n; i++) {
+        const bool aligned16 = (((uintptr_t)nodes[i]->ptr) & 15) == 0 && (nodes[i]->pitch & 15u) == 0;  // (the block kernels store 16 B)
+        const bool nv = in[i]->format == SMR_FRAME_NV12;
+        const int k = !aligned16 ? -1 : conv_420_ok(ctx, in[i]) ? (nv ? 2 : 1) : conv_batchable(ctx, in[i]) ? 0 : -1;
+        if (k < 0) {
+            if (int rc = smr_frame_to_rgba_general(ctx, in[i], nodes[i])) {
+                (void)flush_all();
+                return rc;
+            }
             continue;
         }
-        ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;
-        ConvJob &J = B.j[nb++];
-        const bool nv = in[i]->format == SMR_FRAME_NV12;
+        Queue &Q = q[k];
+        ConvJob &J = Q.B.j[Q.nb++];
         const bool packed = in[i]->format == SMR_FRAME_UYVY422 || in[i]->format == SMR_FRAME_YUYV422 || in[i]->format == SMR_FRAME_BGRA || in[i]->format == SMR_FRAME_ARGB;
         J.yp = view_of(in[i]->planes[0]);
         J.up = packed ? J.yp : view_of(in[i]->planes[1]);
@@ -475,12 +518,15 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         J.nv = nv ? 1 : 0;
         J.sx = in[i]->format != SMR_FRAME_PLANAR_YUV444 ? 1 : 0;
         J.sy = (in[i]->format == SMR_FRAME_PLANAR_YUV420 || in[i]->format == SMR_FRAME_PLANAR_YUVJ420 || nv) ? 1 : 0;
-        mw = (int)in[i]->width > mw ? (int)in[i]->width : mw;
-        mh = (int)in[i]->height > mh ? (int)in[i]->height : mh;
-        if (nb == MAX_CONV_JOBS)
-            if (int rc = flush()) return rc;
+        Q.mw = (int)in[i]->width > Q.mw ? (int)in[i]->width : Q.mw;
+        Q.mh = (int)in[i]->height > Q.mh ? (int)in[i]->height : Q.mh;
+        if (Q.nb == MAX_CONV_JOBS)
+            if (int rc = flush(k)) {
+                (void)flush_all();
+                return rc;
+            }
     }
-    return flush();
+    return flush_all();
 }
 
 extern "C" {
@@ -488,9 +534,6 @@ extern "C" {
 int smr_frame_to_rgba(smr_ctx *ctx, const smr_frame *in, smr_surface *node) {
     SMR_ENTER(ctx);
     if (!ctx || !in || !node) return SMR_ERR_INVALID;
-    if (node->fmt != SMR_PX_RGBA8 || node->w != in->width || node->h != in->height)
-        return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in->width, in->height);
-    if (int rc = smr_validate_frame(ctx, in, "smr_frame_to_rgba")) return rc;
     return smr_frames_to_rgba_batch(ctx, &in, &node, 1);  // (one frame: the batch kernel where it applies, the general kernels elsewhere)
 }
 
@@ -590,7 +633,7 @@ int smr_rgba_to_frame(smr_ctx *ctx, const smr_surface *node, const smr_frame *ou
         const smr_surface *pu = out->planes[1], *pv = nv ? out->planes[1] : out->planes[2];
         auto aligned = [](const smr_surface *s) { return s && (s->pitch & 3u) == 0 && (((uintptr_t)s->ptr) & 3) == 0; };
         if (pv && (!sx || w % 2 == 0) && (!sy || h % 2 == 0) && w >= 2 && h >= 2 && w <= 8192 && h <= 8192 && aligned(out->planes[0]) && aligned(pu) && aligned(pv) &&
-            (((uintptr_t)src.ptr) & 15) == 0 && (src.pitch & 15u) == 0 && !getenv("SMR_CONVERT_GENERAL")) {
+            (((uintptr_t)src.ptr) & 15) == 0 && (src.pitch & 15u) == 0 && ctx->convert_impl != SMR_CONVERT_GENERAL) {
             hipLaunchKernelGGL(k_rgba_to_planes, dim3((unsigned)((w + 255) / 256), (unsigned)((h + 7) / 8), 1), dim3(BLOCK), 0, ctx->stream, src,
                                view_of(out->planes[0]), view_of(pu), view_of(pv), sx, sy, nv ? 1 : 0);
             SMR_HIP(ctx, hipGetLastError());

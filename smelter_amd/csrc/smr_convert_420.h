@@ -1,0 +1,140 @@
+// smr_convert_420.h — the input converter of 4:2:0 frames (planar, NV12; limited or full range), second generation: a thread owns a
+// 4 x 4 pixel block.  Included by smr_convert.hip (k_yuv420_to_rgba) and, for the CPU, by tests/emu/emu_convert.cpp (the very
+// source, one call per block: bit for bit against the oracle without a GPU).
+//
+// What it computes is planar_yuv_to_rgba.wgsl:35-58 / nv12_to_rgba.wgsl:26-48 as the oracle restates them (oracle/smr_oracle.c
+// sample_plane_bilinear + yuv_to_rgb_store), value for value — the same f32 operations in the same order, so the node texture's bytes
+// are the reference's bytes — with the work that several pixels share done once:
+//   * the sample position of luma column x in chroma texels is x / 2 - 1/4, so the 8-bit sub-texel weights are exactly 1/4 and 3/4
+//     (k_yuv_to_rgba_batch's header, smr_convert.hip); a product with 1/4 is exact, hence a * w0 + b * w1 with its two roundings is
+//     fma(x, 1/4, RN(y * 3/4)) — one multiply and one fused multiply-add whose single rounding is the sum's;
+//   * a block of luma rows 4 P .. 4 P + 3 needs chroma rows 2 P - 1 .. 2 P + 2 (clamped like the sampler clamps): four rows of four
+//     bytes per plane become unorm values once (byte / 255 as unorm_of_byte: the IEEE quotient), their horizontal lerps at the four
+//     luma columns share the two 3/4 products of a row (2 multiplies + 4 FMAs), and the vertical lerps of two luma rows share the
+//     3/4 product of the chroma row between them;
+//   * the luma byte's range expansion (y - 16/255) / 0.8588 (correctly rounded division, clamp) is a function of the byte: a 256-entry
+//     table in LDS, built per workgroup with the operations themselves;
+//   * the two chroma range divisions are Markstein correction steps (q0 = a * RN(1/b), q = fma(fma(-q0, b, a), RN(1/b), q0): the
+//     correctly rounded quotient, smr_convert_dev.h), the clamps ride on the instructions that produce their operands.
+// ~46 vector instructions per pixel against k_yuv_to_rgba_batch's 70.
+#pragma once
+
+#include "smr_convert_dev.h"
+
+#ifdef SMR_EMU
+#define cv_perm(hi, lo, sel) dev_perm((hi), (lo), (sel))
+#define cv_alignbyte(hi, lo, sh) dev_alignbyte((hi), (lo), (sh))
+#define cv_clamp01(x) dev_fmed3((x), 0.0f, 1.0f)
+#else
+#define cv_perm(hi, lo, sel) __builtin_amdgcn_perm((hi), (lo), (sel))
+#define cv_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
+#define cv_clamp01(x) __builtin_amdgcn_fmed3f((x), 0.0f, 1.0f)
+#endif
+
+struct ConvJob {
+    SurfView yp, up, vp, dst;
+    int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
+    int sx, sy;    // chroma subsampling: 4:2:0 = (1, 1), 4:2:2 = (1, 0), 4:4:4 = (0, 0)
+    int packed;    // 0 planar / NV12 | 1 UYVY | 2 YUYV: `yp` is the (w / 2) x h plane of U Y0 V Y1 / Y0 U Y1 V groups | 3 BGRA | 4 ARGB: `yp` is the w x h plane, bytes permuted (bgra_to_rgba.wgsl / argb_to_rgba.wgsl:24-28)
+};
+constexpr int MAX_CONV_JOBS = 16;
+struct ConvBatch {
+    ConvJob j[MAX_CONV_JOBS];
+};
+
+#ifdef __HIPCC__
+
+// y' of a luma byte: planar_yuv_to_rgba.wgsl:46 on byte / 255 (limited range), the byte's unorm value itself (full range)
+__device__ __forceinline__ float cv420_luma_of_byte(u32 b, bool full) {
+    const float y = unorm_of_byte(b);
+    if (full) return y;
+    constexpr float ky = 0.85882352941f;
+    const float ry = 1.0f / ky;
+    const float a = y - (16.0f / 255.0f), q = a * ry;
+    return cv_clamp01(__builtin_fmaf(__builtin_fmaf(-q, ky, a), ry, q));
+}
+
+// One 4 x 4 block: columns 4 g .. 4 g + 3, rows 4 P .. 4 P + 3 of job J (rows past the frame's height are not stored).
+// ylut: 256 floats, cv420_luma_of_byte of every byte for this job's range.
+// Requirements (cv420_job_ok on the host): 4:2:0, even height, width a multiple of 4, dword-aligned planes whose rows can be read a
+// dword past the window, 16-byte aligned destination rows.
+template <bool NV>
+__device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut) {
+    const int w = J.dst.w, h = J.dst.h, cw = w >> 1, ch = h >> 1;
+    const bool full = J.full != 0;
+    // ---- chroma window: columns 2 g - 1 .. 2 g + 2, rows 2 P - 1 .. 2 P + 2, clamped to the plane like the sampler clamps
+    const int first = 2 * g - 1, first_ld = first < 0 ? 0 : first;
+    const int byte0 = NV ? 2 * first_ld : first_ld, base = byte0 & ~3;
+    const u32 sh = (u32)(byte0 - base);
+    const int nvalid = cw - first;  // window columns 0 .. nvalid - 1 exist (>= 3: the last block's window starts at cw - 3)
+    const u32 right_fix = nvalid >= 4 ? 0x03020100u : 0x02020100u;
+    float H[2][4][4];  // [plane][window row][luma column]: the row's horizontal lerp at the block's four columns
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int cy = min(max(2 * P - 1 + j, 0), ch - 1);
+        const u8 *ur = J.up.ptr + (u32)cy * J.up.pitch + base;
+        u32 uw, vw;
+        if (NV) {
+            const u32 d0 = *(const u32 *)ur, d1 = *(const u32 *)(ur + 4), d2 = *(const u32 *)(ur + 8);
+            const u32 w0 = cv_alignbyte(d1, d0, sh), w1 = cv_alignbyte(d2, d1, sh);  // U V U V of two columns each
+            uw = cv_perm(w1, w0, 0x06040200u);
+            vw = cv_perm(w1, w0, 0x07050301u);
+        } else {
+            const u8 *vr = J.vp.ptr + (u32)cy * J.vp.pitch + base;
+            uw = cv_alignbyte(*(const u32 *)(ur + 4), *(const u32 *)ur, sh);
+            vw = cv_alignbyte(*(const u32 *)(vr + 4), *(const u32 *)vr, sh);
+        }
+        if (first < 0) {  // columns 0 1 2 3 -> 0 0 1 2
+            uw = (uw << 8) | (uw & 0xffu);
+            vw = (vw << 8) | (vw & 0xffu);
+        }
+        uw = cv_perm(0u, uw, right_fix);
+        vw = cv_perm(0u, vw, right_fix);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const u32 q = c ? vw : uw;
+            const float n0 = unorm_of_byte(q & 0xffu), n1 = unorm_of_byte((q >> 8) & 0xffu), n2 = unorm_of_byte((q >> 16) & 0xffu), n3 = unorm_of_byte(q >> 24);
+            // a * (1 - fx) + b * fx with fx = .75, .25, .75, .25 (sample_plane_bilinear): the 1/4 products are exact
+            const float m1 = n1 * 0.75f, m2 = n2 * 0.75f;
+            H[c][j][0] = __builtin_fmaf(n0, 0.25f, m1);
+            H[c][j][1] = __builtin_fmaf(n2, 0.25f, m1);
+            H[c][j][2] = __builtin_fmaf(n1, 0.25f, m2);
+            H[c][j][3] = __builtin_fmaf(n3, 0.25f, m2);
+        }
+    }
+    // ---- the four luma rows: row 4 P + r takes chroma window rows (0, 1) with fy = .75, (1, 2) with .25, (1, 2) with .75, (2, 3) with .25
+    //      — top * (1 - fy) + bot * fy: the 3/4 product of window row 1 serves luma rows 0 and 1, that of row 2 serves rows 2 and 3
+    constexpr float kc = 0.87843137254f;
+    const float rc = 1.0f / kc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int y = 4 * P + r;
+        if (y >= h) break;
+        const int j34 = r < 2 ? 1 : 2, j14 = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
+        const u32 y4 = *(const u32 *)(J.yp.ptr + (u32)y * J.yp.pitch + 4u * (u32)g);
+        u32 px[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float u = __builtin_fmaf(H[0][j14][i], 0.25f, H[0][j34][i] * 0.75f);
+            float v = __builtin_fmaf(H[1][j14][i], 0.25f, H[1][j34][i] * 0.75f);
+            const float yy = ylut[(y4 >> (8 * i)) & 0xffu];
+            if (!full) {  // planar_yuv_to_rgba.wgsl:47-48: (c - 16/255) / 0.8784, clamp
+                const float au = u - (16.0f / 255.0f), av = v - (16.0f / 255.0f);
+                const float qu = au * rc, qv = av * rc;
+                u = cv_clamp01(__builtin_fmaf(__builtin_fmaf(-qu, kc, au), rc, qu));
+                v = cv_clamp01(__builtin_fmaf(__builtin_fmaf(-qv, kc, av), rc, qv));
+            }
+            const float um = u - 0.5f, vm = v - 0.5f;
+            const float R = yy + 1.5748f * vm;
+            const float G = yy - 0.1873f * um - 0.4681f * vm;
+            const float B = yy + 1.8556f * um;
+            const u32 r8 = (u32)(int)(cv_clamp01(R) * 255.0f + 0.5f);
+            const u32 g8 = (u32)(int)(cv_clamp01(G) * 255.0f + 0.5f);
+            const u32 b8 = (u32)(int)(cv_clamp01(B) * 255.0f + 0.5f);
+            px[i] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+        }
+        *(uint4 *)(J.dst.ptr + (u32)y * J.dst.pitch + 16u * (u32)g) = make_uint4(px[0], px[1], px[2], px[3]);
+    }
+}
+
+#endif  // __HIPCC__

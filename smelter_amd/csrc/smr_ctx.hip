@@ -161,6 +161,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         else if (!strcmp(e, "mfma_wg")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_WG;
         else if (!strcmp(e, "mfma_node")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_NODE;
     }
+    if (const char *e = getenv("SMR_CONVERT_GENERAL")) ctx->convert_impl = (e[0] && e[0] != '0') ? SMR_CONVERT_GENERAL : SMR_CONVERT_AUTO;  // (read once: tools)
     if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
@@ -223,6 +224,10 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     case SMR_OPT_INGEST_IMPL:
         if (value < 0 || value > SMR_INGEST_MFMA_F16_NODE) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
         ctx->ingest_impl = (u32)value;
+        return SMR_OK;
+    case SMR_OPT_CONVERT_IMPL:
+        if (value < 0 || value > SMR_CONVERT_BLOCK_4X2) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown converter implementation %d", value);
+        ctx->convert_impl = (u32)value;
         return SMR_OK;
     case SMR_OPT_DIRECT_OUTPUT:
         ctx->direct_output = value != 0;

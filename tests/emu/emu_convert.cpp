@@ -1,0 +1,58 @@
+// TEST INFRASTRUCTURE — not part of the product; nothing in smelter_amd/ builds, links or loads this.
+//
+// The 4:2:0 input converter's source (smelter_amd/csrc/smr_convert_420.h: cv420_block, one 4 x 4 pixel block per call) compiled for the
+// CPU, so that tests/test_emu_convert.py can hold it to the oracle's planar_yuv_to_rgba / nv12_to_rgba bit for bit without a GPU.
+// Same shims as emu_wave.cpp (SMR_EMU: builtins -> emu_device.h, <hip/hip_runtime.h> -> shim/); no threads are needed here: a block
+// is computed by one lane and lanes do not talk to each other.
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+thread_local dim3 threadIdx, blockIdx;
+dim3 gridDim, blockDim;
+
+#include "emu_device.h"
+EmuBlock *emu_blk = nullptr;
+thread_local unsigned char *emu_smem = nullptr;
+void __syncthreads() {}
+
+#include "smr_convert_420.h"
+
+namespace {
+
+struct Plane {
+    std::vector<u8> buf;
+    SurfView view;
+};
+// rows on a 256-byte pitch like smr_surface_create's, padding filled with a byte no plane contains by accident
+Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill) {
+    Plane p;
+    const u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
+    p.buf.assign((size_t)pitch * h + 64, fill);
+    for (int y = 0; y < h; y++) memcpy(p.buf.data() + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
+    p.view.ptr = p.buf.data(); p.view.pitch = pitch; p.view.w = w; p.view.h = h;
+    return p;
+}
+
+}  // namespace
+
+// y: w x h; planar: u, v: (w / 2) x (h / 2); NV12: u = interleaved (w / 2) x (h / 2) x 2, v ignored.  out: w x h x 4 tight.
+extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, u8 *out) {
+    if (w % 4 || w < 8 || h % 2 || h < 2) return -1;
+    Plane py = make_plane(y, w, h, 1, 0x5a), pu = make_plane(u, w / 2, h / 2, nv12 ? 2 : 1, 0xa5), pv = nv12 ? Plane() : make_plane(v, w / 2, h / 2, 1, 0x3c);
+    std::vector<u8> dst((size_t)w * 4 * h + 64, 0);
+    ConvJob J;
+    memset(&J, 0, sizeof(J));
+    J.yp = py.view; J.up = pu.view; J.vp = nv12 ? pu.view : pv.view;
+    J.dst.ptr = dst.data(); J.dst.pitch = (u32)w * 4; J.dst.w = w; J.dst.h = h;
+    J.full = full; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0;
+    float ylut[256];
+    for (u32 b = 0; b < 256; b++) ylut[b] = cv420_luma_of_byte(b, full != 0);
+    for (int P = 0; 4 * P < h; P++)
+        for (int g = 0; 4 * g < w; g++) {
+            if (nv12) cv420_block<true>(J, g, P, ylut);
+            else cv420_block<false>(J, g, P, ylut);
+        }
+    memcpy(out, dst.data(), (size_t)w * 4 * h);
+    return 0;
+}

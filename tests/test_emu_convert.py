@@ -1,0 +1,90 @@
+"""The 4:2:0 input converter (smelter_amd/csrc/smr_convert_420.h, k_yuv420_to_rgba's per-thread 4 x 4 block) compiled for the CPU by
+tests/emu/emu_convert.cpp, against the oracle's planar_yuv_to_rgba / nv12_to_rgba: EVERY BYTE EQUAL — the node texture the product
+resamples is the reference's node texture.  Test infrastructure only: the product has no CPU path; tests/test_gpu_parity.py holds the
+kernel itself to the WGSL-pass kernels and to the oracle on the device."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu")
+ROOT = os.path.dirname(HERE)
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+P8 = C.POINTER(C.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ to build the emulator with")
+    out_dir = os.path.join(EMU, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    lib = os.path.join(out_dir, "libsmr_emu_convert.so")
+    srcs = [os.path.join(EMU, "emu_convert.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_convert_420.h"),
+            os.path.join(ROOT, "smelter_amd/csrc/smr_convert_dev.h")]
+    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function", "-I", os.path.join(EMU, "shim"),
+               "-I", EMU, "-I", os.path.join(ROOT, "smelter_amd/csrc"), "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0]]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    h = C.CDLL(lib)
+    h.emu_convert_420.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, P8]
+    orc.build()
+    return h
+
+
+def _p(a):
+    return a.ctypes.data_as(P8)
+
+
+def _content(kind, w, h, rng):
+    cw, ch = w // 2, h // 2
+    if kind == "noise":
+        return rng.integers(0, 256, (h, w), dtype=np.uint8), rng.integers(0, 256, (ch, cw, 2), dtype=np.uint8)
+    if kind == "extremes":  # the range clamps' corners and their neighbours
+        return (rng.choice(np.array([0, 1, 15, 16, 17, 234, 235, 236, 254, 255], np.uint8), (h, w)),
+                rng.choice(np.array([0, 15, 16, 17, 127, 128, 129, 239, 240, 241, 255], np.uint8), (ch, cw, 2)))
+    xx, yy = np.meshgrid(np.arange(w), np.arange(h))  # camera-like: smooth luma, slow chroma
+    y = (16 + (xx * 3 + yy * 2) % 200 + rng.integers(0, 8, (h, w))).astype(np.uint8)
+    c = np.stack([(100 + (np.arange(cw)[None, :] + np.arange(ch)[:, None]) % 60), (140 - (np.arange(cw)[None, :] * 2 + np.arange(ch)[:, None]) % 70)], -1).astype(np.uint8)
+    return y, c
+
+
+@pytest.mark.parametrize("w,h", [(8, 2), (8, 6), (12, 4), (64, 36), (132, 74), (256, 18), (1920, 16)])
+@pytest.mark.parametrize("variant", ["420", "j420", "nv12"])
+@pytest.mark.parametrize("kind", ["noise", "extremes", "camera"])
+def test_block_converter_is_the_oracle_bit_for_bit(emu, w, h, variant, kind):
+    rng = np.random.default_rng(hash((w, h, variant, kind)) % 2**32)
+    y, c = _content(kind, w, h, rng)
+    got = np.zeros((h, w, 4), np.uint8)
+    if variant == "nv12":
+        c = np.ascontiguousarray(c)
+        assert emu.emu_convert_420(_p(y), _p(c), _p(c), w, h, 1, 0, _p(got)) == 0
+        want = orc.nv12_to_rgba(y, c, w, h)
+    else:
+        u, v = np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])
+        full = 1 if variant == "j420" else 0
+        assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, _p(got)) == 0
+        want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
+    assert np.array_equal(got, want), (variant, kind, w, h, int((got != want).sum()), np.argwhere(got != want)[:4].tolist())
+
+
+def test_every_luma_byte_against_every_chroma_pair(emu):
+    """All 256 luma bytes x a dense sweep of chroma pairs on flat patches (the interpolated chroma equals the byte: (a/4 + 3a/4 is exact up
+    to the lerp's own rounding, which the oracle performs too), through both ranges: every byte equal."""
+    w, h = 256, 8
+    y = np.tile(np.arange(256, dtype=np.uint8), (h, 1))
+    for full in (0, 1):
+        for cu in range(0, 256, 5):
+            u = np.full((h // 2, w // 2), cu, np.uint8)
+            for cv in (0, 16, 17, 77, 128, 129, 201, 240, 255):
+                v = np.full((h // 2, w // 2), cv, np.uint8)
+                got = np.zeros((h, w, 4), np.uint8)
+                assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, _p(got)) == 0
+                want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
+                assert np.array_equal(got, want), (full, cu, cv)
