@@ -160,27 +160,25 @@ SMR_API const char *smr_last_error(const smr_ctx *ctx);
 SMR_API uint32_t smr_ctx_mode(const smr_ctx *ctx);  /* smr_mode the context was created with (RenderingMode, types.rs:8-18) */
 SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — render_loop.rs:177-183 */
 /* Context options (RendererOptions has no counterpart: these select between equivalent implementations).
- *   SMR_OPT_INGEST_IMPL         arithmetic of the fused ingest + Lanczos kernel (wave A of smr_render_layouts / smr_ingest_resample*):
- *       SMR_INGEST_AUTO      matrix cores where the source / plan allow it (every opaque source, two-pass and box-pre-reduced plans:
- *                            smr_debug_kernel_launches tells), the general pass kernels elsewhere (default)
+ *   SMR_OPT_INGEST_IMPL         how wave A of smr_render_layouts / smr_ingest_resample* turns a Y'CbCr frame into its dst-sized tile:
+ *       SMR_INGEST_AUTO      what the reference does, both halves fast (default): every frame goes through the exact converter
+ *                            (k_yuv420_to_rgba / k_yuv_to_rgba_batch: the WGSL operation sequence value for value — the node texture's bytes
+ *                            ARE the reference's, tests/test_emu_convert.py, tests/test_gpu_parity.py) into its RGBA8 node texture, one launch
+ *                            for all frames of a call, and the matrix-core kernel (k_ingest_wave) resamples the nodes, one launch for all of
+ *                            them; the general pass kernels where a plan leaves the kernel's windows (smr_debug_kernel_launches tells).
+ *                            Within 1 LSB of the reference END TO END on every content class.
  *       SMR_INGEST_VALU_F32  exact f32 everywhere: bit-identical to the pass-per-launch kernels (smr_frame_to_rgba + smr_resample)
- *       SMR_INGEST_MFMA_F16  same coverage as AUTO (kept distinct so a caller can assert the matrix-core path is compiled in)
- *       SMR_INGEST_MFMA_F16_WG  the first matrix-core kernel (k_ingest_mfma: a workgroup pipeline of convert and filter waves
- *                            around LDS) instead of the wave-autonomous one (k_ingest_wave) AUTO prefers; same arithmetic
- *       SMR_INGEST_MFMA_F16_NODE  no fused colour conversion: every frame goes through the exact converter (smr_frame_to_rgba's
- *                            kernels, the WGSL operation sequence) into its RGBA8 node texture, as the reference does, and the
- *                            matrix-core kernel resamples that — within 1 LSB of the reference END TO END on every content class,
- *                            for one more pass over the inputs (configs[2]: 18.0k -> 12.5k frames/s, latency p50 83 -> 98 us; the f32
- *                            kernel: 7.4k frames/s — profiles/r03_ingest_node.txt)
- *     The matrix-core path keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
- *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated
- *     in f32.  Its deviation is bounded per stage: the fused colour conversion is within one code of planar_yuv_to_rgba.wgsl
- *     (2e-5 of the bytes differ on limited-range content, up to 3e-4 on full-range), and the resample is within 1 LSB — on every byte of every content class — of resample.wgsl's
- *     passes applied to that node texture.  End to end that is within 1 LSB on camera-like content; on white noise a flipped
- *     bright texel seen through the linear-light filter at a dark output can show as 2..4 codes (3 bytes in 7.4 million,
- *     tests/test_gpu_fused.py).  Sources that need no fused conversion (RGBA8 / RGBA16F node textures: 4:2:2, 4:4:4, packed YUV,
- *     opaque surfaces, box-pre-reduced plans) are within 1 LSB end to end.  A host that needs <= 1 LSB end to end on adversarial content
- *     selects SMR_INGEST_MFMA_F16_NODE; one that needs the f32 sequence bit for bit (snapshot tests) SMR_INGEST_VALU_F32.
+ *       SMR_INGEST_MFMA_F16, SMR_INGEST_MFMA_F16_NODE  aliases of AUTO (names of earlier revisions, kept for callers)
+ *       SMR_INGEST_MFMA_F16_FUSED  opt-in: no node texture for planar 4:2:0 / NV12 frames — the matrix-core kernel converts on the fly with a
+ *                            folded-FMA form of the BT.709 matrix that is within ONE CODE of planar_yuv_to_rgba.wgsl but not equal to it
+ *                            (2e-5 of the node bytes differ on limited-range content).  Each stage is within 1 LSB; end to end a flipped bright
+ *                            texel seen through the linear-light filter at a dark output can show as 2..4 codes on adversarial content (3 bytes
+ *                            in 7.4 million on white noise), camera-like content stays within 1 LSB.  One pass over the inputs less
+ *                            (HBM traffic), not faster on the whole since round 4.
+ *       (3, round 2's workgroup-pipelined kernel k_ingest_mfma, was retired in round 4: smr_ctx_set_option rejects it)
+ *     The matrix-core resampler keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
+ *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated in f32: within
+ *     1 LSB — on every byte of every content class — of resample.wgsl's passes applied to the node texture.
  *   SMR_OPT_INGEST_STRIP_WIDTH  strip width of the f32 kernel: 0 = chosen per job (default), 32 or 64 (tests, profiling)
  *   SMR_OPT_DIRECT_OUTPUT       1: when smr_render_layouts sees the same layout list again (a scene at rest), the pixels the
  *                               compositor would only copy from a freshly resampled input are converted to Y'CbCr by the resampling
@@ -188,7 +186,7 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *                               algorithmic bytes, at the price of vector-ALU time in a kernel that is instruction-bound: DESIGN.md); 0 (default): always through
  *                               the RGBA8 tile.  Same output bytes either way. */
 typedef enum smr_ingest_impl {
-    SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, SMR_INGEST_MFMA_F16_WG = 3, SMR_INGEST_MFMA_F16_NODE = 4
+    SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, /* 3: retired */ SMR_INGEST_MFMA_F16_NODE = 4, SMR_INGEST_MFMA_F16_FUSED = 5
 } smr_ingest_impl;
 /*   SMR_OPT_CONVERT_IMPL        which kernels smr_frame_to_rgba (InputTexture::convert_to_node_texture) runs — all of them produce the same bytes:
  *       SMR_CONVERT_AUTO       the block converters: k_yuv420_to_rgba (4:2:0 planar / NV12: a thread per 4 x 4 block, shared chroma work) and
@@ -210,12 +208,12 @@ SMR_API int smr_profile_reset(smr_ctx *ctx);
 /* Which kernels a context has launched since it was created (always counted, no events): the tests assert the path a resample plan x
  * input format takes; a host can watch for scenes that leave the fast paths. */
 typedef enum smr_kernel_id {
-    SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave: fused conversion + Lanczos on the matrix cores (planar 4:2:0, NV12) */
-    SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an RGBA8 / box-reduced RGBA16F node texture (every other format after smr_frame_to_rgba; surfaces) */
-    SMR_KERNEL_INGEST_MFMA_WG = 2,   /* k_ingest_mfma (SMR_INGEST_MFMA_F16_WG) */
+    SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave with the fused conversion (SMR_INGEST_MFMA_F16_FUSED: planar 4:2:0, NV12) */
+    SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an RGBA8 / box-reduced RGBA16F node texture (every frame after smr_frame_to_rgba; surfaces) */
+    SMR_KERNEL_INGEST_MFMA_WG = 2,   /* (retired: always 0) */
     SMR_KERNEL_INGEST_VALU = 3,      /* k_ingest_resample: fused conversion + Lanczos, every pass in f32 */
     SMR_KERNEL_RESAMPLE_GENERAL = 4, /* smr_resample on a node texture: box pre-reduction and one or two Lanczos pass kernels */
-    SMR_KERNEL_FRAME_TO_RGBA = 5,    /* the stand-alone converters (InputTexture::convert_to_node_texture) */
+    SMR_KERNEL_FRAME_TO_RGBA = 5,    /* the input converters (InputTexture::convert_to_node_texture): launches — a block-converter launch takes up to 16 frames */
     SMR_KERNEL_COMPOSE_OUTPUT = 6,   /* k_compose_output: layout shader + output conversion */
     SMR_KERNEL_APPLY_LAYOUTS = 7,    /* k_apply_layouts: the general compositor */
     SMR_KERNEL_COUNT_ = 8

@@ -158,8 +158,8 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_INGEST_IMPL")) {  // tools / A-B runs: "valu" or "mfma"; smr_ctx_set_ingest_impl overrides
         if (!strcmp(e, "valu")) ctx->ingest_impl = SMR_INGEST_VALU_F32;
         else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
-        else if (!strcmp(e, "mfma_wg")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_WG;
         else if (!strcmp(e, "mfma_node")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_NODE;
+        else if (!strcmp(e, "fused")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_FUSED;
     }
     if (const char *e = getenv("SMR_CONVERT_GENERAL")) ctx->convert_impl = (e[0] && e[0] != '0') ? SMR_CONVERT_GENERAL : SMR_CONVERT_AUTO;  // (read once: tools)
     if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
@@ -222,7 +222,7 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     if (!ctx) return SMR_ERR_INVALID;
     switch (option) {
     case SMR_OPT_INGEST_IMPL:
-        if (value < 0 || value > SMR_INGEST_MFMA_F16_NODE) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
+        if (value < 0 || value > SMR_INGEST_MFMA_F16_FUSED || value == 3) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
         ctx->ingest_impl = (u32)value;
         return SMR_OK;
     case SMR_OPT_CONVERT_IMPL:

@@ -22,7 +22,6 @@
 // layout — never to the CPU.
 #include "smr_fused_compose.h"
 #include "smr_fused_ingest.h"
-#include "smr_ingest_mfma.h"
 #include "smr_ingest_wave.h"
 
 #include <cstdlib>
@@ -119,8 +118,6 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- resample_scaled_children (layout.rs:238-278): per texture layout decide direct / general / fused
     std::vector<smr_layout> eff(layouts, layouts + n);
     std::vector<IngestJob> jobs;
-    std::vector<MJob> mjobs;
-    std::vector<u32> mjob_layout;
     std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_f16_alpha, wjobs_sa, wjobs_sa_rgba, wjobs_sa_rgba_alpha;
     std::vector<u32> wjob_layout;
     std::vector<MTransposeBack> transposed;
@@ -157,19 +154,6 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     int rc = make_wave_job_transposed(ctx, sources[si].frame, plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
                     if (rc != SMR_OK) return rc;
                     if (on_mfma) { wjobs.push_back(J); wjob_layout.push_back(li); transposed.push_back(back); }
-                }
-                if (!on_mfma && fused && is_frame && can_fuse_mfma(ctx, sources[si].frame, plan, tile)) {
-                    MJob J;
-                    int rc = make_mfma_job(ctx, sources[si].frame, plan, tile, &J, &on_mfma);
-                    if (rc != SMR_OK) return rc;
-                    if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); }
-                }
-                if (!on_mfma && fused && is_frame) {  // a vertical-first plan: the same kernel on the transposed frame
-                    MJob J;
-                    MTransposeBack back;
-                    int rc = make_mfma_job_transposed(ctx, sources[si].frame, plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
-                    if (rc != SMR_OK) return rc;
-                    if (on_mfma) { mjobs.push_back(J); mjob_layout.push_back(li); transposed.push_back(back); }
                 }
                 // a single-axis plan (only one of width / height changes) of an opaque source: the one pass on the matrix cores, its f32
                 // sums encoded directly (k_ingest_wave's 32768 builds); a height-only plan runs on the transposed frame / node
@@ -385,15 +369,6 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (fuse_out) {
 #ifndef SMR_ABLATION_BUILDS
         if (fuse_yuv && ctx->direct_output && ctx->ablate == 0) {
-            for (size_t j = 0; j < mjobs.size(); j++) {
-                const u32 li = mjob_layout[j];
-                const DevLayout &D = packed.host_layouts[li];
-                if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == mjobs[j].dst.ptr && D.ix % 4 == 0 &&
-                    D.iy % 2 == 0) {
-                    direct_mask |= 1ull << li;
-                    mjobs[j].layer = (int)li; mjobs[j].ox = D.ix; mjobs[j].oy = D.iy;
-                }
-            }
             for (size_t j = 0; j < wjobs.size(); j++) {
                 const u32 li = wjob_layout[j];
                 const DevLayout &D = packed.host_layouts[li];
@@ -446,7 +421,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         cm->last_use = ctx->class_clock;
         if (ctx->debug_ingest)
             fprintf(stderr, "[smr] tile classes: %s; direct output: layer mask %llx of %zu resampled tiles\n", classify_now ? "classifying" : "cached",
-                    direct_mask, mjobs.size() + wjobs.size());
+                    direct_mask, wjobs.size());
         if (direct_mask) {
             direct.cls = cm->d_direct;
             direct.tiles_x = (int)b_tiles_x;
@@ -513,10 +488,6 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         rc = launch_wave(ctx, wjobs_sa_rgba, nullptr, true, false, true);
         if (rc != SMR_OK) return rc;
     }
-    if (!mjobs.empty()) {
-        rc = launch_mfma(ctx, mjobs, direct_dev);
-        if (rc != SMR_OK) return rc;
-    }
     for (const MTransposeBack &b : transposed) {
         rc = launch_transpose<u32>(ctx, b.tile_t, b.tile);
         if (rc != SMR_OK) return rc;
@@ -574,9 +545,9 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     return SMR_OK;
 }
 
-// InputTexture::convert_to_node_texture + ResampledChild::render for one input, fused when the
-// plan allows it (wave A with a single job), otherwise convert + general resample.  This is the
-// per-shard step of the multi-GPU path: each GPU turns its inputs into dst-sized tiles.
+// InputTexture::convert_to_node_texture + ResampledChild::render for one input: the exact converter into a node texture and the
+// matrix-core kernel on it (the default), the fused-conversion kernel (SMR_INGEST_MFMA_F16_FUSED), the f32 kernel (SMR_INGEST_VALU_F32),
+// otherwise convert + general resample.  This is the per-shard step of the multi-GPU path: each GPU turns its inputs into dst-sized tiles.
 //
 // `new_call`: open a weight-cache call of its own.  The batch entry point passes false: the bands it already handed to jobs that are
 // not launched yet carry the batch's call id and must keep their eviction protection while this input builds its own.
@@ -590,38 +561,14 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
     if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample: degenerate plan");
     if (kind == 0) return 0;
     if (new_call) ctx->weight_call++;
-    // the exact converter into the node texture, then the matrix-core kernel on it (every Y'CbCr format; plans the kernel holds with the
-    // horizontal pass first): first choice with SMR_INGEST_MFMA_F16_NODE, and what 4:2:2 / 4:4:4 / packed frames take in any case
-    auto node_route = [&](int *done) -> int {
-        *done = 0;
-        if (fused_disabled(ctx) || in->format > SMR_FRAME_NV12) return SMR_OK;
-        smr_surface *node = smr_cached_surface(ctx, SLOT_INGEST_NODE, in->width, in->height, SMR_PX_RGBA8);
-        if (!node) return SMR_ERR_OOM;
-        bool single = false;
-        if (!can_fuse_wave_rgba(ctx, view_of(node), plan, dst, 4, &single)) return SMR_OK;
-        int rc = smr_frame_to_rgba(ctx, in, node);
-        if (rc != SMR_OK) return rc;
-        std::vector<WJob> wjobs(1);
-        rc = make_wave_job_rgba(ctx, view_of(node), plan, dst, &wjobs[0], single);
-        if (rc != SMR_OK) return rc;
-        rc = launch_wave(ctx, wjobs, nullptr, true);
-        if (rc == SMR_OK) *done = 1;
-        return rc;
-    };
-    if (ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) {
-        int done = 0;
-        int rc = node_route(&done);
-        if (rc != SMR_OK) return rc;
-        if (done) return kind;
-    }
-    if (!fused_disabled(ctx) && can_fuse_wave(ctx, in, plan, dst)) {
+    if (!fused_disabled(ctx) && can_fuse_wave(ctx, in, plan, dst)) {  // (fused conversion: opt-in)
         std::vector<WJob> wjobs(1);
         int rc = make_wave_job(ctx, in, plan, dst, &wjobs[0]);
         if (rc != SMR_OK) return rc;
         rc = launch_wave(ctx, wjobs);
         return rc == SMR_OK ? kind : rc;
     }
-    if (!fused_disabled(ctx)) {  // a vertical-first plan: the same kernel on the transposed frame
+    if (!fused_disabled(ctx)) {  // ... a vertical-first plan: the same kernel on the transposed frame
         std::vector<WJob> wjobs(1);
         MTransposeBack back;
         bool ok = false;
@@ -633,35 +580,38 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
             return rc == SMR_OK ? kind : rc;
         }
     }
-    if (!fused_disabled(ctx) && can_fuse_mfma(ctx, in, plan, dst)) {
-        std::vector<MJob> mjobs(1);
-        bool fits = false;
-        int rc = make_mfma_job(ctx, in, plan, dst, &mjobs[0], &fits);
-        if (rc != SMR_OK) return rc;
-        if (fits) {
-            rc = launch_mfma(ctx, mjobs);
+    // the exact converter into the node texture, then the matrix-core kernel on it (every Y'CbCr format; two-pass plans within the kernel's
+    // windows, either pass order)
+    if (!fused_disabled(ctx) && in->format <= SMR_FRAME_NV12 && ctx->ingest_impl != SMR_INGEST_VALU_F32) {
+        smr_surface *node = smr_cached_surface(ctx, SLOT_INGEST_NODE, in->width, in->height, SMR_PX_RGBA8);
+        if (!node) return SMR_ERR_OOM;
+        bool single = false;
+        if (can_fuse_wave_rgba(ctx, view_of(node), plan, dst, 4, &single)) {
+            int rc = smr_frame_to_rgba(ctx, in, node);
+            if (rc != SMR_OK) return rc;
+            std::vector<WJob> wjobs(1);
+            rc = make_wave_job_rgba(ctx, view_of(node), plan, dst, &wjobs[0], single);
+            if (rc != SMR_OK) return rc;
+            rc = launch_wave(ctx, wjobs, nullptr, true);
             return rc == SMR_OK ? kind : rc;
         }
-    }
-    if (!fused_disabled(ctx)) {  // a vertical-first plan: the same kernel on the transposed frame
-        std::vector<MJob> mjobs(1);
-        MTransposeBack back;
-        bool ok = false;
-        int rc = make_mfma_job_transposed(ctx, in, plan, dst, SLOT_TRANSPOSED_SINGLE, &mjobs[0], &ok, &back);
-        if (rc != SMR_OK) return rc;
-        if (ok) {
-            rc = launch_mfma(ctx, mjobs);
-            if (rc == SMR_OK) rc = launch_transpose<u32>(ctx, back.tile_t, back.tile);
-            return rc == SMR_OK ? kind : rc;
+        if (plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1) {  // vertical-first: the node transposed in, the tile back
+            int rc = smr_frame_to_rgba(ctx, in, node);
+            if (rc != SMR_OK) return rc;
+            std::vector<WJob> wjobs(1);
+            MTransposeBack back;
+            bool ok = false;
+            rc = make_wave_job_rgba_transposed(ctx, view_of(node), plan, dst, SLOT_TRANSPOSED_SINGLE, &wjobs[0], &ok, &back);
+            if (rc != SMR_OK) return rc;
+            if (ok) {
+                rc = launch_wave(ctx, wjobs, nullptr, true);
+                if (rc == SMR_OK) rc = launch_transpose<u32>(ctx, back.tile_t, back.tile);
+                return rc == SMR_OK ? kind : rc;
+            }
+            return smr_resample(ctx, node, crop, dst);  // (the node is converted already)
         }
     }
-    if (ctx->ingest_impl != SMR_INGEST_MFMA_F16_NODE) {  // (4:2:2, 4:4:4, packed frames: no fused conversion reads them)
-        int done = 0;
-        int rc = node_route(&done);
-        if (rc != SMR_OK) return rc;
-        if (done) return kind;
-    }
-    if (!fused_disabled(ctx) && can_fuse_ingest(in, plan)) {
+    if (!fused_disabled(ctx) && can_fuse_ingest(in, plan)) {  // (the f32 kernel: bit-identical to the pass kernels, whatever the option)
         std::vector<IngestJob> jobs(1);
         int rc = make_ingest_job(ctx, in, plan, dst, &jobs[0]);
         if (rc != SMR_OK) return rc;
@@ -680,16 +630,19 @@ extern "C" int smr_ingest_resample(smr_ctx *ctx, const smr_frame *in, const floa
     return ingest_resample_one(ctx, in, crop, dst, true);
 }
 
-// The same for all inputs of a shard at once: every fusable input rides in one launch of wave A (its rows are balanced over
-// the blocks together), the others go one by one.  kinds[i] receives the plan kind of input i (0 = direct: dst untouched).
+// The same for all inputs of a shard at once: the inputs the matrix-core kernel takes share ONE conversion launch (a node texture per
+// input) and ONE resampling launch (their rows are balanced over the workgroups together); the others go one by one.  kinds[i] receives
+// the plan kind of input i (0 = direct: dst untouched).
 extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *in, const float *crops, smr_surface *const *dst, uint32_t n,
                                          int *kinds) {
     SMR_ENTER(ctx);
     if (!ctx || (n && (!in || !crops || !dst))) return SMR_ERR_INVALID;
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
+    if (n > 1024) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: too many inputs");
     std::vector<IngestJob> jobs;
-    std::vector<MJob> mjobs;
-    std::vector<WJob> wjobs;
+    std::vector<WJob> wjobs, wjobs_rgba;
+    std::vector<const smr_frame *> conv_in;
+    std::vector<smr_surface *> conv_node;
     ++ctx->weight_call;
     for (uint32_t i = 0; i < n; i++) {
         if (!in[i] || !dst[i] || dst[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: bad input %u", i);
@@ -700,27 +653,33 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         if (kind < 0) return smr_fail(ctx, kind, "smr_ingest_resample_batch: degenerate plan for input %u", i);
         if (kinds) kinds[i] = kind;
         if (kind == 0) continue;
-        bool on_mfma = false;
-        if (ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) {  // (one by one: each input has its own node texture pass)
-            int rc = ingest_resample_one(ctx, in[i], crop, dst[i], false);
-            if (rc < 0) return rc;
-            continue;
-        }
-        if (!fused_disabled(ctx) && can_fuse_wave(ctx, in[i], plan, dst[i])) {
+        const bool fused = !fused_disabled(ctx);
+        if (fused && can_fuse_wave(ctx, in[i], plan, dst[i])) {  // (fused conversion: opt-in)
             WJob J;
             int rc = make_wave_job(ctx, in[i], plan, dst[i], &J);
             if (rc != SMR_OK) return rc;
             wjobs.push_back(J);
-            on_mfma = true;
+            continue;
         }
-        if (!on_mfma && !fused_disabled(ctx) && can_fuse_mfma(ctx, in[i], plan, dst[i])) {
-            MJob J;
-            int rc = make_mfma_job(ctx, in[i], plan, dst[i], &J, &on_mfma);
-            if (rc != SMR_OK) return rc;
-            if (on_mfma) mjobs.push_back(J);
+        if (fused && !fused_conversion(ctx) && ctx->ingest_impl != SMR_INGEST_VALU_F32 && in[i]->format <= SMR_FRAME_NV12) {
+            SurfView probe;  // (the geometry test needs the node's size, not its pixels)
+            probe.ptr = nullptr; probe.pitch = (in[i]->width * 4u + 255u) & ~255u; probe.w = (int)in[i]->width; probe.h = (int)in[i]->height;
+            bool single = false;
+            if (can_fuse_wave_rgba(ctx, probe, plan, dst[i], 4, &single)) {
+                smr_surface *node = smr_cached_surface(ctx, SLOT_NODE0 + i, in[i]->width, in[i]->height, SMR_PX_RGBA8);
+                if (!node) return SMR_ERR_OOM;
+                if (can_fuse_wave_rgba(ctx, view_of(node), plan, dst[i], 4, &single)) {
+                    WJob J;
+                    int rc = make_wave_job_rgba(ctx, view_of(node), plan, dst[i], &J, single);
+                    if (rc != SMR_OK) return rc;
+                    conv_in.push_back(in[i]);
+                    conv_node.push_back(node);
+                    wjobs_rgba.push_back(J);
+                    continue;
+                }
+            }
         }
-        if (on_mfma) {
-        } else if (!fused_disabled(ctx) && can_fuse_ingest(in[i], plan)) {
+        if (fused && can_fuse_ingest(in[i], plan)) {
             IngestJob J;
             int rc = make_ingest_job(ctx, in[i], plan, dst[i], &J);
             if (rc != SMR_OK) return rc;
@@ -730,12 +689,14 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
             if (rc < 0) return rc;
         }
     }
-    if (!wjobs.empty()) {
-        int rc = launch_wave(ctx, wjobs);
+    if (!conv_in.empty()) {
+        int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size());
+        if (rc != SMR_OK) return rc;
+        rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
         if (rc != SMR_OK) return rc;
     }
-    if (!mjobs.empty()) {
-        int rc = launch_mfma(ctx, mjobs);
+    if (!wjobs.empty()) {
+        int rc = launch_wave(ctx, wjobs);
         if (rc != SMR_OK) return rc;
     }
     if (!jobs.empty()) {

@@ -1,7 +1,8 @@
 // smr_ingest_wave.h — wave A of the hot path, second generation: k_ingest_wave (included by smr_fused.hip only).
 //
-// Same job and the same arithmetic as k_ingest_mfma (smr_ingest_mfma.h): planar 4:2:0 / NV12 frame -> dst-sized sRGB RGBA8 tile, i.e.
-// planar_yuv_to_rgba.wgsl:35-58 followed by the two Lanczos3 passes of transformations/layout/resample.wgsl:31-87 with their
+// The matrix-core resampler: an RGBA8 node texture (what the exact input converter wrote: smr_convert_420.h — the default route) or,
+// with SMR_INGEST_MFMA_F16_FUSED, a planar 4:2:0 / NV12 frame converted on the fly -> dst-sized sRGB RGBA8 tile, i.e.
+// (planar_yuv_to_rgba.wgsl:35-58 followed by) the two Lanczos3 passes of transformations/layout/resample.wgsl:31-87 with their
 // Rgba16Float intermediate (layout/resampler.rs:25-28), both passes as banded GEMMs on v_mfma_f32_16x16x32_f16 with f16-pair
 // operands — but organised so that a wave never waits for another wave:
 //
@@ -48,6 +49,9 @@ namespace {
 #endif
 #ifndef SMR_WAVE_MIN_WAVES
 #define SMR_WAVE_MIN_WAVES 2   // waves per SIMD the register allocation must leave room for
+#endif
+#ifndef SMR_WAVE_MIN_WAVES_RG
+#define SMR_WAVE_MIN_WAVES_RG SMR_WAVE_MIN_WAVES   // ... for the narrow class on an opaque RGBA8 node texture (the default route's kernel: 170 VGPRs; A/B knob)
 #endif
 #ifndef SMR_WAVE_ABL
 #define SMR_WAVE_ABL 0  // profiling builds only (tools/variant.sh): 1 no LUT gathers, 2 no pass-1 MFMAs, 4 no conversion, 8 no pass 2 / encode, 16 no stores, 32 no staging
@@ -891,7 +895,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 }
 
 template <int NKS_T, int KV_T, int FL>
-__global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
+__global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (16384 | 32768 | 65536))) ? SMR_WAVE_MIN_WAVES_RG : SMR_WAVE_MIN_WAVES) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
 #ifdef SMR_EMU
     u8 *smem = emu_smem;
 #else
@@ -980,6 +984,49 @@ __global__ __launch_bounds__(W_THREADS, SMR_WAVE_MIN_WAVES) void k_ingest_wave(c
 #ifndef SMR_EMU
 namespace {
 
+// ------------------------------------------------------------------ host side: shared helpers
+// the cached band of (scale, offset, n_dst, n_src, axis), if any: a frame of a scene at rest finds all of its bands here and
+// never walks the tile geometry on the host
+smr_ctx::MfmaTable *find_mfma_table(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src, int axis) {
+    for (auto &t : ctx->mfma_tables)
+        if (t.dev && t.n_dst == n_dst && t.n_src == n_src && t.axis == axis && t.scale == scale && t.offset == offset) return &t;
+    return nullptr;
+}
+bool mfma_plane_ok(const SurfView &p, u32 bytes) { return (p.pitch % 4) == 0 && (((uintptr_t)p.ptr) % 4) == 0 && p.pitch >= ((bytes + 3u) & ~3u); }
+// the fused colour conversion (k_ingest_wave reading Y'CbCr planes) is opt-in: its conversion is within one code of the WGSL pass, not equal
+// to it, and a linear-light filter can amplify a flipped code (include/smr.h) — the default converts exactly, then resamples the node
+inline bool fused_conversion(const smr_ctx *ctx) { return ctx->ingest_impl == SMR_INGEST_MFMA_F16_FUSED; }
+
+// ------------------------------------------------------------------ vertical-first plans: the same kernel on the transposed problem
+// The reference filters the axis with the stronger shrink first (resampler.rs:123-145); for aspect-preserving fits that order hangs
+// on the rounding of the tile size, so a tile that resizes flips between the two from frame to frame.  The kernel below filters
+// horizontally first.  Filtering an image vertically first is filtering its transpose horizontally first — every tap loop runs along
+// one axis — so a vertical-first plan is run as: transpose the node (or the planes), the horizontal-first kernel into a transposed
+// tile, transpose the tile back.  Same quantisation points in the same places as the reference's order.
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose(const u8 *__restrict__ src, u32 spitch, int w, int h, u8 *__restrict__ dst, u32 dpitch) {
+    __shared__ T tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (bx + tx < w && by + r < h) tile[r][tx] = *(const T *)(src + (size_t)(by + r) * spitch + (size_t)(bx + tx) * sizeof(T));
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)  // dst row = src column bx + r, dst column = src row by + tx
+        if (by + tx < h && bx + r < w) *(T *)(dst + (size_t)(bx + r) * dpitch + (size_t)(by + tx) * sizeof(T)) = tile[tx][r];
+}
+
+template <typename T>
+int launch_transpose(smr_ctx *ctx, const smr_surface *src, smr_surface *dst) {  // dst is src->h x src->w
+    hipLaunchKernelGGL(k_transpose<T>, dim3((src->w + 31) / 32, (src->h + 31) / 32), dim3(256), 0, ctx->stream, (const u8 *)src->ptr, (u32)src->pitch,
+                       (int)src->w, (int)src->h, (u8 *)dst->ptr, (u32)dst->pitch);
+    SMR_HIP(ctx, hipGetLastError());
+    return SMR_OK;
+}
+
+struct MTransposeBack {
+    smr_surface *tile_t;  // what the kernel writes (tile->h x tile->w)
+    smr_surface *tile;    // what the caller asked for
+};
+
 // ------------------------------------------------------------------ host side: band cache
 struct WaveBand {
     const void *meta;
@@ -1039,7 +1086,7 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
     return SMR_OK;
 }
 
-// builds the bands of the wave kernel's layouts (axis 2 / 3) the call is missing; the others stay for flush_mfma_builds
+// builds the bands (axis 2 / 3 / 4) the call is missing, one launch for all of them
 int flush_wave_builds(smr_ctx *ctx) {
     std::vector<smr_ctx::PendingBand> rest, mine;
     for (const auto &p : ctx->pending_bands) (p.axis >= 2 ? mine : rest).push_back(p);
@@ -1067,7 +1114,7 @@ int flush_wave_builds(smr_ctx *ctx) {
 // two-pass plan with the horizontal pass first and no box pre-reduction (vertical-first plans come back on the transposed frame,
 // as for k_ingest_mfma), 16-byte aligned tile rows, k-step counts within the kernel's limits.
 bool can_fuse_wave(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG || ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) return false;
+    if (!fused_conversion(ctx)) return false;
     const bool nv12 = f && f->format == SMR_FRAME_NV12;
     if (!f || !f->planes[0] || !f->planes[1] || (!nv12 && !f->planes[2])) return false;
     if (f->format != SMR_FRAME_PLANAR_YUV420 && f->format != SMR_FRAME_PLANAR_YUVJ420 && !nv12) return false;
@@ -1132,7 +1179,7 @@ inline smr_resample_plan single_axis_as_two_pass(const smr_resample_plan &plan) 
 // *single (may be null): the pair windows are too wide but one tile per unit fits (axis 4 bands) — make_wave_job_rgba's `single`
 bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, int bpp = 4, bool *single = nullptr) {
     if (single) *single = false;
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return false;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32) return false;
     if (!(plan.kind == 2 && (bpp == 8 || (plan.levels[0] == 0 && plan.levels[1] == 0)) && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
     if (src.w < 8 || src.h < 2 || (((uintptr_t)src.ptr) % 16) || (src.pitch % 16) || src.pitch < (((size_t)src.w + 3u) & ~(size_t)3u) * (size_t)bpp) return false;
     if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16)) return false;
@@ -1173,11 +1220,13 @@ int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_pla
     return SMR_OK;
 }
 
-// A job for a vertical-first plan: the same kernel on the transposed frame (see make_mfma_job_transposed).
+// A job for a vertical-first plan: the same kernel on the transposed frame (fused conversion only).  `slot0`: four surface-cache slots of
+// the caller's for the transposed planes and tile.  *ok = false: not a case for this route.  The plane transposes are enqueued here; the caller
+// launches the job with its others and then runs launch_transpose<u32> on every MTransposeBack.
 int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, WJob *out, bool *ok,
                              MTransposeBack *back) {
     *ok = false;
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG || ctx->ingest_impl == SMR_INGEST_MFMA_F16_NODE) return SMR_OK;
+    if (!fused_conversion(ctx)) return SMR_OK;
     if (!f || !f->planes[0] || !f->planes[1]) return SMR_OK;
     if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
     const bool nv12 = f->format == SMR_FRAME_NV12;
@@ -1214,7 +1263,7 @@ int make_wave_job_transposed(smr_ctx *ctx, const smr_frame *f, const smr_resampl
 int make_wave_job_rgba_transposed(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, smr_surface *tile, size_t slot0, WJob *out, bool *ok,
                                   MTransposeBack *back) {
     *ok = false;
-    if (ctx->ingest_impl == SMR_INGEST_VALU_F32 || ctx->ingest_impl == SMR_INGEST_MFMA_F16_WG) return SMR_OK;
+    if (ctx->ingest_impl == SMR_INGEST_VALU_F32) return SMR_OK;
     if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 1 && plan.axis[1] == 0)) return SMR_OK;
     smr_surface *node_t = smr_cached_surface(ctx, slot0, (u32)src.h, (u32)src.w, SMR_PX_RGBA8);
     smr_surface *tile_t = smr_cached_surface(ctx, slot0 + 3, tile->h, tile->w, SMR_PX_RGBA8);

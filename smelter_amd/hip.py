@@ -139,7 +139,8 @@ def pack_layouts(layouts) -> "C.Array":
     return arr
 
 
-INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_WG, INGEST_MFMA_F16_NODE = 0, 1, 2, 3, 4
+INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_NODE, INGEST_MFMA_F16_FUSED = 0, 1, 2, 4, 5  # (3: retired)
+CONVERT_AUTO, CONVERT_GENERAL, CONVERT_BLOCK_4X2 = 0, 1, 2
 KERNEL_NAMES = ("ingest_wave", "ingest_wave_rgba", "ingest_mfma_wg", "ingest_valu", "resample_general", "frame_to_rgba", "compose_output", "apply_layouts")
 COMM_ID_BYTES = 128
 
@@ -199,7 +200,7 @@ class Comm:
         if self.handle:
             self.lib.smr_comm_destroy(self.handle)
             self.handle = None
-OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT = 0, 1, 2
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL = 0, 1, 2, 3
 
 
 class Context:
@@ -244,10 +245,14 @@ class Context:
         self._check(self.lib.smr_ctx_set_option(self.handle, option, value))
 
     def set_ingest_impl(self, impl: int):
-        """INGEST_AUTO / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16 (matrix cores, wave-autonomous
-        kernel where it applies) / INGEST_MFMA_F16_WG (the workgroup-pipelined matrix-core kernel) / INGEST_MFMA_F16_NODE (exact converter into the node texture,
-        matrix cores for the resample only: within 1 LSB end to end on every content) — SMR_OPT_INGEST_IMPL."""
+        """INGEST_AUTO (= INGEST_MFMA_F16 = INGEST_MFMA_F16_NODE: exact converter into the node texture, matrix cores for the resample — within
+        1 LSB end to end on every content) / INGEST_VALU_F32 (bit-identical to the pass-per-launch kernels) / INGEST_MFMA_F16_FUSED (opt-in: the
+        matrix-core kernel converts planar 4:2:0 / NV12 on the fly, within one code per stage) — SMR_OPT_INGEST_IMPL."""
         self.set_option(OPT_INGEST_IMPL, impl)
+
+    def set_convert_impl(self, impl: int):
+        """CONVERT_AUTO (block converters) / CONVERT_GENERAL (one kernel per WGSL pass) / CONVERT_BLOCK_4X2 (round 3's) — SMR_OPT_CONVERT_IMPL."""
+        self.set_option(OPT_CONVERT_IMPL, impl)
 
     def set_direct_output(self, on: bool):
         """SMR_OPT_DIRECT_OUTPUT: let the resampling kernel write Y'CbCr for the compositor's copy tiles of a scene at rest (default off)."""

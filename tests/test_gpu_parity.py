@@ -62,12 +62,12 @@ def test_planar_yuv_to_rgba(ctx, hip, w, h, variant):
     assert (got[..., 3] == 255).all()
 
 
-@pytest.mark.parametrize("w,h", [(64, 36), (66, 38), (2, 2), (6, 4), (258, 10), (1920, 1080), (1922, 1082), (38, 21), (37, 21)])
+@pytest.mark.parametrize("w,h", [(64, 36), (66, 38), (2, 2), (6, 4), (8, 2), (12, 6), (260, 10), (258, 10), (1920, 1080), (1924, 1082), (1922, 1082), (3840, 2160), (38, 21), (37, 21)])
 @pytest.mark.parametrize("variant", ["420", "j420", "nv12", "422", "444"])
 def test_batched_converter_equals_the_general_kernel(ctx, hip, w, h, variant):
-    """k_yuv_to_rgba_batch (planar 4:2:0 / 4:2:2 / 4:4:4 and NV12: structure-aware, several frames per launch) against k_yuv_to_rgba (the WGSL
-    pass as it is written, SMR_CONVERT_GENERAL=1): every byte equal, on white noise and on the extremes."""
-    import os
+    """The block converters — k_yuv420_to_rgba (4:2:0 planar / NV12: a thread per 4 x 4 block; the default) and k_yuv_to_rgba_batch (4 x 2
+    blocks: 4:2:2 / 4:4:4, and 4:2:0 with SMR_CONVERT_BLOCK_4X2) — against k_yuv_to_rgba (the WGSL pass as it is written,
+    SMR_CONVERT_GENERAL): every byte equal, on white noise and on the extremes; and the 4:2:0 results equal to the oracle's bytes."""
     rng = np.random.default_rng(hash((w, h, variant)) % 2**32)
     if (variant in ("420", "j420", "nv12") and (w % 2 or h % 2)) or (variant == "422" and w % 2):
         pytest.skip("odd size along a subsampled axis: the general kernel's case")
@@ -84,13 +84,21 @@ def test_batched_converter_equals_the_general_kernel(ctx, hip, w, h, variant):
         else:
             fmt = {"420": hip.FRAME_PLANAR_YUV420, "j420": hip.FRAME_PLANAR_YUVJ420, "422": hip.FRAME_PLANAR_YUV422, "444": hip.FRAME_PLANAR_YUV444}[variant]
             f = ctx.frame(fmt, w, h, [y, np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])])
-        fast = ctx.frame_to_rgba(f).download()
-        os.environ["SMR_CONVERT_GENERAL"] = "1"
         try:
+            fast = ctx.frame_to_rgba(f).download()
+            ctx.set_convert_impl(hip.CONVERT_BLOCK_4X2)
+            block42 = ctx.frame_to_rgba(f).download()
+            ctx.set_convert_impl(hip.CONVERT_GENERAL)
             general = ctx.frame_to_rgba(f).download()
         finally:
-            del os.environ["SMR_CONVERT_GENERAL"]
+            ctx.set_convert_impl(hip.CONVERT_AUTO)
         assert np.array_equal(fast, general), (variant, w, h, content, int((fast != general).sum()))
+        assert np.array_equal(block42, general), (variant, w, h, content, int((block42 != general).sum()))
+        if variant in ("420", "j420"):
+            want = orc.planar_yuv_to_rgba(y, np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1]), w, h, orc.YUVJ420 if variant == "j420" else orc.YUV420)
+            assert np.array_equal(fast, want), (variant, w, h, content, int((fast != want).sum()))
+        elif variant == "nv12":
+            assert np.array_equal(fast, orc.nv12_to_rgba(y, c, w, h)), (variant, w, h, content)
 
 
 def test_nv12_to_rgba(ctx, hip):
@@ -116,15 +124,14 @@ def test_interleaved422_to_rgba(ctx, hip, order):
 def test_batched_packed422_converter_equals_the_general_kernel(ctx, hip, order, w, h):
     """UYVY / YUYV through k_yuv_to_rgba_batch's packed mode against k_interleaved422_to_rgba (SMR_CONVERT_GENERAL=1): every byte equal
     (widths below 8 stay on the general kernel: there both runs are the same kernel)."""
-    import os
     data = np.random.default_rng(60 + order + w).integers(0, 256, (h, w // 2, 4), dtype=np.uint8)
     f = ctx.frame(hip.FRAME_UYVY422 if order == 0 else hip.FRAME_YUYV422, w, h, [data])
     fast = ctx.frame_to_rgba(f).download()
-    os.environ["SMR_CONVERT_GENERAL"] = "1"
+    ctx.set_convert_impl(hip.CONVERT_GENERAL)
     try:
         general = ctx.frame_to_rgba(f).download()
     finally:
-        del os.environ["SMR_CONVERT_GENERAL"]
+        ctx.set_convert_impl(hip.CONVERT_AUTO)
     assert np.array_equal(fast, general), (order, w, h, int((fast != general).sum()))
     check(fast, orc.interleaved422_to_rgba(data, w, h, order), TOL, 0.999, "interleaved422")
 
@@ -197,8 +204,7 @@ def test_rgba_to_frame(ctx, hip, w, h, variant):
 @pytest.mark.parametrize("variant", ["420", "422", "444", "nv12"])
 def test_one_launch_output_converter_equals_the_three_passes(ctx, hip, w, h, variant):
     """k_rgba_to_planes (one launch, a 4 x 2 pixel block per thread) against k_rgba_to_y + k_rgba_to_chroma (rgba_to_yuv.wgsl's passes as
-    they are written, SMR_CONVERT_GENERAL=1): every byte of every plane equal."""
-    import os
+    they are written, SMR_CONVERT_GENERAL): every byte of every plane equal."""
     if (variant in ("420", "nv12") and (w % 2 or h % 2)) or (variant == "422" and w % 2):
         pytest.skip("odd size along a subsampled axis: the three-pass kernels' case")
     rng = np.random.default_rng(hash((w, h, variant)) % 2**32)
@@ -207,11 +213,11 @@ def test_one_launch_output_converter_equals_the_three_passes(ctx, hip, w, h, var
     node = ctx.surface_from(rgba)
     fmt = {"420": hip.FRAME_PLANAR_YUV420, "422": hip.FRAME_PLANAR_YUV422, "444": hip.FRAME_PLANAR_YUV444, "nv12": hip.FRAME_NV12}[variant]
     fast = ctx.rgba_to_frame(node, fmt).download()
-    os.environ["SMR_CONVERT_GENERAL"] = "1"
+    ctx.set_convert_impl(hip.CONVERT_GENERAL)
     try:
         general = ctx.rgba_to_frame(node, fmt).download()
     finally:
-        del os.environ["SMR_CONVERT_GENERAL"]
+        ctx.set_convert_impl(hip.CONVERT_AUTO)
     for a, b, pl in zip(fast, general, "YUV"):
         assert np.array_equal(a, b), (variant, w, h, pl, int((a != b).sum()))
 
