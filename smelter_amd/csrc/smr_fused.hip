@@ -41,14 +41,9 @@ bool fused_disabled(smr_ctx *ctx) {
 // every YUV-family FrameData variant converts to alpha == 1 (wgpu/format/*_to_rgba.wgsl return vec4(.., 1.0))
 bool frame_is_opaque(u32 fmt) { return fmt <= SMR_FRAME_NV12; }
 
-// surface-cache slot ranges (ctx->surf_cache)
-constexpr size_t SLOT_TARGET = 0;
-constexpr size_t SLOT_INGEST_NODE = 1;
-constexpr size_t SLOT_NODE0 = 16;     // + source index
-constexpr size_t SLOT_TILE0 = 2048;   // + layout index
-constexpr size_t SLOT_TRANSPOSED0 = 4096;  // + 4 * layout index: transposed planes and tile of a vertical-first plan
-constexpr size_t SLOT_TRANSPOSED_SINGLE = 3200;  // smr_ingest_resample's own four
-constexpr size_t SLOT_REDUCED0 = 12288;   // + layout index: the box-reduced RGBA16F node of a plan with shrink factors from 4
+// surface-cache slots: smr_internal.h (one table, disjoint ranges)
+constexpr size_t SLOT_TARGET = SMR_SLOT_TARGET, SLOT_INGEST_NODE = SMR_SLOT_INGEST_NODE, SLOT_NODE0 = SMR_SLOT_NODE0, SLOT_TILE0 = SMR_SLOT_TILE0,
+                 SLOT_TRANSPOSED0 = SMR_SLOT_TRANSPOSED0, SLOT_TRANSPOSED_SINGLE = SMR_SLOT_TRANSPOSED_SINGLE, SLOT_REDUCED0 = SMR_SLOT_REDUCED0;
 
 }  // namespace
 
@@ -66,7 +61,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (out)
         if (int rc = smr_validate_frame(ctx, out, "smr_render_layouts (output)")) return rc;
     if (n > ctx->max_layouts) n = ctx->max_layouts;
-    if (n_sources > 1024) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: too many sources");
+    if (n > SMR_SLOT_MAX_LAYOUTS) n = (uint32_t)SMR_SLOT_MAX_LAYOUTS;  // (the packer draws no more than MAX_LAYOUT_WORDS * 32 = 1024 anyway; every per-layout scratch slot stays in its range)
+    if (n_sources > SMR_SLOT_MAX_SOURCES) return smr_fail(ctx, SMR_ERR_INVALID, "smr_render_layouts: too many sources");
     const bool fused = !fused_disabled(ctx);
 
     // ---- sources: node views; frames get a node surface only if some layout needs one
@@ -119,7 +115,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<smr_layout> eff(layouts, layouts + n);
     std::vector<IngestJob> jobs;
     std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_f16_alpha, wjobs_sa, wjobs_sa_rgba, wjobs_sa_rgba_alpha;
-    std::vector<u32> wjob_layout;
+    std::vector<u32> wjob_layout, wjob_rgba_layout;  // layout index of each job (direct output)
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
     u32 next_view = n_sources;
@@ -226,6 +222,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         int rc = make_wave_job_rgba(ctx, views[si], plan, tile, &J, single);
                         if (rc != SMR_OK) return rc;
                         rgba_jobs.push_back(J);
+                        if (kinds[si] == 2) wjob_rgba_layout.push_back(li);
                         on_mfma = true;
                     }
                     if (!on_mfma && plan.kind == 2 && (plan.levels[0] != 0 || plan.levels[1] != 0) && plan.axis[0] == 1 && plan.axis[1] == 0) {
@@ -297,7 +294,11 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         if (rc != SMR_OK) return rc;
                         rc = make_wave_job_rgba_transposed(ctx, views[si], plan, tile, SLOT_TRANSPOSED0 + 4 * (size_t)li, &J, &on_mfma, &back);
                         if (rc != SMR_OK) return rc;
-                        if (on_mfma) { rgba_jobs.push_back(J); transposed.push_back(back); }
+                        if (on_mfma) {
+                            rgba_jobs.push_back(J);
+                            if (kinds[si] == 2) wjob_rgba_layout.push_back(li);  // (never direct: the kernel writes the transposed tile)
+                            transposed.push_back(back);
+                        }
                     }
                 }
                 if (on_mfma) {
@@ -369,15 +370,19 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (fuse_out) {
 #ifndef SMR_ABLATION_BUILDS
         if (fuse_yuv && ctx->direct_output && ctx->ablate == 0) {
-            for (size_t j = 0; j < wjobs.size(); j++) {
-                const u32 li = wjob_layout[j];
-                const DevLayout &D = packed.host_layouts[li];
-                if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == wjobs[j].dst.ptr && D.ix % 4 == 0 &&
-                    D.iy % 2 == 0) {
-                    direct_mask |= 1ull << li;
-                    wjobs[j].layer = (int)li; wjobs[j].ox = D.ix; wjobs[j].oy = D.iy;
+            auto mark = [&](std::vector<WJob> &js, const std::vector<u32> &lis) {
+                for (size_t j = 0; j < js.size() && j < lis.size(); j++) {
+                    const u32 li = lis[j];
+                    const DevLayout &D = packed.host_layouts[li];
+                    if (li < 64 && (D.flags & DL_ALIGNED) && (D.flags & DL_UNROTATED) && D.src_kind == 2 && D.src.ptr == js[j].dst.ptr && D.ix % 4 == 0 &&
+                        D.iy % 2 == 0 && !js[j].single) {
+                        direct_mask |= 1ull << li;
+                        js[j].layer = (int)li; js[j].ox = D.ix; js[j].oy = D.iy;
+                    }
                 }
-            }
+            };
+            mark(wjobs, wjob_layout);
+            mark(wjobs_rgba, wjob_rgba_layout);
         }
 #endif
         // key: everything the classification reads
@@ -421,7 +426,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         cm->last_use = ctx->class_clock;
         if (ctx->debug_ingest)
             fprintf(stderr, "[smr] tile classes: %s; direct output: layer mask %llx of %zu resampled tiles\n", classify_now ? "classifying" : "cached",
-                    direct_mask, wjobs.size());
+                    direct_mask, wjobs.size() + wjobs_rgba.size());
         if (direct_mask) {
             direct.cls = cm->d_direct;
             direct.tiles_x = (int)b_tiles_x;
@@ -461,7 +466,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_rgba.empty()) {
-        rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
+        rc = launch_wave(ctx, wjobs_rgba, direct_dev, true);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_rgba_alpha.empty()) {
@@ -692,7 +697,7 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
     if (!conv_in.empty()) {
         int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size());
         if (rc != SMR_OK) return rc;
-        rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
+        if (!wjobs_rgba.empty()) rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs.empty()) {

@@ -360,6 +360,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // 16384 (with 8192): that node texture is RGBA16F in linear light — what the box pre-reduction of a plan with shrink factors from 4
     // leaves (resampler.rs: downsample.wgsl into an Rgba16Float texture): the f16 texels ARE the operand's hi halves, lo = 0.
     constexpr bool RG = (FL & 8192) != 0, RH = RG && (FL & 16384) != 0;
+
     // 32768: a single-axis plan (ResampledChild with one pass, resampler.rs:123-145 — only the width changes): pass 1's f32 sums are
     // encoded and stored as they are, row for row; there is no f16 rounding and no pass 2.  The job's vertical band (scale 1) only
     // supplies the chunk ranges of the pieces.  (Height-only plans run on the transposed frame.)
@@ -895,7 +896,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 }
 
 template <int NKS_T, int KV_T, int FL>
-__global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (16384 | 32768 | 65536))) ? SMR_WAVE_MIN_WAVES_RG : SMR_WAVE_MIN_WAVES) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
+__global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (2048 | 16384 | 32768 | 65536))) ? SMR_WAVE_MIN_WAVES_RG : SMR_WAVE_MIN_WAVES) void k_ingest_wave(const WArgs args, const float *__restrict__ tables, const u32 *__restrict__ lut) {
 #ifdef SMR_EMU
     u8 *smem = emu_smem;
 #else
@@ -1296,6 +1297,9 @@ constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 constexpr WaveKernel W_KERNELS_82[] = {k_ingest_wave<8, 2, 0>, k_ingest_wave<8, 2, 2048>, k_ingest_wave<8, 2, 4096>, k_ingest_wave<8, 2, 6144>};
 // RGBA8 node textures as the source: the same four classes
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
+// ... with direct output (2048: the tile's copy-class pixels leave as Y'CbCr, smr_fused.hip)
+constexpr WaveKernel W_KERNELS_RGBA_DIRECT[] = {k_ingest_wave<0, 0, 8192 + 2048>, k_ingest_wave<4, 2, 8192 + 2048>, k_ingest_wave<4, 2, 8193 + 2048>,
+                                                k_ingest_wave<8, 3, 8192 + 2048>};
 // ... with an alpha channel (premultiplied RGBA8: text, images, nested layout nodes, BGRA / ARGB frames): four channels
 constexpr WaveKernel W_KERNELS_RGBA_ALPHA[] = {k_ingest_wave<0, 0, 8192 + 65536>, k_ingest_wave<4, 2, 8192 + 65536>, k_ingest_wave<4, 2, 8193 + 65536>,
                                                k_ingest_wave<8, 3, 8192 + 65536>};
@@ -1311,6 +1315,7 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
         all.insert(all.end(), W_KERNELS_82, W_KERNELS_82 + 4);
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
+        all.insert(all.end(), W_KERNELS_RGBA_DIRECT, W_KERNELS_RGBA_DIRECT + 4);
         all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
         all.push_back(W_KERNEL_RGBA16F);
         all.push_back(W_KERNEL_RGBA16F_ALPHA);
@@ -1355,10 +1360,11 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         const WaveKernel kern = cls82 ? W_KERNELS_82[(direct ? 1 : 0) + (any_nv ? 2 : 0)]
                                 : sa ? W_KERNELS_SA[sa_i]
                                    : f16 ? (alpha ? W_KERNEL_RGBA16F_ALPHA : W_KERNEL_RGBA16F)
-                                         : alpha ? W_KERNELS_RGBA_ALPHA[ki] : rgba ? W_KERNELS_RGBA[ki] : W_KERNELS[ki];
+                                         : alpha ? W_KERNELS_RGBA_ALPHA[ki]
+                                                 : rgba ? (direct ? W_KERNELS_RGBA_DIRECT[ki] : W_KERNELS_RGBA[ki]) : W_KERNELS[ki];
         if (cls82) ki = 500 + (direct ? 1 : 0) + (any_nv ? 2 : 0);  // (occupancy cache key)
         else if (sa) ki = 300 + sa_i;
-        else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : 100;
+        else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : (direct ? 150 : 100);
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);

@@ -170,6 +170,20 @@ extern "C" int smr_validate_frame(smr_ctx *ctx, const smr_frame *f, const char *
 // smr_frame_to_rgba for several frames at once (smr_convert.hip): planar 4:2:0 / 4:2:2 / 4:4:4 and NV12 frames share one launch per 16
 int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n);
 
+// surface-cache slots (ctx->surf_cache), one table for every translation unit: disjoint for up to SMR_SLOT_MAX_LAYOUTS layouts and
+// SMR_SLOT_MAX_SOURCES sources per call (smr_render_layouts clamps / rejects beyond)
+constexpr size_t SMR_SLOT_MAX_LAYOUTS = 1024, SMR_SLOT_MAX_SOURCES = 1024;
+constexpr size_t SMR_SLOT_TARGET = 0;
+constexpr size_t SMR_SLOT_INGEST_NODE = 1;            // smr_ingest_resample's node texture
+constexpr size_t SMR_SLOT_PRE_NODE = 3, SMR_SLOT_PRE_SCALED = 4;   // smr_frame_preprocess
+constexpr size_t SMR_SLOT_TRANSPOSED_SINGLE = 8;      // smr_ingest_resample's own four (.. 11)
+constexpr size_t SMR_SLOT_NODE0 = 16;                                              // + source index: RGBA8 node textures
+constexpr size_t SMR_SLOT_TILE0 = SMR_SLOT_NODE0 + SMR_SLOT_MAX_SOURCES;           // + layout index: resampled tiles
+constexpr size_t SMR_SLOT_REDUCED0 = SMR_SLOT_TILE0 + SMR_SLOT_MAX_LAYOUTS;        // + layout index: box-reduced RGBA16F nodes
+constexpr size_t SMR_SLOT_TRANSPOSED0 = SMR_SLOT_REDUCED0 + SMR_SLOT_MAX_LAYOUTS;  // + 4 * layout index: transposed planes / node and tile of a vertical-first plan
+constexpr size_t SMR_SLOT_END = SMR_SLOT_TRANSPOSED0 + 4 * SMR_SLOT_MAX_LAYOUTS;
+static_assert(SMR_SLOT_TRANSPOSED_SINGLE + 4 <= SMR_SLOT_NODE0 && SMR_SLOT_PRE_SCALED < SMR_SLOT_TRANSPOSED_SINGLE, "surface-cache slot ranges overlap");
+
 // stage-timing helper: brackets kernel launches of one class with HIP events when profiling.
 struct StageScope {
     smr_ctx *ctx;

@@ -351,7 +351,7 @@ int smr_frame_preprocess(smr_ctx *ctx, const smr_frame *in, uint32_t dst_w, uint
     if (!ctx || !in || !host) return SMR_ERR_INVALID;
     if ((dst_w == 0) != (dst_h == 0)) return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_preprocess: target %ux%u (both zero = no rescale)", dst_w, dst_h);
     if (int rc = smr_validate_frame(ctx, in, "smr_frame_preprocess")) return rc;
-    constexpr size_t SLOT_PRE_NODE = 3300, SLOT_PRE_SCALED = 3301;
+    constexpr size_t SLOT_PRE_NODE = SMR_SLOT_PRE_NODE, SLOT_PRE_SCALED = SMR_SLOT_PRE_SCALED;
     smr_surface *node = smr_cached_surface(ctx, SLOT_PRE_NODE, in->width, in->height, SMR_PX_RGBA8);
     if (!node) return SMR_ERR_OOM;
     int rc = smr_frame_to_rgba(ctx, in, node);

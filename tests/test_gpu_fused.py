@@ -564,9 +564,10 @@ DIRECT_CASES = [
 ]
 
 
+@pytest.mark.parametrize("route", ["node", "fused_conversion"])
 @pytest.mark.parametrize("fmt_name", ["planar", "nv12"])
 @pytest.mark.parametrize("name,mk,iw,ih,W,H", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
-def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih, W, H, fmt_name):
+def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih, W, H, fmt_name, route):
     """SMR_OPT_DIRECT_OUTPUT: from the second frame of an unchanged layout list on, the resampling kernel writes the Y'CbCr of the
     compositor's copy tiles itself and their RGBA8 texels are never stored.  Every frame must equal the first one (rendered through
     the RGBA8 tile) and the frames of a context with the option off, byte for byte; the output frames start out poisoned, so a
@@ -575,8 +576,8 @@ def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih
     layouts, res = mk()
     c_on, c_off = hip.Context(0), hip.Context(0)
     try:
-        c_on.set_ingest_impl(hip.INGEST_MFMA_F16_FUSED)  # (direct output is a build of the fused-conversion kernel)
-        c_off.set_ingest_impl(hip.INGEST_MFMA_F16_FUSED)
+        for c in (c_on, c_off):  # (direct output is a build of the matrix-core kernel: one per source kind)
+            c.set_ingest_impl(hip.INGEST_MFMA_F16_FUSED if route == "fused_conversion" else hip.INGEST_AUTO)
         c_on.set_direct_output(True)
         c_off.set_direct_output(False)
         n_in = sum(1 for r in res if r == (iw, ih))
