@@ -172,8 +172,10 @@ def main():
     ap.add_argument("--convert", choices=["auto", "general", "block4x2"], default="auto", help="input converter kernels (SMR_OPT_CONVERT_IMPL; A/B)")
     ap.add_argument("--direct-output", action="store_true",
                     help="SMR_OPT_DIRECT_OUTPUT: the resampling kernel writes Y'CbCr for the compositor's copy tiles (A/B; default off)")
+    ap.add_argument("--no-long", action="store_true", help="skip the >= 2 s `value_long` loop (profiling runs: keeps traces small)")
     ap.add_argument("--no-target", action="store_true", help="skip the north-star target block (8x4K -> 4K on one GPU, run as a child process)")
-    ap.add_argument("--inflight", type=int, default=3, help="frames in flight on one GPU (renderer contexts / HIP streams)")
+    ap.add_argument("--inflight", type=int, default=2, help="frames in flight on one GPU (renderer contexts / HIP streams); 2 measured best with three kernels per "
+                                                           "frame (profiles/r04_inflight.txt: 15.8k / 14.6k / 14.1k frames/s at 2 / 3 / 4)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (ingest per shard, gather, compose) with the ranks given")
     ap.add_argument("--transfers", action="store_true", help="also time host buffers in -> host buffers out (PCIe inclusive, informational)")
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
@@ -370,7 +372,7 @@ def main():
         elapsed = float(t.item())
     # the same loop over >= 2 s of device work (a K = 20 run lasts about a millisecond: the pipeline's fill and drain weigh on it and an outside
     # observer sampling GPU activity cannot see it), reported as `value_long` beside `value` — never instead of it
-    long_steps = min(max(args.steps, int(2.0 * args.steps / max(elapsed, 1e-9))), 200000)
+    long_steps = args.steps if args.no_long else min(max(args.steps, int(2.0 * args.steps / max(elapsed, 1e-9))), 200000)
     tl = time.perf_counter()
     for s in range(long_steps):
         step_fn(s)

@@ -324,13 +324,14 @@ __global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView
 // a 64 x 4 thread block per 256 x 16 pixels; the workgroup's first 256 threads build the luma table of the job's range in LDS.
 template <bool NV>
 __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
-    __shared__ float s_ylut[256];
+    __shared__ float s_ylut[256], s_nlut[256];
     const ConvJob &J = B.j[blockIdx.z];
     s_ylut[threadIdx.x & 255] = cv420_luma_of_byte(threadIdx.x & 255u, J.full != 0);
+    s_nlut[threadIdx.x & 255] = unorm_of_byte(threadIdx.x & 255u);
     __syncthreads();
     const int g = blockIdx.x * 64 + (threadIdx.x & 63), P = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (4 * g >= J.dst.w || 4 * P >= J.dst.h) return;
-    cv420_block<NV>(J, g, P, s_ylut);
+    cv420_block<NV>(J, g, P, s_ylut, s_nlut);
 }
 
 // rgba_to_yuv.wgsl's three passes (k_rgba_to_y + k_rgba_to_chroma) in one launch for even-sized frames: a thread owns a 4 x 2 pixel block,
@@ -483,8 +484,8 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         StageScope scope(ctx, SMR_STAGE_INGEST);
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;  // (per launch)
         if (k == 0) hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 7) / 8), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
-        else if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
-        else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
+        else if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
+        else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
         Q.nb = 0; Q.mw = 0; Q.mh = 0;
         SMR_HIP(ctx, hipGetLastError());
         return SMR_OK;

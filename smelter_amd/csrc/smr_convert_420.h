@@ -58,8 +58,9 @@ __device__ __forceinline__ float cv420_luma_of_byte(u32 b, bool full) {
 // ylut: 256 floats, cv420_luma_of_byte of every byte for this job's range.
 // Requirements (cv420_job_ok on the host): 4:2:0, even height, width a multiple of 4, dword-aligned planes whose rows can be read a
 // dword past the window, 16-byte aligned destination rows.
+// nlut: 256 floats, unorm_of_byte of every byte (the chroma bytes' byte / 255: a table gather instead of a conversion and two multiply-adds)
 template <bool NV>
-__device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut) {
+__device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut, const float *nlut) {
     const int w = J.dst.w, h = J.dst.h, cw = w >> 1, ch = h >> 1;
     const bool full = J.full != 0;
     // ---- chroma window: columns 2 g - 1 .. 2 g + 2, rows 2 P - 1 .. 2 P + 2, clamped to the plane like the sampler clamps
@@ -93,7 +94,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             const u32 q = c ? vw : uw;
-            const float n0 = unorm_of_byte(q & 0xffu), n1 = unorm_of_byte((q >> 8) & 0xffu), n2 = unorm_of_byte((q >> 16) & 0xffu), n3 = unorm_of_byte(q >> 24);
+            const float n0 = nlut[q & 0xffu], n1 = nlut[(q >> 8) & 0xffu], n2 = nlut[(q >> 16) & 0xffu], n3 = nlut[q >> 24];
             // a * (1 - fx) + b * fx with fx = .75, .25, .75, .25 (sample_plane_bilinear): the 1/4 products are exact
             const float m1 = n1 * 0.75f, m2 = n2 * 0.75f;
             H[c][j][0] = __builtin_fmaf(n0, 0.25f, m1);

@@ -40,6 +40,7 @@
 #include "smr_ingest_common.h"
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -52,6 +53,13 @@ namespace {
 #endif
 #ifndef SMR_WAVE_MIN_WAVES_RG
 #define SMR_WAVE_MIN_WAVES_RG SMR_WAVE_MIN_WAVES   // ... for the narrow class on an opaque RGBA8 node texture (the default route's kernel: 170 VGPRs; A/B knob)
+#endif
+#ifndef SMR_WAVE_RG_EARLY_WAIT
+#define SMR_WAVE_RG_EARLY_WAIT 1   // node-texture builds: wait for the outstanding loads at the top of a chunk (0: A/B — configs[3] 128.6 -> 109.5 us, configs[2] unchanged)
+#endif
+#ifndef SMR_WAVE_STAGGER
+#define SMR_WAVE_STAGGER 0   // A/B: waves in odd hardware slots of a SIMD start s_sleep(N) later (N x 64 cycles), so that the two waves of a SIMD are not in the
+                             // same phase (LDS gathers / matrix cores / encode) at the same time
 #endif
 #ifndef SMR_WAVE_ABL
 #define SMR_WAVE_ABL 0  // profiling builds only (tools/variant.sh): 1 no LUT gathers, 2 no pass-1 MFMAs, 4 no conversion, 8 no pass 2 / encode, 16 no stores, 32 no staging
@@ -611,6 +619,13 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 
     W_MARK(0);
     for (int c = c_first; c <= c_last; c++) {
+        // (node-texture builds: the blocks of chunk c + 1 are requested while chunk c is converted, i.e. BEFORE this chunk's tile rows read their
+        //  pass-2 weights, and the memory counter is in order.  The weights were requested a tile row ago; a wait for them must not include the
+        //  blocks requested a moment ago — a full memory latency per tile row, 37 % of a wave's time when it did (profiles/r04_wave_timing.txt).
+        //  Three things keep the waits where they cost nothing: the block loads are unconditional (the last chunk re-requests itself: the compiler can
+        //  count the loads in flight), the first tile row of a chunk is its own copy of the code (below), and everything outstanding is waited for
+        //  here, at the top of the chunk, where it is old — this chunk's blocks, the next tile row's weights.)
+        if (RG && SMR_WAVE_RG_EARLY_WAIT) dev_wait_vmcnt0();
         // ---- conversion + pass 1 of chunk c: k-step by k-step, straight into the accumulators of the tiles it feeds
         f32x4 acc[2][4];
 #pragma unroll
@@ -643,7 +658,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             auto convert = [&](int j, const Raw &r, uint4 (&a)[4]) {
                 if (RG) {
                     convert_rgba(j, a);
-                    if (c < c_last) rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(c + 1, j);
+                    rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(min(c + 1, c_last), j);  // (unconditional: the compiler can then count the loads in flight — see the chunk loop)
                     return;
                 }
                 const u32 ua = dev_alignbyte(r.u1, r.u0, shb), ub = dev_alignbyte(r.u3, r.u2, shb);
@@ -721,7 +736,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     uint4 a[4];
                     if (RG) {
                         convert_rgba(j, a);
-                        if (c < c_last) rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(c + 1, j);
+                        rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(min(c + 1, c_last), j);  // (unconditional: the compiler can then count the loads in flight — see the chunk loop)
                     } else if (SMR_WAVE_ABL & 4) {
                         a[0] = make_uint4(yy, ua, ub, va); a[1] = make_uint4(vb, yy, ua, ub); a[2] = make_uint4(va, vb, yy, ua);
                     } else {
@@ -812,8 +827,15 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             }
         slot = slot + 1 == 2 * KV ? 0 : slot + 1;
         W_MARK(3);
-        // ---- pass 2 + encode + store of every output tile whose window ends with chunk c
-        while (vt <= vt1 && vm.y == c) {
+        // ---- pass 2 + encode + store of every output tile whose window ends with chunk c.
+        //      The first tile row of a chunk and any further one (up-scaling: several tile rows per chunk) are two copies of the code: the
+        //      weights of the first were requested a tile row ago and need no wait (node-texture builds: the wait at the top of the chunk;
+        //      fused builds: the chunk's own loads go out after this loop), those of a further row were requested a moment ago.  As ONE loop the
+        //      compiler has to wait at its header for the youngest loads of either path — behind the next chunk's blocks (see above).
+        auto tile_row = [&](auto first_of_chunk) {
+#ifndef SMR_EMU
+            if (decltype(first_of_chunk)::value) asm volatile("; first tile row of the chunk");  // (keeps the two copies from being merged back)
+#endif
 #pragma unroll
             for (int i = 0; i < W_NTI; i++) {
                 if (klo[i] == 0xff) continue;  // (uniform: no second tile in the last pair of an odd tile count)
@@ -877,6 +899,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 vm_next = J.v_meta[min(vt + 1, vt1)];
                 if (!(SMR_WAVE_ABL & 512)) fetch_bv(vt);  // (512: profiling, every tile with the first tile's weights)
             }
+        };
+        if (vt <= vt1 && vm.y == c) {
+            tile_row(std::true_type{});
+            while (vt <= vt1 && vm.y == c) tile_row(std::false_type{});
         }
         W_MARK(7);
         // ---- the footprint of chunk c + 2 goes out now: it has the whole next conversion to arrive, and the loop's waits for the pass-2
@@ -904,6 +930,9 @@ __global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (20
 #endif
     const int tid = threadIdx.x;
     const int wave = dev_readfirstlane(tid >> 6);
+#if SMR_WAVE_STAGGER && !defined(SMR_EMU)
+    if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u) __builtin_amdgcn_s_sleep(SMR_WAVE_STAGGER);  // HW_ID.wave_id (this wave's slot in its SIMD)
+#endif
     // XCD-aware order: workgroup ids that share an XCD are neighbours in unit space (piece-group major, pair fastest: neighbouring
     // pairs read the same source lines at the same time)
     const int per_xcd = ((int)gridDim.x + 7) >> 3;

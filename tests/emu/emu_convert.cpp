@@ -46,12 +46,15 @@ extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int
     J.yp = py.view; J.up = pu.view; J.vp = nv12 ? pu.view : pv.view;
     J.dst.ptr = dst.data(); J.dst.pitch = (u32)w * 4; J.dst.w = w; J.dst.h = h;
     J.full = full; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0;
-    float ylut[256];
-    for (u32 b = 0; b < 256; b++) ylut[b] = cv420_luma_of_byte(b, full != 0);
+    float ylut[256], nlut[256];
+    for (u32 b = 0; b < 256; b++) {
+        ylut[b] = cv420_luma_of_byte(b, full != 0);
+        nlut[b] = unorm_of_byte(b);
+    }
     for (int P = 0; 4 * P < h; P++)
         for (int g = 0; 4 * g < w; g++) {
-            if (nv12) cv420_block<true>(J, g, P, ylut);
-            else cv420_block<false>(J, g, P, ylut);
+            if (nv12) cv420_block<true>(J, g, P, ylut, nlut);
+            else cv420_block<false>(J, g, P, ylut, nlut);
         }
     memcpy(out, dst.data(), (size_t)w * 4 * h);
     return 0;

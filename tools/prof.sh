@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH=${PROF_CMD:-"python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --latency-frames 5 $*"}  # PROF_CMD: profile another command
+BENCH=${PROF_CMD:-"python $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-long --latency-frames 5 $*"}  # PROF_CMD: profile another command
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 i=0
 MAXG=${PROF_GROUPS:-99}
@@ -23,4 +23,6 @@ for GROUP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
 done
 cd $R
 python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+# (the per-dispatch traces are large and gpurun_out/ is capped at 64 MiB: keep the summaries)
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 cat $OUT/summary.txt

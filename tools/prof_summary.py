@@ -9,7 +9,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for k in ("k_ingest_wave", "k_build_wave_weights", "k_ingest_mfma", "k_build_mfma_weights", "k_ingest_resample", "k_compose_output", "k_classify_tiles", "k_apply_layouts", "k_build_weights", "k_resample_pass", "k_yuv_to_rgba",
+    for k in ("k_ingest_wave", "k_build_wave_weights", "k_yuv420_to_rgba", "k_yuv_to_rgba_batch", "k_ingest_resample", "k_compose_output", "k_classify_tiles", "k_apply_layouts", "k_build_weights", "k_resample_pass", "k_yuv_to_rgba",
               "k_rgba_to_y", "k_rgba_to_chroma", "k_blit_glyphs", "k_downsample"):
         if k in name:
             return k
@@ -35,7 +35,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc*"))):
             cnt[(k, row.get("Counter_Name"))] += 1
         print("== pmc:", os.path.relpath(f, out))
         for k, cs in acc.items():
-            if k not in ("k_ingest_wave", "k_ingest_mfma", "k_ingest_resample", "k_compose_output"):
+            if k not in ("k_ingest_wave", "k_yuv420_to_rgba", "k_yuv_to_rgba_batch", "k_ingest_resample", "k_compose_output"):
                 continue
             print("  " + k)
             for c, v in sorted(cs.items()):

@@ -7,7 +7,7 @@ import json
 import os
 import sys
 
-KERNELS = ("k_ingest_mfma", "k_build_mfma_weights", "k_ingest_resample", "k_compose_output", "k_classify_tiles", "k_apply_layouts", "k_build_weights",
+KERNELS = ("k_ingest_wave", "k_yuv420_to_rgba", "k_yuv_to_rgba_batch", "k_ingest_resample", "k_compose_output", "k_classify_tiles", "k_apply_layouts", "k_build_weights",
            "k_resample_pass", "k_yuv_to_rgba", "k_rgba_to_y", "k_rgba_to_chroma", "k_blit_glyphs", "k_downsample", "k_gauss_axis")
 
 
