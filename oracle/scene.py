@@ -10,7 +10,8 @@ Restates:
   scene/layout.rs:109-262                    layout_content / absolute children / update_state
   transformations/layout/flatten.rs:10-390   NestedLayout::flatten
   scene/types.rs:109-117                     BorderRadius::clip_to_size
-Transitions (scene/transition.rs) are restated in oracle/transition.py.
+Transitions (scene/transition.rs, the stateful components, interpolation by component / tile id) are restated in oracle/transition.py,
+which drives this module's layout pass with the component parameters of a given pts.
 """
 from __future__ import annotations
 
@@ -81,6 +82,7 @@ class AbsolutePosition:
 class InputStream:
     input_index: int          # index into the node's input list (order of appearance)
     size: Tuple[float, float] = (0.0, 0.0)   # filled by update_state from the input resolution
+    id: Optional[str] = None  # component id (a Tiles parent keys its tiles by it: oracle/transition.py)
 
 
 @dataclass
@@ -104,6 +106,8 @@ class View:
     border_color: Tuple[int, int, int, int] = (0, 0, 0, 0)
     box_shadow: List[BoxShadow] = field(default_factory=list)
     padding: Padding = field(default_factory=Padding)
+    id: Optional[str] = None          # component id: a scene update continues the component of the same id (oracle/transition.py)
+    transition: Optional[object] = None   # oracle.transition.TransitionOptions
 
 
 @dataclass
@@ -119,6 +123,8 @@ class Rescaler:
     border_width: float = 0.0
     border_color: Tuple[int, int, int, int] = (0, 0, 0, 0)
     box_shadow: List[BoxShadow] = field(default_factory=list)
+    id: Optional[str] = None
+    transition: Optional[object] = None
 
 
 @dataclass
@@ -133,6 +139,8 @@ class Tiles:
     horizontal_align: str = "center"
     vertical_align: str = "center"
     absolute: None = None  # Tiles are always statically positioned (tiles_component.rs:77-82)
+    id: Optional[str] = None
+    transition: Optional[object] = None
 
 
 def _is_layout(c) -> bool:
@@ -441,9 +449,20 @@ def tiles_positions(c: Tiles, count: int, w, h):
 
 
 def _tiles_layout(c: Tiles, w, h) -> Nested:
-    tiles = tiles_positions(c, len(c.children), w, h) if c.children else []
+    state = getattr(c, "tiles_state", None)
+    if state is not None:
+        # a scene with history (oracle/transition.py): the tile list at this pts — interpolated from the previous layout's, entries of
+        # tiles that stay hidden during the transition are None (tiles_component.rs:56-65, layout.rs:44-53)
+        scene, node, pts_ns, record = state
+        tiles = scene.tiles_for_layout(node, w, h, pts_ns, record)
+    else:
+        tiles = tiles_positions(c, len(c.children), w, h) if c.children else []
     kids = []
-    for ch, (top, left, tw, th) in zip(c.children, tiles):
+    for ch, tile in zip(c.children, tiles):
+        if tile is None:
+            kids.append(_placeholder(len(node_children(ch)) if _is_layout(ch) else 1))
+            continue
+        top, left, tw, th = tile
         if _is_layout(ch):
             kids.append(_wrap_layout_child(ch, top, left, tw, th))
         else:

@@ -9,12 +9,14 @@ render-test scenes do not come out of the C++ engine under test:
   Tiles     component_into.rs:382-416  (defaults: 16:9, margin 0, padding 0, centre / centre)
   BoxShadow component_into.rs:418-432  (defaults: offsets 0, blur 0, white)
 Input streams are numbered in order of appearance (depth first): the n-th one is child n of the root layout node.
-Components with a `transition`, and node kinds other than input streams (text, image, shader, web view), are outside what
-oracle/scene.py restates: `Unsupported` is raised and the caller keeps to the scenes that are static.
+Component ids and `transition` objects (smelter-api/src/video/transition.rs:11-69: duration_ms, easing_function {function_name, points},
+should_interrupt) are carried onto the oracle's components; oracle/transition.py runs the scene's history from them.
+Node kinds other than input streams (text, image, shader, web view) are outside what oracle/scene.py restates: `Unsupported` is raised.
 """
 from __future__ import annotations
 
 from oracle import scene as S
+from oracle import transition as T
 
 
 class Unsupported(Exception):
@@ -48,18 +50,34 @@ def _decor(js, kw):
                                     colour(b["color"]) if "color" in b else (255, 255, 255, 255)) for b in js.get("box_shadow", [])]
 
 
+def transition(js):
+    """Transition -> scene::Transition (transition.rs:33-69)."""
+    if js is None:
+        return None
+    ef = js.get("easing_function") or {"function_name": "linear"}
+    name = ef.get("function_name", "linear")
+    if name == "cubic_bezier":
+        pts = tuple(float(x) for x in ef["points"])
+        if not (0.0 <= pts[0] <= 1.0 and 0.0 <= pts[2] <= 1.0):
+            raise Unsupported("cubic bezier control points outside [0, 1]")
+        easing = T.Easing("cubic_bezier", pts)
+    elif name in ("linear", "bounce"):
+        easing = T.Easing(name)
+    else:
+        raise Unsupported(f"easing function {name!r}")
+    return T.TransitionOptions(duration_ns=int(round(float(js["duration_ms"]) / 1000.0 * 1e9)), easing=easing, should_interrupt=bool(js.get("should_interrupt", False)))
+
+
 class Converter:
     def __init__(self):
         self.input_ids = []  # input_id of every input stream component, in order of appearance
 
     def component(self, js):
-        if "transition" in js:
-            raise Unsupported("transition")
         kind = js.get("type")
         if kind == "input_stream":
             self.input_ids.append(js["input_id"])
-            return S.InputStream(len(self.input_ids) - 1)
-        kw = {}
+            return S.InputStream(len(self.input_ids) - 1, id=js.get("id"))
+        kw = {"id": js.get("id"), "transition": transition(js.get("transition"))}
         if kind == "view":
             _position(js, kw)
             _decor(js, kw)

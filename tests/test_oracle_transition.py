@@ -1,0 +1,141 @@
+"""oracle/transition.py — the reference's transition state machine restated for the oracle — pinned three ways:
+
+* the reference's own easing vectors (smelter-render/src/scene/transition/cubic_bezier.rs:136-148),
+* hand-computed mid-transition layouts of the reference's render-test scenes (arithmetic in the comments: transition.rs:88-101 with a
+  linear curve is plain interpolation in f64, cast to f32),
+* the product's C++ scene engine on EVERY scene of the corpus (tests/golden/render_test_scenes.json: 110 tests, every update and every
+  rendered pts, the 22 transition / tiles-transition tests included): two restatements of the same Rust written from the source
+  independently — the engine in C++ for the product, this one in Python for the oracle — must give the same flattened layout lists.
+tests/test_gpu_reference_scenes.py renders the oracle picture of every snapshot from this module's layouts."""
+import json
+import os
+
+import pytest
+
+from oracle import transition as T
+from smelter_amd import _ffi
+from smelter_amd.scene import Scene
+from tests import scene_json
+from tests.test_scene_engine import assert_same_layouts
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORPUS = json.load(open(os.path.join(ROOT, "tests", "golden", "render_test_scenes.json")))["tests"]
+BY_NAME = {(t["module"], t["name"]): t for t in CORPUS}
+
+
+def test_reference_easing_vectors():
+    close = lambda a, b: abs(a - b) < 1e-7  # noqa: E731  (F64Ext::is_close_to)
+    assert close(T.cubic_bezier_easing(0.0, 0.0, 0.0, 1.0, 1.0), 0.0)
+    assert close(T.cubic_bezier_easing(1.0, 0.0, 0.0, 1.0, 1.0), 1.0)
+    assert close(T.cubic_bezier_easing(0.5, 0.0, 0.0, 1.0, 1.0), 0.5)
+    assert close(T.cubic_bezier_easing(0.294, 0.25, 0.1, 0.25, 1.0), 0.5014012915764126)
+    assert close(T.cubic_bezier_easing(0.5, 0.85, 0.0, 0.15, 1.0), 0.5)
+    # bounce.rs: the four branches meet their closed forms
+    assert T.bounce_easing(0.0) == 0.0 and abs(T.bounce_easing(1.0) - 1.0) < 1e-12
+    assert abs(T.bounce_easing(1.0 / 2.75) - 1.0) < 1e-12 and abs(T.bounce_easing(1.5 / 2.75) - 0.75) < 1e-12
+
+
+def test_transition_state_machine_rules():
+    """TransitionState::new (transition.rs:39-76): a finished or absent previous transition starts a new one only when the parameters changed;
+    an unfinished one continues from its current progress over its remaining time unless the update both changes the parameters and asks to
+    interrupt."""
+    lin = T.TransitionOptions(10 * T.NS)
+    assert T.TransitionState.new(lin, None, False, False, 0) is None
+    t0 = T.TransitionState.new(lin, None, True, False, 0)
+    assert (t0.start_ns, t0.duration_ns, t0.offset_progress) == (0, 10 * T.NS, 0.0) and t0.state(5 * T.NS) == 0.5 and t0.state(20 * T.NS) == 1.0
+    # continued at 4 s without new options: 6 s left, starts at progress 0.4 of the old curve, reaches 1 at the old end
+    t1 = T.TransitionState.new(None, t0, False, False, 4 * T.NS)
+    assert (t1.start_ns, t1.duration_ns) == (4 * T.NS, 6 * T.NS) and abs(t1.offset_progress - 0.4) < 1e-15
+    assert abs(t1.state(4 * T.NS)) < 1e-15 and abs(t1.state(7 * T.NS) - 0.5) < 1e-15 and t1.state(10 * T.NS) == 1.0
+    # interrupted: a fresh transition from the current pts
+    t2 = T.TransitionState.new(T.TransitionOptions(2 * T.NS, should_interrupt=True), t0, True, True, 4 * T.NS)
+    assert (t2.start_ns, t2.duration_ns, t2.offset_progress) == (4 * T.NS, 2 * T.NS, 0.0)
+    # the previous one is over: like no previous one
+    assert T.TransitionState.new(lin, t0, False, False, 11 * T.NS) is None
+
+
+def _run(case, on_frame):
+    """Both witnesses through the test's steps.  on_frame(pts_ms, step, oracle layouts, engine (arr, n))."""
+    W, H = case["resolution"]
+    srgb = case["mode"] == "gpu_optimized"
+    mode = _ffi.MODE_GPU_OPTIMIZED if srgb else _ffi.MODE_CPU_OPTIMIZED
+    by_id = {i["id"]: (i["width"], i["height"]) for i in case["inputs"]}
+    engine, oracle, input_ids = Scene(), T.SceneState(), None
+    for step in case["steps"]:
+        if "update" in step:
+            root, input_ids = scene_json.to_oracle(step["update"])
+            oracle.update(root, W, H)
+            graph = engine.update(step["update"], W, H)
+            assert [graph[k].ref_id for k in graph[0].children] == input_ids
+            continue
+        pts_ms = step.get("snapshot_ms", step.get("render_ms"))
+        res = [by_id.get(i) for i in input_ids]
+        want = oracle.layouts(int(round(pts_ms * 1e6)), res, srgb=srgb)
+        arr, n, w, h = engine.node_layouts(0, int(round(pts_ms * 1e6)), res, mode)
+        assert (w, h) == (W, H)
+        on_frame(pts_ms, step, want, (arr, n))
+
+
+@pytest.mark.parametrize("case", CORPUS, ids=[f'{t["module"]}.{t["name"]}' for t in CORPUS])
+def test_engine_and_transition_oracle_agree_on_every_reference_scene(case):
+    frames = [0]
+
+    def check(pts_ms, step, want, got):
+        assert_same_layouts(got[0], got[1], want)
+        frames[0] += 1
+    _run(case, check)
+    assert frames[0] >= 1
+
+
+# (type, top, left, width, height) per layout, in order — worked out by hand
+KNOWN = {
+    # row root 640x360: red 50 wide | green `resize_1` 50 -> 250 over 10 s, linear | blue takes the rest.
+    # width(t) = 50 + 200 t / 10 s; blue: left = 50 + width, width = 640 - 50 - width(t)
+    ("transition", "change_view_width"): {
+        0.0: [(1, 0, 0, 50, 360), (1, 0, 50, 50, 360), (1, 0, 100, 540, 360)],
+        2500.0: [(1, 0, 0, 50, 360), (1, 0, 50, 100, 360), (1, 0, 150, 490, 360)],
+        5000.0: [(1, 0, 0, 50, 360), (1, 0, 50, 150, 360), (1, 0, 200, 440, 360)],
+        7500.0: [(1, 0, 0, 50, 360), (1, 0, 50, 200, 360), (1, 0, 250, 390, 360)],
+        9000.0: [(1, 0, 0, 50, 360), (1, 0, 50, 230, 360), (1, 0, 280, 360, 360)],
+        10000.0: [(1, 0, 0, 50, 360), (1, 0, 50, 250, 360), (1, 0, 300, 340, 360)],
+    },
+    # green view, absolute: (w, h, right, top) = (200, 200, 20, 20) -> (640, 360, 0, 0) over 10 s, linear:
+    # w = 200 + 440 s, h = 200 + 160 s, right = 20 (1 - s), top = 20 (1 - s), left = 640 - right - w
+    ("transition", "change_view_absolute"): {
+        0.0: [(1, 20, 420, 200, 200)],
+        2500.0: [(1, 15, 315, 310, 240)],
+        5000.0: [(1, 10, 210, 420, 280)],
+        7500.0: [(1, 5, 105, 530, 320)],
+        9000.0: [(1, 2, 42, 596, 344)],
+        10000.0: [(1, 0, 0, 640, 360)],
+    },
+    # the same update followed by one WITHOUT a transition and without the id: the component is new, no history -> the end state at once
+    ("transition", "change_view_width_and_send_abort_transition"): {
+        0.0: [(1, 0, 0, 50, 360), (1, 0, 50, 250, 360), (1, 0, 300, 340, 360)],
+        5000.0: [(1, 0, 0, 50, 360), (1, 0, 50, 250, 360), (1, 0, 300, 340, 360)],
+    },
+    # ... followed by one without a transition but WITH the id and the same parameters: the running transition goes on (transition.rs:50-67)
+    ("transition", "change_view_width_and_send_next_update"): {
+        2500.0: [(1, 0, 0, 50, 360), (1, 0, 50, 100, 360), (1, 0, 150, 490, 360)],
+        7500.0: [(1, 0, 0, 50, 360), (1, 0, 50, 200, 360), (1, 0, 250, 390, 360)],
+    },
+}
+
+
+@pytest.mark.parametrize("key", sorted(KNOWN), ids=[".".join(k) for k in sorted(KNOWN)])
+def test_known_mid_transition_layouts(key):
+    seen = set()
+
+    def check(pts_ms, step, want, got):
+        if pts_ms not in KNOWN[key]:
+            return
+        seen.add(pts_ms)
+        exp = KNOWN[key][pts_ms]
+        o = [(l.type, l.top, l.left, l.width, l.height) for l in want]
+        e = [(int(got[0][i].type), got[0][i].top, got[0][i].left, got[0][i].width, got[0][i].height) for i in range(got[1])]
+        for who, rec in (("oracle/transition.py", o), ("C++ scene engine", e)):
+            assert len(rec) == len(exp), (who, key, pts_ms, rec)
+            for r, x in zip(rec, exp):
+                assert r[0] == x[0] and all(abs(a - b) <= 1e-3 for a, b in zip(r[1:], x[1:])), (who, key, pts_ms, rec, exp)
+    _run(BY_NAME[key], check)
+    assert seen == set(KNOWN[key])
