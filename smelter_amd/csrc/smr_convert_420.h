@@ -14,8 +14,8 @@
 //     3/4 product of the chroma row between them;
 //   * the luma byte's range expansion (y - 16/255) / 0.8588 (correctly rounded division, clamp) is a function of the byte: a 256-entry
 //     table in LDS, built per workgroup with the operations themselves;
-//   * the two chroma range divisions are Markstein correction steps (q0 = a * RN(1/b), q = fma(fma(-q0, b, a), RN(1/b), q0): the
-//     correctly rounded quotient, smr_convert_dev.h), the clamps ride on the instructions that produce their operands.
+//   * the two chroma range divisions are a multiply and a fused multiply-add with a two-term reciprocal — the IEEE quotient on the whole
+//     domain, checked exhaustively (below); the clamps ride on the instructions that produce their operands.
 // ~46 vector instructions per pixel against k_yuv_to_rgba_batch's 70.
 #pragma once
 
@@ -73,7 +73,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int cy = min(max(2 * P - 1 + j, 0), ch - 1);
-        const u8 *ur = J.up.ptr + (u32)cy * J.up.pitch + base;
+        const u8 *ur = J.up.ptr + ((u32)cy * J.up.pitch + (u32)base);  // (one 32-bit offset from a uniform base: a plane is far below 4 GiB)
         u32 uw, vw;
         if (NV) {
             const u32 d0 = *(const u32 *)ur, d1 = *(const u32 *)(ur + 4), d2 = *(const u32 *)(ur + 8);
@@ -81,7 +81,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
             uw = cv_perm(w1, w0, 0x06040200u);
             vw = cv_perm(w1, w0, 0x07050301u);
         } else {
-            const u8 *vr = J.vp.ptr + (u32)cy * J.vp.pitch + base;
+            const u8 *vr = J.vp.ptr + ((u32)cy * J.vp.pitch + (u32)base);
             uw = cv_alignbyte(*(const u32 *)(ur + 4), *(const u32 *)ur, sh);
             vw = cv_alignbyte(*(const u32 *)(vr + 4), *(const u32 *)vr, sh);
         }
@@ -105,14 +105,17 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
     }
     // ---- the four luma rows: row 4 P + r takes chroma window rows (0, 1) with fy = .75, (1, 2) with .25, (1, 2) with .75, (2, 3) with .25
     //      — top * (1 - fy) + bot * fy: the 3/4 product of window row 1 serves luma rows 0 and 1, that of row 2 serves rows 2 and 3
+    // (c - 16/255) / 0.8784 as RN(a * y_hi + RN(a * y_lo)) with y_hi + y_lo = 1 / 0.8784 to 48 bits: the IEEE quotient for EVERY f32 a in
+    // [-16/255, 1] — all 636 524 221 of them checked against the division (tools/check_div_by_constant.py), as unorm_of_byte's form is
+    // for the 256 bytes.  One multiply and one fused multiply-add.
     constexpr float kc = 0.87843137254f;
-    const float rc = 1.0f / kc;
+    constexpr float rc_hi = 1.0f / kc, rc_lo = (float)(1.0 / (double)kc - (double)rc_hi);
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = 4 * P + r;
         if (y >= h) break;
         const int j34 = r < 2 ? 1 : 2, j14 = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-        const u32 y4 = *(const u32 *)(J.yp.ptr + (u32)y * J.yp.pitch + 4u * (u32)g);
+        const u32 y4 = *(const u32 *)(J.yp.ptr + ((u32)y * J.yp.pitch + 4u * (u32)g));
         u32 px[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -121,9 +124,8 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
             const float yy = ylut[(y4 >> (8 * i)) & 0xffu];
             if (!full) {  // planar_yuv_to_rgba.wgsl:47-48: (c - 16/255) / 0.8784, clamp
                 const float au = u - (16.0f / 255.0f), av = v - (16.0f / 255.0f);
-                const float qu = au * rc, qv = av * rc;
-                u = cv_clamp01(__builtin_fmaf(__builtin_fmaf(-qu, kc, au), rc, qu));
-                v = cv_clamp01(__builtin_fmaf(__builtin_fmaf(-qv, kc, av), rc, qv));
+                u = cv_clamp01(__builtin_fmaf(au, rc_hi, au * rc_lo));
+                v = cv_clamp01(__builtin_fmaf(av, rc_hi, av * rc_lo));
             }
             const float um = u - 0.5f, vm = v - 0.5f;
             const float R = yy + 1.5748f * vm;
@@ -134,7 +136,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
             const u32 b8 = (u32)(int)(cv_clamp01(B) * 255.0f + 0.5f);
             px[i] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
         }
-        *(uint4 *)(J.dst.ptr + (u32)y * J.dst.pitch + 16u * (u32)g) = make_uint4(px[0], px[1], px[2], px[3]);
+        *(uint4 *)(J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g)) = make_uint4(px[0], px[1], px[2], px[3]);
     }
 }
 
