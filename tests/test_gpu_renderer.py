@@ -172,13 +172,16 @@ def test_transition_animates_between_updates(ctx, hip, renderer):
     assert not (a[0] == mid[0]).all()
 
 
-def test_animated_grid_with_blur_layer_matches_the_oracle_mid_transition(ctx, hip, renderer):
-    """BASELINE configs[4] at a quarter of its size: 16 inputs in a Tiles grid that is half way through a transition (tiles at
-    fractional positions: bilinear-sampled, not copy tiles) plus a layer through the gaussian-blur shader.  The frame is compared
-    with the oracle's pass sequence run on the layout lists the scene engine produces for the same pts."""
+@pytest.mark.parametrize("size", ["quarter", "full"])
+def test_animated_grid_with_blur_layer_matches_the_oracle_mid_transition(ctx, hip, renderer, size):
+    """BASELINE configs[4] — at a quarter of its size and at FULL size (16 x 1920x1080 -> 3840x2160, 960x540 blur layer: what bench.py
+    --config 4 runs): 16 inputs in a Tiles grid that is 40 % through a transition (tiles at fractional positions: bilinear-sampled, not
+    copy tiles) plus a layer through the gaussian-blur shader.  The frame is compared with the oracle's pass sequence (OpenMP build at
+    full size) run on the layout lists the scene engine produces for the same pts: <= 1 LSB."""
     from smelter_amd import synth
     from smelter_amd.scene import Scene
-    iw, ih, W, H, n, lw, lh = 480, 270, 960, 540, 16, 240, 136
+    iw, ih, W, H, n, lw, lh = (480, 270, 960, 540, 16, 240, 136) if size == "quarter" else (1920, 1080, 3840, 2160, 16, 960, 540)
+    omp = size == "full"
     planes, frames = _frames(ctx, hip, n, iw, ih)
     frames = {f"input_{i}": frames[f"in{i}"] for i in range(n)}
     for k in frames:
@@ -200,16 +203,61 @@ def test_animated_grid_with_blur_layer_matches_the_oracle_mid_transition(ctx, hi
     root_kids = list(nodes[0].children)
     shader = root_kids[-1]
     inner = list(nodes[shader].children)[0]
-    rgba = [orc.planar_yuv_to_rgba(*p, iw, ih) for p in planes]
-    inner_px = refpipe.layout_node_render(sc.layouts(inner, int(t * 1e9), [(iw, ih)]), [rgba[0]], lw, lh)
+    rgba = [orc.planar_yuv_to_rgba(*p, iw, ih, omp=omp) for p in planes]
+    inner_px = refpipe.layout_node_render(sc.layouts(inner, int(t * 1e9), [(iw, ih)]), [rgba[0]], lw, lh, omp=omp)
     layer = orc.gaussian_blur(inner_px, 3.0)
     root_layouts = sc.layouts(0, int(t * 1e9), res)
     moving = [L for L in root_layouts if L.type == 0 and (L.left != round(L.left) or L.top != round(L.top))]
     assert len(moving) >= 8                              # really mid-flight
     order = [(i + 3) % n for i in range(n)]              # child k of the grid shows input order[k]
-    want, _ = refpipe.render_yuv420(root_layouts, [rgba[i] for i in order] + [layer], W, H)
+    want, _ = refpipe.render_yuv420(root_layouts, [rgba[i] for i in order] + [layer], W, H, omp=omp)
     for g, w_ in zip(got, want):
         assert refpipe.max_diff(g, w_) <= 1 and refpipe.exact_fraction(g, w_) >= 0.99
+    for f in frames.values():
+        f.destroy()
+
+
+def test_configs0_two_720p_packed_rgba_inputs_static_view_cpu_optimized_is_bit_exact(hip):
+    """BASELINE configs[0] — the integration-tests plumbing scene (pixel_input_format_tests.rs:30-150 at 720p): two 1280x720 inputs handed
+    over as FrameData::Bgra / FrameData::Argb bytes, a static View, RenderingMode::CpuOptimized, RGBA output.  Integer work end to end
+    (byte swizzle, 1:1 texel-aligned blit over a transparent background, RGBA texture out): every byte equal to the oracle's pass sequence,
+    and the visible part of either input equal to the reference's swizzle of its bytes ([3, 2, 1, 4] / [4, 1, 2, 3] for [1, 2, 3, 4])."""
+    from oracle import scene as S
+    from smelter_amd.renderer import Renderer
+    from tests import scene_json
+    w, h, W, H = 1280, 720, 1280, 720
+    rng = np.random.default_rng(720)
+    data = [rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for _ in range(2)]
+    data[0][: h // 2, :, 3] = 255  # (BGRA: alpha is byte 3 — the upper half opaque, the rest arbitrary, taken as premultiplied: bgra_to_rgba.wgsl:26-27)
+    data[1][: h // 2, :, 2] = 255  # (ARGB: the reference's swizzle is [x3, x0, x1, x2] — byte 2 ends up as alpha, pixel_input_format_tests.rs:133-135)
+    scene = {"type": "view", "children": [
+        {"type": "view", "width": 640.0, "children": [{"type": "input_stream", "input_id": "bgra"}]},
+        {"type": "view", "width": 640.0, "children": [{"type": "input_stream", "input_id": "argb"}]}]}
+    c = hip.Context(0, mode=hip.MODE_CPU_OPTIMIZED)
+    r = Renderer(c)
+    try:
+        frames = {"bgra": c.frame(hip.FRAME_BGRA, w, h, [data[0]]), "argb": c.frame(hip.FRAME_ARGB, w, h, [data[1]])}
+        for k in frames:
+            r.register_input(k)
+        r.update_scene("out", W, H, scene, output_format=hip.FRAME_RGBA)
+        got = r.render(0.0, frames)["out"].download()
+        got = got[0] if isinstance(got, (list, tuple)) else got
+        got = np.asarray(got).reshape(H, W, 4)
+        nodes = [orc.swizzle_to_rgba(data[0], w, h, 0), orc.swizzle_to_rgba(data[1], w, h, 1)]
+        assert np.array_equal(nodes[0][0, 0], data[0][0, 0][[2, 1, 0, 3]]) and np.array_equal(nodes[1][0, 0], data[1][0, 0][[3, 0, 1, 2]])
+        root, ids = scene_json.to_oracle(scene)
+        assert ids == ["bgra", "argb"]
+        layouts = S.scene_layouts(root, W, H, [(w, h), (w, h)], srgb=False)
+        want = refpipe.layout_node_render(layouts, nodes, W, H, srgb=False, omp=True)
+        assert np.array_equal(got, want), int((got != want).sum())
+        # ... and the blit is the swizzled bytes themselves where a texel is opaque (premultiplied OVER a transparent background adds nothing)
+        for half, node in ((slice(0, 640), nodes[0]), (slice(640, 1280), nodes[1])):
+            vis = node[:, 0:640]
+            opaque = vis[..., 3] == 255
+            assert np.array_equal(got[:, half][opaque], vis[opaque])
+    finally:
+        r.close()
+        c.close()
 
 
 def test_frames_in_flight_share_one_scene_state(ctx, hip, renderer):
