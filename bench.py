@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 IN_W, IN_H, OUT_W, OUT_H, N_IN = 1920, 1080, 3840, 2160, 8
-RING = 12  # distinct input frame sets cycled through, 12 x 24.9 MB > the 256 MB Infinity Cache
+RING = int(os.environ.get("SMR_BENCH_RING", "12"))  # distinct input frame sets cycled through, 12 x 24.9 MB > the 256 MB Infinity Cache (the env: diagnostics only)
 
 
 def yuv420_bytes(w, h):

@@ -195,7 +195,12 @@ typedef enum smr_ingest_impl {
  *                              block converters are held to these bit for bit; SMR_CONVERT_GENERAL=1 in the environment selects it at creation)
  *       SMR_CONVERT_BLOCK_4X2  k_yuv_to_rgba_batch for 4:2:0 frames too (round 3's converter; A/B) */
 typedef enum smr_convert_impl { SMR_CONVERT_AUTO = 0, SMR_CONVERT_GENERAL = 1, SMR_CONVERT_BLOCK_4X2 = 2 } smr_convert_impl;
-typedef enum smr_option { SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3 } smr_option;
+/*   SMR_OPT_COMPACT_NODES       1 (default): the node texture of a 4:2:0 frame that only the matrix-core resampler reads is written as RGB12 — 12 bytes
+ *                               per four pixels (R x 4, G x 4, B x 4; alpha is 1 for every Y'CbCr frame and is not stored): a quarter less traffic on
+ *                               either side of the intermediate the default route is bound by; 0: always RGBA8.  Same codes, same tiles bit for bit. */
+typedef enum smr_option {
+    SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3, SMR_OPT_COMPACT_NODES = 4
+} smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
 SMR_API int smr_timer_stop(smr_ctx *ctx, float *ms); /* records, synchronises, returns elapsed ms */

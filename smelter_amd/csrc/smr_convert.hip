@@ -461,14 +461,20 @@ static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) {
     return in->planes[0]->pitch >= in->width;
 }
 
+bool smr_conv_rgb12_ok(const smr_ctx *ctx, const smr_frame *in) { return in && conv_420_ok(ctx, in) && 3u * in->width <= 7682u * 2u; }
+
 // smr_frame_to_rgba for several frames: one launch for every 16 frames of a kind (k_yuv420_to_rgba planar / NV12, k_yuv_to_rgba_batch), the
 // others one by one.  Everything queued is launched before the call returns, errors included.
-int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n) {
+int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n, const u8 *rgb12) {
     if (!ctx || (n && (!in || !nodes))) return SMR_ERR_INVALID;
     // validate first, enqueue afterwards: no frame is left half-queued by a bad one behind it
     for (u32 i = 0; i < n; i++) {
         if (!in[i] || !nodes[i]) return SMR_ERR_INVALID;
-        if (nodes[i]->fmt != SMR_PX_RGBA8 || nodes[i]->w != in[i]->width || nodes[i]->h != in[i]->height)
+        if (rgb12 && rgb12[i]) {
+            if (nodes[i]->fmt != SMR_PX_R8 || nodes[i]->w != 3 * in[i]->width || nodes[i]->h != in[i]->height || (nodes[i]->pitch & 3u) || (((uintptr_t)nodes[i]->ptr) & 3) ||
+                !conv_420_ok(ctx, in[i]))
+                return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: an RGB12 node must be R8 %ux%u of a 4:2:0 frame the block converter takes", 3 * in[i]->width, in[i]->height);
+        } else if (nodes[i]->fmt != SMR_PX_RGBA8 || nodes[i]->w != in[i]->width || nodes[i]->h != in[i]->height)
             return smr_fail(ctx, SMR_ERR_INVALID, "smr_frame_to_rgba: node surface must be RGBA8 %ux%u", in[i]->width, in[i]->height);
         if (int rc = smr_validate_frame(ctx, in[i], "smr_frame_to_rgba")) return rc;
     }
@@ -497,7 +503,8 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         return rc;
     };
     for (u32 i = 0; i < n; i++) {
-        const bool aligned16 = (((uintptr_t)nodes[i]->ptr) & 15) == 0 && (nodes[i]->pitch & 15u) == 0;  // (the block kernels store 16 B)
+        const bool c12 = rgb12 && rgb12[i];
+        const bool aligned16 = c12 || ((((uintptr_t)nodes[i]->ptr) & 15) == 0 && (nodes[i]->pitch & 15u) == 0);  // (the block kernels store 16 B)
         const bool nv = in[i]->format == SMR_FRAME_NV12;
         const int k = !aligned16 ? -1 : conv_420_ok(ctx, in[i]) ? (nv ? 2 : 1) : conv_batchable(ctx, in[i]) ? 0 : -1;
         if (k < 0) {
@@ -515,6 +522,8 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         J.vp = packed || nv ? J.up : view_of(in[i]->planes[2]);
         J.packed = in[i]->format == SMR_FRAME_UYVY422 ? 1 : in[i]->format == SMR_FRAME_YUYV422 ? 2 : in[i]->format == SMR_FRAME_BGRA ? 3 : in[i]->format == SMR_FRAME_ARGB ? 4 : 0;
         J.dst = view_of(nodes[i]);
+        J.rgb12 = c12 ? 1 : 0;
+        if (c12) J.dst.w = (int)in[i]->width;  // (in pixels: the kernel's geometry; the rows hold 3 w bytes)
         J.full = in[i]->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
         J.nv = nv ? 1 : 0;
         J.sx = in[i]->format != SMR_FRAME_PLANAR_YUV444 ? 1 : 0;

@@ -16,7 +16,13 @@
 //     table in LDS, built per workgroup with the operations themselves;
 //   * the two chroma range divisions are a multiply and a fused multiply-add with a two-term reciprocal — the IEEE quotient on the whole
 //     domain, checked exhaustively (below); the clamps ride on the instructions that produce their operands.
-// ~46 vector instructions per pixel against k_yuv_to_rgba_batch's 70.
+// ~40 vector instructions per pixel against k_yuv_to_rgba_batch's 70.
+//
+// Output: the RGBA8 node texture (16 bytes per thread and row) or — ConvJob::rgb12, for node textures that only the matrix-core resampler
+// reads — 12 bytes per four pixels: R0 R1 R2 R3 G0 G1 G2 G3 B0 B1 B2 B3 (alpha is 1 for every Y'CbCr frame, planar_yuv_to_rgba.wgsl:57, and
+// is not stored).  The route is bound by the traffic of its intermediates (profiles/r04_wave_ablation.txt): a quarter less to write here
+// and to read there, and a lane of the resampler still fetches its four texels with ONE load (three planes needed three: slower,
+// profiles/r04_planar_nodes.txt).
 #pragma once
 
 #include "smr_convert_dev.h"
@@ -35,6 +41,7 @@ struct ConvJob {
     SurfView yp, up, vp, dst;
     int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
     int sx, sy;    // chroma subsampling: 4:2:0 = (1, 1), 4:2:2 = (1, 0), 4:4:4 = (0, 0)
+    int rgb12;     // k_yuv420_to_rgba only: dst is an R8 surface of 3 w x h — the node texture as 12-byte groups of four pixels (R x 4, G x 4, B x 4)
     int packed;    // 0 planar / NV12 | 1 UYVY | 2 YUYV: `yp` is the (w / 2) x h plane of U Y0 V Y1 / Y0 U Y1 V groups | 3 BGRA | 4 ARGB: `yp` is the w x h plane, bytes permuted (bgra_to_rgba.wgsl / argb_to_rgba.wgsl:24-28)
 };
 constexpr int MAX_CONV_JOBS = 16;
@@ -116,7 +123,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
         if (y >= h) break;
         const int j34 = r < 2 ? 1 : 2, j14 = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
         const u32 y4 = *(const u32 *)(J.yp.ptr + ((u32)y * J.yp.pitch + 4u * (u32)g));
-        u32 px[4];
+        u32 px[4], r4 = 0u, g4 = 0u, b4 = 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             float u = __builtin_fmaf(H[0][j14][i], 0.25f, H[0][j34][i] * 0.75f);
@@ -135,8 +142,14 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
             const u32 g8 = (u32)(int)(cv_clamp01(G) * 255.0f + 0.5f);
             const u32 b8 = (u32)(int)(cv_clamp01(B) * 255.0f + 0.5f);
             px[i] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+            r4 |= r8 << (8 * i); g4 |= g8 << (8 * i); b4 |= b8 << (8 * i);
         }
-        *(uint4 *)(J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g)) = make_uint4(px[0], px[1], px[2], px[3]);
+        if (J.rgb12) {  // (uniform)
+            u32 *d = (u32 *)(J.dst.ptr + ((u32)y * J.dst.pitch + 12u * (u32)g));
+            d[0] = r4; d[1] = g4; d[2] = b4;
+        } else {
+            *(uint4 *)(J.dst.ptr + ((u32)y * J.dst.pitch + 16u * (u32)g)) = make_uint4(px[0], px[1], px[2], px[3]);
+        }
     }
 }
 

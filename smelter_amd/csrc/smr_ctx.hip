@@ -163,6 +163,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     }
     if (const char *e = getenv("SMR_CONVERT_GENERAL")) ctx->convert_impl = (e[0] && e[0] != '0') ? SMR_CONVERT_GENERAL : SMR_CONVERT_AUTO;  // (read once: tools)
     if (const char *e = getenv("SMR_CONVERT_LDS_PAD")) ctx->convert_lds_pad = (u32)atoi(e);
+    if (const char *e = getenv("SMR_COMPACT_NODES")) ctx->compact_nodes = atoi(e) != 0;  // (tools / A-B)
     if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
@@ -229,6 +230,9 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     case SMR_OPT_CONVERT_IMPL:
         if (value < 0 || value > SMR_CONVERT_BLOCK_4X2) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown converter implementation %d", value);
         ctx->convert_impl = (u32)value;
+        return SMR_OK;
+    case SMR_OPT_COMPACT_NODES:
+        ctx->compact_nodes = value != 0;
         return SMR_OK;
     case SMR_OPT_DIRECT_OUTPUT:
         ctx->direct_output = value != 0;

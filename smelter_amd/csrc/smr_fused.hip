@@ -45,6 +45,30 @@ bool frame_is_opaque(u32 fmt) { return fmt <= SMR_FRAME_NV12; }
 constexpr size_t SLOT_TARGET = SMR_SLOT_TARGET, SLOT_INGEST_NODE = SMR_SLOT_INGEST_NODE, SLOT_NODE0 = SMR_SLOT_NODE0, SLOT_TILE0 = SMR_SLOT_TILE0,
                  SLOT_TRANSPOSED0 = SMR_SLOT_TRANSPOSED0, SLOT_TRANSPOSED_SINGLE = SMR_SLOT_TRANSPOSED_SINGLE, SLOT_REDUCED0 = SMR_SLOT_REDUCED0;
 
+// An RGB12 node texture (12 bytes per four pixels: smr_convert_420.h) serves a layout when the frame is one k_yuv420_to_rgba takes and the plan
+// is a plain two-pass, horizontal-first one within the kernel's pair windows — every input of the benchmark scenes.
+bool rgb12_node_serves(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
+    if (!ctx->compact_nodes || !smr_conv_rgb12_ok(ctx, f)) return false;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
+    SurfView probe;  // (the geometry test needs the node's size, not its pixels)
+    probe.ptr = nullptr; probe.pitch = (3u * f->width + 255u) & ~255u; probe.w = (int)f->width; probe.h = (int)f->height;
+    bool single = false;
+    if (!can_fuse_wave_rgba(ctx, probe, plan, tile, 3, &single) || single) return false;
+    // ... and only where it was measured to pay: the two class builds (scales around 1.5 and around 3 — configs[2] 59.6 -> 58.1 us of converter +
+    // resampler per frame, configs[3] 189 -> 167 us); the generic build is slower on RGB12 (configs[1] 29.0 -> 31.7 us), profiles/r04_rgb12.txt
+    int NKS, KV, unused;
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2)) NKS = t->K;
+    else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &NKS, &unused);
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3)) KV = t->K;
+    else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3, &KV, &unused);
+    return (NKS <= 4 && KV == 2) || (NKS <= 8 && KV == 3);
+}
+SurfView rgb12_view(const smr_surface *node, const smr_frame *f) {  // the node in pixels; its rows hold 3 w bytes
+    SurfView v = view_of(node);
+    v.w = (int)f->width;
+    return v;
+}
+
 }  // namespace
 
 extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint32_t n, const smr_source *sources,
@@ -92,6 +116,21 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     //  the first kernel that reads a node texture: flush_nodes)
     std::vector<const smr_frame *> conv_in;
     std::vector<smr_surface *> conv_node;
+    std::vector<u8> conv_rgb12;
+    std::vector<SurfView> cviews(n_sources + 1);   // RGB12 node textures, for the matrix-core resampler only
+    std::vector<u8> cnode_ready(n_sources + 1, 0);
+    auto ensure_rgb12_node = [&](u32 i) -> int {
+        if (cnode_ready[i]) return SMR_OK;
+        const smr_frame *f = sources[i].frame;
+        smr_surface *node = smr_cached_surface(ctx, SMR_SLOT_NODE_RGB12_0 + i, 3 * f->width, f->height, SMR_PX_R8);
+        if (!node) return SMR_ERR_OOM;
+        conv_in.push_back(f);
+        conv_node.push_back(node);
+        conv_rgb12.push_back(1);
+        cviews[i] = rgb12_view(node, f);
+        cnode_ready[i] = 1;
+        return SMR_OK;
+    };
     auto ensure_node = [&](u32 i) -> int {
         if (node_ready[i]) return SMR_OK;
         const smr_frame *f = sources[i].frame;
@@ -99,23 +138,25 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         if (!node) return SMR_ERR_OOM;
         conv_in.push_back(f);
         conv_node.push_back(node);
+        conv_rgb12.push_back(0);
         views[i] = view_of(node);
         node_ready[i] = 1;
         return SMR_OK;
     };
     auto flush_nodes = [&]() -> int {
         if (conv_in.empty()) return SMR_OK;
-        int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size());
+        int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size(), conv_rgb12.data());
         conv_in.clear();
         conv_node.clear();
+        conv_rgb12.clear();
         return rc;
     };
 
     // ---- resample_scaled_children (layout.rs:238-278): per texture layout decide direct / general / fused
     std::vector<smr_layout> eff(layouts, layouts + n);
     std::vector<IngestJob> jobs;
-    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_f16_alpha, wjobs_sa, wjobs_sa_rgba, wjobs_sa_rgba_alpha;
-    std::vector<u32> wjob_layout, wjob_rgba_layout;  // layout index of each job (direct output)
+    std::vector<WJob> wjobs, wjobs_rgb12, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_f16_alpha, wjobs_sa, wjobs_sa_rgba, wjobs_sa_rgba_alpha;
+    std::vector<u32> wjob_layout, wjob_rgb12_layout, wjob_rgba_layout;  // layout index of each job (direct output)
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
     u32 next_view = n_sources;
@@ -206,7 +247,17 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     // (kinds 1: the node has an alpha channel — the four-channel builds)
                     std::vector<WJob> &rgba_jobs = kinds[si] == 2 ? wjobs_rgba : wjobs_rgba_alpha;
                     std::vector<WJob> &f16_jobs = kinds[si] == 2 ? wjobs_f16 : wjobs_f16_alpha;
-                    if (is_frame && !node_ready[si]) {
+                    if (is_frame && kinds[si] == 2 && rgb12_node_serves(ctx, sources[si].frame, plan, tile)) {
+                        // the default route of a 4:2:0 frame: exact converter -> RGB12 node -> the matrix-core kernel
+                        int rc = ensure_rgb12_node(si);
+                        if (rc != SMR_OK) return rc;
+                        WJob J;
+                        rc = make_wave_job_rgba(ctx, cviews[si], plan, tile, &J, false, true);
+                        if (rc != SMR_OK) return rc;
+                        wjobs_rgb12.push_back(J); wjob_rgb12_layout.push_back(li);
+                        on_mfma = true;
+                    }
+                    if (!on_mfma && is_frame && !node_ready[si]) {
                         // (only convert when the kernel will take the job: the geometry test needs the node's size, not its pixels)
                         SurfView probe;
                         probe.ptr = nullptr; probe.pitch = ((u32)src_w[si] * 4u + 255u) & ~255u; probe.w = src_w[si]; probe.h = src_h[si];
@@ -217,7 +268,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                         }
                     }
                     bool single = false;
-                    if (node_ready[si] && can_fuse_wave_rgba(ctx, views[si], plan, tile, 4, &single)) {
+                    if (!on_mfma && node_ready[si] && can_fuse_wave_rgba(ctx, views[si], plan, tile, 4, &single)) {
                         WJob J;
                         int rc = make_wave_job_rgba(ctx, views[si], plan, tile, &J, single);
                         if (rc != SMR_OK) return rc;
@@ -382,6 +433,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 }
             };
             mark(wjobs, wjob_layout);
+            mark(wjobs_rgb12, wjob_rgb12_layout);
             mark(wjobs_rgba, wjob_rgba_layout);
         }
 #endif
@@ -426,7 +478,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         cm->last_use = ctx->class_clock;
         if (ctx->debug_ingest)
             fprintf(stderr, "[smr] tile classes: %s; direct output: layer mask %llx of %zu resampled tiles\n", classify_now ? "classifying" : "cached",
-                    direct_mask, wjobs.size() + wjobs_rgba.size());
+                    direct_mask, wjobs.size() + wjobs_rgb12.size() + wjobs_rgba.size());
         if (direct_mask) {
             direct.cls = cm->d_direct;
             direct.tiles_x = (int)b_tiles_x;
@@ -463,6 +515,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     // ---- wave A (job descriptors ride in the kernel arguments)
     if (!wjobs.empty()) {
         rc = launch_wave(ctx, wjobs, direct_dev);
+        if (rc != SMR_OK) return rc;
+    }
+    if (!wjobs_rgb12.empty()) {
+        rc = launch_wave(ctx, wjobs_rgb12, direct_dev, true, false, false, false, true);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_rgba.empty()) {
@@ -587,6 +643,18 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
     }
     // the exact converter into the node texture, then the matrix-core kernel on it (every Y'CbCr format; two-pass plans within the kernel's
     // windows, either pass order)
+    if (!fused_disabled(ctx) && ctx->ingest_impl != SMR_INGEST_VALU_F32 && rgb12_node_serves(ctx, in, plan, dst)) {
+        smr_surface *cnode = smr_cached_surface(ctx, SMR_SLOT_INGEST_NODE_RGB12, 3 * in->width, in->height, SMR_PX_R8);
+        if (!cnode) return SMR_ERR_OOM;
+        const u8 one = 1;
+        int rc = smr_frames_to_rgba_batch(ctx, &in, &cnode, 1, &one);
+        if (rc != SMR_OK) return rc;
+        std::vector<WJob> wjobs(1);
+        rc = make_wave_job_rgba(ctx, rgb12_view(cnode, in), plan, dst, &wjobs[0], false, true);
+        if (rc != SMR_OK) return rc;
+        rc = launch_wave(ctx, wjobs, nullptr, true, false, false, false, true);
+        return rc == SMR_OK ? kind : rc;
+    }
     if (!fused_disabled(ctx) && in->format <= SMR_FRAME_NV12 && ctx->ingest_impl != SMR_INGEST_VALU_F32) {
         smr_surface *node = smr_cached_surface(ctx, SLOT_INGEST_NODE, in->width, in->height, SMR_PX_RGBA8);
         if (!node) return SMR_ERR_OOM;
@@ -645,9 +713,10 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
     if (n > 1024) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: too many inputs");
     std::vector<IngestJob> jobs;
-    std::vector<WJob> wjobs, wjobs_rgba;
+    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgb12;
     std::vector<const smr_frame *> conv_in;
     std::vector<smr_surface *> conv_node;
+    std::vector<u8> conv_rgb12;
     ++ctx->weight_call;
     for (uint32_t i = 0; i < n; i++) {
         if (!in[i] || !dst[i] || dst[i]->fmt != SMR_PX_RGBA8) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: bad input %u", i);
@@ -666,6 +735,18 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
             wjobs.push_back(J);
             continue;
         }
+        if (fused && !fused_conversion(ctx) && ctx->ingest_impl != SMR_INGEST_VALU_F32 && rgb12_node_serves(ctx, in[i], plan, dst[i])) {
+            smr_surface *cnode = smr_cached_surface(ctx, SMR_SLOT_NODE_RGB12_0 + i, 3 * in[i]->width, in[i]->height, SMR_PX_R8);
+            if (!cnode) return SMR_ERR_OOM;
+            WJob J;
+            int rc = make_wave_job_rgba(ctx, rgb12_view(cnode, in[i]), plan, dst[i], &J, false, true);
+            if (rc != SMR_OK) return rc;
+            conv_in.push_back(in[i]);
+            conv_node.push_back(cnode);
+            conv_rgb12.push_back(1);
+            wjobs_rgb12.push_back(J);
+            continue;
+        }
         if (fused && !fused_conversion(ctx) && ctx->ingest_impl != SMR_INGEST_VALU_F32 && in[i]->format <= SMR_FRAME_NV12) {
             SurfView probe;  // (the geometry test needs the node's size, not its pixels)
             probe.ptr = nullptr; probe.pitch = (in[i]->width * 4u + 255u) & ~255u; probe.w = (int)in[i]->width; probe.h = (int)in[i]->height;
@@ -679,6 +760,7 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
                     if (rc != SMR_OK) return rc;
                     conv_in.push_back(in[i]);
                     conv_node.push_back(node);
+                    conv_rgb12.push_back(0);
                     wjobs_rgba.push_back(J);
                     continue;
                 }
@@ -695,7 +777,9 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         }
     }
     if (!conv_in.empty()) {
-        int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size());
+        int rc = smr_frames_to_rgba_batch(ctx, conv_in.data(), conv_node.data(), (u32)conv_in.size(), conv_rgb12.data());
+        if (rc != SMR_OK) return rc;
+        if (!wjobs_rgb12.empty()) rc = launch_wave(ctx, wjobs_rgb12, nullptr, true, false, false, false, true);
         if (rc != SMR_OK) return rc;
         if (!wjobs_rgba.empty()) rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
         if (rc != SMR_OK) return rc;

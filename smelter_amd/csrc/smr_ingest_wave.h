@@ -29,7 +29,9 @@
 // in FL: 1 two always-zero fragments skipped | 2048 direct output | 4096 NV12-capable staging | 8192 the source is an RGBA8 node
 // texture (16-byte loads straight into the conversion layout, decode table only: 4:2:2 / 4:4:4 / packed YUV after the exact
 // converter, opaque surfaces) | + 16384 that texture is RGBA16F, linear light (box-pre-reduced plans) | + 65536 it has an alpha
-// channel (four channels) | 32768 single-axis plan: pass 1's f32 sums are encoded and stored directly (no f16 rounding, no pass 2).
+// channel (four channels) | 32768 single-axis plan: pass 1's f32 sums are encoded and stored directly (no f16 rounding, no pass 2) |
+// + 131072 (with 8192) the node texture is RGB12: 12 bytes per four pixels, R x 4, G x 4, B x 4 (what k_yuv420_to_rgba writes for nodes only
+// this kernel reads: alpha is 1 everywhere and not stored) — one 12-byte load per lane and k-step instead of 16.
 //
 // Work split: a workgroup = W_WAVES waves on the same column pair (they share its pass-1 band in LDS), each with its own vertical
 // piece; workgroups are ordered pair-fastest within a band of rows, so neighbouring pairs read the same source lines at the same
@@ -368,6 +370,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // 16384 (with 8192): that node texture is RGBA16F in linear light — what the box pre-reduction of a plan with shrink factors from 4
     // leaves (resampler.rs: downsample.wgsl into an Rgba16Float texture): the f16 texels ARE the operand's hi halves, lo = 0.
     constexpr bool RG = (FL & 8192) != 0, RH = RG && (FL & 16384) != 0;
+    // 131072 (with 8192): the node texture as 12-byte groups of four pixels (smr_convert_420.h rgb12): lane (m, q) loads the group of texels
+    // 4 q .. 4 q + 3 — a dword per channel
+    constexpr bool RP = RG && !RH && (FL & 131072) != 0;
+    static_assert(!RP || !(FL & 65536), "RGB12 nodes carry no alpha");
 
     // 32768: a single-axis plan (ResampledChild with one pass, resampler.rs:123-145 — only the width changes): pass 1's f32 sums are
     // encoded and stored as they are, row for row; there is no f16 rounding and no pass 2.  The job's vertical band (scale 1) only
@@ -518,6 +524,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             rg2[RH ? (j < RG_N ? j : 0) : 0] = t2;
             return t;
         }
+        if (RP) {
+            const u32 *p = (const u32 *)(y_ptr + dev_mad24(row, y_pitch, 3u * col));  // (col is a multiple of 4: group col / 4 at byte 12 (col / 4))
+            return make_uint4(p[0], p[1], p[2], 0u);
+        }
         return *(const uint4 *)(y_ptr + dev_mad24(row, y_pitch, 4u * col));
     };
     // ... and its texel bytes -> decode table (entries 256 .. 511 of the LUT are the codes themselves)
@@ -533,8 +543,25 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
         const u32 px[4] = {t.x, t.y, t.z, t.w};
         u32 o[4][4];
+        if (RP) {  // px[ch] = the four texels of channel ch
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                o[ch][0] = dev_lds_u32(((px[ch] << 2) & 0x3fcu) + 1024u);
+                o[ch][1] = dev_lds_u32(((px[ch] >> 6) & 0x3fcu) + 1024u);
+                o[ch][2] = dev_lds_u32(((px[ch] >> 14) & 0x3fcu) + 1024u);
+                o[ch][3] = dev_lds_u32(((px[ch] >> 22) & 0x3fcu) + 1024u);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+            if (SMR_WAVE_ABL & 1) {  // profiling: no table gathers
+                o[0][k] = ((px[k] << 2) & 0x3fcu) + 1024u; o[1][k] = ((px[k] >> 6) & 0x3fcu) + 1024u; o[2][k] = ((px[k] >> 14) & 0x3fcu) + 1024u;
+                if (AL) o[3][k] = (px[k] >> 22) & 0x3fcu;
+                continue;
+            }
             o[0][k] = dev_lds_u32(((px[k] << 2) & 0x3fcu) + 1024u);
             o[1][k] = dev_lds_u32(((px[k] >> 6) & 0x3fcu) + 1024u);
             o[2][k] = dev_lds_u32(((px[k] >> 14) & 0x3fcu) + 1024u);
@@ -666,6 +693,13 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 m_convert_px<(SMR_WAVE_ABL & 1) != 0>(K, r.yy, ua, ub, va, vb, w13, w31, a);  // (ABL & 1: profiling, no table gathers)
             };
             auto mfmas = [&](int j, const uint4 (&a)[4], const uint4 (&bq)[2][2]) {
+                if (SMR_WAVE_ABL & 2) {  // profiling: no pass-1 MFMAs (the operands stay alive)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        acc[0][ch][0] += __uint_as_float(a[ch].x ^ a[ch].y ^ bq[0][0].x); acc[W_NTI - 1][ch][1] += __uint_as_float(a[ch].z ^ a[ch].w ^ bq[W_NTI - 1][1].y);
+                    }
+                    return;
+                }
 #if SMR_WAVE_SETPRIO
                 __builtin_amdgcn_s_setprio(SMR_WAVE_SETPRIO);
 #endif
@@ -836,68 +870,83 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #ifndef SMR_EMU
             if (decltype(first_of_chunk)::value) asm volatile("; first tile row of the chunk");  // (keeps the two copies from being merged back)
 #endif
+            // pass 2 of BOTH tiles first, then the next tile row's weights are requested (the registers are free), then both encodes with all
+            // their lookups in flight together, then the stores.  (Measured neutral on configs[2] against one tile after the other — 34.5 vs
+            // 33.8 us: the kernel's floor is its memory traffic, profiles/r04_wave_ablation.txt — and kept for the earlier weight request.)
+            f32x4 o[2][4];
+            u32 px[2][4];
 #pragma unroll
             for (int i = 0; i < W_NTI; i++) {
-                if (klo[i] == 0xff) continue;  // (uniform: no second tile in the last pair of an odd tile count)
-                f32x4 o[4];
 #pragma unroll
-                for (int ch = 0; ch < NCH; ch++) o[ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (SMR_WAVE_ABL & 8) {
-                    const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
-                    if (!(SMR_WAVE_ABL & 16) && y < d_h && x + 3 < d_w)
-                        *(uint4 *)(d_ptr + (size_t)y * d_pitch + (size_t)x * 4) = make_uint4(ring[i][0][0] ^ ring[i][1][1], ring[i][2][2], ring[i][0][4 * KV_N - 1], ring[i][1][4 * KV_N - 4]);
-                    continue;
-                }
+                for (int ch = 0; ch < NCH; ch++) o[i][ch] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (klo[i] == 0xff || (SMR_WAVE_ABL & 8)) continue;  // (uniform: no second tile in the last pair of an odd tile count)
 #pragma unroll
                 for (int p = 0; p < KV_N; p++) {
                     if (p < KV) {
 #pragma unroll
                         for (int ch = 0; ch < NCH; ch++)
-                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvh[p]), o[ch]);
+                            o[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvh[p]), o[i][ch]);
 #pragma unroll
                         for (int ch = 0; ch < NCH; ch++)
-                            o[ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvl[p]), o[ch]);
-                    }
-                }
-                W_MARK(4);
-                // lane holds columns x .. x + 3 of output row y
-                const int y = 16 * vt + l16, x = tx0 + 16 * i + 4 * lq;
-                u32 px[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    px[k] = w_encode8(o[0][k], s_thr) | (w_encode8(o[1][k], s_thr) << 8) | (w_encode8(o[2][k], s_thr) << 16) |
-                            (AL ? unorm8(o[AL ? 3 : 0][k]) << 24 : 0xff000000u);
-#ifndef SMR_EMU
-#pragma unroll
-                for (int k = 0; k < 4; k++) asm volatile("" : "+v"(px[k]));  // (all twelve lookups in flight together: not sunk into the store branches)
-#endif
-                W_MARK(6);
-                bool direct = false;
-                if (dj) {
-                    // (m_direct_yuv: the arithmetic of k_compose_output's copy tiles on the bytes above; every lane takes part in its
-                    //  lane swaps, the lanes of a direct tile store)
-                    direct = cls_next[i] == (u32)d_layer;
-                    const bool odd = (l16 & 1) != 0;
-                    u32 mine, other;
-                    const u32 yq = m_direct_yuv(px, odd, &mine, &other);
-                    if (direct) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);
-                }
-                if (!direct && y < d_h && x < d_w && (!(SMR_WAVE_ABL & 16) || px[0] == 0x12345678u)) {  // (16: profiling, all work but no store traffic)
-                    u8 *op = d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u);  // (a tile is far below 4 GiB)
-                    if (x + 3 < d_w) {
-                        *(uint4 *)op = make_uint4(px[0], px[1], px[2], px[3]);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            if (x + k < d_w) ((u32 *)op)[k] = px[k];
+                            o[i][ch] = dev_mfma_16x16x32_f16(__builtin_bit_cast(f16x8, ring_quad(i, ch, p)), __builtin_bit_cast(f16x8, bvl[p]), o[i][ch]);
                     }
                 }
             }
+            W_MARK(4);
+            const int vt_now = vt;
+            u32 cls_now[2] = {cls_next[0], cls_next[1]};
+            // (the weights are consumed: the next tile row's go out now, under the encode)
             vt++;
             if (vt <= vt1) {
                 vm = vm_next;
                 vm_next = J.v_meta[min(vt + 1, vt1)];
                 if (!(SMR_WAVE_ABL & 512)) fetch_bv(vt);  // (512: profiling, every tile with the first tile's weights)
+            }
+#pragma unroll
+            for (int i = 0; i < W_NTI; i++) {
+                if (klo[i] == 0xff) continue;
+                if (SMR_WAVE_ABL & 8) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) px[i][k] = ring[i][k & 1][k] ^ ring[i][2][4 * KV_N - 1 - k];
+                    continue;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    px[i][k] = w_encode8(o[i][0][k], s_thr) | (w_encode8(o[i][1][k], s_thr) << 8) | (w_encode8(o[i][2][k], s_thr) << 16) |
+                               (AL ? unorm8(o[i][AL ? 3 : 0][k]) << 24 : 0xff000000u);
+            }
+#ifndef SMR_EMU
+#pragma unroll
+            for (int i = 0; i < W_NTI; i++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) asm volatile("" : "+v"(px[i][k]));  // (all the lookups in flight together: not sunk into the store branches)
+#endif
+            W_MARK(6);
+#pragma unroll
+            for (int i = 0; i < W_NTI; i++) {
+                if (klo[i] == 0xff) continue;
+                // lane holds columns x .. x + 3 of output row y
+                const int y = 16 * vt_now + l16, x = tx0 + 16 * i + 4 * lq;
+                bool direct = false;
+                if (dj) {
+                    // (m_direct_yuv: the arithmetic of k_compose_output's copy tiles on the bytes above; every lane takes part in its
+                    //  lane swaps, the lanes of a direct tile store)
+                    direct = cls_now[i] == (u32)d_layer;
+                    const bool odd = (l16 & 1) != 0;
+                    u32 mine, other;
+                    const u32 yq = m_direct_yuv(px[i], odd, &mine, &other);
+                    if (direct) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);
+                }
+                if (!direct && y < d_h && x < d_w && (!(SMR_WAVE_ABL & 16) || px[i][0] == 0x12345678u)) {  // (16: profiling, all work but no store traffic)
+                    u8 *op = d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u);  // (a tile is far below 4 GiB)
+                    if (x + 3 < d_w) {
+                        *(uint4 *)op = make_uint4(px[i][0], px[i][1], px[i][2], px[i][3]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (x + k < d_w) ((u32 *)op)[k] = px[i][k];
+                    }
+                }
             }
         };
         if (vt <= vt1 && vm.y == c) {
@@ -1205,7 +1254,8 @@ inline smr_resample_plan single_axis_as_two_pass(const smr_resample_plan &plan) 
 // An RGBA8 node texture with alpha == 1 as the source (k_ingest_wave's 8192 builds): a frame of a format the fused conversion does not
 // read (4:2:2, 4:4:4, packed YUV, BGRA / ARGB) after the exact converter, or an opaque surface.  Horizontal-first Lanczos plans with
 // the kernel's window limits (shrink factors up to ~3.5).
-// (bpp 8: an RGBA16F surface that is already box-reduced — the plan's levels then describe what was done to get it)
+// (bpp 8: an RGBA16F surface that is already box-reduced — the plan's levels then describe what was done to get it;
+//  bpp 3: an RGB12 node — src describes the node in PIXELS (w x h), its rows hold 3 w bytes: make_wave_job_rgba's `rgb12`)
 // *single (may be null): the pair windows are too wide but one tile per unit fits (axis 4 bands) — make_wave_job_rgba's `single`
 bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, int bpp = 4, bool *single = nullptr) {
     if (single) *single = false;
@@ -1227,7 +1277,7 @@ bool can_fuse_wave_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_pl
     return NKS <= W_NKS_MAX && KV <= W_KV_MAX;
 }
 
-int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, WJob *out, bool single = false) {
+int make_wave_job_rgba(smr_ctx *ctx, const SurfView &src, const smr_resample_plan &plan, const smr_surface *tile, WJob *out, bool single = false, bool rgb12 = false) {
     WaveBand bh, bv;
     int rc = get_wave_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, src.w, single ? 4 : 2, &bh);
     if (rc != SMR_OK) return rc;
@@ -1326,6 +1376,11 @@ constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 constexpr WaveKernel W_KERNELS_82[] = {k_ingest_wave<8, 2, 0>, k_ingest_wave<8, 2, 2048>, k_ingest_wave<8, 2, 4096>, k_ingest_wave<8, 2, 6144>};
 // RGBA8 node textures as the source: the same four classes
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
+// ... RGB12 node textures (the default route of 4:2:0 frames), plain and with direct output
+constexpr WaveKernel W_KERNELS_RGB12[] = {k_ingest_wave<0, 0, 8192 + 131072>, k_ingest_wave<4, 2, 8192 + 131072>, k_ingest_wave<4, 2, 8193 + 131072>,
+                                          k_ingest_wave<8, 3, 8192 + 131072>};
+constexpr WaveKernel W_KERNELS_RGB12_DIRECT[] = {k_ingest_wave<0, 0, 8192 + 131072 + 2048>, k_ingest_wave<4, 2, 8192 + 131072 + 2048>,
+                                                 k_ingest_wave<4, 2, 8193 + 131072 + 2048>, k_ingest_wave<8, 3, 8192 + 131072 + 2048>};
 // ... with direct output (2048: the tile's copy-class pixels leave as Y'CbCr, smr_fused.hip)
 constexpr WaveKernel W_KERNELS_RGBA_DIRECT[] = {k_ingest_wave<0, 0, 8192 + 2048>, k_ingest_wave<4, 2, 8192 + 2048>, k_ingest_wave<4, 2, 8193 + 2048>,
                                                 k_ingest_wave<8, 3, 8192 + 2048>};
@@ -1339,12 +1394,14 @@ constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave
                                        k_ingest_wave<0, 0, 32768 + 8192 + 65536>};
 
 int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false,
-                bool alpha = false) {
+                bool alpha = false, bool rgb12 = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
         std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
         all.insert(all.end(), W_KERNELS_82, W_KERNELS_82 + 4);
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
         all.insert(all.end(), W_KERNELS_RGBA_DIRECT, W_KERNELS_RGBA_DIRECT + 4);
+        all.insert(all.end(), W_KERNELS_RGB12, W_KERNELS_RGB12 + 4);
+        all.insert(all.end(), W_KERNELS_RGB12_DIRECT, W_KERNELS_RGB12_DIRECT + 4);
         all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
         all.push_back(W_KERNEL_RGBA16F);
         all.push_back(W_KERNEL_RGBA16F_ALPHA);
@@ -1390,10 +1447,11 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
                                 : sa ? W_KERNELS_SA[sa_i]
                                    : f16 ? (alpha ? W_KERNEL_RGBA16F_ALPHA : W_KERNEL_RGBA16F)
                                          : alpha ? W_KERNELS_RGBA_ALPHA[ki]
-                                                 : rgba ? (direct ? W_KERNELS_RGBA_DIRECT[ki] : W_KERNELS_RGBA[ki]) : W_KERNELS[ki];
+                                                 : rgb12 ? (direct ? W_KERNELS_RGB12_DIRECT[ki] : W_KERNELS_RGB12[ki])
+                                                         : rgba ? (direct ? W_KERNELS_RGBA_DIRECT[ki] : W_KERNELS_RGBA[ki]) : W_KERNELS[ki];
         if (cls82) ki = 500 + (direct ? 1 : 0) + (any_nv ? 2 : 0);  // (occupancy cache key)
         else if (sa) ki = 300 + sa_i;
-        else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : (direct ? 150 : 100);
+        else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : rgb12 ? (direct ? 650 : 600) : (direct ? 150 : 100);
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);

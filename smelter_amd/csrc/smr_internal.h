@@ -152,6 +152,7 @@ struct smr_ctx {
     int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
     std::vector<u32> compose_bitmap;  // compose_predict's scratch
     int ingest_min_rows = 0;     // SMR_INGEST_MIN_ROWS (profiling): least tile rows per wave of k_ingest_wave (0: the default, 1)
+    bool compact_nodes = true;   // SMR_OPT_COMPACT_NODES: node textures that only the matrix-core resampler reads are RGB12 (12 bytes per four pixels), not RGBA8
     bool direct_output = false;  // SMR_OPT_DIRECT_OUTPUT: wave A writes Y'CbCr for the compositor's copy tiles of a scene at rest
     std::vector<uint8_t> class_key_scratch;
     std::vector<TileClassMap> class_maps;  // tile classes of the last few layout lists (smr_fused.hip)
@@ -169,17 +170,22 @@ int smr_check_hip(smr_ctx *ctx, hipError_t e, const char *what);
 void *smr_scratch(smr_ctx *ctx, int slot, size_t bytes);  // nullptr on OOM (error set)
 extern "C" int smr_validate_frame(smr_ctx *ctx, const smr_frame *f, const char *what);  // plane geometry / formats against the frame's format
 // smr_frame_to_rgba for several frames at once (smr_convert.hip): planar 4:2:0 / 4:2:2 / 4:4:4 and NV12 frames share one launch per 16
-int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n);
+// rgb12 (may be null): rgb12[i] != 0 -> nodes[i] is an R8 surface of 3 * width x height, the node texture as 12-byte groups of four pixels
+// (smr_convert_420.h) — only for frames smr_conv_rgb12_ok() accepts, and only for nodes that nothing but the matrix-core resampler reads
+int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surface *const *nodes, u32 n, const u8 *rgb12 = nullptr);
+bool smr_conv_rgb12_ok(const smr_ctx *ctx, const smr_frame *in);
 
 // surface-cache slots (ctx->surf_cache), one table for every translation unit: disjoint for up to SMR_SLOT_MAX_LAYOUTS layouts and
 // SMR_SLOT_MAX_SOURCES sources per call (smr_render_layouts clamps / rejects beyond)
 constexpr size_t SMR_SLOT_MAX_LAYOUTS = 1024, SMR_SLOT_MAX_SOURCES = 1024;
 constexpr size_t SMR_SLOT_TARGET = 0;
 constexpr size_t SMR_SLOT_INGEST_NODE = 1;            // smr_ingest_resample's node texture
+constexpr size_t SMR_SLOT_INGEST_NODE_RGB12 = 2;      // ... as RGB12
 constexpr size_t SMR_SLOT_PRE_NODE = 3, SMR_SLOT_PRE_SCALED = 4;   // smr_frame_preprocess
 constexpr size_t SMR_SLOT_TRANSPOSED_SINGLE = 8;      // smr_ingest_resample's own four (.. 11)
 constexpr size_t SMR_SLOT_NODE0 = 16;                                              // + source index: RGBA8 node textures
-constexpr size_t SMR_SLOT_TILE0 = SMR_SLOT_NODE0 + SMR_SLOT_MAX_SOURCES;           // + layout index: resampled tiles
+constexpr size_t SMR_SLOT_NODE_RGB12_0 = SMR_SLOT_NODE0 + SMR_SLOT_MAX_SOURCES;    // + source index: RGB12 node textures
+constexpr size_t SMR_SLOT_TILE0 = SMR_SLOT_NODE_RGB12_0 + SMR_SLOT_MAX_SOURCES;    // + layout index: resampled tiles
 constexpr size_t SMR_SLOT_REDUCED0 = SMR_SLOT_TILE0 + SMR_SLOT_MAX_LAYOUTS;        // + layout index: box-reduced RGBA16F nodes
 constexpr size_t SMR_SLOT_TRANSPOSED0 = SMR_SLOT_REDUCED0 + SMR_SLOT_MAX_LAYOUTS;  // + 4 * layout index: transposed planes / node and tile of a vertical-first plan
 constexpr size_t SMR_SLOT_END = SMR_SLOT_TRANSPOSED0 + 4 * SMR_SLOT_MAX_LAYOUTS;

@@ -200,7 +200,7 @@ class Comm:
         if self.handle:
             self.lib.smr_comm_destroy(self.handle)
             self.handle = None
-OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL = 0, 1, 2, 3
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES = 0, 1, 2, 3, 4
 
 
 class Context:
@@ -253,6 +253,10 @@ class Context:
     def set_convert_impl(self, impl: int):
         """CONVERT_AUTO (block converters) / CONVERT_GENERAL (one kernel per WGSL pass) / CONVERT_BLOCK_4X2 (round 3's) — SMR_OPT_CONVERT_IMPL."""
         self.set_option(OPT_CONVERT_IMPL, impl)
+
+    def set_compact_nodes(self, on: bool):
+        """SMR_OPT_COMPACT_NODES: node textures only the matrix-core resampler reads as RGB12 instead of RGBA8 (default on)."""
+        self.set_option(OPT_COMPACT_NODES, 1 if on else 0)
 
     def set_direct_output(self, on: bool):
         """SMR_OPT_DIRECT_OUTPUT: let the resampling kernel write Y'CbCr for the compositor's copy tiles of a scene at rest (default off)."""

@@ -37,15 +37,17 @@ Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill) {
 }  // namespace
 
 // y: w x h; planar: u, v: (w / 2) x (h / 2); NV12: u = interleaved (w / 2) x (h / 2) x 2, v ignored.  out: w x h x 4 tight.
-extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, u8 *out) {
+// rgb12 != 0: out = h rows of 3 w bytes (12-byte groups of four pixels: R x 4, G x 4, B x 4)
+extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, int rgb12, u8 *out) {
     if (w % 4 || w < 8 || h % 2 || h < 2) return -1;
     Plane py = make_plane(y, w, h, 1, 0x5a), pu = make_plane(u, w / 2, h / 2, nv12 ? 2 : 1, 0xa5), pv = nv12 ? Plane() : make_plane(v, w / 2, h / 2, 1, 0x3c);
-    std::vector<u8> dst((size_t)w * 4 * h + 64, 0);
+    const u32 dpitch = rgb12 ? (u32)((3 * w + 255) & ~255) : (u32)w * 4;
+    std::vector<u8> dst((size_t)dpitch * h + 64, 0);
     ConvJob J;
     memset(&J, 0, sizeof(J));
     J.yp = py.view; J.up = pu.view; J.vp = nv12 ? pu.view : pv.view;
-    J.dst.ptr = dst.data(); J.dst.pitch = (u32)w * 4; J.dst.w = w; J.dst.h = h;
-    J.full = full; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0;
+    J.dst.ptr = dst.data(); J.dst.pitch = dpitch; J.dst.w = w; J.dst.h = h;
+    J.full = full; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0; J.rgb12 = rgb12;
     float ylut[256], nlut[256];
     for (u32 b = 0; b < 256; b++) {
         ylut[b] = cv420_luma_of_byte(b, full != 0);
@@ -56,6 +58,10 @@ extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int
             if (nv12) cv420_block<true>(J, g, P, ylut, nlut);
             else cv420_block<false>(J, g, P, ylut, nlut);
         }
-    memcpy(out, dst.data(), (size_t)w * 4 * h);
+    if (rgb12) {
+        for (int r = 0; r < h; r++) memcpy(out + (size_t)r * 3 * w, dst.data() + (size_t)r * dpitch, (size_t)3 * w);
+    } else {
+        memcpy(out, dst.data(), (size_t)w * 4 * h);
+    }
     return 0;
 }

@@ -108,9 +108,11 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     }
     const bool f16 = nv12 == 3 || nv12 == 5;   // y = an RGBA16F node texture (linear light): the 8192 + 16384 build (5: with an alpha channel)
     const bool alpha = nv12 == 4 || nv12 == 5; // y = a premultiplied node texture with an alpha channel: the + 65536 builds
-    const bool rgba = nv12 == 2 || f16 || alpha;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
+    const bool rgb12 = nv12 == 6;              // y = the node texture as RGB12 (12 bytes per four pixels; sw a multiple of 4): the 8192 + 131072 builds
+    const bool rgba = nv12 == 2 || f16 || alpha || rgb12;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
     if (rgba) nv12 = 0;
-    Plane py = make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1);
+    Plane py = rgb12 ? make_plane(y, 3 * sw, sh, 1) : make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1);
+    if (rgb12) py.view.w = sw;
     Plane pu = rgba ? py : (nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1));
     Plane pv = (nv12 || rgba) ? pu : make_plane(v, sw / 2, sh / 2, 1);
     std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
@@ -168,6 +170,11 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192 + 65536>(args, tables, lut16); });
         else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192 + 65536>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 65536>(args, tables, lut16); });
+    } else if (rgb12) {
+        if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193 + 131072>(args, tables, lut16); });
+        else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192 + 131072>(args, tables, lut16); });
+        else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192 + 131072>(args, tables, lut16); });
+        else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 131072>(args, tables, lut16); });
     } else if (rgba) {
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193>(args, tables, lut16); });
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192>(args, tables, lut16); });

@@ -33,7 +33,7 @@ def emu():
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
     h = C.CDLL(lib)
-    h.emu_convert_420.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, P8]
+    h.emu_convert_420.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P8]
     orc.build()
     return h
 
@@ -64,14 +64,19 @@ def test_block_converter_is_the_oracle_bit_for_bit(emu, w, h, variant, kind):
     got = np.zeros((h, w, 4), np.uint8)
     if variant == "nv12":
         c = np.ascontiguousarray(c)
-        assert emu.emu_convert_420(_p(y), _p(c), _p(c), w, h, 1, 0, _p(got)) == 0
+        assert emu.emu_convert_420(_p(y), _p(c), _p(c), w, h, 1, 0, 0, _p(got)) == 0
         want = orc.nv12_to_rgba(y, c, w, h)
+        u = v = c
     else:
         u, v = np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])
         full = 1 if variant == "j420" else 0
-        assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, _p(got)) == 0
+        assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, 0, _p(got)) == 0
         want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
     assert np.array_equal(got, want), (variant, kind, w, h, int((got != want).sum()), np.argwhere(got != want)[:4].tolist())
+    # the node as RGB12 (what the matrix-core resampler reads on the default route): the same codes, 12 bytes per four pixels
+    packed = np.zeros((h, 3 * w), np.uint8)
+    assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 1 if variant == "nv12" else 0, 1 if variant == "j420" else 0, 1, _p(packed)) == 0
+    assert np.array_equal(packed.reshape(h, w // 4, 3, 4).transpose(0, 1, 3, 2).reshape(h, w, 3), want[..., :3]) and (want[..., 3] == 255).all()
 
 
 def test_every_luma_byte_against_every_chroma_pair(emu):
@@ -85,6 +90,6 @@ def test_every_luma_byte_against_every_chroma_pair(emu):
             for cv in (0, 16, 17, 77, 128, 129, 201, 240, 255):
                 v = np.full((h // 2, w // 2), cv, np.uint8)
                 got = np.zeros((h, w, 4), np.uint8)
-                assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, _p(got)) == 0
+                assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, 0, _p(got)) == 0
                 want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
                 assert np.array_equal(got, want), (full, cu, cv)

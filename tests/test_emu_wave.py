@@ -144,6 +144,31 @@ def test_emulated_kernel_on_an_rgba_node_texture(emu, src, dst, crop, pieces, sp
     assert (got[..., 3] == 255).all()
 
 
+@pytest.mark.parametrize("src,dst,crop,pieces,spec", [c for c in RGBA_CASES if c[0][0] % 4 == 0])
+def test_emulated_kernel_on_an_rgb12_node_texture(emu, src, dst, crop, pieces, spec):
+    """The 8192 + 131072 builds — the default route of 4:2:0 frames: the node texture as 12-byte groups of four pixels (R x 4, G x 4, B x 4:
+    what k_yuv420_to_rgba writes for nodes only this kernel reads).  Same codes as the RGBA8 node, so the tile must be the RGBA8 build's tile
+    bit for bit, and within 1 LSB of the oracle's resample."""
+    (sw, sh), (dw, dh) = src, dst
+    rng = np.random.default_rng(sw * 7 + dh)
+    node = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+    node[..., 3] = 255
+    crop = crop or (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    _, want = orc.resample(node, crop, dw, dh)
+    # rows of groups: [R0 R1 R2 R3 G0 G1 G2 G3 B0 B1 B2 B3] per four pixels
+    packed = np.ascontiguousarray(node[..., :3].reshape(sh, sw // 4, 4, 3).transpose(0, 1, 3, 2)).reshape(sh, 3 * sw)
+    got, ref = np.zeros((dh, dw, 4), np.uint8), np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    tail = (plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1])
+    assert emu.emu_ingest_wave(_p(packed), _p(packed), _p(packed), sw, sh, 0, 6, *tail, _p(got), dw, dh, pieces, spec, info) == 0
+    flat = np.ascontiguousarray(node)
+    assert emu.emu_ingest_wave(_p(flat), _p(flat), _p(flat), sw, sh, 0, 2, *tail, _p(ref), dw, dh, pieces, spec, info) == 0
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.9995 and (got[..., 3] == 255).all(), (d.max(), (d == 0).mean())
+
+
 @pytest.mark.parametrize("src,dst,pieces", [((96, 60), (64, 40), 2), ((130, 74), (69, 40), 3), ((100, 56), (64, 36), 1)])
 def test_emulated_kernel_on_a_box_reduced_rgba16f_texture(emu, src, dst, pieces):
     """The 8192 + 16384 build: the source is the RGBA16F texture downsample.wgsl leaves (linear light, alpha 1); its f16 texels are

@@ -564,7 +564,7 @@ DIRECT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("route", ["node", "fused_conversion"])
+@pytest.mark.parametrize("route", ["rgb12_node", "rgba8_node", "fused_conversion"])
 @pytest.mark.parametrize("fmt_name", ["planar", "nv12"])
 @pytest.mark.parametrize("name,mk,iw,ih,W,H", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
 def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih, W, H, fmt_name, route):
@@ -578,6 +578,7 @@ def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih
     try:
         for c in (c_on, c_off):  # (direct output is a build of the matrix-core kernel: one per source kind)
             c.set_ingest_impl(hip.INGEST_MFMA_F16_FUSED if route == "fused_conversion" else hip.INGEST_AUTO)
+            c.set_compact_nodes(route == "rgb12_node")
         c_on.set_direct_output(True)
         c_off.set_direct_output(False)
         n_in = sum(1 for r in res if r == (iw, ih))
@@ -797,5 +798,45 @@ def test_vertical_first_plans_run_on_the_transposed_frame(hip, geom, fmt_name, i
         d = np.abs(t.download().astype(np.int16) - want.astype(np.int16))
         assert d.max() <= 1, f"max {d.max()}"
         assert (d == 0).mean() >= 0.998, f"{(d == 0).mean():.5f} identical"  # (noisy chroma; measured 0.9988)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("fmt_name", ["planar", "nv12", "j420"])
+@pytest.mark.parametrize("geom", [(1920, 1080, 1280, 720), (640, 360, 426, 240), (1280, 720, 640, 360), (328, 182, 250, 140), (5760, 1080, 1280, 240)],
+                         ids=["1080p", "360p", "half", "ragged", "wider_than_an_rgb12_row"])
+def test_compact_node_textures_give_the_same_tiles(hip, geom, fmt_name):
+    """SMR_OPT_COMPACT_NODES (default on): the node texture of a 4:2:0 frame that only the matrix-core resampler reads is RGB12 (12 bytes
+    per four pixels) instead of RGBA8 — the same codes, so the tile is the same bit for bit; and both are within 1 LSB of the oracle's
+    converter + resampler on white noise.  (A frame whose RGB12 rows would exceed the surface limit keeps the RGBA8 node.)"""
+    iw, ih, dw, dh = geom
+    crop = (0.0, 0.0, float(iw), float(ih))
+    rng = np.random.default_rng(iw + dh)
+    y = rng.integers(0, 256, (ih, iw), dtype=np.uint8)
+    u = rng.integers(0, 256, (ih // 2, iw // 2), dtype=np.uint8)
+    v = rng.integers(0, 256, (ih // 2, iw // 2), dtype=np.uint8)
+    if fmt_name == "nv12":
+        node = orc.nv12_to_rgba(y, np.stack([u, v], axis=-1), iw, ih)
+    else:
+        node = orc.planar_yuv_to_rgba(y, u, v, iw, ih, orc.YUVJ420 if fmt_name == "j420" else orc.YUV420, omp=True)
+    _, want = orc.resample(node, crop, dw, dh, omp=True)
+    c = hip.Context(0)
+    try:
+        if fmt_name == "nv12":
+            f = c.frame(hip.FRAME_NV12, iw, ih, [y, np.stack([u, v], axis=-1)])
+        else:
+            f = c.frame(hip.FRAME_PLANAR_YUVJ420 if fmt_name == "j420" else hip.FRAME_PLANAR_YUV420, iw, ih, [y, u, v])
+        tiles = []
+        for on in (True, False):
+            c.set_compact_nodes(on)
+            t = c.surface(dw, dh)
+            before = c.kernel_launches()
+            c.ingest_resample(f, crop, t)
+            ran = {k: v_ - before[k] for k, v_ in c.kernel_launches().items()}
+            assert ran["frame_to_rgba"] == 1 and ran["ingest_wave_rgba"] + ran["resample_general"] >= 1 and ran["ingest_wave"] == 0, ran
+            tiles.append(t.download())
+        assert np.array_equal(tiles[0], tiles[1]), int((tiles[0] != tiles[1]).sum())
+        d = np.abs(tiles[0].astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1 and (d == 0).mean() >= 0.999, (int(d.max()), float((d == 0).mean()))
     finally:
         c.close()

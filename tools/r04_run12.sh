@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+O=gpurun_out/r04_12; mkdir -p $O
+B="--no-cpu-baseline --no-target --no-long --steps 400 --warmup 40 --latency-frames 100"
+for e in 1 0; do
+for a in "" "--config 3" "--config 1" "--config 4"; do
+SMR_COMPACT_NODES=$e timeout 200 python bench.py $B $a 2>/dev/null | python -c "
+import json,sys; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('compact $e [$a]', r['value'], 'fps', r['config']['frames_per_s_one_in_flight'], 'serial', {k:v['avg_us'] for k,v in r['kernels'].items()}, 'p50', r['latency_ms']['p50'])" | tee -a $O/bench.txt
+done
+done
+bash tools/gpu_tests.sh r04_12
