@@ -187,7 +187,7 @@ def main():
     if args.config is None:
         # N > 1 shards BASELINE's multi-GPU workload (configs[3]: 8x4K, one input per GPU at N = 8): configs[2]'s 1080p inputs leave a GPU
         # 7 us of work per tile it then sends over one xGMI link for 24 us — link-bound beyond one GPU
-        args.config = 3 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1) else 2
+        args.config = 3 if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1 or args.force_sharded) else 2
     global IN_W, IN_H, OUT_W, OUT_H, N_IN, ALGO_BYTES_PER_FRAME, PLAIN_TILES, ANIMATED
     if args.config == 1:
         IN_W, IN_H, OUT_W, OUT_H, N_IN, PLAIN_TILES = 1920, 1080, 1920, 1080, 4, True
@@ -434,7 +434,9 @@ def main():
         for L in layouts:
             if L.type == 0 and res[L.source_index] == (IN_W, IN_H):
                 tile_bytes += max(int(np.floor(L.width + 0.5)), 1) * max(int(np.floor(L.height + 0.5)), 1) * 4
-        node_bytes = N_IN * IN_W * IN_H * 4 if "ingest" in stages else 0   # the RGBA8 node textures (default route: written by the converter, read by the resampler)
+        # the node textures of the default route (written by the converter, read by the resampler): RGB12 — 3 bytes per pixel — where the
+        # resampler runs a class build (configs[2], configs[3]: SMR_OPT_COMPACT_NODES), RGBA8 elsewhere
+        node_bytes = N_IN * IN_W * IN_H * (3 if args.config in (2, 3) else 4) if "ingest" in stages else 0
         kernel_bytes = {
             "ingest": N_IN * yuv420_bytes(IN_W, IN_H) + node_bytes,                                     # converter: planes in, node textures out
             "fused_ingest_resample": (node_bytes or N_IN * yuv420_bytes(IN_W, IN_H)) + tile_bytes,       # resampler: nodes (or planes) in, tiles out
@@ -470,8 +472,11 @@ def main():
                                   "all_kernels_of_a_frame": {"sum_us": round(sum(v["avg_us"] for v in stages.values()), 3),
                                                              "frac": round(ALGO_BYTES_PER_FRAME / (sum(v["avg_us"] for v in stages.values()) * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
                                                              "wave_a_us": round(wave_a_us, 3), "wave_a_kernels": [knames[k] for k in wave_a]},
-                                  "limiter": ("exact conversion is vector-ALU bound (47 instructions per pixel, the WGSL sequence value for value); the "
-                                              "resampler is bound by LDS table gathers + matrix-core issue at two waves per SIMD; see DESIGN.md section 3")
+                                  "limiter": ("the route's own intermediates: per frame the counters see ~6x the algorithmic bytes (node textures written by the exact "
+                                              "converter and read by the resampler, RGBA8 tiles written and read by the compositor) moving at ~3.9 TB/s with two frames "
+                                              "in flight, 80 % of a device copy; the resampler alone, arithmetic compiled out, runs at copy bandwidth "
+                                              "(profiles/r04_wave_ablation.txt); the converter is vector-ALU bound (40 instructions per pixel: the WGSL sequence value for "
+                                              "value); see DESIGN.md section 3")
                                   if args.ingest == "auto" else "see DESIGN.md section 3"}
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM

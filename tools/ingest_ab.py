@@ -1,14 +1,14 @@
-"""A/B of the three ingest + Lanczos kernels on wave A of BASELINE configs[2] (8 x 1920x1080 4:2:0 -> 8 x 1280x720 tiles) and of the
-north-star target (8 x 3840x2160 -> 8 x 1280x720):
+"""A/B of the three routes of wave A on BASELINE configs[2] (8 x 1920x1080 4:2:0 -> 8 x 1280x720 tiles) and on the north-star target
+(8 x 3840x2160 -> 8 x 1280x720):
 
-    f32_valu   k_ingest_resample  every pass as the WGSL writes it (bit-identical to the oracle up to FMA contraction)
-    mfma_wg    k_ingest_mfma      round 2: workgroup pipeline of convert / filter waves around LDS, single-f16 pass-2 weights
-    wave       k_ingest_wave      round 3: wave-autonomous, operands from registers, f16-pair weights in both passes
+    f32_valu   k_ingest_resample                    every pass as the WGSL writes it (bit-identical to the pass-per-launch kernels)
+    fused      k_ingest_wave on the planes          opt-in: conversion fused into the matrix-core resampler (within one code per stage)
+    node       k_yuv420_to_rgba + k_ingest_wave     the default: exact converter into node textures, matrix-core resampler on them
 
-per content class: mean launch time over `reps` launches (HIP events around each launch, smr_profile_*), max |difference| and share of
-identical bytes against the CPU oracle on the first two inputs.  Writes gpurun_out/r03_ingest_ab.json.
+per content class: mean time of wave A per call (HIP events around each launch, smr_profile_*: converter + resampler), max |difference| and
+share of identical bytes against the CPU oracle on the first two inputs.  Writes gpurun_out/r04_ingest_ab.json.
 
-python tools/ingest_ab.py [reps] [--4k] [--impls wave,mfma_wg,f32_valu] [--contents bench,smooth,noise]"""
+python tools/ingest_ab.py [reps] [--4k] [--impls node,fused,f32_valu] [--contents bench,smooth,noise]"""
 import json
 import os
 import sys
@@ -44,7 +44,9 @@ def run(ctx, impl, frames, crops, dsts, reps):
     for _ in range(reps):
         ctx.ingest_resample_batch(frames, crops, dsts)
     ctx.sync()
-    ms, n = ctx.profile_read()["fused_ingest_resample"]
+    prof = ctx.profile_read()
+    ms, n = prof["fused_ingest_resample"]
+    ms += prof["ingest"][0]  # (the node route's converter launch)
     ctx.profile_enable(False)
     return [d.download() for d in dsts], 1000.0 * ms / max(n, 1), n // max(reps, 1)
 
@@ -54,14 +56,14 @@ def stats(a, b):
     return {"max_lsb": int(d.max()), "identical_pct": round(100.0 * float((d == 0).mean()), 4), "bytes_off_by_more_than_1": int((d > 1).sum())}
 
 
-IMPLS = {"f32_valu": hip.INGEST_VALU_F32, "mfma_wg": hip.INGEST_MFMA_F16_WG, "wave": hip.INGEST_MFMA_F16, "wave_node": hip.INGEST_MFMA_F16_NODE}
+IMPLS = {"f32_valu": hip.INGEST_VALU_F32, "node": hip.INGEST_AUTO, "fused": hip.INGEST_MFMA_F16_FUSED}
 
 
 def main():
     argv = sys.argv[1:]
     reps = int(argv[0]) if argv and argv[0].isdigit() else 50
     four_k = "--4k" in argv
-    impls = argv[argv.index("--impls") + 1].split(",") if "--impls" in argv else ["f32_valu", "mfma_wg", "wave"]
+    impls = argv[argv.index("--impls") + 1].split(",") if "--impls" in argv else ["f32_valu", "fused", "node"]
     kinds = argv[argv.index("--contents") + 1].split(",") if "--contents" in argv else ["bench", "smooth", "noise"]
     iw, ih = (3840, 2160) if four_k else (1920, 1080)
     dw, dh, n = 1280, 720, 8
@@ -85,7 +87,7 @@ def main():
             d.destroy()
     ctx.close()
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/r03_ingest_ab%s.json" % ("_4k" if four_k else ""), "w") as f:
+    with open("gpurun_out/r04_ingest_ab%s.json" % ("_4k" if four_k else ""), "w") as f:
         json.dump(out, f, indent=1)
 
 
