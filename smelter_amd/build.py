@@ -20,8 +20,6 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
 if os.environ.get("SMR_ABLATION_BUILDS"):  # profiling only: extra instantiations of the ingest kernel with phases compiled out
     FLAGS.append("-DSMR_ABLATION_BUILDS")
-if os.environ.get("SMR_MFMA_CONV_WAVES"):  # A/B: convert waves per workgroup of k_ingest_mfma (4 or 8)
-    FLAGS.append("-DSMR_MFMA_CONV_WAVES=" + os.environ["SMR_MFMA_CONV_WAVES"])
 
 
 def _sources():

@@ -7,8 +7,11 @@
 // 37 MB of algorithmic bytes).
 //
 // Here:
-//   wave A  k_ingest_mfma (smr_ingest_mfma.h; k_ingest_resample of smr_fused_ingest.h is its exact-f32 twin) — raw Y/U/V planes
-//           -> dst-sized RGBA8 tiles, all inputs of the frame in one launch; node texture and f16 intermediate live only in LDS.
+//   wave A  k_yuv420_to_rgba (smr_convert_420.h: every frame of the call in one launch, the reference's node texture bit for bit,
+//           RGB12 where only the resampler reads it) + k_ingest_wave (smr_ingest_wave.h: both Lanczos passes on the matrix cores,
+//           node textures -> dst-sized RGBA8 tiles, all inputs of the frame in one launch; the f16 intermediate lives in registers).
+//           Options: the conversion folded into k_ingest_wave (SMR_INGEST_MFMA_F16_FUSED: no node texture at all, not exact);
+//           k_ingest_resample (smr_fused_ingest.h: every pass in f32, SMR_INGEST_VALU_F32).
 //   wave B  k_compose_output (smr_fused_compose.h) — all layouts + RGBA->Y'CbCr (or an RGBA8 node target) in one launch, driven
 //           by per-tile class records (k_classify_tiles) that are kept while the layout list repeats; the RGBA8 output frame
 //           lives only in registers.
@@ -16,7 +19,7 @@
 // each draw) is reproduced; the compositor and the f32 ingest kernel keep the f32 operation sequence of the general kernels
 // (the only substitutions are exact ones: LUTs for u8 -> f32, correctly rounded division through a reciprocal + FMAs, operations
 // that cannot act on the operands at hand, layers an opaque layer overwrites) — tests/test_gpu_fused.py checks fused ==
-// pass-per-launch bit for bit; the matrix-core ingest kernel spends the resampler's 1-LSB budget.
+// pass-per-launch bit for bit; the matrix-core resampler stays within 1 LSB of the f32 passes on the same node texture.
 // Anything the fused kernels do not cover (single-pass plans, box pre-reduction, packed inputs, odd
 // output sizes, 4:2:2 / 4:4:4 outputs) falls back to the general kernels of smr_convert / smr_resample / smr_layout per
 // layout — never to the CPU.

@@ -1,4 +1,4 @@
-// smr_ingest_common.h — pieces shared by the two matrix-core ingest kernels (smr_ingest_mfma.h, smr_ingest_wave.h):
+// smr_ingest_common.h — pieces of the matrix-core ingest kernel (smr_ingest_wave.h) that its fused-conversion builds use:
 // the Y'CbCr -> linear (hi, lo) f16-pair conversion of one 4x1 pixel block (planar_yuv_to_rgba.wgsl:35-58 + the sRGB decode of the
 // node texture's view), the direct-output record, and thin names for the gfx950 builtins the kernels use.
 //
@@ -77,7 +77,7 @@ inline MConv m_conv_constants(bool full) {
 // One 4x1 pixel block: luma dword yy, chroma neighbourhoods (4 bytes: columns 2q-1 .. 2q+2) of chroma rows p (ua, va) and p + 1
 // (ub, vb), w13 / w31 = the row's bilinear weight vectors -> (hi | lo << 16) linear texels: o[c] = the four texels of channel c,
 // i.e. eight consecutive K values of a v_mfma_f32_16x16x32_f16 A operand.
-//   NOLUT (profiling builds of k_ingest_mfma only): no table gathers.
+//   NOLUT (profiling builds only): no table gathers.
 template <bool NOLUT>
 __device__ __forceinline__ void m_convert_px(const MConv &J, u32 yy, u32 ua, u32 ub, u32 va, u32 vb, u32 w13, u32 w31, uint4 o[3]) {
     const u32 pu0 = dev_perm(ub, ua, 0x05040100u), pu1 = dev_perm(ub, ua, 0x06050201u), pu2 = dev_perm(ub, ua, 0x07060302u);

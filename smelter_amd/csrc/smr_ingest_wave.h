@@ -1190,8 +1190,7 @@ int flush_wave_builds(smr_ctx *ctx) {
 
 // ------------------------------------------------------------------ host side: jobs
 // What k_ingest_wave covers: planar 4:2:0 (limited or full range) or NV12 with even luma size and dword-aligned planes, a separable
-// two-pass plan with the horizontal pass first and no box pre-reduction (vertical-first plans come back on the transposed frame,
-// as for k_ingest_mfma), 16-byte aligned tile rows, k-step counts within the kernel's limits.
+// two-pass plan with the horizontal pass first and no box pre-reduction (vertical-first plans come back on the transposed frame), 16-byte aligned tile rows, k-step counts within the kernel's limits.
 bool can_fuse_wave(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile) {
     if (!fused_conversion(ctx)) return false;
     const bool nv12 = f && f->format == SMR_FRAME_NV12;

@@ -122,7 +122,7 @@ struct smr_ctx {
     std::vector<WeightTable> weight_tables;
     uint64_t weight_clock = 0;
     uint64_t weight_call = 0;  // id of the public call building jobs: tables it already handed out are never evicted
-    // Lanczos weight bands in MFMA B-operand layout (smr_ingest_mfma.h), keyed by (axis, scale, offset, n_dst, n_src)
+    // Lanczos weight bands in MFMA B-operand layout (smr_ingest_wave.h), keyed by (axis, scale, offset, n_dst, n_src)
     struct MfmaTable {
         float scale = 0.f, offset = 0.f;
         int n_dst = 0, n_src = 0, axis = 0, K = 0, max_span = 0;
@@ -135,7 +135,7 @@ struct smr_ctx {
     struct PendingBand { float scale, offset; int taps, n_dst, n_src, axis, K, n_tiles; void *meta, *frag; };
     std::vector<PendingBand> pending_bands;  // bands allocated by the current call, built in one launch before the kernel that reads them
     struct MfmaOccupancy { int kernel; size_t lds; int per_cu; };
-    std::vector<MfmaOccupancy> mfma_occupancy;  // resident k_ingest_mfma workgroups per CU, per (kernel build, LDS bytes)
+    std::vector<MfmaOccupancy> mfma_occupancy;  // resident k_ingest_wave workgroups per CU, per (kernel build, LDS bytes)
     u32 *d_lut16 = nullptr;      // 256 x (f16 hi | f16 lo << 16) of the sRGB decode table
     u32 ingest_impl = 0;         // smr_ingest_impl
     u32 convert_lds_pad = 0;     // SMR_CONVERT_LDS_PAD (A/B): extra dynamic LDS per workgroup of the block converter, i.e. a cap on its resident workgroups per CU
@@ -144,7 +144,7 @@ struct smr_ctx {
     bool wave_attr_set = false;
     bool valu_attr_set = false;
     int ingest_reserve_cus = -1; // SMR_INGEST_RESERVE_CUS (profiling), read once per ctx
-    int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (profiling): cap on resident k_ingest_mfma workgroups per CU, 0 = as many as fit
+    int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (profiling): cap on resident k_ingest_wave workgroups per CU, 0 = as many as fit
     bool debug_ingest = false;   // SMR_DEBUG_INGEST: print the launch geometry
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use

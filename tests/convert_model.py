@@ -1,6 +1,6 @@
 """The node texture the matrix-core ingest kernels see (test infrastructure).
 
-k_ingest_wave / k_ingest_mfma never materialise the reference's RGBA8 node texture: m_convert_px (smelter_amd/csrc/smr_ingest_common.h)
+k_ingest_wave's fused-conversion builds (SMR_INGEST_MFMA_F16_FUSED, opt-in) never materialise the reference's RGBA8 node texture: m_convert_px (smelter_amd/csrc/smr_ingest_common.h)
 turns Y'CbCr into the u8 code of every channel with the range expansion, the chroma up-sampling (exact, in 1/16 units) and the BT.709
 matrix folded into one FMA chain per channel — the same values as planar_yuv_to_rgba.wgsl:35-58 up to f32 rounding, i.e. the same code
 except where 255 R' + 0.5 lands within ~1e-4 of an integer (a few texels per hundred thousand, then one code off).  This module restates

@@ -1,9 +1,9 @@
 """CPU model of the matrix-core resampler's arithmetic (tools/mfma_precision_sim.py: f16 hi/lo operands, f32 accumulation, the
 reference's quantisation points) against the oracle.  No GPU: the device kernel is compared with the oracle in test_gpu_fused.py;
 this pins the *formulation* — that banded GEMMs on f16 pairs stay inside the north star's 1-LSB budget on every content class when
-all three operands are (hi, lo) pairs (k_ingest_wave's choice), and that round 2's single-f16 pass-2 weights (k_ingest_mfma) do not
-on white noise.  (The three bytes the device kernels show end to end on white noise are a different effect — the fused colour
-conversion's one-code flips, DESIGN.md section 4 — which this resample-only model does not contain.)"""
+all three operands are (hi, lo) pairs (k_ingest_wave's choice), and that round 2's single-f16 pass-2 weights (a kernel retired since) do not
+on white noise.  (The three bytes the opt-in fused-conversion route shows end to end on white noise are a different effect — its colour
+conversion's one-code flips, DESIGN.md section 3b — which this resample-only model does not contain.)"""
 import os
 import sys
 
@@ -34,7 +34,7 @@ def test_pairs_in_pass_2_keep_white_noise_within_one_lsb_and_single_f16_weights_
     crop = (0.0, 0.0, float(iw), float(ih))
     node = list(sim.contents(iw, ih))[1][1]
     _, want = orc.resample(node, crop, dw, dh, omp=True)
-    mx_k, ident_k, over_k = sim.compare(sim.simulate(node, crop, dw, dh), want)                      # k_ingest_mfma: one f16 per pass-2 weight
+    mx_k, ident_k, over_k = sim.compare(sim.simulate(node, crop, dw, dh), want)                      # round 2's kernel: one f16 per pass-2 weight
     mx_p, ident_p, over_p = sim.compare(sim.simulate(node, crop, dw, dh, "pair", "pair", "pair"), want)  # k_ingest_wave: pairs everywhere
     assert mx_k <= 4 and over_k <= 4 and ident_k >= 98.0   # a byte or so per 300 000 off by 2, bounded
     assert mx_p <= 1 and over_p == 0 and ident_p >= 99.99  # none with pairs

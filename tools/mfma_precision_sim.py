@@ -1,7 +1,7 @@
-"""CPU model of the matrix-core resamplers' arithmetic (k_ingest_mfma, round 2: T pair, Wh pair, Wv feedback — the default below;
-k_ingest_wave, round 3: pairs for all three) against the oracle: where the matrix-core formulation
+"""CPU model of the matrix-core resamplers' arithmetic (round 2's kernel, retired since: T pair, Wh pair, Wv feedback — the default below;
+k_ingest_wave: pairs for all three) against the oracle: where the matrix-core formulation
 of the two Lanczos passes spends the resampler's 1-LSB budget, variant by variant.  numpy only — the f32 accumulation order of the
-matrix cores is not modelled (np.matmul's is used), so the counts are close to, not equal to, what tools/mfma_ab.py measures on
+matrix cores is not modelled (np.matmul's is used), so the counts are close to, not equal to, what tools/ingest_ab.py measures on
 the device.
 
     T      sRGB-decoded texel of the u8 node texture:  "pair" = f16 hi + f16 lo (the kernel), "single" = one f16
