@@ -514,8 +514,13 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
 
 // Copy tiles per workgroup of the kernel's second part (their records, then all their texels, are fetched back to back).
 // Measured on configs[2]: 1 -> 29 us, 4 -> 37 us for the whole kernel — the conversion arithmetic of four tiles in one workgroup
-// outweighs the launches saved.
-constexpr int B_COPY_TILES = 1;
+// outweighs the launches saved.  Round 4, same kernel three rounds later (tools/r04_run16.sh, -DSMR_COPY_TILES=2): 22.5 -> 29.9 us on configs[2],
+// 45.3 -> 53.1 us on configs[4]: still one.
+#ifndef SMR_COPY_TILES
+#define SMR_COPY_TILES 1
+#endif
+constexpr int B_COPY_TILES = SMR_COPY_TILES;
+static_assert(B_COPY_TILES == 1 || B_COPY_TILES == 2, "one or two tiles per workgroup");
 
 template <int NV, bool BIG>
 __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp, SurfView up, SurfView vp, int W, int H,
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
     // (the compositing path is most of the kernel's code: it is instantiated once, at the end, and both ways into it — a band of a
     //  listed tile; a tile the list had no room for — only choose its arguments)
     const int rest = (int)blockIdx.x - slices * n_banded;
-    const TileFull *full_entry = nullptr;
+    const TileFull *full_entry = nullptr, *full_entry2 = nullptr;
     int full_band = 0, full_end = B_TILE_H, full_rows = B_BAND_ROWS;
     if (rest < 0) {
         const u32 gi = blockIdx.x / (u32)slices;
@@ -621,13 +626,22 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
         }
     }
     // a tile that needs compositing and found no room on the band list (the host's bound was short): here, band after band
-    static_assert(B_COPY_TILES == 1, "one tile per workgroup is handed on to the compositing path");
     if (c[0].kind == TC_FULL && (int)c[0].pitch_or_px >= n_banded) full_entry = &full->e[c[0].pitch_or_px];
+    if (B_COPY_TILES > 1 && c[B_COPY_TILES - 1].kind == TC_FULL && (int)c[B_COPY_TILES - 1].pitch_or_px >= n_banded) {
+        const TileFull *e = &full->e[c[B_COPY_TILES - 1].pitch_or_px];
+        if (full_entry) full_entry2 = e;
+        else full_entry = e;
     }
-    if (full_entry)  // (uniform; one band of a listed tile, or the four bands of a tile the list's bound left out)
+    }
+    // (uniform; one band of a listed tile, or the four bands of a tile — of each tile of the group — the list's bound left out)
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+        const TileFull *e = q == 0 ? full_entry : full_entry2;
+        if (!e) break;
 #pragma unroll 1
         for (int band = full_band; band < full_end; band += full_rows)
-            compose_full<NV, BIG>(full_entry, band, full_rows, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+            compose_full<NV, BIG>(e, band, full_rows, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+    }
 }
 
 }  // namespace
