@@ -325,11 +325,27 @@ __global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView
 template <bool NV>
 __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
     __shared__ float s_ylut[256], s_nlut[256];
-    const ConvJob &J = B.j[blockIdx.z];
+    // Workgroups go to the XCDs round robin (id mod 8), and every XCD has its own L2.  A workgroup's chroma window reaches a byte or two into
+    // the cache lines of its neighbours left and right and a chroma row into those above and below: walked in launch order, a box of
+    // gx = 8 column blocks put each column on its own XCD and every XCD fetched three lines for one (counters: 40 MB for 24.9 MB of planes).
+    // So XCD k takes the block rows k, k + 8, ... of every frame, each from left to right: neighbours in x run on the same L2 one after the
+    // other, and all eight XCDs stay within 128 lines of each other in the same frame (an XCD per frame fetched the least and was slower:
+    // eight streams at the same offsets of eight equally aligned buffers, profiles/r04_xcd_order.txt).
+    u32 bx, by, bz;
+    if (B.order == 2) {
+        const u32 gy8 = ((u32)B.gy + 7u) / 8u, r = blockIdx.x >> 3;
+        bx = r % (u32)B.gx; by = ((r / (u32)B.gx) % gy8) * 8u + (blockIdx.x & 7u); bz = r / ((u32)B.gx * gy8);
+    } else {
+        const u32 total = (u32)(B.gx * B.gy * B.n), per_xcd = (total + 7u) / 8u;
+        const u32 at = B.order == 1 ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+        bx = at % (u32)B.gx; by = (at / (u32)B.gx) % (u32)B.gy; bz = at / (u32)(B.gx * B.gy);
+    }
+    if (by >= (u32)B.gy || bz >= (u32)B.n) return;  // (uniform)
+    const ConvJob &J = B.j[bz];
     s_ylut[threadIdx.x & 255] = cv420_luma_of_byte(threadIdx.x & 255u, J.full != 0);
     s_nlut[threadIdx.x & 255] = unorm_of_byte(threadIdx.x & 255u);
     __syncthreads();
-    const int g = blockIdx.x * 64 + (threadIdx.x & 63), P = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int g = (int)bx * 64 + (threadIdx.x & 63), P = (int)by * 4 + (threadIdx.x >> 6);
     if (4 * g >= J.dst.w || 4 * P >= J.dst.h) return;
     cv420_block<NV>(J, g, P, s_ylut, s_nlut);
 }
@@ -490,8 +506,13 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         StageScope scope(ctx, SMR_STAGE_INGEST);
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;  // (per launch)
         if (k == 0) hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 7) / 8), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
-        else if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
-        else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 15) / 16), Q.nb), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
+        else {
+            Q.B.gx = (Q.mw + 255) / 256; Q.B.gy = (Q.mh + 15) / 16; Q.B.n = (int)Q.nb;
+            Q.B.order = ctx->convert_order;
+            const unsigned blocks = (unsigned)(8 * Q.B.gx * ((Q.B.gy + 7) / 8) * Q.B.n);  // (block rows in rounds of eight: one per XCD)
+            if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3(blocks), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
+            else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
+        }
         Q.nb = 0; Q.mw = 0; Q.mh = 0;
         SMR_HIP(ctx, hipGetLastError());
         return SMR_OK;

@@ -47,6 +47,8 @@ struct ConvJob {
 constexpr int MAX_CONV_JOBS = 16;
 struct ConvBatch {
     ConvJob j[MAX_CONV_JOBS];
+    int order;      // (profiling: SMR_CONVERT_ORDER) 0 box in launch order | 1 an eighth of the box per XCD | 2 block rows round robin over the XCDs
+    int gx, gy, n;  // k_yuv420_to_rgba: the launch as a gx x gy x n box of workgroups (its 1-D grid is that box walked XCD by XCD)
 };
 
 #ifdef __HIPCC__
@@ -70,6 +72,11 @@ template <bool NV>
 __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut, const float *nlut) {
     const int w = J.dst.w, h = J.dst.h, cw = w >> 1, ch = h >> 1;
     const bool full = J.full != 0;
+    // ---- the four luma dwords first, with the chroma window's loads: every load of the block is in flight before the first store (a row's
+    //      luma load behind the previous row's store waited for that store and for itself: four memory round trips per block instead of one)
+    u32 yrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) yrow[r] = *(const u32 *)(J.yp.ptr + ((u32)min(4 * P + r, h - 1) * J.yp.pitch + 4u * (u32)g));
     // ---- chroma window: columns 2 g - 1 .. 2 g + 2, rows 2 P - 1 .. 2 P + 2, clamped to the plane like the sampler clamps
     const int first = 2 * g - 1, first_ld = first < 0 ? 0 : first;
     const int byte0 = NV ? 2 * first_ld : first_ld, base = byte0 & ~3;
@@ -122,7 +129,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
         const int y = 4 * P + r;
         if (y >= h) break;
         const int j34 = r < 2 ? 1 : 2, j14 = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
-        const u32 y4 = *(const u32 *)(J.yp.ptr + ((u32)y * J.yp.pitch + 4u * (u32)g));
+        const u32 y4 = yrow[r];
         u32 px[4], r4 = 0u, g4 = 0u, b4 = 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
