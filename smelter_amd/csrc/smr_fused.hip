@@ -497,7 +497,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (classify_now) {
         SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, 4, ctx->stream));
         hipLaunchKernelGGL(k_classify_tiles, dim3((b_tiles + B_CLASSIFY_TILES - 1) / B_CLASSIFY_TILES), dim3(64 * B_CLASSIFY_TILES), 0, ctx->stream,
-                           packed.layouts, packed.masks, packed.n, (int)out_w, (int)out_h, (int)b_tiles_x, (int)b_tiles, direct_mask, (TileClass *)cm->d_class, cm->d_direct, (TileList *)cm->d_list);
+                           packed.layouts, packed.masks, packed.n, (int)out_w, (int)out_h, (int)b_tiles_x, (int)b_tiles, direct_mask, (TileClass *)cm->d_class, cm->d_direct, (TileList *)cm->d_list,
+                           ctx->compose_select ? 1 : 0);
         SMR_HIP(ctx, hipGetLastError());
     }
     if (fuse_out) {

@@ -145,7 +145,11 @@ __device__ __forceinline__ void tile_needs(const u32 *s_touch, int start, int *s
 //   TC_SKIP     wave A writes the tile's Y'CbCr (direct output)
 //   TC_SAMPLED  the whole tile lies in the solid region of one opaque texture layer that is not a 1:1 blit (a video tile at a
 //               fractional position or another scale: every tile of a grid in mid-transition), nothing above: px = that layer
-enum { TC_CLEAR = 0, TC_COLOUR = 1, TC_TEXTURE = 2, TC_FULL = 3, TC_SKIP = 4, TC_SAMPLED = 5 };
+//   TC_SELECT   every layer that touches the tile (from the start layer up; at most four) is an opaque 1:1 texture or an opaque colour
+//               and SOLID wherever it touches it — the seam between two video tiles of a grid, a tile's edge on the background:
+//               a pixel is a copy from the topmost of them whose pixel box holds it (dst * (1 - 1) == 0 wipes what is below, and a
+//               layer draws nothing outside its box), no blending arithmetic.  px = the layers, topmost first, a byte each, 0xff = none
+enum { TC_CLEAR = 0, TC_COLOUR = 1, TC_TEXTURE = 2, TC_FULL = 3, TC_SKIP = 4, TC_SAMPLED = 5, TC_SELECT = 6 };
 struct alignas(16) TileClass {
     const u8 *base;
     u32 pitch_or_px;
@@ -174,7 +178,8 @@ constexpr int B_CLASSIFY_TILES = 16;  // tiles per workgroup of k_classify_tiles
                                       // kernel: 15.3 -> 7.7 us for a 4K output in transition)
 __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks, int n,
                                                                           int W, int H, int tiles_x, int tiles, unsigned long long direct_layers,
-                                                                          TileClass *__restrict__ tc, u8 *__restrict__ direct, TileList *__restrict__ full) {
+                                                                          TileClass *__restrict__ tc, u8 *__restrict__ direct, TileList *__restrict__ full,
+                                                                          int allow_select) {
     __shared__ u32 s_touch_w[B_CLASSIFY_TILES][MAX_LAYOUT_WORDS], s_solid_w[B_CLASSIFY_TILES][MAX_LAYOUT_WORDS];
     __shared__ int s_start_w[B_CLASSIFY_TILES], s_general_w[B_CLASSIFY_TILES], s_slot_w[B_CLASSIFY_TILES];
     __shared__ TileClass s_class_w[B_CLASSIFY_TILES];
@@ -196,7 +201,33 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
         TileClass c;
         c.base = nullptr; c.pitch_or_px = 0u; c.kind = TC_FULL;
         u32 d = B_CLASS_NONE;
-        if (s_general == 2 && start >= 0) {
+        if (s_general == 1 && allow_select) {  // some layer above the start: a tile of plain copies all the same?  (serial: a handful of layers)
+            const int x1 = min(tx0 + B_TILE_W, W), y1 = min(ty0 + B_TILE_H, H);
+            u32 ids = 0xffffffffu;
+            int cnt = 0;
+            bool ok = true;
+            for (int wi = (n + 31) / 32 - 1; ok && wi >= 0; wi--) {
+                u32 bits = s_touch[wi];
+                while (ok && bits) {
+                    const int b = 31 - __clz(bits);
+                    bits &= ~(1u << b);
+                    const int i = wi * 32 + b;
+                    if (i < start) continue;
+                    const DevLayout &L = layouts[i];
+                    const int ax0 = max(L.bx0, tx0), ay0 = max(L.by0, ty0), ax1 = min(L.bx1, x1), ay1 = min(L.by1, y1);  // (touching: not empty)
+                    ok = cnt < 4 && i < 255 && layout_base_opaque(L) && (L.type != 0 || (L.flags & DL_ALIGNED)) &&
+                         layout_solid_box(L, masks, (float)ax0 + 0.5f, (float)ay0 + 0.5f, (float)ax1 - 0.5f, (float)ay1 - 0.5f);
+                    if (ok) {
+                        ids = (ids & ~(0xffu << (8 * cnt))) | ((u32)i << (8 * cnt));
+                        cnt++;
+                    }
+                }
+            }
+            if (ok && cnt > 0) {
+                c.kind = TC_SELECT;
+                c.pitch_or_px = ids;
+            }
+        } else if (s_general == 2 && start >= 0) {
             c.kind = TC_SAMPLED;
             c.pitch_or_px = (u32)start;
         } else if (s_general == 0) {
@@ -624,6 +655,34 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
                 for (int q = 0; q < 4; q++) a[r * 4 + q] = composite_sampled_opaque(L, px0 + q, py0 + r, srgb_and_ablate & 1, s_tab, s_tab + 256);
             store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
         }
+    }
+    // select tiles: every pixel a copy from the topmost listed layer whose pixel box holds it (records through scalar loads: the layer
+    // numbers are the workgroup's)
+#pragma unroll 1
+    for (int k = 0; k < B_COPY_TILES; k++) {
+        if (c[k].kind != TC_SELECT) continue;
+        const int tile = t0 + k, ty = tile / tiles_x;
+        const int px0 = (tile - ty * tiles_x) * B_TILE_W + bx, py0 = ty * B_TILE_H + by;
+        u32 a[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        u32 open_px = 0xffu;  // pixels no layer has claimed yet
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {
+            const u32 li = (c[k].pitch_or_px >> (8 * q)) & 0xffu;
+            if (li == 0xffu) break;  // (uniform)
+            const DevLayout &L = layouts_g[li];
+            const int lx0 = L.bx0, ly0 = L.by0, lx1 = L.bx1, ly1 = L.by1;
+            const bool colour = L.type != 0;
+            const u32 solid = L.solid_px;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int px = px0 + (i & 3), py = py0 + (i >> 2);
+                if (((open_px >> i) & 1u) && px >= lx0 && px < lx1 && py >= ly0 && py < ly1) {
+                    a[i] = colour ? solid : aligned_texel(L, px, py);
+                    open_px &= ~(1u << i);
+                }
+            }
+        }
+        if (px0 < W && py0 < H) store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
     }
     // a tile that needs compositing and found no room on the band list (the host's bound was short): here, band after band
     if (c[0].kind == TC_FULL && (int)c[0].pitch_or_px >= n_banded) full_entry = &full->e[c[0].pitch_or_px];

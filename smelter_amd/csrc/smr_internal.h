@@ -150,6 +150,7 @@ struct smr_ctx {
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
     int ablate = 0;           // SMR_ABLATE (profiling experiments only)
+    bool compose_select = true;  // SMR_COMPOSE_SELECT=0 (tests, profiling): no TC_SELECT tiles — seams between opaque 1:1 layers take the compositing path
     int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
     std::vector<u32> compose_bitmap;  // compose_predict's scratch
     int ingest_min_rows = 0;     // SMR_INGEST_MIN_ROWS (profiling): least tile rows per wave of k_ingest_wave (0: the default, 1)

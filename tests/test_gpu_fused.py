@@ -622,6 +622,39 @@ def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih
         c_off.close()
 
 
+@pytest.mark.parametrize("fmt_name", ["planar", "nv12", "rgba"])
+@pytest.mark.parametrize("geom", [(640, 360, 1920, 1080, 16), (482, 274, 1000, 562, 5), (320, 180, 3840, 2160, 9)], ids=["4x4", "ragged", "3x3_4k"])
+def test_seam_tiles_copy_from_the_topmost_layer(hip, monkeypatch, geom, fmt_name):
+    """A grid of video tiles that abut: the seams run through the compositor's 128 x 16 tiles, where every pixel still is a plain copy
+    from one layer (TC_SELECT).  Bit for bit what the compositing path makes of those tiles (SMR_COMPOSE_SELECT=0), on every output route."""
+    iw, ih, W, H, n = geom
+    layouts, res = scenes.cfg2_scene(iw, ih, W, H, n)
+    fmt = {"planar": hip.FRAME_PLANAR_YUV420, "nv12": hip.FRAME_NV12, "rgba": hip.FRAME_RGBA}[fmt_name]
+    monkeypatch.setenv("SMR_COMPOSE_SELECT", "0")
+    c_off = hip.Context(0)
+    monkeypatch.delenv("SMR_COMPOSE_SELECT")
+    c_on = hip.Context(0)
+    try:
+        planes, _ = _inputs(c_on, hip, n, iw, ih)
+        outs = []
+        for c in (c_on, c_off):
+            srcs = [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(p)) for p in planes]
+            frames = []
+            for rep in range(3):  # (the class records are kept while the list repeats: the cached path too)
+                out = c.frame(fmt, W, H)
+                out.upload([np.full(p.shape, 0x40 + rep, np.uint8) for p in out.download()])
+                c.render_layouts(layouts, srcs, W, H, out=out)
+                frames.append(out.download())
+            for f in frames[1:]:
+                assert all(np.array_equal(a, b) for a, b in zip(f, frames[0]))
+            outs.append(frames[0])
+        for a, b, pl in zip(outs[0], outs[1], "YUV"):
+            assert np.array_equal(a, b), f"plane {pl}: {int((a != b).sum())} bytes differ"
+    finally:
+        c_on.close()
+        c_off.close()
+
+
 def test_full_size_white_noise_within_one_lsb(hip):
     """White noise at the benchmark geometry (1920x1080 -> 1280x720) is the worst case for every approximation: dark output pixels that
     are cancelling sums of bright texels.  The default route (SMR_INGEST_AUTO — what bench.py measures) and the f32 kernel are within 1 LSB
