@@ -347,7 +347,8 @@ __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
     __syncthreads();
     const int g = (int)bx * 64 + (threadIdx.x & 63), P = (int)by * 4 + (threadIdx.x >> 6);
     if (4 * g >= J.dst.w || 4 * P >= J.dst.h) return;
-    cv420_block<NV>(J, g, P, s_ylut, s_nlut);
+    if (J.rgb12) cv420_block<NV, true>(J, g, P, s_ylut, s_nlut);  // (uniform: a job is one frame)
+    else cv420_block<NV, false>(J, g, P, s_ylut, s_nlut);
 }
 
 // rgba_to_yuv.wgsl's three passes (k_rgba_to_y + k_rgba_to_chroma) in one launch for even-sized frames: a thread owns a 4 x 2 pixel block,

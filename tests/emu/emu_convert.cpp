@@ -55,8 +55,10 @@ extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int
     }
     for (int P = 0; 4 * P < h; P++)
         for (int g = 0; 4 * g < w; g++) {
-            if (nv12) cv420_block<true>(J, g, P, ylut, nlut);
-            else cv420_block<false>(J, g, P, ylut, nlut);
+            if (nv12 && rgb12) cv420_block<true, true>(J, g, P, ylut, nlut);
+            else if (nv12) cv420_block<true, false>(J, g, P, ylut, nlut);
+            else if (rgb12) cv420_block<false, true>(J, g, P, ylut, nlut);
+            else cv420_block<false, false>(J, g, P, ylut, nlut);
         }
     if (rgb12) {
         for (int r = 0; r < h; r++) memcpy(out + (size_t)r * 3 * w, dst.data() + (size_t)r * dpitch, (size_t)3 * w);
