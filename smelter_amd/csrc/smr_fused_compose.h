@@ -18,6 +18,10 @@
 
 namespace {
 
+// row * pitch + offset as one full-rate v_mad_u32_u24 (rows and pitches are below 2^24, a surface below 4 GiB); the 64-bit form is a
+// quarter-rate 32 x 32 multiply per address
+__device__ __forceinline__ u32 b_off(int row, u32 pitch, int col_bytes) { return (u32)__umul24((u32)row, pitch) + (u32)col_bytes; }
+
 constexpr int B_TILE_W = 128, B_TILE_H = 16;  // pixels; 32 x 8 threads, one 4x2 pixel block each
 constexpr int B_MAX_LAYOUTS = 48;             // LDS-resident layout list (larger lists take the general compositor)
 constexpr int B_MAX_MASKS = 96;
@@ -305,7 +309,7 @@ __device__ __forceinline__ float4 decode_texel(u32 raw, int srgb, const float *_
 //     to exactly 1) stores its own bytes: encode(decode(b)) == b;
 //   * `is_base`: the caller established that this layer is opaque and solid at the pixel.
 __device__ __forceinline__ u32 aligned_texel(const DevLayout &L, int px, int py) {
-    return *(const u32 *)(L.src.ptr + (size_t)clampi(py - L.iy, 0, L.tex_h - 1) * L.src.pitch + (size_t)clampi(px - L.ix, 0, L.tex_w - 1) * 4);
+    return *(const u32 *)(L.src.ptr + b_off(clampi(py - L.iy, 0, L.tex_h - 1), L.src.pitch, clampi(px - L.ix, 0, L.tex_w - 1) * 4));
 }
 
 // `raw_pre`: the texel of an aligned texture layer, fetched by the caller ahead of the arithmetic (aligned_texel)
@@ -339,7 +343,7 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     // (W is even: the last block of a row holds four or two pixels)
     const bool half = px0 + 3 >= W;
     if (NV == 2) {  // an RGBA8 node texture (LayoutNode::render into a NodeTexture): the composited bytes as they are
-        u8 *o = yp.ptr + (size_t)py0 * yp.pitch + (size_t)px0 * 4;
+        u8 *o = yp.ptr + b_off(py0, yp.pitch, px0 * 4);
         if (half) {
             *(uint2 *)o = make_uint2(acc[0], acc[1]);
             *(uint2 *)(o + yp.pitch) = make_uint2(acc[4], acc[5]);
@@ -365,11 +369,11 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
         yrow1 |= yuv_byte(cr[4 + k], cg[4 + k], cb[4 + k], 0) << (8 * k);
     }
     if (half) {
-        *(u16 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = (u16)yrow0;
-        *(u16 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = (u16)yrow1;
+        *(u16 *)(yp.ptr + b_off(py0, yp.pitch, px0)) = (u16)yrow0;
+        *(u16 *)(yp.ptr + b_off(py0 + 1, yp.pitch, px0)) = (u16)yrow1;
     } else {
-        *(u32 *)(yp.ptr + (size_t)py0 * yp.pitch + px0) = yrow0;
-        *(u32 *)(yp.ptr + (size_t)(py0 + 1) * yp.pitch + px0) = yrow1;
+        *(u32 *)(yp.ptr + b_off(py0, yp.pitch, px0)) = yrow0;
+        *(u32 *)(yp.ptr + b_off(py0 + 1, yp.pitch, px0)) = yrow1;
     }
     // chroma: the bilinear tap at the chroma texel centre = weights (1/2, 1/2) x (1/2, 1/2):
     //     (a * .5 + b * .5) * .5 + (c * .5 + d * .5) * .5  ==  ((a + b) + (c + d)) * .25   bit for bit
@@ -387,16 +391,16 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     const int cx = px0 >> 1, cy = py0 >> 1;
     if (NV == 0) {
         if (half) {
-            up.ptr[(size_t)cy * up.pitch + cx] = (u8)uv[0][0];
-            vp.ptr[(size_t)cy * vp.pitch + cx] = (u8)uv[0][1];
+            up.ptr[b_off(cy, up.pitch, cx)] = (u8)uv[0][0];
+            vp.ptr[b_off(cy, vp.pitch, cx)] = (u8)uv[0][1];
         } else {
-            *(u16 *)(up.ptr + (size_t)cy * up.pitch + cx) = (u16)(uv[0][0] | (uv[1][0] << 8));
-            *(u16 *)(vp.ptr + (size_t)cy * vp.pitch + cx) = (u16)(uv[0][1] | (uv[1][1] << 8));
+            *(u16 *)(up.ptr + b_off(cy, up.pitch, cx)) = (u16)(uv[0][0] | (uv[1][0] << 8));
+            *(u16 *)(vp.ptr + b_off(cy, vp.pitch, cx)) = (u16)(uv[0][1] | (uv[1][1] << 8));
         }
     } else if (half) {
-        *(u16 *)(up.ptr + (size_t)cy * up.pitch + (size_t)cx * 2) = (u16)(uv[0][0] | (uv[0][1] << 8));
+        *(u16 *)(up.ptr + b_off(cy, up.pitch, cx * 2)) = (u16)(uv[0][0] | (uv[0][1] << 8));
     } else {
-        *(u32 *)(up.ptr + (size_t)cy * up.pitch + (size_t)cx * 2) = uv[0][0] | (uv[0][1] << 8) | (uv[1][0] << 16) | (uv[1][1] << 24);
+        *(u32 *)(up.ptr + b_off(cy, up.pitch, cx * 2)) = uv[0][0] | (uv[0][1] << 8) | (uv[1][0] << 16) | (uv[1][1] << 24);
     }
 }
 
@@ -603,7 +607,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
 #pragma unroll
         for (int k = 0; k < B_COPY_TILES; k++) {
             const bool tex = on[k] && c[k].kind == TC_TEXTURE;
-            const u8 *r0 = tex ? c[k].base + (size_t)by * c[k].pitch_or_px + (size_t)bx * 4 : (const u8 *)tables;
+            const u8 *r0 = tex ? c[k].base + b_off(by, c[k].pitch_or_px, bx * 4) : (const u8 *)tables;
             const u8 *r1 = tex ? r0 + c[k].pitch_or_px : (const u8 *)tables;
             ra[k] = *(const uint4 *)r0;
             rb[k] = *(const uint4 *)r1;
@@ -622,7 +626,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
 #pragma unroll
             for (int q = 0; q < 8; q++) acc[k][q] = fill;
             if (on[k] && c[k].kind == TC_TEXTURE) {
-                const u8 *r0 = c[k].base + (size_t)by * c[k].pitch_or_px + (size_t)bx * 4, *r1 = r0 + c[k].pitch_or_px;
+                const u8 *r0 = c[k].base + b_off(by, c[k].pitch_or_px, bx * 4), *r1 = r0 + c[k].pitch_or_px;
                 const int tile = t0 + k, cols = W - ((tile - (tile / tiles_x) * tiles_x) * B_TILE_W + bx);  // >= 2
 #pragma unroll
                 for (int q = 0; q < 4; q++)

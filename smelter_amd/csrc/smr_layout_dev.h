@@ -305,8 +305,10 @@ __device__ __forceinline__ u32 composite_sampled_opaque(const DevLayout &L, int 
     const float fx = subtexel(sx - fx0), fy = subtexel(sy - fy0);
     const int x0 = clampi((int)fx0, 0, s.w - 1), x1 = clampi((int)fx0 + 1, 0, s.w - 1);
     const int y0 = clampi((int)fy0, 0, s.h - 1), y1 = clampi((int)fy0 + 1, 0, s.h - 1);
-    const u8 *r0 = s.ptr + (size_t)y0 * s.pitch, *r1 = s.ptr + (size_t)y1 * s.pitch;
-    const u32 ta = ((const u32 *)r0)[x0], tb = ((const u32 *)r0)[x1], tc = ((const u32 *)r1)[x0], td = ((const u32 *)r1)[x1];
+    // (row offsets as 24-bit multiplies: rows and pitches are below 2^24, a surface below 4 GiB — a 32 x 32 multiply is quarter rate)
+    const u32 o0 = (u32)__umul24((u32)y0, s.pitch), o1 = (u32)__umul24((u32)y1, s.pitch);
+    const u32 ta = *(const u32 *)(s.ptr + (o0 + 4u * (u32)x0)), tb = *(const u32 *)(s.ptr + (o0 + 4u * (u32)x1));
+    const u32 tc = *(const u32 *)(s.ptr + (o1 + 4u * (u32)x0)), td = *(const u32 *)(s.ptr + (o1 + 4u * (u32)x1));
     const float gx = 1.0f - fx, gy = 1.0f - fy;
     u32 out = 0xff000000u;
 #pragma unroll
