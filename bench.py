@@ -472,11 +472,11 @@ def main():
                                   "all_kernels_of_a_frame": {"sum_us": round(sum(v["avg_us"] for v in stages.values()), 3),
                                                              "frac": round(ALGO_BYTES_PER_FRAME / (sum(v["avg_us"] for v in stages.values()) * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
                                                              "wave_a_us": round(wave_a_us, 3), "wave_a_kernels": [knames[k] for k in wave_a]},
-                                  "limiter": ("the route's own intermediates: per frame the counters see ~6x the algorithmic bytes (node textures written by the exact "
-                                              "converter and read by the resampler, RGBA8 tiles written and read by the compositor) moving at ~3.9 TB/s with two frames "
-                                              "in flight, 80 % of a device copy; the resampler alone, arithmetic compiled out, runs at copy bandwidth "
-                                              "(profiles/r04_wave_ablation.txt); the converter is vector-ALU bound (40 instructions per pixel: the WGSL sequence value for "
-                                              "value); see DESIGN.md section 3")
+                                  "limiter": ("vector-instruction issue, not HBM: the exact f32 operation sequences (WGSL value for value) cost ~25 M wave instructions + 1.2 M "
+                                              "matrix instructions per frame over 1 024 SIMDs; the converter runs as fast with its loads and stores compiled out "
+                                              "(profiles/r04_xcd_order.txt), the resampler's memory skeleton runs at copy bandwidth underneath its arithmetic "
+                                              "(profiles/r04_wave_ablation.txt), and frames in flight share the same issue slots (1.18x from two lanes).  The counters see "
+                                              "~5.8x the algorithmic bytes per frame (node textures, RGBA8 tiles) riding along; see DESIGN.md section 3")
                                   if args.ingest == "auto" else "see DESIGN.md section 3"}
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM
