@@ -149,7 +149,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     }
     // (local buffers: two threads creating contexts at once must not share a half-built table)
     float tables[SMR_TABLE_FLOATS];
-    u32 lut16[256];  // decode table as an f16 pair per entry (hi, lo = t - hi): the A operand of the matrix-core resamplers
+    u32 lut16[SMR_LUT16_WORDS];  // decode table as an f16 pair per entry (hi, lo = t - hi): the A operand of the matrix-core resamplers
     if (!smr_build_tables(tables, lut16)) {
         smr_ctx_destroy(ctx);
         return SMR_ERR_INTERNAL;

@@ -36,7 +36,7 @@
 // Work split: a workgroup = W_WAVES waves on the same column pair (they share its pass-1 band in LDS), each with its own vertical
 // piece; workgroups are ordered pair-fastest within a band of rows, so neighbouring pairs read the same source lines at the same
 // time on the same XCD.  Per-wave state is registers (~48 for the ring, 24 accumulators); LDS per workgroup = decode / encode
-// tables (5.8 KB) + the pair's band (4 KB per k-step) + 2 KB of raw Y/U/V staging per wave.
+// tables (9.5 KB) + the pair's band (4 KB per k-step) + 2 KB of raw Y/U/V staging per wave.
 #pragma once
 
 #include "smr_ingest_common.h"
@@ -315,7 +315,10 @@ struct WArgs {
 };
 
 constexpr int W_OFF_THR = M_LUT_ENTRIES * 4;
-constexpr int W_OFF_B = W_OFF_THR + (SMR_TABLE_FLOATS - 256) * 4;  // thr[257] + pad + encode estimate table
+#ifndef SMR_WAVE_ENC1
+#define SMR_WAVE_ENC1 1  // 1: one table gather per encoded value (6.5 KB of buckets), 0: estimate byte + threshold (2.7 KB) — A/B
+#endif
+constexpr int W_OFF_B = W_OFF_THR + (SMR_WAVE_ENC1 ? SMR_ENC_ENTRIES * 4 : (SMR_TABLE_FLOATS - 256) * 4);  // the encode buckets (smr_internal.h: SMR_LUT16_WORDS) | thr[257] + pad + estimate bytes
 static_assert(W_OFF_B % 16 == 0, "the band must start on a 16-byte boundary");
 __host__ __device__ inline int w_ys(int nks) { return 4 * nks + 1; }  // staged luma dwords per chunk row (+ 1: rows fall on different banks)
 __host__ __device__ inline int w_cs(int nks) { return 2 * nks + 2; }  // staged chroma dwords per row: columns base/2 - 1 .. base/2 + 8 nks, from a 4-aligned start
@@ -331,12 +334,22 @@ __host__ __device__ inline int w_band_bytes(int nks) { return 2 * nks * 2 * 64 *
 // `finish_prologue`: stores the workgroup's tables into LDS and meets the other waves — called once, after this wave's first global
 // loads are in flight and before its first LDS access.
 // srgb_encode8 (smr_internal.h) with the clamp as one median: the operand is a finite matrix-core sum, never a NaN to be quieted first.
-__device__ __forceinline__ u32 w_encode8(float x, const float *__restrict__ thr) {
-    const u8 *enc = (const u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
+// One table gather per value instead of two (estimate byte, then the threshold above it): a bucket — 7 mantissa bits — holds at most one
+// threshold, so its entry carries the code of its lowest x and where in the bucket the code steps up.  The clamped operand decides both
+// (below 2^-13: bucket 0, code 0, no threshold; at and above 1: the last bucket's top, past its threshold): the values of srgb_encode8.
+__device__ __forceinline__ u32 w_encode8(float x, const u32 *__restrict__ enc) {
     const float xc = dev_fmed3(x, 1.220703125e-4f, 0.99999994f);
-    u32 c = enc[(__float_as_uint(xc) - 0x39000000u) >> 16];
+#if SMR_WAVE_ENC1
+    const u32 b = __float_as_uint(xc) - 0x39000000u;
+    const u32 e = enc[b >> 16];
+    return (e & 0xffffu) + ((b & 0xffffu) > (e >> 16) ? 1u : 0u);
+#else
+    const float *thr = (const float *)enc;
+    const u8 *est = (const u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
+    u32 c = est[(__float_as_uint(xc) - 0x39000000u) >> 16];
     c += thr[c + 1] <= x ? 1u : 0u;
     return c;
+#endif
 }
 
 template <int NKS_T, int KV_T, int FL, typename Pro>
@@ -388,7 +401,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     constexpr int RG_N = RG ? NKS_N : 1;
     uint4 rg[RG_N];  // block j of the chunk at hand; refilled with the next chunk's block j as soon as it has been converted
     uint4 rg2[RH ? RG_N : 1];  // (RGBA16F: texels 2, 3 of the block; rg holds 0, 1)
-    const float *s_thr = (const float *)(smem + W_OFF_THR);
+    const u32 *s_thr = (const u32 *)(smem + W_OFF_THR);  // (the encode buckets)
     const uint4 *Bs = (const uint4 *)(smem + b_off);
 
     // ---- pair geometry
@@ -999,16 +1012,17 @@ __global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (20
     const int NKS = (NKS_T > 0 && NKS_T <= 4) ? NKS_T : J.NKS;  // (as in wave_piece)
     const uint4 *src = J.h_frag + (size_t)pair * 2 * J.NKS * 2 * 64;
     uint4 *Bs = (uint4 *)(smem + W_OFF_B);
-    constexpr int NL = (M_LUT_ENTRIES + W_THREADS - 1) / W_THREADS, NT = (SMR_TABLE_FLOATS - 256 + W_THREADS - 1) / W_THREADS;
+    constexpr int NL = (M_LUT_ENTRIES + W_THREADS - 1) / W_THREADS, NT = ((SMR_WAVE_ENC1 ? SMR_ENC_ENTRIES : SMR_TABLE_FLOATS - 256) + W_THREADS - 1) / W_THREADS;
     constexpr bool B_REGS = NKS_T > 0 && NKS_T <= 4 && SMR_WAVE_PIPE && SMR_WAVE_B_REGS;  // (as in wave_piece: no LDS band)
     constexpr int NB = NKS_T && !B_REGS ? (2 * NKS_T * 2 * 64 + W_THREADS - 1) / W_THREADS : 1;
     u32 r_lut[NL];
-    float r_thr[NT];
+    u32 r_thr[NT];
     uint4 r_b[NB];
 #pragma unroll
     for (int k = 0; k < NL; k++) r_lut[k] = lut[min(max(tid + k * W_THREADS - 256, 0), 255)];
 #pragma unroll
-    for (int k = 0; k < NT; k++) r_thr[k] = tables[256 + min(tid + k * W_THREADS, SMR_TABLE_FLOATS - 257)];
+    for (int k = 0; k < NT; k++)
+        r_thr[k] = SMR_WAVE_ENC1 ? lut[256 + min(tid + k * W_THREADS, SMR_ENC_ENTRIES - 1)] : __float_as_uint(tables[256 + min(tid + k * W_THREADS, SMR_TABLE_FLOATS - 257)]);
     if (NKS_T && !B_REGS) {
 #pragma unroll
         for (int k = 0; k < NB; k++) {  // (a job of the class with a narrower window: its band in the class's layout, zero beyond)
@@ -1023,7 +1037,7 @@ __global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (20
             if (tid + k * W_THREADS < M_LUT_ENTRIES) ((u32 *)smem)[tid + k * W_THREADS] = r_lut[k];
 #pragma unroll
         for (int k = 0; k < NT; k++)
-            if (tid + k * W_THREADS < SMR_TABLE_FLOATS - 256) ((float *)(smem + W_OFF_THR))[tid + k * W_THREADS] = r_thr[k];
+            if (tid + k * W_THREADS < (SMR_WAVE_ENC1 ? SMR_ENC_ENTRIES : SMR_TABLE_FLOATS - 256)) ((u32 *)(smem + W_OFF_THR))[tid + k * W_THREADS] = r_thr[k];
         if (B_REGS) {
         } else if (NKS_T) {
 #pragma unroll
@@ -1454,7 +1468,8 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);
-        args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;
+        // (node-texture builds stage nothing: the area behind the band only holds the alpha builds' 1 KB table)
+        args.raw_bytes = rgba ? (alpha ? 1024 / W_WAVES : 0) : (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;
         const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
         if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of LDS", lds);
         // as many waves as are resident at once (registers and LDS), one piece each: every wave starts and ends with the launch

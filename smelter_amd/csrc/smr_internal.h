@@ -21,6 +21,9 @@ typedef uint32_t u32;
 #define SMR_TABLE_FLOATS 932
 #define SMR_ENC_OFFSET_FROM_THR 260
 #define SMR_ENC_ENTRIES 1664
+// lut16 block (device: ctx->d_lut16): [0,256) the decode table as (f16 hi | f16 lo << 16) | [256, 256 + SMR_ENC_ENTRIES) the encode table of the
+// matrix-core resampler: per estimate bucket (code of its lowest x) | (offset of the one threshold inside it - 1, 0xffff = none) << 16
+#define SMR_LUT16_WORDS (256 + SMR_ENC_ENTRIES)
 
 #define SMR_NUM_STAGES 8
 enum {

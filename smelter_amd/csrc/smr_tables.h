@@ -13,7 +13,7 @@ static inline double smr_srgb_to_linear_f64(double c) {
     return pow((c + 0.055) / 1.055, 2.4);
 }
 
-// tables[SMR_TABLE_FLOATS]: decode LUT | thr[257] | pad | encode estimate bytes; lut16[256]: (f16 hi | f16 lo << 16), lo = t - hi.
+// tables[SMR_TABLE_FLOATS]: decode LUT | thr[257] | pad | encode estimate bytes; lut16[SMR_LUT16_WORDS]: (f16 hi | f16 lo << 16), lo = t - hi, then the encode buckets (smr_internal.h).
 // Returns false if an estimate bucket straddles more than two codes (the one-step fix-up of srgb_encode8 would not suffice).
 static inline bool smr_build_tables(float *tables, u32 *lut16) {
     memset(tables, 0, sizeof(float) * SMR_TABLE_FLOATS);
@@ -37,6 +37,16 @@ static inline bool smr_build_tables(float *tables, u32 *lut16) {
         const int cl = code_of(lo), chh = code_of(hi);
         if (chh - cl > 1) return false;
         enc[idx] = (u8)cl;
+        // the same bucket for k_ingest_wave's one-gather encode: at most one threshold lies inside a bucket (just checked), strictly above
+        // its lowest x; code = cl + (low 16 bits of x > that threshold's low 16 bits - 1)
+        u32 above = 0xffffu;
+        if (chh > cl) {
+            u32 tb;
+            memcpy(&tb, &thr[cl + 1], 4);
+            if (tb <= lo_bits || tb > hi_bits) return false;
+            above = tb - lo_bits - 1u;
+        }
+        lut16[256 + idx] = (u32)cl | (above << 16);
     }
     for (int i = 0; i < 256; i++) {
         const _Float16 hi = (_Float16)tables[i];

@@ -100,7 +100,7 @@ Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
 extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, int sh, int full_range, int nv12, float scale_h, float off_h, float scale_v,
                                float off_v, u8 *dst, int dw, int dh, int pieces, int specialised, int *info) {
     static float tables[SMR_TABLE_FLOATS];
-    static u32 lut16[256];
+    static u32 lut16[SMR_LUT16_WORDS];
     static bool have_tables = false;
     if (!have_tables) {
         if (!smr_build_tables(tables, lut16)) return -9;
