@@ -64,7 +64,7 @@ bool rgb12_node_serves(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan
     else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &NKS, &unused);
     if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3)) KV = t->K;
     else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 3, &KV, &unused);
-    return (NKS <= 4 && KV == 2) || (NKS <= 8 && KV == 3);
+    return (NKS <= 4 && KV == 2) || (NKS <= 8 && KV == 3) || (ctx->rgb12_cls82 && NKS <= 8 && KV == 2);
 }
 SurfView rgb12_view(const smr_surface *node, const smr_frame *f) {  // the node in pixels; its rows hold 3 w bytes
     SurfView v = view_of(node);

@@ -1401,6 +1401,9 @@ constexpr WaveKernel W_KERNELS_RGBA_DIRECT[] = {k_ingest_wave<0, 0, 8192 + 2048>
 constexpr WaveKernel W_KERNELS_RGBA_ALPHA[] = {k_ingest_wave<0, 0, 8192 + 65536>, k_ingest_wave<4, 2, 8192 + 65536>, k_ingest_wave<4, 2, 8193 + 65536>,
                                                k_ingest_wave<8, 3, 8192 + 65536>};
 // ... and RGBA16F ones (box-pre-reduced plans: residual scales of 2 .. 4; above ~3.2 as one-tile units, WJob::single)
+// node textures at scales around 2 (8 k-steps, pass-2 window 2: a 4 x 4 grid of 1080p inputs on a 4K output, 4 x 1080p on 1080p): the wide class's
+// software pipeline instead of the generic build's predicated loops
+constexpr WaveKernel W_KERNEL_RGBA_82 = k_ingest_wave<8, 2, 8192>, W_KERNEL_RGB12_82 = k_ingest_wave<8, 2, 8192 + 131072>;
 constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>, W_KERNEL_RGBA16F_ALPHA = k_ingest_wave<0, 0, 8192 + 16384 + 65536>;
 // ... and single-axis plans (generic build): planar | NV12-capable | RGBA8 node texture
 constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>,
@@ -1416,6 +1419,8 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         all.insert(all.end(), W_KERNELS_RGB12, W_KERNELS_RGB12 + 4);
         all.insert(all.end(), W_KERNELS_RGB12_DIRECT, W_KERNELS_RGB12_DIRECT + 4);
         all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
+        all.push_back(W_KERNEL_RGBA_82);
+        all.push_back(W_KERNEL_RGB12_82);
         all.push_back(W_KERNEL_RGBA16F);
         all.push_back(W_KERNEL_RGBA16F_ALPHA);
         all.insert(all.end(), W_KERNELS_SA, W_KERNELS_SA + 4);
@@ -1448,6 +1453,7 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
         if (f16 || sa) cls432 = cls83 = cls82 = false;  // (one generic build)
+        const bool node82 = cls82 && !cls432 && rgba && !alpha && !direct && ctx->wave_node82;  // (node textures: its own two builds)
         if (rgba || cls432) cls82 = false;
         int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
         if (!rgba && !sa) {
@@ -1456,13 +1462,15 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
         const int sa_i = rgba ? (alpha ? 3 : 2) : (any_nv ? 1 : 0);
-        const WaveKernel kern = cls82 ? W_KERNELS_82[(direct ? 1 : 0) + (any_nv ? 2 : 0)]
+        const WaveKernel kern = node82 ? (rgb12 ? W_KERNEL_RGB12_82 : W_KERNEL_RGBA_82)
+                                : cls82 ? W_KERNELS_82[(direct ? 1 : 0) + (any_nv ? 2 : 0)]
                                 : sa ? W_KERNELS_SA[sa_i]
                                    : f16 ? (alpha ? W_KERNEL_RGBA16F_ALPHA : W_KERNEL_RGBA16F)
                                          : alpha ? W_KERNELS_RGBA_ALPHA[ki]
                                                  : rgb12 ? (direct ? W_KERNELS_RGB12_DIRECT[ki] : W_KERNELS_RGB12[ki])
                                                          : rgba ? (direct ? W_KERNELS_RGBA_DIRECT[ki] : W_KERNELS_RGBA[ki]) : W_KERNELS[ki];
-        if (cls82) ki = 500 + (direct ? 1 : 0) + (any_nv ? 2 : 0);  // (occupancy cache key)
+        if (node82) ki = rgb12 ? 710 : 700;  // (occupancy cache keys)
+        else if (cls82) ki = 500 + (direct ? 1 : 0) + (any_nv ? 2 : 0);
         else if (sa) ki = 300 + sa_i;
         else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : rgb12 ? (direct ? 650 : 600) : (direct ? 150 : 100);
         ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
