@@ -92,6 +92,31 @@ Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
 
 }  // namespace
 
+// The matrix-core kernel's one-gather sRGB encode (w_encode8, smr_ingest_wave.h) against the step function it stands for, u8 = #{i : thr[i] <= x}
+// (srgb_encode8's definition, smr_internal.h), on EVERY f32 from 0 up to 1.5 (the clamp's far side included), their negatives and the specials:
+// returns how many disagree (0), -9 when the tables cannot be built.
+extern "C" long long emu_check_encode(void) {
+    static float tables[SMR_TABLE_FLOATS];
+    static u32 lut16[SMR_LUT16_WORDS];
+    if (!smr_build_tables(tables, lut16)) return -9;
+    const float *thr = tables + 256;
+    long long bad = 0;
+    u32 code = 0;  // #{i >= 1 : thr[i] <= x}, kept up to date while x walks upwards
+    u32 top;
+    const float top_f = 1.5f;
+    memcpy(&top, &top_f, 4);
+    for (u32 bits = 0; bits <= top; bits++) {
+        float x;
+        memcpy(&x, &bits, 4);
+        while (code < 255 && thr[code + 1] <= x) code++;
+        if (w_encode8(x, lut16 + 256) != code) bad++;
+        if (w_encode8(-x, lut16 + 256) != 0u) bad++;
+    }
+    const float inf = __builtin_inff();
+    if (w_encode8(inf, lut16 + 256) != 255u || w_encode8(-inf, lut16 + 256) != 0u || w_encode8(3.0e38f, lut16 + 256) != 255u) bad++;
+    return bad;
+}
+
 // One job through k_ingest_wave.  Planes tightly packed (NV12: u = interleaved UV, v ignored); dst = dw x dh RGBA8, tight.
 // (scale, offset) per axis as smr_resample_plan_make gives them for a two-pass, horizontal-first plan.  `pieces`: vertical pieces
 // per column pair (rounded up to a multiple of the workgroup's waves); `specialised` != 0 asks for the <4, 3, 2> build when the

@@ -36,8 +36,15 @@ def emu():
     h = C.CDLL(lib)
     h.emu_ingest_wave.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, P8, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.POINTER(C.c_int)]
+    h.emu_check_encode.restype = C.c_longlong
     orc.build()
     return h
+
+
+def test_one_gather_encode_is_the_step_function_on_every_float(emu):
+    """k_ingest_wave's sRGB encode takes one table gather per value (bucket entry = code of the bucket's lowest x | offset of the one threshold inside
+    it): equal to u8 = #{i : thr[i] <= x} on all 1.07 billion f32 values of [0, 1.5], on their negatives and at the infinities."""
+    assert emu.emu_check_encode() == 0
 
 
 def _planes(sw, sh, noise, seed):
