@@ -655,6 +655,35 @@ def test_seam_tiles_copy_from_the_topmost_layer(hip, monkeypatch, geom, fmt_name
         c_off.close()
 
 
+@pytest.mark.parametrize("geom", [(7680, 4320, 1920, 1080), (7680, 4320, 3840, 2160), (7680, 2, 3840, 2)], ids=["8k_to_1080p", "8k_to_4k", "8k_x_2"])
+def test_maximum_node_resolution(hip, geom):
+    """The reference's largest node (MAX_NODE_RESOLUTION, types.rs:146-149: 7682 x 4320): an 8K 4:2:0 frame through the default route.  The
+    converter's node texture is the oracle's byte for byte; the tile (a factor-4 plan with a box pre-reduction, a factor-2 two-pass plan, a
+    two-row sliver) is within 1 LSB of the oracle's resample on every byte; the f32 kernels agree."""
+    iw, ih, dw, dh = geom
+    rng = np.random.default_rng(iw * 31 + dh)
+    xx, yy = np.meshgrid(np.arange(iw), np.arange(ih))
+    y = ((xx * 5 + yy * 3) % 220 + 16 + rng.integers(0, 12, (ih, iw))).astype(np.uint8)
+    u = rng.integers(0, 256, (ih // 2, iw // 2), dtype=np.uint8)
+    v = ((xx[::2, ::2] // 3 + yy[::2, ::2]) % 256).astype(np.uint8)
+    crop = (0.0, 0.0, float(iw), float(ih))
+    node_o = orc.planar_yuv_to_rgba(y, u, v, iw, ih, omp=True)
+    _, want = orc.resample(node_o, crop, dw, dh, omp=True)
+    c = hip.Context(0)
+    try:
+        f = c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, [y, u, v])
+        assert np.array_equal(c.frame_to_rgba(f).download(), node_o), "the converter's 8K node texture is not the oracle's"
+        for impl in (hip.INGEST_AUTO, hip.INGEST_VALU_F32):
+            c.set_ingest_impl(impl)
+            t = c.surface(dw, dh)
+            c.ingest_resample(f, crop, t)
+            de = np.abs(t.download().astype(np.int16) - want.astype(np.int16))
+            assert de.max() <= 1, f"impl {impl}: max {de.max()}, {(de > 1).sum()} bytes off by more than 1"
+            assert (de == 0).mean() >= 0.999, f"impl {impl}: {(de == 0).mean():.5f} identical"
+    finally:
+        c.close()
+
+
 def test_full_size_white_noise_within_one_lsb(hip):
     """White noise at the benchmark geometry (1920x1080 -> 1280x720) is the worst case for every approximation: dark output pixels that
     are cancelling sums of bright texels.  The default route (SMR_INGEST_AUTO — what bench.py measures) and the f32 kernel are within 1 LSB
