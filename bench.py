@@ -472,12 +472,22 @@ def main():
                                   "all_kernels_of_a_frame": {"sum_us": round(sum(v["avg_us"] for v in stages.values()), 3),
                                                              "frac": round(ALGO_BYTES_PER_FRAME / (sum(v["avg_us"] for v in stages.values()) * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
                                                              "wave_a_us": round(wave_a_us, 3), "wave_a_kernels": [knames[k] for k in wave_a]},
-                                  "limiter": ("vector-instruction issue, not HBM: the exact f32 operation sequences (WGSL value for value) cost ~25 M wave instructions + 1.2 M "
-                                              "matrix instructions per frame over 1 024 SIMDs; the converter runs as fast with its loads and stores compiled out "
+                                  "limiter": ("vector-instruction issue, not HBM: the exact f32 operation sequences (WGSL value for value) cost ~24 M wave instructions + 1.2 M "
+                                              "matrix instructions per frame over 1 024 SIMDs (roofline.issue); the converter runs as fast with its loads and stores compiled out "
                                               "(profiles/r04_xcd_order.txt), the resampler's memory skeleton runs at copy bandwidth underneath its arithmetic "
                                               "(profiles/r04_wave_ablation.txt), and frames in flight share the same issue slots (1.18x from two lanes).  The counters see "
                                               "~5.8x the algorithmic bytes per frame (node textures, RGBA8 tiles) riding along; see DESIGN.md section 3")
                                   if args.ingest == "auto" else "see DESIGN.md section 3"}
+        # the roofline that does bound this path: instruction issue.  Wave-instruction counts per frame from the committed PMC passes of this same
+        # command (profiles/r04_issue.json <- tools/prof.sh), priced at the issue rates measured on this device (profiles/r02_valu_rate.txt)
+        ipath = os.path.join(ROOT, "profiles", "r04_issue.json")
+        if args.config == 2 and args.ingest == "auto" and os.path.exists(ipath):
+            iss = json.load(open(ipath))
+            floor_us = iss["issue_floor_us_per_frame"]
+            result["roofline"]["issue"] = {"valu_wave_instructions_per_frame": iss["per_frame"]["valu_wave_instructions"],
+                                           "mfma_wave_instructions_per_frame": iss["per_frame"]["mfma_wave_instructions"],
+                                           "floor_us_per_frame": floor_us, "frac_of_issue_floor": round(floor_us / (result["ms_per_step"] * 1e3), 4),
+                                           "source": "profiles/r04_issue.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA of this command; issue rates: profiles/r02_valu_rate.txt)"}
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM
         lat, enq = [], []
