@@ -173,7 +173,7 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
     args.n_jobs = 1;
     if (sa) J.perp = (int)off_v;
-    const bool spec = specialised && cls432, spec83 = specialised && !cls432 && cls83;
+    const bool spec = specialised && cls432, spec83 = specialised && !cls432 && cls83, spec82 = specialised && !cls432 && !cls83 && cls82;
     const int cls_nks = spec ? 4 : 0;
     args.b_bytes = w_band_bytes(cls_nks ? cls_nks : bh.K);
     args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : bh.K) + 15) & ~15;
@@ -199,11 +199,13 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193 + 131072>(args, tables, lut16); });
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192 + 131072>(args, tables, lut16); });
         else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192 + 131072>(args, tables, lut16); });
+        else if (spec82) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 8192 + 131072>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192 + 131072>(args, tables, lut16); });
     } else if (rgba) {
         if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8193>(args, tables, lut16); });
         else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 8192>(args, tables, lut16); });
         else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192>(args, tables, lut16); });
+        else if (spec82) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 8192>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192>(args, tables, lut16); });
     } else if (spec && bh.k01) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4097>(args, tables, lut16); });

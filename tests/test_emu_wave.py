@@ -122,6 +122,7 @@ RGBA_CASES = [
     ((130, 74), (86, 49), None, 2, 0),         # odd sizes: partial tiles, a width that is not a multiple of 4
     ((64, 36), (96, 54), None, 2, 0),          # upscale
     ((256, 144), (128, 72), None, 2, 0),       # scale 2
+    ((256, 144), (128, 72), None, 3, 1),       # ... and its class build (<8, 2>: 5 k-steps, pass-2 windows of 2)
     ((384, 216), (128, 72), None, 3, 1),       # scale 3: the wide class build
     ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, 1),  # crop
 ]
