@@ -320,35 +320,50 @@ __global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView
     }
 }
 
-// 4:2:0 frames (planar or NV12, limited or full range) the 4 x 4 block converter takes (smr_convert_420.h): one launch for up to 16 frames,
-// a 64 x 4 thread block per 256 x 16 pixels; the workgroup's first 256 threads build the luma table of the job's range in LDS.
+// 4:2:0 frames (planar or NV12, limited or full range) the 4 x 4 block converter takes (smr_convert_420.h): one launch for up to 16 frames.
+//
+// The launch is PERSISTENT and its work is cut into EQUAL SHARES: as many workgroups as the device holds at once (the host sizes the grid
+// and, through the dynamic LDS request, how many a CU admits — so every SIMD gets the same number of waves), and wave w computes the w-th
+// share of the launch's unit sequence (ConvBatch: block rows fastest, then column blocks, then jobs): a vertical run of blocks in one
+// column block, or the end of one and the start of the next.  Why (wave stamps, profiles/r05_convert_waves.txt): the kernel is bound by
+// vector-instruction issue — a SIMD's waves finish one after the other, oldest first, at ~3.9 cycles per vector instruction and 2.0 GHz —
+// so its time is the busiest SIMD's instruction count.  A grid of one block row per wave (4 608 workgroups) paid the table build + barrier
+// 4 608 times (a quarter of a wave's life) and ran 2.4 rounds of waves with a tail; a grid of fixed runs put 5, 6 or 7 workgroups on a CU as
+// the dispatcher saw fit (CUs finished between 14 and 20 us).  Equal shares on an even placement end together, and a share's blocks are
+// vertical neighbours: cv420_run keeps the chroma rows they share.  (A ticket counter instead of fixed shares was measured first: one word
+// serves ~90 atomics per microsecond — 150 us for this launch's 8 640 tickets.)
+#ifdef CV_TIMING
+__device__ unsigned long long g_cv_stamps[32768][10];  // per wave of the last launch: entry (shader clock), tables built, first task: loads in, window converted, first block done; queue dry, stores done; [7] / [8] = realtime at entry / exit, [9] = XCC_ID << 32 | HW_ID
+extern "C" __attribute__((visibility("default"))) int smr_debug_convert_stamps(unsigned long long *out, unsigned n_waves) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cv_stamps), (size_t)n_waves * 10 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 template <bool NV>
 __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
     __shared__ float s_ylut[256], s_nlut[256];
-    // Workgroups go to the XCDs round robin (id mod 8), and every XCD has its own L2.  A workgroup's chroma window reaches a byte or two into
-    // the cache lines of its neighbours left and right and a chroma row into those above and below: walked in launch order, a box of
-    // gx = 8 column blocks put each column on its own XCD and every XCD fetched three lines for one (counters: 40 MB for 24.9 MB of planes).
-    // So XCD k takes the block rows k, k + 8, ... of every frame, each from left to right: neighbours in x run on the same L2 one after the
-    // other, and all eight XCDs stay within 128 lines of each other in the same frame (an XCD per frame fetched the least and was slower:
-    // eight streams at the same offsets of eight equally aligned buffers, profiles/r04_xcd_order.txt).
-    u32 bx, by, bz;
-    if (B.order == 2) {
-        const u32 gy8 = ((u32)B.gy + 7u) / 8u, r = blockIdx.x >> 3;
-        bx = r % (u32)B.gx; by = ((r / (u32)B.gx) % gy8) * 8u + (blockIdx.x & 7u); bz = r / ((u32)B.gx * gy8);
-    } else {
-        const u32 total = (u32)(B.gx * B.gy * B.n), per_xcd = (total + 7u) / 8u;
-        const u32 at = B.order == 1 ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-        bx = at % (u32)B.gx; by = (at / (u32)B.gx) % (u32)B.gy; bz = at / (u32)(B.gx * B.gy);
-    }
-    if (by >= (u32)B.gy || bz >= (u32)B.n) return;  // (uniform)
-    const ConvJob &J = B.j[bz];
-    s_ylut[threadIdx.x & 255] = cv420_luma_of_byte(threadIdx.x & 255u, J.full != 0);
+#ifdef CV_TIMING
+    unsigned long long *st = g_cv_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 32767u];
+    if ((threadIdx.x & 63) == 0) { st[7] = __builtin_amdgcn_s_memrealtime(); st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0; }
+    CV_STAMP(st, 0, "s_nop 0");
+#else
+    unsigned long long *st = nullptr;
+#endif
+    const u32 lane = threadIdx.x & 63u;
+    // both ranges' luma tables: a wave's share may touch several jobs (the full-range luma value of a byte is byte / 255 itself: s_nlut)
+    s_ylut[threadIdx.x & 255] = cv420_luma_of_byte(threadIdx.x & 255u, false);
     s_nlut[threadIdx.x & 255] = unorm_of_byte(threadIdx.x & 255u);
     __syncthreads();
-    const int g = (int)bx * 64 + (threadIdx.x & 63), P = (int)by * 4 + (threadIdx.x >> 6);
-    if (4 * g >= J.dst.w || 4 * P >= J.dst.h) return;
-    if (J.rgb12) cv420_block<NV, true>(J, g, P, s_ylut, s_nlut);  // (uniform: a job is one frame)
-    else cv420_block<NV, false>(J, g, P, s_ylut, s_nlut);
+    CV_STAMP(st, 1, "s_nop 0");
+    cv420_share<NV>(B, cv_uniform(blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6)), gridDim.x * (BLOCK / 64u), lane, s_ylut, s_nlut, st);
+#ifdef CV_TIMING
+    st = g_cv_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 32767u];
+#endif
+    CV_STAMP(st, 5, "s_nop 0");                // the queue is dry, the last stores are issued
+    CV_STAMP(st, 6, "s_waitcnt vmcnt(0)");     // ... and acknowledged
+#ifdef CV_TIMING
+    if ((threadIdx.x & 63) == 0) { st[8] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); st[9] = ((unsigned long long)xcc << 32) | hw; }
+#endif
 }
 
 // rgba_to_yuv.wgsl's three passes (k_rgba_to_y + k_rgba_to_chroma) in one launch for even-sized frames: a thread owns a 4 x 2 pixel block,
@@ -508,11 +523,23 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;  // (per launch)
         if (k == 0) hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 7) / 8), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
         else {
-            Q.B.gx = (Q.mw + 255) / 256; Q.B.gy = (Q.mh + 15) / 16; Q.B.n = (int)Q.nb;
-            Q.B.order = ctx->convert_order;
-            const unsigned blocks = (unsigned)(8 * Q.B.gx * ((Q.B.gy + 7) / 8) * Q.B.n);  // (block rows in rounds of eight: one per XCD)
-            if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3(blocks), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
-            else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), ctx->convert_lds_pad, ctx->stream, Q.B);
+            // the unit sequence (k_yuv420_to_rgba's header): block rows fastest, then column blocks, then jobs
+            Q.B.n = (int)Q.nb;
+            Q.B.first_unit[0] = 0;
+            for (u32 j = 0; j < Q.nb; j++) {
+                const u32 cols = ((u32)Q.B.j[j].dst.w + 255u) / 256u, rows = ((u32)Q.B.j[j].dst.h + 3u) / 4u;
+                Q.B.rows[j] = rows;
+                Q.B.first_unit[j + 1] = Q.B.first_unit[j] + cols * rows;
+            }
+            const u32 total = Q.B.first_unit[Q.nb];
+            // as many workgroups as stay resident together: convert_wg_per_cu per CU — the dynamic LDS request caps what a CU admits at that
+            // number, so the grid spreads evenly and every SIMD holds the same number of waves — and never more waves than units
+            const u32 per_cu = (u32)(ctx->convert_wg_per_cu < 1 ? 1 : ctx->convert_wg_per_cu > 6 ? 6 : ctx->convert_wg_per_cu);
+            u32 blocks = (u32)ctx->cu_count * per_cu;
+            if (blocks > (total + 3u) / 4u) blocks = (total + 3u) / 4u;
+            const u32 lds_pad = ctx->convert_lds_pad ? ctx->convert_lds_pad : (160u * 1024u / per_cu - 2048u) & ~255u;
+            if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
+            else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
         }
         Q.nb = 0; Q.mw = 0; Q.mh = 0;
         SMR_HIP(ctx, hipGetLastError());

@@ -32,7 +32,9 @@
 #define cv_alignbyte(hi, lo, sh) dev_alignbyte((hi), (lo), (sh))
 #define cv_clamp01(x) dev_fmed3((x), 0.0f, 1.0f)
 #define cv_mad24(a, b, c) dev_mad24((a), (b), (c))
+#define cv_uniform(x) (x)
 #else
+#define cv_uniform(x) __builtin_amdgcn_readfirstlane(x)  // a value every lane of the wave holds alike, moved to a scalar register
 #define cv_perm(hi, lo, sel) __builtin_amdgcn_perm((hi), (lo), (sel))
 #define cv_alignbyte(hi, lo, sh) __builtin_amdgcn_alignbyte((hi), (lo), (sh))
 #define cv_clamp01(x) __builtin_amdgcn_fmed3f((x), 0.0f, 1.0f)
@@ -49,8 +51,12 @@ struct ConvJob {
 constexpr int MAX_CONV_JOBS = 16;
 struct ConvBatch {
     ConvJob j[MAX_CONV_JOBS];
-    int order;      // (profiling: SMR_CONVERT_ORDER) 0 box in launch order | 1 an eighth of the box per XCD | 2 block rows round robin over the XCDs
-    int gx, gy, n;  // k_yuv420_to_rgba: the launch as a gx x gy x n box of workgroups (its 1-D grid is that box walked XCD by XCD)
+    // k_yuv420_to_rgba: the launch's work as ONE sequence of units — a unit = 64 column groups (256 pixels) x one block row (4 rows) of one
+    // job, what a wave computes per cv420_run step; job j owns units [first_unit[j], first_unit[j + 1]), block rows fastest inside a column
+    // block (rows[j] of them per column block) — cut into equal contiguous shares, one per wave of the launch
+    int n;
+    u32 first_unit[MAX_CONV_JOBS + 1];
+    u32 rows[MAX_CONV_JOBS];
 };
 
 #ifndef CV_ABL
@@ -58,6 +64,14 @@ struct ConvBatch {
 #endif
 
 #ifdef __HIPCC__
+
+// CV_TIMING (tools/variant_convert.sh timing -DCV_TIMING): lane 0 of every wave stamps the shader clock at the phase boundaries of its run —
+// each stamp behind an explicit wait for what the phase requested — into g_cv_stamps[wave][...]; tools/r05/conv_timing.py reads them back.
+#if defined(CV_TIMING) && !defined(SMR_EMU)
+#define CV_STAMP(st, i, waits) do { asm volatile(waits ::: "memory"); if ((st) && (threadIdx.x & 63) == 0) (st)[i] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define CV_STAMP(st, i, waits) do { } while (0)
+#endif
 
 // y' of a luma byte: planar_yuv_to_rgba.wgsl:46 on byte / 255 (limited range), the byte's unorm value itself (full range)
 __device__ __forceinline__ float cv420_luma_of_byte(u32 b, bool full) {
@@ -69,71 +83,98 @@ __device__ __forceinline__ float cv420_luma_of_byte(u32 b, bool full) {
     return cv_clamp01(__builtin_fmaf(__builtin_fmaf(-q, ky, a), ry, q));
 }
 
-// One 4 x 4 block: columns 4 g .. 4 g + 3, rows 4 P .. 4 P + 3 of job J (rows past the frame's height are not stored).
-// ylut: 256 floats, cv420_luma_of_byte of every byte for this job's range.
-// Requirements (cv420_job_ok on the host): 4:2:0, even height, width a multiple of 4, dword-aligned planes whose rows can be read a
-// dword past the window, 16-byte aligned destination rows.
-// nlut: 256 floats, unorm_of_byte of every byte (the chroma bytes' byte / 255: a table gather instead of a conversion and two multiply-adds)
-// RGB12: the node texture as 12-byte groups (ConvJob::rgb12), else RGBA8 — separate instantiations: each packs its own bytes only
-template <bool NV, bool RGB12>
-__device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut, const float *nlut) {
-    const int w = J.dst.w, h = J.dst.h, cw = w >> 1, ch = h >> 1;
-    const bool full = J.full != 0;
-    // ---- the four luma dwords first, with the chroma window's loads: every load of the block is in flight before the first store (a row's
-    //      luma load behind the previous row's store waited for that store and for itself: four memory round trips per block instead of one)
-    u32 yrow[4];
+// ---- the pieces of a block (cv420_block below = one block; cv420_run = a vertical run of blocks that shares what neighbouring blocks share)
+
+// Where column group g's chroma window (columns 2 g - 1 .. 2 g + 2, clamped to the plane like the sampler clamps) sits in a chroma row
+struct Cv420Win {
+    u32 base;       // byte offset of the dword the window's first byte lies in
+    u32 sh;         // ... and the byte's offset inside that dword
+    u32 right_fix;  // v_perm selector: the window's last column repeats the one before it at the plane's right edge
+    bool left;      // the window starts left of the plane: columns 0 1 2 3 -> 0 0 1 2
+};
+template <bool NV>
+__device__ __forceinline__ Cv420Win cv420_window(const ConvJob &J, int g) {
+    const int cw = J.dst.w >> 1;
+    const int first = 2 * g - 1, first_ld = first < 0 ? 0 : first;
+    const int byte0 = NV ? 2 * first_ld : first_ld, base = byte0 & ~3;
+    const int nvalid = cw - first;  // window columns 0 .. nvalid - 1 exist (>= 3: the last block's window starts at cw - 3)
+    Cv420Win W;
+    W.base = (u32)base; W.sh = (u32)(byte0 - base); W.right_fix = nvalid >= 4 ? 0x03020100u : 0x02020100u; W.left = first < 0;
+    return W;
+}
+
+// The dwords of one chroma row that hold the window, as loaded (planar: U, U + 4, V, V + 4; NV12: three dwords of U V pairs)
+template <bool NV>
+struct Cv420Raw {
+    u32 d[NV ? 3 : 4];
+};
+template <bool NV>
+__device__ __forceinline__ Cv420Raw<NV> cv420_load_chroma(const ConvJob &J, const Cv420Win &W, int crow) {
+    const int ch = J.dst.h >> 1;
+    const int cy = min(max(crow, 0), ch - 1);
+    Cv420Raw<NV> R;
+    const u8 *ur = J.up.ptr + cv_mad24((u32)cy, J.up.pitch, W.base);  // (one 32-bit offset from a uniform base: a plane is far below 4 GiB)
+    if (CV_ABL & 2) {
+#pragma unroll
+        for (int k = 0; k < (NV ? 3 : 4); k++) R.d[k] = 0x01020304u * (u32)(crow + k) + W.base;
+    } else if (NV) {
+        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + 4); R.d[2] = *(const u32 *)(ur + 8);
+    } else {
+        const u8 *vr = J.vp.ptr + cv_mad24((u32)cy, J.vp.pitch, W.base);
+        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + 4); R.d[2] = *(const u32 *)vr; R.d[3] = *(const u32 *)(vr + 4);
+    }
+    return R;
+}
+__device__ __forceinline__ void cv420_load_luma(const ConvJob &J, int g, int P, u32 yrow[4]) {
+    const int h = J.dst.h;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (CV_ABL & 4) yrow[r] = 0x10203040u * (u32)(g + r) + (u32)P;
         else yrow[r] = *(const u32 *)(J.yp.ptr + cv_mad24((u32)min(4 * P + r, h - 1), J.yp.pitch, 4u * (u32)g));
     }
-    // ---- chroma window: columns 2 g - 1 .. 2 g + 2, rows 2 P - 1 .. 2 P + 2, clamped to the plane like the sampler clamps
-    const int first = 2 * g - 1, first_ld = first < 0 ? 0 : first;
-    const int byte0 = NV ? 2 * first_ld : first_ld, base = byte0 & ~3;
-    const u32 sh = (u32)(byte0 - base);
-    const int nvalid = cw - first;  // window columns 0 .. nvalid - 1 exist (>= 3: the last block's window starts at cw - 3)
-    const u32 right_fix = nvalid >= 4 ? 0x03020100u : 0x02020100u;
-    float H[2][4][4];  // [plane][window row][luma column]: the row's horizontal lerp at the block's four columns
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int cy = min(max(2 * P - 1 + j, 0), ch - 1);
-        const u8 *ur = J.up.ptr + cv_mad24((u32)cy, J.up.pitch, (u32)base);  // (one 32-bit offset from a uniform base: a plane is far below 4 GiB)
-        u32 uw, vw;
-        if (CV_ABL & 2) {
-            uw = 0x01020304u * (u32)(g + j) + (u32)cy; vw = uw ^ 0x55aa55aau;
-        } else if (NV) {
-            const u32 d0 = *(const u32 *)ur, d1 = *(const u32 *)(ur + 4), d2 = *(const u32 *)(ur + 8);
-            const u32 w0 = cv_alignbyte(d1, d0, sh), w1 = cv_alignbyte(d2, d1, sh);  // U V U V of two columns each
-            uw = cv_perm(w1, w0, 0x06040200u);
-            vw = cv_perm(w1, w0, 0x07050301u);
-        } else {
-            const u8 *vr = J.vp.ptr + cv_mad24((u32)cy, J.vp.pitch, (u32)base);
-            uw = cv_alignbyte(*(const u32 *)(ur + 4), *(const u32 *)ur, sh);
-            vw = cv_alignbyte(*(const u32 *)(vr + 4), *(const u32 *)vr, sh);
-        }
-        if (first < 0) {  // columns 0 1 2 3 -> 0 0 1 2
-            uw = (uw << 8) | (uw & 0xffu);
-            vw = (vw << 8) | (vw & 0xffu);
-        }
-        uw = cv_perm(0u, uw, right_fix);
-        vw = cv_perm(0u, vw, right_fix);
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const u32 q = c ? vw : uw;
-            const float n0 = nlut[q & 0xffu], n1 = nlut[(q >> 8) & 0xffu], n2 = nlut[(q >> 16) & 0xffu], n3 = nlut[q >> 24];
-            // a * (1 - fx) + b * fx with fx = .75, .25, .75, .25 (sample_plane_bilinear): the 1/4 products are exact
-            const float m1 = n1 * 0.75f, m2 = n2 * 0.75f;
-            H[c][j][0] = __builtin_fmaf(n0, 0.25f, m1);
-            H[c][j][1] = __builtin_fmaf(n2, 0.25f, m1);
-            H[c][j][2] = __builtin_fmaf(n1, 0.25f, m2);
-            H[c][j][3] = __builtin_fmaf(n3, 0.25f, m2);
-        }
+}
+
+// One chroma row of the window -> its horizontal lerps at the block's four luma columns, per plane: H[plane][column]
+template <bool NV>
+__device__ __forceinline__ void cv420_hrow(const Cv420Raw<NV> &R, const Cv420Win &W, const float *nlut, float H[2][4]) {
+    u32 uw, vw;
+    if (NV) {
+        const u32 w0 = cv_alignbyte(R.d[1], R.d[0], W.sh), w1 = cv_alignbyte(R.d[2], R.d[1], W.sh);  // U V U V of two columns each
+        uw = cv_perm(w1, w0, 0x06040200u);
+        vw = cv_perm(w1, w0, 0x07050301u);
+    } else {
+        uw = cv_alignbyte(R.d[1], R.d[0], W.sh);
+        vw = cv_alignbyte(R.d[3], R.d[2], W.sh);
     }
-    // ---- the four luma rows: row 4 P + r takes chroma window rows (0, 1) with fy = .75, (1, 2) with .25, (1, 2) with .75, (2, 3) with .25
-    //      — top * (1 - fy) + bot * fy: the 3/4 product of window row 1 serves luma rows 0 and 1, that of row 2 serves rows 2 and 3
-    // (c - 16/255) / 0.8784 as RN(a * y_hi + RN(a * y_lo)) with y_hi + y_lo = 1 / 0.8784 to 48 bits: the IEEE quotient for EVERY f32 a in
-    // [-16/255, 1] — all 636 524 221 of them checked against the division (tools/check_div_by_constant.py), as unorm_of_byte's form is
-    // for the 256 bytes.  One multiply and one fused multiply-add.
+    if (W.left) {  // columns 0 1 2 3 -> 0 0 1 2
+        uw = (uw << 8) | (uw & 0xffu);
+        vw = (vw << 8) | (vw & 0xffu);
+    }
+    uw = cv_perm(0u, uw, W.right_fix);
+    vw = cv_perm(0u, vw, W.right_fix);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const u32 q = c ? vw : uw;
+        const float n0 = nlut[q & 0xffu], n1 = nlut[(q >> 8) & 0xffu], n2 = nlut[(q >> 16) & 0xffu], n3 = nlut[q >> 24];
+        // a * (1 - fx) + b * fx with fx = .75, .25, .75, .25 (sample_plane_bilinear): the 1/4 products are exact
+        const float m1 = n1 * 0.75f, m2 = n2 * 0.75f;
+        H[c][0] = __builtin_fmaf(n0, 0.25f, m1);
+        H[c][1] = __builtin_fmaf(n2, 0.25f, m1);
+        H[c][2] = __builtin_fmaf(n1, 0.25f, m2);
+        H[c][3] = __builtin_fmaf(n3, 0.25f, m2);
+    }
+}
+
+// The four luma rows of block (g, P) from its luma dwords and the window's four chroma rows H[window row][plane][column]:
+// row 4 P + r takes window rows (0, 1) with fy = .75, (1, 2) with .25, (1, 2) with .75, (2, 3) with .25 — top * (1 - fy) + bot * fy:
+// the 3/4 product of window row 1 serves luma rows 0 and 1, that of row 2 serves rows 2 and 3.
+// (c - 16/255) / 0.8784 as RN(a * y_hi + RN(a * y_lo)) with y_hi + y_lo = 1 / 0.8784 to 48 bits: the IEEE quotient for EVERY f32 a in
+// [-16/255, 1] — all 636 524 221 of them checked against the division (tools/check_div_by_constant.py), as unorm_of_byte's form is
+// for the 256 bytes.  One multiply and one fused multiply-add.
+template <bool RGB12, bool FULL>
+__device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const u32 yrow[4], const float H[4][2][4], const float *ylut) {
+    const int h = J.dst.h;
+    constexpr bool full = FULL;  // (a template parameter: as a run-time flag it was a scalar branch per pixel)
     constexpr float kc = 0.87843137254f;
     constexpr float rc_hi = 1.0f / kc, rc_lo = (float)(1.0 / (double)kc - (double)rc_hi);
 #pragma unroll
@@ -147,12 +188,12 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
         for (int i = 0; i < 4; i++) {
             if (CV_ABL & 8) {
                 const u32 b = (y4 >> (8 * i)) & 0xffu;
-                px[i] = b | (__float_as_uint(H[0][j14][i] + H[1][j34][i]) & 0xffff00u) | 0xff000000u;
-                r4 |= b << (8 * i); g4 |= (__float_as_uint(H[0][j14][i]) & 0xffu) << (8 * i); b4 |= (__float_as_uint(H[1][j34][i]) & 0xffu) << (8 * i);
+                px[i] = b | (__float_as_uint(H[j14][0][i] + H[j34][1][i]) & 0xffff00u) | 0xff000000u;
+                r4 |= b << (8 * i); g4 |= (__float_as_uint(H[j14][0][i]) & 0xffu) << (8 * i); b4 |= (__float_as_uint(H[j34][1][i]) & 0xffu) << (8 * i);
                 continue;
             }
-            float u = __builtin_fmaf(H[0][j14][i], 0.25f, H[0][j34][i] * 0.75f);
-            float v = __builtin_fmaf(H[1][j14][i], 0.25f, H[1][j34][i] * 0.75f);
+            float u = __builtin_fmaf(H[j14][0][i], 0.25f, H[j34][0][i] * 0.75f);
+            float v = __builtin_fmaf(H[j14][1][i], 0.25f, H[j34][1][i] * 0.75f);
             const float yy = ylut[(y4 >> (8 * i)) & 0xffu];
             if (!full) {  // planar_yuv_to_rgba.wgsl:47-48: (c - 16/255) / 0.8784, clamp
                 const float au = u - (16.0f / 255.0f), av = v - (16.0f / 255.0f);
@@ -176,6 +217,128 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
         } else {
             *(uint4 *)(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 16u * (u32)g)) = make_uint4(px[0], px[1], px[2], px[3]);
         }
+    }
+}
+
+// One 4 x 4 block: columns 4 g .. 4 g + 3, rows 4 P .. 4 P + 3 of job J (rows past the frame's height are not stored).
+// ylut: 256 floats, cv420_luma_of_byte of every byte for this job's range.
+// Requirements (cv420_job_ok on the host): 4:2:0, even height, width a multiple of 4, dword-aligned planes whose rows can be read a
+// dword past the window, 16-byte aligned destination rows.
+// nlut: 256 floats, unorm_of_byte of every byte (the chroma bytes' byte / 255: a table gather instead of a conversion and two multiply-adds)
+// RGB12: the node texture as 12-byte groups (ConvJob::rgb12), else RGBA8 — separate instantiations: each packs its own bytes only
+template <bool NV, bool RGB12, bool FULL>
+__device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut, const float *nlut) {
+    // every load of the block is in flight before the first store (a row's luma load behind the previous row's store waited for that
+    // store and for itself: four memory round trips per block instead of one)
+    u32 yrow[4];
+    cv420_load_luma(J, g, P, yrow);
+    const Cv420Win W = cv420_window<NV>(J, g);
+    Cv420Raw<NV> raw[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) raw[j] = cv420_load_chroma<NV>(J, W, 2 * P - 1 + j);  // chroma rows 2 P - 1 .. 2 P + 2
+    float H[4][2][4];  // [window row][plane][luma column]
+#pragma unroll
+    for (int j = 0; j < 4; j++) cv420_hrow<NV>(raw[j], W, nlut, H[j]);
+    cv420_rows<RGB12, FULL>(J, g, P, yrow, H, ylut);
+}
+
+// A vertical run of blocks: columns 4 g .. 4 g + 3, block rows P0 .. P0 + nb - 1 (those that exist).  The same values as cv420_block on
+// each of them — the same operations on the same operands — with what two vertically adjacent blocks share done once and the memory
+// latency of block P + 1 spent under the arithmetic of block P:
+//   * block P + 1's chroma window rows 0, 1 are block P's rows 2, 3 (chroma rows 2 P + 1, 2 P + 2, clamped alike): their loads, byte / 255
+//     gathers and horizontal lerps are kept — half of the chroma work of every block after the run's first;
+//   * block P + 1's luma dwords and its two new chroma rows are requested BEFORE block P's rows are computed and stored, so they arrive
+//     while the wave's vector ALU is busy (a one-block thread loads, waits, computes, stores: its waves all wait at the same time);
+//     the last block's "next" loads go to clamped rows and are dropped (unconditional: the compiler can count what is outstanding).
+template <bool NV, bool RGB12, bool FULL>
+__device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int nb, const float *ylut, const float *nlut, unsigned long long *st = nullptr) {
+    const int Pend = min(P0 + nb, (J.dst.h + 3) >> 2);
+    if (P0 >= Pend) return;
+    const Cv420Win W = cv420_window<NV>(J, g);
+    u32 yrow[4];
+    cv420_load_luma(J, g, P0, yrow);
+    float H[4][2][4];
+    {
+        Cv420Raw<NV> raw[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[j] = cv420_load_chroma<NV>(J, W, 2 * P0 - 1 + j);
+        CV_STAMP(st, 2, "s_waitcnt vmcnt(0)");  // the first block's loads have arrived
+#pragma unroll
+        for (int j = 0; j < 4; j++) cv420_hrow<NV>(raw[j], W, nlut, H[j]);
+        CV_STAMP(st, 3, "s_waitcnt lgkmcnt(0)");  // its chroma window is converted
+    }
+    for (int P = P0;;) {
+        u32 ynext[4];
+        cv420_load_luma(J, g, P + 1, ynext);
+        const Cv420Raw<NV> n2 = cv420_load_chroma<NV>(J, W, 2 * P + 3), n3 = cv420_load_chroma<NV>(J, W, 2 * P + 4);
+        cv420_rows<RGB12, FULL>(J, g, P, yrow, H, ylut);
+        if (P == P0) CV_STAMP(st, 4, "s_nop 0");  // the first block's rows are computed, its stores issued
+        if (++P >= Pend) break;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { H[0][c][i] = H[2][c][i]; H[1][c][i] = H[3][c][i]; }
+        cv420_hrow<NV>(n2, W, nlut, H[2]);
+        cv420_hrow<NV>(n3, W, nlut, H[3]);
+#pragma unroll
+        for (int r = 0; r < 4; r++) yrow[r] = ynext[r];
+    }
+}
+
+// A job's geometry as VALUES in scalar registers.  Read in place (B.j[j].dst.pitch ...) the compiler treats the kernel-argument segment as
+// memory it may re-read whenever that is cheaper than keeping a register: it did, behind every row's store — an s_load_dword plus
+// s_waitcnt lgkmcnt(0) (scalar loads return out of order, so the wait also drains the table gathers in flight) per row, ~200 cycles
+// each, in every wave at once.  A value that went through v_readfirstlane is a computed value: it stays where it is.
+__device__ __forceinline__ SurfView cv420_view_in_registers(const SurfView &v) {
+#ifdef SMR_EMU
+    return v;
+#else
+    SurfView r;
+    const unsigned long long p = (unsigned long long)(uintptr_t)v.ptr;
+    const u32 lo = cv_uniform((u32)p), hi = cv_uniform((u32)(p >> 32));
+    r.ptr = (u8 *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    r.pitch = cv_uniform(v.pitch);
+    r.w = cv_uniform(v.w);
+    r.h = cv_uniform(v.h);
+    return r;
+#endif
+}
+__device__ __forceinline__ ConvJob cv420_job_in_registers(const ConvJob &j) {
+    ConvJob J = j;
+    J.yp = cv420_view_in_registers(j.yp); J.up = cv420_view_in_registers(j.up); J.vp = cv420_view_in_registers(j.vp); J.dst = cv420_view_in_registers(j.dst);
+    return J;
+}
+
+// Wave w of `waves` computes the w-th of `waves` equal contiguous shares of the launch's unit sequence (ConvBatch): total / waves units,
+// the first total % waves waves one more — one vertical run of blocks, or the end of a column block and the start of the next (in the
+// next job, too).  ylut: the limited-range luma table; nlut: byte / 255, which is also the full-range luma table.
+template <bool NV>
+__device__ __forceinline__ void cv420_share(const ConvBatch &B, u32 w, u32 waves, u32 lane, const float *ylut, const float *nlut, unsigned long long *st = nullptr) {
+    const u32 total = B.first_unit[B.n];
+    const u32 share = total / waves, extra = total - share * waves;
+    u32 lo = w * share + (w < extra ? w : extra);
+    const u32 hi = lo + share + (w < extra ? 1u : 0u);
+    int j = 0;
+    while (lo < hi) {  // (uniform: one or two runs per share, more only across tiny jobs)
+#pragma unroll 1
+        while (lo >= B.first_unit[j + 1]) j++;
+        const ConvJob J = cv420_job_in_registers(B.j[j]);
+        const u32 local = lo - B.first_unit[j], rows = B.rows[j];
+        const u32 col = local / rows, P0 = local - col * rows;
+        const u32 nrun = hi - lo < rows - P0 ? hi - lo : rows - P0;
+        const int g = (int)(col * 64u + lane);
+        if (4 * g < J.dst.w) {
+            // (uniform branches: a job is one frame; range and node format are template parameters — as run-time flags they cost a scalar branch per pixel)
+            if (J.rgb12) {
+                if (J.full) cv420_run<NV, true, true>(J, g, (int)P0, (int)nrun, nlut, nlut, st);
+                else cv420_run<NV, true, false>(J, g, (int)P0, (int)nrun, ylut, nlut, st);
+            } else {
+                if (J.full) cv420_run<NV, false, true>(J, g, (int)P0, (int)nrun, nlut, nlut, st);
+                else cv420_run<NV, false, false>(J, g, (int)P0, (int)nrun, ylut, nlut, st);
+            }
+        }
+        st = nullptr;  // (timing builds: only the share's first run is stamped phase by phase)
+        lo += nrun;
     }
 }
 

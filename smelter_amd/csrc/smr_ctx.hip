@@ -167,7 +167,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
     if (const char *e = getenv("SMR_WAVE_NODE82")) ctx->wave_node82 = atoi(e) != 0;
     if (const char *e = getenv("SMR_RGB12_CLS82")) ctx->rgb12_cls82 = atoi(e) != 0;
-    if (const char *e = getenv("SMR_CONVERT_ORDER")) ctx->convert_order = atoi(e);
+    if (const char *e = getenv("SMR_CONVERT_WG_PER_CU")) ctx->convert_wg_per_cu = atoi(e);
     if (const char *e = getenv("SMR_INGEST_RESERVE_CUS")) ctx->ingest_reserve_cus = atoi(e);
     if (const char *e = getenv("SMR_INGEST_WG_PER_CU")) ctx->ingest_wg_per_cu = atoi(e);
     if (const char *e = getenv("SMR_NO_PACK_REUSE")) ctx->no_pack_reuse = atoi(e) != 0;

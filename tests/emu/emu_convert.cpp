@@ -1,6 +1,6 @@
 // TEST INFRASTRUCTURE — not part of the product; nothing in smelter_amd/ builds, links or loads this.
 //
-// The 4:2:0 input converter's source (smelter_amd/csrc/smr_convert_420.h: cv420_block, one 4 x 4 pixel block per call) compiled for the
+// The 4:2:0 input converter's source (smelter_amd/csrc/smr_convert_420.h: cv420_block, one 4 x 4 pixel block per call; cv420_run, a vertical run of blocks per call) compiled for the
 // CPU, so that tests/test_emu_convert.py can hold it to the oracle's planar_yuv_to_rgba / nv12_to_rgba bit for bit without a GPU.
 // Same shims as emu_wave.cpp (SMR_EMU: builtins -> emu_device.h, <hip/hip_runtime.h> -> shim/); no threads are needed here: a block
 // is computed by one lane and lanes do not talk to each other.
@@ -38,7 +38,8 @@ Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill) {
 
 // y: w x h; planar: u, v: (w / 2) x (h / 2); NV12: u = interleaved (w / 2) x (h / 2) x 2, v ignored.  out: w x h x 4 tight.
 // rgb12 != 0: out = h rows of 3 w bytes (12-byte groups of four pixels: R x 4, G x 4, B x 4)
-extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, int rgb12, u8 *out) {
+// nb = 0: one cv420_block call per block; nb >= 1: cv420_run over runs of nb block rows (what k_yuv420_to_rgba's waves execute)
+extern "C" int emu_convert_420_run(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, int rgb12, int nb, u8 *out) {
     if (w % 4 || w < 8 || h % 2 || h < 2) return -1;
     Plane py = make_plane(y, w, h, 1, 0x5a), pu = make_plane(u, w / 2, h / 2, nv12 ? 2 : 1, 0xa5), pv = nv12 ? Plane() : make_plane(v, w / 2, h / 2, 1, 0x3c);
     const u32 dpitch = rgb12 ? (u32)((3 * w + 255) & ~255) : (u32)w * 4;
@@ -53,17 +54,79 @@ extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int
         ylut[b] = cv420_luma_of_byte(b, full != 0);
         nlut[b] = unorm_of_byte(b);
     }
-    for (int P = 0; 4 * P < h; P++)
+    for (int P = 0; 4 * P < h; P += nb ? nb : 1)
         for (int g = 0; 4 * g < w; g++) {
-            if (nv12 && rgb12) cv420_block<true, true>(J, g, P, ylut, nlut);
-            else if (nv12) cv420_block<true, false>(J, g, P, ylut, nlut);
-            else if (rgb12) cv420_block<false, true>(J, g, P, ylut, nlut);
-            else cv420_block<false, false>(J, g, P, ylut, nlut);
+#define EMU_CV(NVv, R12, FULLv) \
+    do { if (nb) cv420_run<NVv, R12, FULLv>(J, g, P, nb, ylut, nlut); else cv420_block<NVv, R12, FULLv>(J, g, P, ylut, nlut); } while (0)
+            if (full) {
+                if (nv12 && rgb12) EMU_CV(true, true, true);
+                else if (nv12) EMU_CV(true, false, true);
+                else if (rgb12) EMU_CV(false, true, true);
+                else EMU_CV(false, false, true);
+            } else {
+                if (nv12 && rgb12) EMU_CV(true, true, false);
+                else if (nv12) EMU_CV(true, false, false);
+                else if (rgb12) EMU_CV(false, true, false);
+                else EMU_CV(false, false, false);
+            }
+#undef EMU_CV
         }
     if (rgb12) {
         for (int r = 0; r < h; r++) memcpy(out + (size_t)r * 3 * w, dst.data() + (size_t)r * dpitch, (size_t)3 * w);
     } else {
         memcpy(out, dst.data(), (size_t)w * 4 * h);
+    }
+    return 0;
+}
+
+extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, int rgb12, u8 *out) {
+    return emu_convert_420_run(y, u, v, w, h, nv12, full, rgb12, 0, out);
+}
+
+// What a launch of k_yuv420_to_rgba computes: `n` frames of one kind (all planar or all NV12; widths / heights / ranges / node formats per
+// frame) as ONE unit sequence cut into `waves` equal shares (cv420_share), every lane of every wave emulated in turn.
+// ys / us / vs / outs: n pointers; ws / hs / fulls / rgb12s: n ints.  Output layout per frame as emu_convert_420_run.
+extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *const *us, const u8 *const *vs, const int *ws, const int *hs, int nv12,
+                                      const int *fulls, const int *rgb12s, int waves, u8 *const *outs) {
+    if (n < 1 || n > MAX_CONV_JOBS || waves < 1) return -1;
+    std::vector<Plane> py(n), pu(n), pv(n);
+    std::vector<std::vector<u8>> dst(n);
+    std::vector<u32> dpitch(n);
+    ConvBatch B;
+    memset(&B, 0, sizeof(B));
+    B.n = n;
+    for (int i = 0; i < n; i++) {
+        const int w = ws[i], h = hs[i];
+        if (w % 4 || w < 8 || h % 2 || h < 2) return -1;
+        py[i] = make_plane(ys[i], w, h, 1, 0x5a); pu[i] = make_plane(us[i], w / 2, h / 2, nv12 ? 2 : 1, 0xa5);
+        if (!nv12) pv[i] = make_plane(vs[i], w / 2, h / 2, 1, 0x3c);
+        dpitch[i] = rgb12s[i] ? (u32)((3 * w + 255) & ~255) : (u32)w * 4;
+        dst[i].assign((size_t)dpitch[i] * h + 64, 0);
+        ConvJob &J = B.j[i];
+        J.yp = py[i].view; J.up = pu[i].view; J.vp = nv12 ? pu[i].view : pv[i].view;
+        J.dst.ptr = dst[i].data(); J.dst.pitch = dpitch[i]; J.dst.w = w; J.dst.h = h;
+        J.full = fulls[i]; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0; J.rgb12 = rgb12s[i];
+        const u32 cols = ((u32)w + 255u) / 256u, rows = ((u32)h + 3u) / 4u;  // (the host's arithmetic: smr_frames_to_rgba_batch)
+        B.rows[i] = rows;
+        B.first_unit[i + 1] = B.first_unit[i] + cols * rows;
+    }
+    float ylut[256], nlut[256];
+    for (u32 b = 0; b < 256; b++) {
+        ylut[b] = cv420_luma_of_byte(b, false);
+        nlut[b] = unorm_of_byte(b);
+    }
+    for (u32 w = 0; w < (u32)waves; w++)
+        for (u32 lane = 0; lane < 64; lane++) {
+            if (nv12) cv420_share<true>(B, w, (u32)waves, lane, ylut, nlut);
+            else cv420_share<false>(B, w, (u32)waves, lane, ylut, nlut);
+        }
+    for (int i = 0; i < n; i++) {
+        const int w = ws[i], h = hs[i];
+        if (rgb12s[i]) {
+            for (int r = 0; r < h; r++) memcpy(outs[i] + (size_t)r * 3 * w, dst[i].data() + (size_t)r * dpitch[i], (size_t)3 * w);
+        } else {
+            memcpy(outs[i], dst[i].data(), (size_t)w * 4 * h);
+        }
     }
     return 0;
 }

@@ -34,6 +34,9 @@ def emu():
         assert r.returncode == 0, r.stderr
     h = C.CDLL(lib)
     h.emu_convert_420.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P8]
+    h.emu_convert_420_run.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P8]
+    PP8, PI = C.POINTER(P8), C.POINTER(C.c_int)
+    h.emu_convert_420_shares.argtypes = [C.c_int, PP8, PP8, PP8, PI, PI, C.c_int, PI, PI, C.c_int, PP8]
     orc.build()
     return h
 
@@ -93,3 +96,59 @@ def test_every_luma_byte_against_every_chroma_pair(emu):
                 assert emu.emu_convert_420(_p(y), _p(u), _p(v), w, h, 0, full, 0, _p(got)) == 0
                 want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
                 assert np.array_equal(got, want), (full, cu, cv)
+
+
+@pytest.mark.parametrize("w,h", [(8, 2), (8, 6), (12, 4), (64, 36), (132, 74), (256, 130), (1920, 22)])
+@pytest.mark.parametrize("variant", ["420", "j420", "nv12"])
+@pytest.mark.parametrize("nb", [1, 2, 3, 4, 7])
+def test_runs_of_blocks_equal_the_oracle_bit_for_bit(emu, w, h, variant, nb):
+    """cv420_run — what a wave of k_yuv420_to_rgba executes: a vertical run of nb blocks that keeps the two chroma window rows neighbouring
+    blocks share and requests block P + 1 before it computes block P — writes the oracle's bytes whatever the run length, at every frame
+    height (runs that end inside a block, heights of 2 mod 4), RGBA8 and RGB12."""
+    rng = np.random.default_rng(hash((w, h, variant, nb)) % 2**32)
+    y, c = _content("noise", w, h, rng)
+    nv, full = (1 if variant == "nv12" else 0), (1 if variant == "j420" else 0)
+    if nv:
+        u = v = np.ascontiguousarray(c)
+        want = orc.nv12_to_rgba(y, u, w, h)
+    else:
+        u, v = np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])
+        want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
+    got = np.zeros((h, w, 4), np.uint8)
+    assert emu.emu_convert_420_run(_p(y), _p(u), _p(v), w, h, nv, full, 0, nb, _p(got)) == 0
+    assert np.array_equal(got, want), (variant, nb, w, h, int((got != want).sum()), np.argwhere(got != want)[:4].tolist())
+    packed = np.zeros((h, 3 * w), np.uint8)
+    assert emu.emu_convert_420_run(_p(y), _p(u), _p(v), w, h, nv, full, 1, nb, _p(packed)) == 0
+    assert np.array_equal(packed.reshape(h, w // 4, 3, 4).transpose(0, 1, 3, 2).reshape(h, w, 3), want[..., :3])
+
+
+@pytest.mark.parametrize("nv", [0, 1])
+@pytest.mark.parametrize("waves", [1, 3, 7, 64, 1000])
+def test_a_launch_cut_into_equal_shares_writes_the_oracles_bytes(emu, nv, waves):
+    """k_yuv420_to_rgba's partition (cv420_share): frames of different sizes, ranges and node formats in ONE unit sequence, cut into
+    `waves` equal contiguous shares — shares that start and end anywhere inside a column of blocks, straddle column blocks and frames,
+    more waves than units — every byte of every frame the oracle's."""
+    rng = np.random.default_rng(17 * waves + nv)
+    sizes = [(264, 38), (8, 2), (516, 26), (64, 130), (20, 6)]
+    fulls = [0, 0, 0, 0, 0] if nv else [0, 1, 0, 1, 1]
+    rgb12 = [1, 0, 0, 1, 0]
+    ys, us, vs, outs, wants = [], [], [], [], []
+    for (w, h), full, r12 in zip(sizes, fulls, rgb12):
+        y, c = _content("noise", w, h, rng)
+        if nv:
+            u = v = np.ascontiguousarray(c)
+            want = orc.nv12_to_rgba(y, u, w, h)
+        else:
+            u, v = np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])
+            want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if full else orc.YUV420)
+        ys.append(y); us.append(u); vs.append(v); wants.append(want)
+        outs.append(np.zeros((h, 3 * w), np.uint8) if r12 else np.zeros((h, w, 4), np.uint8))
+    n = len(sizes)
+    arr = lambda xs: (P8 * n)(*[_p(x) for x in xs])
+    ints = lambda xs: (C.c_int * n)(*xs)
+    assert emu.emu_convert_420_shares(n, arr(ys), arr(us), arr(vs), ints([s[0] for s in sizes]), ints([s[1] for s in sizes]), nv, ints(fulls),
+                                      ints(rgb12), waves, arr(outs)) == 0
+    for (w, h), r12, got, want in zip(sizes, rgb12, outs, wants):
+        if r12:
+            got = np.concatenate([got.reshape(h, w // 4, 3, 4).transpose(0, 1, 3, 2).reshape(h, w, 3), np.full((h, w, 1), 255, np.uint8)], -1)
+        assert np.array_equal(got, want), (w, h, waves, int((got != want).sum()))
