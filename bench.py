@@ -141,14 +141,18 @@ def cpu_baseline(layouts, res):
     one_frame()
     first = time.perf_counter() - t0
     reps = int(min(max(12.0 / first, 1), 200))
-    t0 = time.perf_counter()
+    per_frame = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         one_frame()
-    dt = (time.perf_counter() - t0) / reps
+        per_frame.append(time.perf_counter() - t0)
+    dt = sum(per_frame) / reps
     t0 = time.perf_counter()
     one_frame(omp=False)  # all host cores and one core
     dt1 = time.perf_counter() - t0
     return {"value": round(1.0 / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "spread": {"min_frames_per_s": round(1.0 / max(per_frame), 4), "max_frames_per_s": round(1.0 / min(per_frame), 4), "frames": reps,
+                       "what": "slowest and fastest single frame of the sample (the box's host cores are shared: the figure moves between runs)"},
             "context": "a plain restatement of the reference's passes (test oracle), not a tuned CPU renderer: the GPU / CPU ratio says nothing about "
                        "kernel quality (the roofline fraction does).  The reference's own software path (wgpu on lavapipe) is published at 60 composited "
                        "1080p frames/s on 16 vCPU (c5.4xlarge; benchmarks/2025_04_28_9891af76/full_c5.4xlarge.json:607-610, BASELINE.md row 1) — "
@@ -157,6 +161,112 @@ def cpu_baseline(layouts, res):
             "sample": f"{reps} composited frames of the same workload ({N_IN}x{IN_W}x{IN_H} YUV420 -> {OUT_W}x{OUT_H} YUV420, all passes; "
                       f"first frame {first:.2f} s discarded as warm-up), oracle/smr_oracle.c all-C frame loop (-O3 -mavx2 -mfma, "
                       f"OpenMP over rows) on {cores} threads, {dt:.3f} s per frame"}
+
+
+class Watchdog:
+    """The N > 1 path's first contact with hardware must not cost the driver its whole slot: every step and every barrier beats; a rank that
+    makes no progress for `seconds` (a stuck smr_gather_tiles / RCCL send-recv pair, a peer that died) prints an error — rank 0 as the ONE JSON
+    line, with "error" and a null value — and ends the process with rc 3 (torchrun then ends the other ranks)."""
+
+    def __init__(self, seconds, rank, world, config):
+        import threading
+        self.seconds, self.rank, self.world, self.config = seconds, rank, world, config
+        self.t, self.where, self.on = time.monotonic(), "start", seconds > 0
+        if self.on:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, where):
+        self.t, self.where = time.monotonic(), where
+
+    def stop(self):
+        self.on = False
+
+    def _run(self):
+        while self.on:
+            time.sleep(0.5)
+            idle = time.monotonic() - self.t
+            if self.on and idle > self.seconds:
+                msg = f"watchdog: rank {self.rank} of {self.world} made no progress for {idle:.0f} s in `{self.where}`"
+                print("[bench] " + msg, file=sys.stderr, flush=True)
+                if self.rank == 0:
+                    print(json.dumps({"metric": "composited frames/sec", "value": None, "unit": "frames/s", "n_gpus": self.world, "error": msg,
+                                      "config": {"workload": f"configs[{self.config}] sharded"}, "higher_is_better": True}), flush=True)
+                os._exit(3)
+
+
+def quoted_profile(name):
+    """A committed counter profile (profiles/<name>) — quoted only if it was collected on the library being timed: the file records the
+    sha256 of that library's device code (tools/traffic_json.py, tools/issue_json.py <- smelter_amd/build.py:kernels_sha256)."""
+    from smelter_amd import _ffi, build as hip_build
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None, {"stale": True, "why": f"profiles/{name} does not exist"}
+    data = json.load(open(path))
+    want = (data.get("_identity") or {}).get("lib_kernels_sha256")
+    have = hip_build.kernels_sha256(_ffi.LIB_PATH)
+    if want != have:
+        return None, {"stale": True, "why": f"profiles/{name} was collected on device code {str(want)[:12]}, this library is {have[:12]}"}
+    return data, {"stale": False, "lib_kernels_sha256": have}
+
+
+def roofline_block(args, stages, kernel_bytes, knames, ms_per_step, algo_bytes=None):
+    """The HBM roofline entry of the line.  The path spans three launches per frame, so "the kernel" of the contract is ambiguous: the
+    figure of ONE launch rises whenever work is split across more launches (round 4: 0.087 -> 0.139 by splitting wave A).  The headline
+    therefore prices the frame's algorithmic bytes (inputs read once in their native format + output written once)
+    against ALL the launches of a frame — the sum of their mean durations (HIP events on the ctx stream, one frame in flight) — which no
+    split can move; the single dominant launch (the contract's literal reading) and the pipelined frame period are reported beside it."""
+    if not stages:
+        return None
+    ALGO_BYTES_PER_FRAME = algo_bytes if algo_bytes is not None else globals()["ALGO_BYTES_PER_FRAME"]
+    dom = max(stages, key=lambda k: stages[k]["avg_us"])
+    sum_us = sum(v["avg_us"] for v in stages.values())
+    dom_us = stages[dom]["avg_us"]
+    ach = ALGO_BYTES_PER_FRAME / (sum_us * 1e-6) / 1e9
+    traffic, ident = None, None
+    tname = {2: "r05_traffic.json", 3: "r05_traffic_configs3.json"}.get(args.config)  # the committed counter passes: default workload, target
+    per_kernel_traffic = None
+    if tname and args.ingest == "auto":
+        data, ident = quoted_profile(tname)
+        if data:
+            per_kernel_traffic = {knames[k]: data[knames[k]]["hbm_bytes_per_launch"] for k in stages if knames.get(k) in data}
+            traffic = sum(per_kernel_traffic.values()) if len(per_kernel_traffic) == len(stages) else None
+    wave_a = [k for k in ("ingest", "fused_ingest_resample") if k in stages]
+    block = {"bound": "hbm", "kernel": " + ".join(knames.get(k, k) for k in stages), "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "frac": round(ach / HBM_PEAK_GBPS, 5), "bytes_per_launch": ALGO_BYTES_PER_FRAME, "avg_launch_us": round(sum_us, 3),
+             "definition": "the frame's algorithmic bytes / the sum of the mean launch durations of the frame's kernels (one frame in flight, HIP events)",
+             "traffic": traffic, "traffic_per_kernel": per_kernel_traffic, "traffic_stale": bool(ident and ident.get("stale")),
+             "traffic_source": (f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE, separate passes; device code {ident['lib_kernels_sha256'][:12]})"
+                                if traffic is not None else (ident or {}).get("why")),
+             "traffic_over_algorithmic": round(traffic / ALGO_BYTES_PER_FRAME, 3) if traffic else None,
+             "dominant_kernel": {"kernel": knames.get(dom, dom), "avg_launch_us": dom_us,
+                                 "achieved": round(ALGO_BYTES_PER_FRAME / (dom_us * 1e-6) / 1e9, 2),
+                                 "frac": round(ALGO_BYTES_PER_FRAME / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
+                                 "own_bytes": kernel_bytes.get(dom), "own_GBps": round(kernel_bytes.get(dom, 0) / (dom_us * 1e-6) / 1e9, 2),
+                                 "what": "the contract's literal reading (frame bytes / the longest single launch); own_* = that launch's own inputs + outputs"},
+             "pipelined_frame": {"us": round(ms_per_step * 1e3, 3), "frac": round(ALGO_BYTES_PER_FRAME / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                                 "what": "frame bytes / ms_per_step of the timed loop (frames in flight overlap)"},
+             "wave_a_us": round(sum(stages[k]["avg_us"] for k in wave_a), 3),
+             "limiter": ("vector-instruction issue, not HBM.  Evidence: cycle stamps of the converter's waves (profiles/r05_convert_waves.txt) — a SIMD's waves "
+                         "finish one after the other, oldest first, at ~3.9 cycles per vector instruction and 2.05 GHz; with every load and store compiled out the "
+                         "kernel is as slow (19.1 vs 20.9 us); the float arithmetic runs near its rate (2.3 cycles per instruction), the byte extracts, packs, "
+                         "conversions and table-address arithmetic around it at ~4.  The resampler's memory skeleton runs at copy bandwidth underneath its "
+                         "arithmetic (profiles/r04_wave_ablation.txt); two frames in flight share the same issue slots.  DESIGN.md section 3")
+             if args.ingest == "auto" else "see DESIGN.md section 3"}
+    if args.config == 2 and args.ingest == "auto":
+        iss, ident2 = quoted_profile("r05_issue.json")
+        if iss:
+            fl = iss["floors_us_per_frame"]
+            block["issue"] = {"valu_wave_instructions_per_frame": iss["per_frame"]["valu_wave_instructions"],
+                              "mfma_wave_instructions_per_frame": iss["per_frame"]["mfma_wave_instructions"],
+                              "floors_us_per_frame": {k: v["floor_us_pipes_overlapped"] for k, v in fl.items()},
+                              "frame_us": round(ms_per_step * 1e3, 2),
+                              "frame_over_floor": {k: round(ms_per_step * 1e3 / v["floor_us_pipes_overlapped"], 2) for k, v in fl.items()},
+                              "reading": iss.get("reading"),
+                              "source": "profiles/r05_issue.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA of this command on this device code; vector and "
+                                        "matrix pipes overlap: floor = the larger)"}
+        else:
+            block["issue"] = {"stale": True, "why": ident2.get("why")}
+    return block
 
 
 def main():
@@ -172,8 +282,12 @@ def main():
     ap.add_argument("--convert", choices=["auto", "general", "block4x2"], default="auto", help="input converter kernels (SMR_OPT_CONVERT_IMPL; A/B)")
     ap.add_argument("--direct-output", action="store_true",
                     help="SMR_OPT_DIRECT_OUTPUT: the resampling kernel writes Y'CbCr for the compositor's copy tiles (A/B; default off)")
-    ap.add_argument("--no-long", action="store_true", help="skip the >= 2 s `value_long` loop (profiling runs: keeps traces small)")
-    ap.add_argument("--no-target", action="store_true", help="skip the north-star target block (8x4K -> 4K on one GPU, run as a child process)")
+    ap.add_argument("--no-long", action="store_true", help="skip the `value_long` loop (profiling runs: keeps traces small)")
+    ap.add_argument("--long-seconds", type=float, default=12.0,
+                    help="length of the `value_long` loop — the same timed loop run right after `value`, BEFORE any CPU work, long enough for an outside "
+                         "observer sampling GPU activity every few seconds to see it")
+    ap.add_argument("--no-target", action="store_true", help="skip the child-process blocks: the north-star target (8x4K -> 4K on one GPU) and the sharded code path with one rank")
+    ap.add_argument("--watchdog-seconds", type=float, default=60.0, help="N > 1 / --force-sharded: a step that makes no progress for this long ends the run with an error line and rc 3")
     ap.add_argument("--inflight", type=int, default=2, help="frames in flight on one GPU (renderer contexts / HIP streams); 2 measured best with three kernels per "
                                                            "frame (profiles/r04_inflight.txt: 15.8k / 14.6k / 14.1k frames/s at 2 / 3 / 4)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (ingest per shard, gather, compose) with the ranks given")
@@ -308,6 +422,8 @@ def main():
         # the exchange goes through the C ABI (smr_comm_create_rank + smr_gather_tiles: RCCL send / recv on the ctx stream);
         # torch.distributed only carries the 128-byte communicator id and the barriers
         comm = None
+        watchdog = Watchdog(args.watchdog_seconds, rank, world, args.config)
+        watchdog.beat("communicator set-up (smr_comm_create_rank: ncclCommInitRank)")
         if world > 1:
             uid = torch.zeros(hip.COMM_ID_BYTES, dtype=torch.uint8, device="cuda")
             if rank == 0:
@@ -327,6 +443,7 @@ def main():
         sharded = smr_dist.ShardedCompositor(ctx, hip, plan, rank, layouts, res, input_source_slot, label, torch, dist, comm=comm)
 
         def step_fn(step):
+            watchdog.beat(f"step {step}")
             t = tick[0]
             tick[0] += 1
             if ANIMATED:
@@ -345,6 +462,7 @@ def main():
 
     def barrier():
         if not single:
+            watchdog.beat("barrier: flush + sync")
             sharded.flush()  # the frame still in flight
         if world > 1:
             dist.barrier()
@@ -372,7 +490,7 @@ def main():
         elapsed = float(t.item())
     # the same loop over >= 2 s of device work (a K = 20 run lasts about a millisecond: the pipeline's fill and drain weigh on it and an outside
     # observer sampling GPU activity cannot see it), reported as `value_long` beside `value` — never instead of it
-    long_steps = args.steps if args.no_long else min(max(args.steps, int(2.0 * args.steps / max(elapsed, 1e-9))), 200000)
+    long_steps = args.steps if args.no_long else min(max(args.steps, int(args.long_seconds * args.steps / max(elapsed, 1e-9))), 2000000)
     tl = time.perf_counter()
     for s in range(long_steps):
         step_fn(s)
@@ -395,11 +513,14 @@ def main():
     if rank == 0:
         fps = args.steps / elapsed
         result = {
-            "metric": "composited frames/sec, 8x1080p->1 4K scene", "value": round(fps, 2), "unit": "frames/s",
+            "metric": {1: "composited frames/sec, 4x1080p->1 1080p scene", 2: "composited frames/sec, 8x1080p->1 4K scene",
+                       3: "composited frames/sec, 8x4K->1 4K scene", 4: "composited frames/sec, 16x1080p animated grid + blur layer->1 4K scene"}[args.config],
+            "value": round(fps, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000.0 * elapsed / args.steps, 5),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "value_long": {"frames_per_s": round(long_steps / long_elapsed, 2), "steps": long_steps, "seconds": round(long_elapsed, 3),
-                           "what": "the same timed loop over >= 2 s of device work (fill / drain of the pipeline amortised)"},
+                           "what": f"the same timed loop over ~{args.long_seconds:g} s of device work, run before any CPU work (fill / drain of the pipeline amortised; "
+                                   "long enough for an outside GPU-activity sampler to see)"},
             "dtype": "u8 (f32 colour conversion: the WGSL sequence value for value; Lanczos on f16-pair MFMA with f32 accumulate, f16 resampler intermediate)"
             if args.ingest != "valu" else "u8 (f32 arithmetic, f16 resampler intermediate)", "data": "synthetic",
             "config": {"workload": {1: "configs[1]: 4x1080p YUV420 inputs -> 1920x1080 YUV420, Tiles, rescale + blend only, GpuOptimized",
@@ -444,50 +565,7 @@ def main():
         }
         knames = {"ingest": "k_yuv420_to_rgba" if args.convert == "auto" else {"general": "k_yuv_to_rgba", "block4x2": "k_yuv_to_rgba_batch"}[args.convert],
                   "fused_ingest_resample": "k_ingest_resample" if args.ingest == "valu" else "k_ingest_wave", "fused_compose_output": "k_compose_output"}
-        dom = max(stages, key=lambda k: stages[k]["avg_us"]) if stages else None
-        if dom is not None:
-            # `achieved` = the frame's ALGORITHMIC bytes (inputs read once in their native format + output written once; one
-            # launch of every kernel of the path processes one frame) / the dominant kernel's mean launch time.  What that kernel itself
-            # has to move (its own inputs + outputs, node textures and tiles included) is reported beside it, not as the roofline figure.
-            us = stages[dom]["avg_us"]
-            ach = ALGO_BYTES_PER_FRAME / (us * 1e-6) / 1e9
-            kname = knames.get(dom, dom)
-            # HBM bytes per launch from the PMC passes of tools/prof.sh on this same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-            # separate --pmc runs): counters cannot be read from inside the process, so the committed summary is quoted
-            traffic, traffic_src = None, None
-            tname = {2: "r04_traffic.json", 3: "r04_traffic_configs3.json"}.get(args.config)  # the committed counter passes: default workload, target
-            tpath = os.path.join(ROOT, "profiles", tname) if tname else None
-            if tpath and os.path.exists(tpath) and args.ingest == "auto":
-                t = json.load(open(tpath)).get(kname)
-                if t:
-                    traffic, traffic_src = t["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-            wave_a = [k for k in ("ingest", "fused_ingest_resample") if k in stages]
-            wave_a_us = sum(stages[k]["avg_us"] for k in wave_a)
-            result["roofline"] = {"bound": "hbm", "kernel": kname,
-                                  "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-                                  "bytes_per_launch": ALGO_BYTES_PER_FRAME, "avg_launch_us": us, "traffic": traffic,
-                                  "traffic_source": traffic_src,
-                                  "kernel_moves": {"bytes": kernel_bytes.get(dom), "GBps": round(kernel_bytes.get(dom, 0) / (us * 1e-6) / 1e9, 2),
-                                                   "what": "this kernel's own inputs + outputs per launch (node textures / tiles included)"},
-                                  "all_kernels_of_a_frame": {"sum_us": round(sum(v["avg_us"] for v in stages.values()), 3),
-                                                             "frac": round(ALGO_BYTES_PER_FRAME / (sum(v["avg_us"] for v in stages.values()) * 1e-6) / 1e9 / HBM_PEAK_GBPS, 5),
-                                                             "wave_a_us": round(wave_a_us, 3), "wave_a_kernels": [knames[k] for k in wave_a]},
-                                  "limiter": ("vector-instruction issue, not HBM: the exact f32 operation sequences (WGSL value for value) cost ~24 M wave instructions + 1.2 M "
-                                              "matrix instructions per frame over 1 024 SIMDs (roofline.issue); the converter runs as fast with its loads and stores compiled out "
-                                              "(profiles/r04_xcd_order.txt), the resampler's memory skeleton runs at copy bandwidth underneath its arithmetic "
-                                              "(profiles/r04_wave_ablation.txt), and frames in flight share the same issue slots (1.18x from two lanes).  The counters see "
-                                              "~5.8x the algorithmic bytes per frame (node textures, RGBA8 tiles) riding along; see DESIGN.md section 3")
-                                  if args.ingest == "auto" else "see DESIGN.md section 3"}
-        # the roofline that does bound this path: instruction issue.  Wave-instruction counts per frame from the committed PMC passes of this same
-        # command (profiles/r04_issue.json <- tools/prof.sh), priced at the issue rates measured on this device (profiles/r02_valu_rate.txt)
-        ipath = os.path.join(ROOT, "profiles", "r04_issue.json")
-        if args.config == 2 and args.ingest == "auto" and os.path.exists(ipath):
-            iss = json.load(open(ipath))
-            floor_us = iss["issue_floor_us_per_frame"]
-            result["roofline"]["issue"] = {"valu_wave_instructions_per_frame": iss["per_frame"]["valu_wave_instructions"],
-                                           "mfma_wave_instructions_per_frame": iss["per_frame"]["mfma_wave_instructions"],
-                                           "floor_us_per_frame": floor_us, "frac_of_issue_floor": round(floor_us / (result["ms_per_step"] * 1e3), 4),
-                                           "source": "profiles/r04_issue.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA of this command; issue rates: profiles/r02_valu_rate.txt)"}
+        result["roofline"] = roofline_block(args, stages, kernel_bytes, knames, result["ms_per_step"])
         result["kernels"] = stages
         # latency: one frame in flight, inputs resident -> output planes resident in HBM
         lat, enq = [], []
@@ -593,16 +671,29 @@ def main():
             # program (child process, same library) so that the judged line carries it: frames/s, roofline, latency over >= 2000 frames
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--config", "3", "--steps", "300", "--warmup", "30", "--no-cpu-baseline",
-                   "--latency-frames", "2000", "--ingest", args.ingest]
+                   "--latency-frames", "2000", "--ingest", args.ingest, "--long-seconds", "2"]
             try:
                 child = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 tj = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
                 result["target"] = {"workload": tj["config"]["workload"], "frames_per_s": tj["value"], "ms_per_frame": tj["ms_per_step"],
+                                    "frames_per_s_long": tj.get("value_long", {}).get("frames_per_s"),
                                     "frames_per_s_one_in_flight": tj["config"]["frames_per_s_one_in_flight"], "goal_frames_per_s": 60,
                                     "frame": tj["frame"], "roofline": tj.get("roofline"), "kernels": tj.get("kernels"),
                                     "latency_ms": tj.get("latency_ms"), "latency_host_visible_ms": tj.get("latency_host_visible_ms")}
             except Exception as e:  # the judged line must survive a failing child
                 result["target"] = {"error": f"{type(e).__name__}: {e}"}
+            # the N > 1 code path (ingest per shard -> gather -> compose on the root, what `--gpus N` runs) with ONE rank on the same workload: the N = 1
+            # point a SCALE record's curve starts from, measured by the same program beside the renderer path's figure above
+            cmd = [sys.executable, os.path.abspath(__file__), "--force-sharded", "--steps", "300", "--warmup", "30", "--no-cpu-baseline", "--no-long",
+                   "--ingest", args.ingest]
+            try:
+                child = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                tj = json.loads([ln for ln in child.stdout.splitlines() if ln.startswith("{")][-1])
+                result["sharded_one_rank"] = {"workload": tj["config"]["workload"], "frames_per_s": tj["value"], "ms_per_frame": tj["ms_per_step"],
+                                              "kernels": tj.get("kernels"), "roofline": tj.get("roofline"),
+                                              "what": "bench.py --force-sharded: configs[3] through ShardedCompositor with world_size 1 (no exchange): SCALE's N = 1 point"}
+            except Exception as e:
+                result["sharded_one_rank"] = {"error": f"{type(e).__name__}: {e}"}
     else:
         # N > 1: every rank runs a few more steps with per-launch HIP events on; rank 0 reports the kernels of the root
         # (its own shard's ingest + the compose of the gathered tiles) and the dominant one's roofline entry
@@ -621,17 +712,23 @@ def main():
                     tile_px[L.source_index] = max(int(np.floor(L.width + 0.5)), 1) * max(int(np.floor(L.height + 0.5)), 1) * 4
             tile_bytes = sum(tile_px.values())
             local_tiles = sum(tile_px[input_source_slot[i]] for i in my_inputs if input_source_slot[i] in tile_px)
-            node_b = len(my_inputs) * IN_W * IN_H * 4 if "ingest" in stages else 0
+            # (node textures of the batch path: RGB12 — 3 bytes per pixel — for the class builds of configs[2] / configs[3], RGBA8 elsewhere)
+            node_b = len(my_inputs) * IN_W * IN_H * (3 if args.config in (2, 3) else 4) if "ingest" in stages else 0
             kernel_bytes = {"ingest": len(my_inputs) * yuv420_bytes(IN_W, IN_H) + node_b,
                             "fused_ingest_resample": (node_b or len(my_inputs) * yuv420_bytes(IN_W, IN_H)) + local_tiles,
                             "fused_compose_output": tile_bytes + yuv420_bytes(OUT_W, OUT_H)}
-            dom = max((k for k in stages if k in kernel_bytes), key=lambda k: stages[k]["avg_us"], default=None)
-            if dom is not None:
-                ach = kernel_bytes[dom] / (stages[dom]["avg_us"] * 1e-6) / 1e9
-                result["roofline"] = {"bound": "hbm", "kernel": {"ingest": "k_yuv420_to_rgba", "fused_ingest_resample": "k_ingest_wave", "fused_compose_output": "k_compose_output"}[dom],
-                                      "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-                                      "bytes_per_launch": kernel_bytes[dom], "avg_launch_us": stages[dom]["avg_us"], "traffic": None,
-                                      "rank": 0}
+            knames = {"ingest": "k_yuv420_to_rgba", "fused_ingest_resample": "k_ingest_wave", "fused_compose_output": "k_compose_output"}
+            # the single-GPU definition: the algorithmic bytes this rank's launches stand for (its shard's inputs in their native format; on the root
+            # also the output frame) / the sum of its launches' mean durations
+            rb = roofline_block(args, {k: v for k, v in stages.items() if k in kernel_bytes}, kernel_bytes, knames, result["ms_per_step"],
+                                algo_bytes=len(my_inputs) * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H))
+            if rb:
+                rb["rank"] = 0
+                rb["traffic"], rb["traffic_per_kernel"], rb["traffic_over_algorithmic"], rb["traffic_stale"] = None, None, None, False
+                rb["traffic_source"] = "not collected for the sharded path"
+                rb.pop("issue", None)
+                rb["definition"] += " — rank 0's share of the frame: its shard's input bytes + the output frame"
+                result["roofline"] = rb
             result["kernels"] = stages
             # the exchange step against the xGMI point-to-point roof: every peer sends its tiles to the root over its own link
             per_peer = {}
@@ -647,6 +744,8 @@ def main():
                                       else "torch.distributed isend / irecv (fallback)",
                                       "note": "dst-sized RGBA8 tiles gathered on the root, one xGMI link per peer"}
 
+    if not single:
+        watchdog.stop()
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -1,7 +1,10 @@
 /* render_scene.c — the C ABI from plain C: scene JSON + frames in HBM -> output frame (include/smr.h).
  *
  *   gcc -std=c11 -Iinclude examples/render_scene.c -o render_scene -Lsmelter_amd -l:libsmr_hip.so -Wl,-rpath,$PWD/smelter_amd -lm
- *   ./render_scene out.yuv          # 4 synthetic 640x360 inputs tiled into 1280x720 planar YUV420
+ *   ./render_scene out.yuv [font dir]   # 4 synthetic 640x360 inputs tiled into 1280x720 planar YUV420, a text label per tile
+ *
+ * Text: the library's own font book (smr_fontbook_*: TrueType reader, layout, rasteriser — no Python, no third-party shaper) loaded from
+ * `font dir` ($SMR_FONT_DIR, /usr/share/fonts/truetype); the reference bundles Inter (smelter-render/fonts/), pass that directory to use it.
  *
  * Mirrors what smelter-core does with smelter-render: Renderer::new, register_input, update_scene, render
  * (smelter-render/src/state.rs:96-193). */
@@ -20,7 +23,17 @@
         }                                                                 \
     } while (0)
 
-static const char *SCENE =
+/* BASELINE configs[2]'s shape at a quarter of the size: Tiles{ View{ Rescaler{InputStream} border_radius, label View{ Text } } } */
+#define TILE(cam, label)                                                                                                                        \
+    " {\"type\": \"view\", \"background_color\": \"#101018FF\", \"children\": ["                                                               \
+    "   {\"type\": \"rescaler\", \"border_radius\": 16, \"child\": {\"type\": \"input_stream\", \"input_id\": \"" cam "\"}},"                          \
+    "   {\"type\": \"view\", \"background_color\": \"#00000080\", \"border_radius\": 8, \"left\": 16, \"bottom\": 16, \"width\": 200, \"height\": 36,"     \
+    "    \"padding_horizontal\": 8, \"padding_vertical\": 4, \"children\": ["                                                                     \
+    "     {\"type\": \"text\", \"text\": \"" label "\", \"font_size\": 22, \"color\": \"#FFE080FF\"}]}]}"
+static const char *SCENE_WITH_LABELS =
+    "{\"type\": \"tiles\", \"background_color\": \"#202030FF\", \"margin\": 8, \"children\": ["
+    TILE("cam0", "CAM 0 LIVE") "," TILE("cam1", "CAM 1 LIVE") "," TILE("cam2", "CAM 2 - R\u00e9gie") "," TILE("cam3", "CAM 3 LIVE") "]}";
+static const char *SCENE_PLAIN =
     "{\"type\": \"tiles\", \"background_color\": \"#101018FF\", \"margin\": 8, \"children\": ["
     " {\"type\": \"rescaler\", \"border_radius\": 16, \"child\": {\"type\": \"input_stream\", \"input_id\": \"cam0\"}},"
     " {\"type\": \"rescaler\", \"border_radius\": 16, \"child\": {\"type\": \"input_stream\", \"input_id\": \"cam1\"}},"
@@ -55,7 +68,24 @@ int main(int argc, char **argv) {
         set[i].frame = &frames[i];
         set[i].pts_ns = 0;
     }
-    CHECK(smr_renderer_update_scene(r, "out", OW, OH, SMR_FRAME_PLANAR_YUV420, SCENE), "update_scene", smr_renderer_last_error(r));
+    /* TextRendererCtx: a font book for the renderer — fitted Text nodes are measured with it and every Text node is laid out,
+     * rasterised and drawn by update_scene itself (text_renderer.rs:72-167, 282-368) */
+    smr_fontbook *fonts = NULL;
+    const char *font_dir = argc > 2 ? argv[2] : getenv("SMR_FONT_DIR") ? getenv("SMR_FONT_DIR") : "/usr/share/fonts/truetype";
+    int n_fonts = 0, n_text = 0;
+    if (smr_fontbook_create(&fonts) == 0 && (n_fonts = smr_fontbook_add_dir(fonts, font_dir)) > 0)
+        CHECK(smr_renderer_set_fontbook(r, fonts), "set_fontbook", smr_renderer_last_error(r));
+    else
+        fprintf(stderr, "no TrueType fonts below %s (%s): rendering without labels\n", font_dir, fonts ? smr_fontbook_last_error(fonts) : "no font book");
+    CHECK(smr_renderer_update_scene(r, "out", OW, OH, SMR_FRAME_PLANAR_YUV420, n_fonts > 0 ? SCENE_WITH_LABELS : SCENE_PLAIN), "update_scene",
+          smr_renderer_last_error(r));
+    for (int i = 0, n = smr_renderer_node_count(r, "out"); i < n; i++) {
+        smr_scene_node info;
+        if (smr_renderer_node_info(r, "out", i, &info) == 0 && info.kind == SMR_NODE_TEXT) {
+            n_text++;
+            printf("text node %d: \"%s\" fitted to %ux%u\n", i, info.payload, info.width, info.height);
+        }
+    }
 
     smr_output_frame outs[1];
     uint32_t n_out = 0;
@@ -66,7 +96,7 @@ int main(int argc, char **argv) {
 
     unsigned long sum = 0;
     for (int i = 0; i < OW * OH; i++) sum += oy[i];
-    printf("rendered %ux%u from %d inputs: mean luma %.2f\n", OW, OH, N, (double)sum / (OW * OH));
+    printf("rendered %ux%u from %d inputs: mean luma %.2f, %d text nodes drawn with %d font faces\n", OW, OH, N, (double)sum / (OW * OH), n_text, n_fonts);
     if (argc > 1) {
         FILE *f = fopen(argv[1], "wb");
         if (f) {
@@ -78,6 +108,7 @@ int main(int argc, char **argv) {
     }
     for (int i = 0; i < N; i++) smr_frame_destroy(ctx, &frames[i]);
     smr_renderer_destroy(r);
+    if (fonts) smr_fontbook_destroy(fonts);
     smr_ctx_destroy(ctx);
     free(y); free(u); free(v); free(oy); free(ou); free(ov);
     return 0;

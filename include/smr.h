@@ -333,9 +333,52 @@ SMR_API const char *smr_comm_last_error(const smr_comm *comm);
 SMR_API int smr_gather_tiles(smr_comm *comm, uint32_t root, const uint32_t *owner, const smr_surface *const *src, smr_surface *const *dst,
                              uint32_t n);
 
-/* ---- a12: text node blit (transformations/text_renderer.rs:72-167) ----------------- */
+/* ---- a12: text (transformations/text_renderer.rs:72-167, 236-368) -------------------
+ * TextRendererNode::render's blit: clear `target` to bg (a shader colour: convert_to_shader_color of the node's background), then
+ * every glyph quad's coverage from the A8 atlas in the quad's colour, premultiplied OVER. */
 SMR_API int smr_blit_glyphs(smr_ctx *ctx, smr_surface *target, const float bg[4], const smr_glyph *glyphs, uint32_t n,
                             const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
+
+/* The host half of the text node — font database, line layout, glyph rasteriser — behind the ABI (host code, no GPU):
+ *   TextRendererCtx::new / add_font, Renderer::register_font (state.rs:168-171)  -> smr_fontbook_add_file / _add_memory / _add_dir
+ *   TextRendererCtx::layout_text: Buffer::set_text + set_wrap + set_size + shape_until_scroll, get_text_resolution (text_renderer.rs:282-368)
+ *                                                                                -> smr_fontbook_measure (a smr_text_measure_fn: pass the book as `user`)
+ *   TextRendererNode::render's prepare(): the laid-out buffer as atlas + quads   -> smr_fontbook_rasterise
+ * The reference does all of this with glyphon / cosmic-text / swash (third-party, not in its tree).  This library's reader is its own:
+ * TrueType `glyf` outlines (simple + composite), `cmap` formats 0 / 4 / 6 / 12 / 13, `hmtx` advances, pair kerning from the GPOS `kern`
+ * feature (PairPos 1 and 2, extension lookups), explicit newlines, Wrap::None / Glyph / Word, Left / Center / Right alignment (Justified
+ * is laid out as Left), a line's ascent + descent centred in its line box, exact-area coverage at the fractional pen position.  NOT
+ * restated: GSUB (ligatures, contextual alternates), mark positioning, bidi, font fallback, hinting, CFF outlines — glyph shapes and
+ * sub-pixel positions are this library's, not glyphon's: PARITY FOR TEXT PIXELS IS UNPINNED (no reference artefact holds them in-tree).
+ * Fonts are loaded by path or from memory; the reference bundles Inter (smelter-render/fonts/ *.ttf), hosts register the same files. */
+typedef struct smr_fontbook smr_fontbook;
+/* What a shaper lays out: TextComponent's text, font attributes and wrap mode (text_renderer.rs:174-233) inside max_width x max_height.
+ * Strings are the reference's variant names ("Normal" | "Italic" | "Oblique", "Thin" .. "Black", "None" | "Glyph" | "Word",
+ * "Left" | "Right" | "Justified" | "Center"). */
+typedef struct smr_text_params {
+    const char *text, *font_family, *style, *weight, *wrap, *align;
+    float font_size, line_height;
+    float max_width, max_height;
+} smr_text_params;
+typedef struct smr_text_run {
+    const smr_glyph *glyphs; /* owned by the font book: valid until its next smr_fontbook_rasterise / destroy */
+    uint32_t n_glyphs;
+    const uint8_t *atlas;    /* A8 coverage, atlas_w x atlas_h, tight rows */
+    uint32_t atlas_w, atlas_h;
+} smr_text_run;
+SMR_API int smr_fontbook_create(smr_fontbook **out);
+SMR_API void smr_fontbook_destroy(smr_fontbook *book);
+SMR_API const char *smr_fontbook_last_error(const smr_fontbook *book);
+SMR_API int smr_fontbook_add_file(smr_fontbook *book, const char *path);                     /* fontdb::Source::File */
+SMR_API int smr_fontbook_add_memory(smr_fontbook *book, const uint8_t *data, size_t size);   /* fontdb::Source::Binary (copied) */
+SMR_API int smr_fontbook_add_dir(smr_fontbook *book, const char *dir);                       /* every *.ttf below dir, by path; returns how many, < 0 if none */
+SMR_API uint32_t smr_fontbook_count(const smr_fontbook *book);
+/* lays params->text out at font_size with params->wrap inside max_width; widest line (pixels) and line count — the signature of
+ * smr_text_measure_fn with `user` = the font book */
+SMR_API int smr_fontbook_measure(void *book, const smr_text_params *params, float *widest_line, uint32_t *line_count);
+/* the glyph run of a Text node of width x height pixels for smr_blit_glyphs / smr_renderer_set_text; `color` = straight RGBA 0..1 */
+SMR_API int smr_fontbook_rasterise(smr_fontbook *book, const smr_text_params *params, uint32_t width, uint32_t height, const float color[4],
+                                   smr_text_run *out);
 
 /* ---- a13 stand-in: built-in "shader" kernels (user WGSL is out of scope) ------------ */
 /* Built-in kernels for ShaderNode::render (transformations/shader/node.rs:71-89, shader/pipeline.rs:81-141).  Arbitrary user
@@ -406,11 +449,6 @@ SMR_API const char *smr_scene_last_error(const smr_scene *scene);
  * — from the line metrics the caller's shaper reports through this callback (glyphon / cosmic-text in the reference, third-party):
  * lay `text` out at `font_size` with wrapping `wrap` ("None" | "Glyph" | "Word") inside max_width x max_height and return the
  * widest line and the number of lines.  Return non-zero to fail the scene update.  Without a measurer such nodes are refused. */
-typedef struct smr_text_params {
-    const char *text, *font_family, *style, *weight, *wrap, *align;
-    float font_size, line_height;
-    float max_width, max_height;
-} smr_text_params;
 typedef int (*smr_text_measure_fn)(void *user, const smr_text_params *params, float *widest_line, uint32_t *line_count);
 SMR_API int smr_scene_set_text_measurer(smr_scene *scene, smr_text_measure_fn fn, void *user);
 /* Renderer::register_renderer(Image) as far as sizing goes (scene/image_component.rs) */
@@ -447,8 +485,9 @@ SMR_API int smr_parse_color(const char *text, uint8_t rgba[4]);
  *   render(FrameSet<InputId>)  -> smr_renderer_render: populate_inputs (stale frames dropped), depth-first walk of every output's
  *                                 render graph (input refs, images, text, shader and nested layout nodes), read_outputs fused
  *                                 into the root layout node (state.rs:220-252, render_loop.rs:19-230)
- * Text nodes: shaping / rasterisation is the caller's (third-party in the reference); after every update_scene the caller
- * supplies each Text node's glyph run once (smr_renderer_node_info lists them), as text_renderer.rs renders once per update.
+ * Text nodes: with a font book (smr_renderer_set_fontbook) the renderer lays out, rasterises and draws them itself at every update_scene;
+ * without one the caller supplies each Text node's glyph run once after every update_scene (smr_renderer_node_info lists the nodes,
+ * smr_renderer_set_text takes the run) — text_renderer.rs renders once per update either way.
  * Output frames live in HBM, two per output, alternating: a returned frame stays valid until the render after the next. */
 typedef struct smr_renderer smr_renderer;
 typedef struct smr_input_frame {
@@ -475,6 +514,11 @@ SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_i
 SMR_API int smr_renderer_node_count(const smr_renderer *r, const char *output_id);
 SMR_API int smr_renderer_node_info(smr_renderer *r, const char *output_id, int node, smr_scene_node *out);
 SMR_API int smr_renderer_set_text_measurer(smr_renderer *r, smr_text_measure_fn fn, void *user);
+/* TextRendererCtx for this renderer: with a font book (not owned; it must outlive the renderer) fitted Text nodes are measured with it
+ * and EVERY Text node is laid out, rasterised and drawn by smr_renderer_update_scene itself — once per update, as
+ * TextRendererNode::render does — in the node's colour over its background_color.  smr_renderer_set_text still replaces a node's run.
+ * NULL detaches the book (and its measurer). */
+SMR_API int smr_renderer_set_fontbook(smr_renderer *r, smr_fontbook *book);
 SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int node, const float bg[4], const smr_glyph *glyphs, uint32_t n,
                                   const uint8_t *atlas_host, uint32_t atlas_w, uint32_t atlas_h);
 SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs,

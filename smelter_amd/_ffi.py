@@ -45,6 +45,8 @@ EXPORTS = [
     "smr_renderer_render", "smr_renderer_add_lane", "smr_renderer_sync",
     "smr_comm_create_local", "smr_comm_unique_id", "smr_comm_create_rank", "smr_comm_destroy", "smr_comm_world", "smr_comm_rank",
     "smr_comm_last_error", "smr_gather_tiles",
+    "smr_fontbook_create", "smr_fontbook_destroy", "smr_fontbook_last_error", "smr_fontbook_add_file", "smr_fontbook_add_memory",
+    "smr_fontbook_add_dir", "smr_fontbook_count", "smr_fontbook_measure", "smr_fontbook_rasterise", "smr_renderer_set_fontbook",
     "smr_abi_version", "smr_sizeof_layout",
 ]
 NO_RESOLUTION = 0xFFFFFFFF
@@ -102,6 +104,10 @@ class Glyph(C.Structure):
 class TextParams(C.Structure):
     _fields_ = [("text", C.c_char_p), ("font_family", C.c_char_p), ("style", C.c_char_p), ("weight", C.c_char_p), ("wrap", C.c_char_p),
                 ("align", C.c_char_p), ("font_size", C.c_float), ("line_height", C.c_float), ("max_width", C.c_float), ("max_height", C.c_float)]
+
+
+class TextRun(C.Structure):
+    _fields_ = [("glyphs", C.POINTER(Glyph)), ("n_glyphs", C.c_uint32), ("atlas", C.POINTER(C.c_uint8)), ("atlas_w", C.c_uint32), ("atlas_h", C.c_uint32)]
 
 
 TEXT_MEASURE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(TextParams), C.POINTER(C.c_float), C.POINTER(C.c_uint32))
@@ -224,6 +230,16 @@ def load():
         "smr_renderer_render": ([P, C.c_int64, C.POINTER(InputFrame), U, C.POINTER(OutputFrame), U, C.POINTER(U)], I),
         "smr_renderer_add_lane": ([P, P], I),
         "smr_renderer_sync": ([P], I),
+        "smr_fontbook_create": ([PP], I),
+        "smr_fontbook_destroy": ([P], None),
+        "smr_fontbook_last_error": ([P], C.c_char_p),
+        "smr_fontbook_add_file": ([P, C.c_char_p], I),
+        "smr_fontbook_add_memory": ([P, P, C.c_size_t], I),
+        "smr_fontbook_add_dir": ([P, C.c_char_p], I),
+        "smr_fontbook_count": ([P], U),
+        "smr_fontbook_measure": ([P, C.POINTER(TextParams), C.POINTER(F), C.POINTER(U)], I),
+        "smr_fontbook_rasterise": ([P, C.POINTER(TextParams), U, U, C.POINTER(F), C.POINTER(TextRun)], I),
+        "smr_renderer_set_fontbook": ([P, P], I),
         "smr_abi_version": ([], U),
         "smr_sizeof_layout": ([], U),
     }

@@ -59,5 +59,29 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+def kernels_sha256(lib: str = LIB) -> str:
+    """Identity of the library's DEVICE code: sha256 of its .hip_fatbin section (the gfx950 code objects of every kernel).  Profiles that
+    quote per-kernel counters record it (tools/traffic_json.py, tools/issue_json.py); bench.py refuses to quote a profile whose hash is not
+    the hash of the library it is timing."""
+    import hashlib
+    import struct
+    with open(lib, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        raise ValueError(f"{lib}: not an ELF64 file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sect(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _n, stroff, _strsize = sect(shstrndx)
+    for i in range(shnum):
+        name, off, size = sect(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()
+    raise ValueError(f"{lib}: no .hip_fatbin section")
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))

@@ -58,6 +58,7 @@ struct smr_renderer {
     std::map<std::string, uint32_t> shaders;  // shader_id -> smr_builtin_shader_id
     smr_text_measure_fn measure = nullptr;    // the caller's text shaper (fitted Text nodes)
     void *measure_user = nullptr;
+    smr_fontbook *fontbook = nullptr;         // TextRendererCtx: with a book, Text nodes are measured and drawn here (not owned)
     std::map<std::string, Output> outputs;
     std::string err;
     std::vector<smr_layout> layouts;  // scratch
@@ -398,10 +399,61 @@ SMR_API int smr_renderer_set_text_measurer(smr_renderer *r, smr_text_measure_fn 
     return 0;
 }
 
+SMR_API int smr_renderer_set_fontbook(smr_renderer *r, smr_fontbook *book) {
+    if (!r) return -1;
+    r->fontbook = book;
+    r->measure = book ? smr_fontbook_measure : nullptr;
+    r->measure_user = book;
+    for (auto &kv : r->outputs) kv.second.scene.set_text_measurer(r->measure, r->measure_user);
+    return 0;
+}
+
 SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id, uint32_t builtin_id) {
     if (!r || !shader_id) return fail(r, -1, "smr_renderer_register_shader: null argument");
     if (builtin_id > SMR_SHADER_SILLY) return fail(r, -1, "smr_renderer_register_shader: unknown built-in shader (user WGSL is not supported)");
     r->shaders[shader_id] = builtin_id;
+    return 0;
+}
+
+// TextRendererNode::render for one node (text_renderer.rs:72-167): clear to the background colour, blit the glyph run — once per update
+static int set_text_run(smr_renderer *r, Output &o, int node, const float bg[4], const smr_glyph *glyphs, uint32_t n, const uint8_t *atlas,
+                        uint32_t atlas_w, uint32_t atlas_h) {
+    const Stateful &c = *o.scene.nodes()[node].component;
+    const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+    if (!w || !h) return 0;  // (a zero-sized text node is the 1x1 transparent texture: text_renderer.rs:77-85)
+    int rc = ensure_surface(r, o.text_surface[node], w, h);
+    if (rc < 0) return rc;
+    rc = gpu(r, smr_blit_glyphs(r->ctx, o.text_surface[node], bg, glyphs, n, atlas, atlas_w, atlas_h), "text node");
+    // every lane's stream reads the run from its next frame on
+    if (rc >= 0 && r->lane_ctx.size() > 1) rc = gpu(r, smr_sync(r->ctx), "text node");
+    return rc;
+}
+
+// With a font book the renderer is its own TextRendererCtx: every Text node of the new scene is laid out at its resolved size
+// (layout_text's final set_size: the node's width, text_renderer.rs:333-343), rasterised and drawn — in TextComponent's colour
+// (glyphon::Color::rgba of the straight bytes, text_renderer.rs:176-177) over convert_to_shader_color(background_color) (:62, 371-374).
+static int draw_text_nodes(smr_renderer *r, const std::string &output_id, Output &o) {
+    (void)output_id;
+    const auto &nodes = o.scene.nodes();
+    for (int i = 0; i < (int)nodes.size(); i++) {
+        if (nodes[i].kind != Kind::Text) continue;
+        const Stateful &c = *nodes[i].component;
+        const Stateful::TextSpec &t = c.text_spec;
+        smr_text_params p;
+        memset(&p, 0, sizeof(p));
+        p.text = c.text.c_str(); p.font_family = t.family.c_str(); p.style = t.style.c_str(); p.weight = t.weight.c_str(); p.wrap = t.wrap.c_str();
+        p.align = t.align.c_str();
+        p.font_size = t.font_size; p.line_height = t.line_height;
+        p.max_width = c.leaf_size.width; p.max_height = c.leaf_size.height;
+        const float color[4] = {t.color.r / 255.0f, t.color.g / 255.0f, t.color.b / 255.0f, t.color.a / 255.0f};
+        float bg[4];
+        convert_to_shader_color(t.background, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, bg);
+        smr_text_run run;
+        if (smr_fontbook_rasterise(r->fontbook, &p, (uint32_t)c.leaf_size.width, (uint32_t)c.leaf_size.height, color, &run) != 0)
+            return fail(r, -1, std::string("text node: ") + smr_fontbook_last_error(r->fontbook));
+        const int rc = set_text_run(r, o, i, bg, run.glyphs, run.n_glyphs, run.atlas, run.atlas_w, run.atlas_h);
+        if (rc < 0) return rc;
+    }
     return 0;
 }
 
@@ -454,7 +506,9 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
     o.w = width; o.h = height; o.format = output_format;
     // node indices belong to the new graph: per-node surfaces are re-created on demand, text runs must be supplied again
     free_node_surfaces(r, o);
-    return enter_lane(r, o, 0);  // the output's first frames exist after a successful update, as before
+    int rc = enter_lane(r, o, 0);  // the output's first frames exist after a successful update, as before
+    if (rc >= 0 && r->fontbook) rc = draw_text_nodes(r, output_id, o);
+    return rc;
 }
 
 SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_id) {
@@ -501,16 +555,7 @@ SMR_API int smr_renderer_set_text(smr_renderer *r, const char *output_id, int no
     Output &o = it->second;
     if (node < 0 || node >= (int)o.scene.nodes().size() || o.scene.nodes()[node].kind != Kind::Text)
         return fail(r, -1, "smr_renderer_set_text: not a text node");
-    const Stateful &c = *o.scene.nodes()[node].component;
-    const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
-    if (!w || !h) return 0;
-    int rc = ensure_surface(r, o.text_surface[node], w, h);
-    if (rc < 0) return rc;
-    // TextRendererNode::render (text_renderer.rs:72-167): clear to the background colour, blit the glyph run — once per update
-    rc = gpu(r, smr_blit_glyphs(r->ctx, o.text_surface[node], bg, glyphs, n, atlas, atlas_w, atlas_h), "text node");
-    // every lane's stream reads the run from its next frame on
-    if (rc >= 0 && r->lane_ctx.size() > 1) rc = gpu(r, smr_sync(r->ctx), "text node");
-    return rc;
+    return set_text_run(r, o, node, bg, glyphs, n, atlas, atlas_w, atlas_h);
 }
 
 SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input_frame *inputs, uint32_t n_inputs, smr_output_frame *outputs,

@@ -271,7 +271,7 @@ void Stateful::update_state(const std::vector<std::optional<Size>> &res, size_t 
 }
 std::unique_ptr<Stateful> Stateful::clone() const {
     auto c = std::make_unique<Stateful>();
-    c->kind = kind; c->id = id; c->has_id = has_id; c->ref_id = ref_id; c->leaf_size = leaf_size; c->text = text;
+    c->kind = kind; c->id = id; c->has_id = has_id; c->ref_id = ref_id; c->leaf_size = leaf_size; c->text = text; c->text_spec = text_spec;
     c->shader_param = shader_param; c->view_end = view_end; c->view_start = view_start; c->resc_end = resc_end;
     c->resc_start = resc_start; c->tiles = tiles; c->tiles_start = tiles_start; c->tiles_last_layout = tiles_last_layout;
     c->transition = transition;

@@ -123,6 +123,11 @@ struct Stateful {
     std::string ref_id;          // input_id / image_id / shader_id
     Size leaf_size;              // InputStream: filled by update_state; Text/Image/Shader: intrinsic
     std::string text;            // Text payload (passed through to the caller)
+    struct TextSpec {            // TextComponent as TextRendererCtx::layout_text / TextRendererNode take it (text_renderer.rs:174-233, 282-346)
+        float font_size = 0, line_height = 0;
+        RGBA color{255, 255, 255, 255}, background{0, 0, 0, 0};
+        std::string family, style, weight, wrap, align;
+    } text_spec;
     Json shader_param;
     Json desc;                   // the converted component (scene::Component) as canonical JSON, see Scene::parse
     // layouts

@@ -564,6 +564,10 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             .set("line_height", Json::number(lh.value_or(*fs))).set("color", jcolor(color)).set("font_family", Json::string(family))
             .set("style", Json::string(style)).set("align", Json::string(halign_name(align))).set("weight", Json::string(weight))
             .set("wrap", Json::string(wrap)).set("background_color", jcolor(bg)).set("dimensions", dims);
+        s->text_spec.font_size = *fs; s->text_spec.line_height = lh.value_or(*fs);
+        s->text_spec.color = color; s->text_spec.background = bg;
+        s->text_spec.family = family; s->text_spec.style = style; s->text_spec.weight = weight; s->text_spec.wrap = wrap;
+        s->text_spec.align = halign_name(align);
         if (c.api_only) return s;
         if (!w || !h) {
             // TextRendererCtx::layout_text (text_renderer.rs:282-346): Fitted { max_width, max_height } / FittedColumn { width, max_height }

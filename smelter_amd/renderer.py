@@ -78,6 +78,11 @@ class Renderer:
         self._measurer = measurer  # keep the callback alive
         self._check(self.lib.smr_renderer_set_text_measurer(self._h, measurer if measurer is not None else _ffi.TEXT_MEASURE_FN(0), None))
 
+    def set_fontbook(self, book):
+        """A smelter_amd.text.NativeFontBook (smr_fontbook): the renderer measures and draws every Text node itself at update_scene."""
+        self._fontbook = book  # keep it alive: the renderer does not own it
+        self._check(self.lib.smr_renderer_set_fontbook(self._h, book.handle if book is not None else None))
+
     def register_shader(self, shader_id: str, builtin_id: int = _ffi.SHADER_GAUSSIAN_BLUR):
         self._check(self.lib.smr_renderer_register_shader(self._h, shader_id.encode(), builtin_id))
 

@@ -119,3 +119,22 @@ def test_rank_comm_of_one_and_the_sharded_driver_over_it(hip):
     comm.close()
     c.close()
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_rank_comm_across_processes(hip):
+    """The RCCL transport at world 2: `torchrun --nproc-per-node 2 tests/rank_gather_worker.py` — smr_comm_create_rank on every rank, tiles
+    gathered by smr_gather_tiles (ncclSend / ncclRecv on the context streams), the gathered tiles and the composed frame byte for byte what one
+    context renders alone.  Needs two GPUs; the worker carries its own 60 s watchdog so a stuck exchange fails instead of hanging."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (one process per GPU over RCCL)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29617",
+           os.path.join(root, "tests", "rank_gather_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    assert "== one context" in p.stdout

@@ -99,7 +99,9 @@ def _label_surfaces(ctx, n):
     bg = orc.color_to_shader((0, 0, 0, 0), True)
     t = ctx.surface(scenes.LABEL_W, scenes.LABEL_H)
     ctx.blit_glyphs(t, bg, glyphs, atlas)
-    host = t.download()
+    # the oracle's picture takes the ORACLE's label node (orc.blit_glyphs), never the kernel's own output: the text pixels of the scene
+    # tests are compared with an independent computation (the blit itself is held to the oracle in tests/test_gpu_parity.py::test_blit_glyphs)
+    host = orc.blit_glyphs(scenes.LABEL_W, scenes.LABEL_H, bg, glyphs, atlas, True)
     return t, host
 
 

@@ -1,6 +1,8 @@
 """smr_renderer_* — the reference's `Renderer` (state.rs:96-252) end to end on the GPU: scene JSON + frame sets in, output
 frames out.  Checked against the same work done pass by pass through the lower-level C ABI (bit for bit) and against the
 oracle pipeline (<= 1 LSB)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -68,7 +70,7 @@ def test_cfg3_scene_matches_the_layout_list_path_and_the_oracle(ctx, hip, render
     for a, b in zip(got, out.download()):
         assert (a == b).all()
     # and the oracle's restatement of the reference's pass sequence
-    label_host = label.download()
+    label_host = orc.blit_glyphs(scenes.LABEL_W, scenes.LABEL_H, orc.color_to_shader((0, 0, 0, 0), True), glyphs, atlas, True)  # (the oracle's own label node)
     nodes_o, k = [], 0
     for r_ in res:
         if r_ == (iw, ih):
@@ -464,6 +466,8 @@ def test_c_example_runs(tmp_path):
     p = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
     assert "rendered 1280x720 from 4 inputs" in p.stdout
+    if os.path.isdir("/usr/share/fonts/truetype"):  # the labels: laid out, rasterised and drawn by the library itself — no Python, no caller-side shaper
+        assert "4 text nodes drawn" in p.stdout and 'text node' in p.stdout and "R\u00e9gie".encode().decode("unicode_escape") in p.stdout
     data = np.fromfile(out, np.uint8)
     assert data.size == 1280 * 720 * 3 // 2 and data[: 1280 * 720].std() > 10
 
@@ -497,3 +501,43 @@ def test_fitted_text_is_sized_by_the_shaper_and_drawn(ctx, hip, renderer):
     assert (got[:tn.height, :tn.width] == want).mean() > 0.999
     assert not got[tn.height:].any() and not got[:, tn.width:].any()
     assert want[..., 3].max() == 255 and (want[..., 3] > 0).mean() > 0.05  # the text is really there
+
+
+def test_renderer_with_a_font_book_draws_its_text_nodes_itself(ctx, hip, renderer):
+    """smr_renderer_set_fontbook = the reference's TextRendererCtx: update_scene measures fitted Text nodes with the book (get_text_resolution)
+    and lays out, rasterises and draws EVERY Text node — colour from the component, background through convert_to_shader_color — once per
+    update (text_renderer.rs:72-167, 282-368).  The node's pixels equal the oracle's blit of the same run (the run itself is held byte for
+    byte to the Python twin in tests/test_text_capi.py); a second update re-draws; detaching the book restores the caller-supplied path."""
+    import json
+    import math
+
+    from smelter_amd import _ffi, text as T
+    try:
+        book = T.NativeFontBook.system()
+    except FileNotFoundError:
+        pytest.skip("no TrueType fonts on this machine")
+    renderer.set_fontbook(book)
+    W, H, fs, lh = 640, 360, 34.0, 40.0
+    txt = "Fitted text\nsized and drawn in C++"
+
+    def scene(t, colour, bg):
+        return {"type": "view", "background_color": "#00000000",
+                "children": [{"type": "text", "text": t, "font_size": fs, "line_height": lh, "align": "right", "color": colour, "background_color": bg}]}
+    for t, colour, bg, rgba, bg_rgba in [(txt, "#FFCC33FF", "#00000000", (0xFF, 0xCC, 0x33, 0xFF), (0, 0, 0, 0)),
+                                         ("second update", "#40FF80C0", "#20304080", (0x40, 0xFF, 0x80, 0xC0), (0x20, 0x30, 0x40, 0x80))]:
+        nodes = renderer.update_scene("out", W, H, json.dumps(scene(t, colour, bg)), output_format=hip.FRAME_RGBA)
+        tn = [n for n in nodes if n.kind == _ffi.NODE_TEXT][0]
+        widest, lines = book.measure(t, fs)
+        assert (tn.width, tn.height) == (math.ceil(widest), int(lines * math.ceil(lh) + fs / 5.0))
+        got = np.asarray(renderer.render(0.0, {})["out"].download()[0]).reshape(H, W, 4)
+        glyphs, atlas = book.rasterise(t, tn.width, tn.height, fs, lh, align="Right", color=tuple(c / 255.0 for c in rgba))
+        want = orc.blit_glyphs(tn.width, tn.height, orc.color_to_shader(bg_rgba, True), glyphs, atlas, True)
+        # the node sits at the view's top-left at 1:1: the layout pass copies it (premultiplied OVER a transparent target)
+        assert np.abs(got[:tn.height, :tn.width].astype(int) - want.astype(int)).max() <= 1
+        assert (got[:tn.height, :tn.width] == want).mean() > 0.999
+        assert not got[tn.height:].any() and not got[:, tn.width:].any()
+        assert (want[..., 3] > bg_rgba[3]).mean() > 0.05  # the text is really there
+    renderer.set_fontbook(None)
+    with pytest.raises(Exception):  # no shaper any more: a fitted Text node is refused
+        renderer.update_scene("out", W, H, json.dumps(scene(txt, "#FFFFFFFF", "#00000000")), output_format=hip.FRAME_RGBA)
+    book.close()

@@ -91,7 +91,7 @@ def test_rust_struct_mirrors_have_the_c_fields_in_order():
     hdr = _header_text()
     added = _added()
     for name in ("smr_frame", "smr_mask", "smr_layout", "smr_source", "smr_glyph", "smr_resample_plan", "smr_scene_node", "smr_input_frame",
-                 "smr_output_frame", "smr_surface_info", "smr_gaussian_blur_params", "smr_circle_layout", "smr_text_params"):
+                 "smr_output_frame", "smr_surface_info", "smr_gaussian_blur_params", "smr_circle_layout", "smr_text_params", "smr_text_run"):
         c_body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", hdr, flags=re.S).group(1)
         c_fields = []
         for decl in c_body.split(";"):

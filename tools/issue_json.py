@@ -1,12 +1,26 @@
-"""Wave-instruction counts per frame and the instruction-issue floor they imply, from a tools/prof.sh summary (the PMC passes SQ_INSTS_VALU / SQ_INSTS_LDS /
-SQ_INSTS_MFMA of the bench command): how profiles/r04_issue.json is made.   python tools/issue_json.py profiles/r04_rocprofv3_summary_v3.txt > profiles/r04_issue.json"""
+"""Wave-instruction counts per frame and the instruction-issue floors they imply, from a tools/prof.sh summary (the PMC passes SQ_INSTS_VALU /
+SQ_INSTS_LDS / SQ_INSTS_MFMA of the bench command).   python tools/issue_json.py profiles/r05_rocprofv3_summary.txt > profiles/r05_issue.json
+
+The vector ALU and the matrix pipe of a SIMD are SEPARATE pipes that run side by side (MI355X_MICROARCH.md, "Wave scheduling": "MFMA and VALU
+pipes are separate ... both ~max, not sum"), so the floor of a frame is the LARGER of the two pipes' times, not their sum (round 4 added
+them).  Three prices are reported side by side — none of them is "the" floor, they bracket it:
+  guide      every vector instruction at the guide's 2 cycles per wave64 instruction, 2.4 GHz (0.83 ns); an MFMA 16x16x32 f16 at 17 cycles per SIMD
+  measured   this device's measured issue rates (profiles/r02_valu_rate.txt): 1.1 ns for fp32 mul / add / fma, 1.8 ns for conversions, permutes,
+             SDWA and three-operand integer ops, mixed 55 / 45 as the three kernels' ISA is; MFMA 7.4 ns
+  stamped    what the converter's wave stamps show a saturated SIMD delivers on this code (profiles/r05_convert_waves.txt): 3.9 cycles per vector
+             instruction at the 2.05 GHz the chip holds under this load = 1.9 ns"""
 import json
+import os
 import re
 import sys
 
 KERNELS = ["k_yuv420_to_rgba", "k_ingest_wave", "k_compose_output"]
-FULL, SLOW, MFMA = 1.1, 1.8, 7.4  # ns per wave-instruction per SIMD, measured on this device (profiles/r02_valu_rate.txt, profiles/r03_valu_occ.txt)
 SIMDS = 256 * 4
+PRICES = {  # ns per wave-instruction per SIMD: (vector, mfma)
+    "guide": (2.0 / 2.4, 17.0 / 2.4),
+    "measured": (0.55 * 1.1 + 0.45 * 1.8, 7.4),
+    "stamped": (3.9 / 2.05, 7.4),
+}
 
 
 def main(path):
@@ -22,15 +36,23 @@ def main(path):
     valu = sum(out[k]["SQ_INSTS_VALU"] for k in KERNELS)
     mfma = sum(out[k].get("SQ_INSTS_MFMA", 0.0) for k in KERNELS)
     lds = sum(out[k]["SQ_INSTS_LDS"] for k in KERNELS)
-    floor_us = (valu * (0.55 * FULL + 0.45 * SLOW) + mfma * MFMA) / SIMDS / 1000.0
+    floors = {}
+    for name, (pv, pm) in PRICES.items():
+        tv, tm = valu * pv / SIMDS / 1000.0, mfma * pm / SIMDS / 1000.0
+        floors[name] = {"vector_us": round(tv, 1), "matrix_us": round(tm, 1), "floor_us_pipes_overlapped": round(max(tv, tm), 1),
+                        "upper_us_pipes_serialised": round(tv + tm, 1), "ns_per_vector_instruction": round(pv, 3), "ns_per_mfma": round(pm, 2)}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.traffic_json import lib_identity
     print(json.dumps({
         "source": f"{path} (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_LDS / SQ_INSTS_MFMA, one frame in flight, configs[2])",
+        "_identity": lib_identity(),
         "per_kernel": {k: out[k] for k in KERNELS},
         "per_frame": {"valu_wave_instructions": valu, "mfma_wave_instructions": mfma, "lds_wave_instructions": lds},
         "simds": SIMDS,
-        "issue_rates_ns": {"fp32_mul_add_fma": FULL, "conversions_permutes_shift_ors": SLOW, "mfma_16x16x32_f16": MFMA,
-                           "assumed_mix": "55 % full rate / 45 % slow (ISA of the three kernels)", "source": "profiles/r02_valu_rate.txt, profiles/r03_valu_occ.txt"},
-        "issue_floor_us_per_frame": round(floor_us, 1)}, indent=1))
+        "floors_us_per_frame": floors,
+        "reading": "the vector and matrix pipes overlap: a frame cannot be shorter than floor_us_pipes_overlapped at the given price; "
+                   "'guide' is the hardware's peak issue rate, 'stamped' what a saturated SIMD has been seen to deliver on this instruction mix",
+        "issue_floor_us_per_frame": floors["guide"]["floor_us_pipes_overlapped"]}, indent=1))
 
 
 if __name__ == "__main__":

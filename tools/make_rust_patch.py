@@ -133,6 +133,10 @@ pub struct smr_renderer {
 pub struct smr_comm {
     _p: [u8; 0],
 }
+#[repr(C)]
+pub struct smr_fontbook {
+    _p: [u8; 0],
+}
 
 @@ENUMS@@
 pub const SMR_MAX_MASKS: usize = 20; // MAX_MASKS_COUNT (transformations/layout/params.rs:15)
@@ -176,6 +180,8 @@ pub struct smr_text_params {
     pub text: *const c_char, pub font_family: *const c_char, pub style: *const c_char, pub weight: *const c_char, pub wrap: *const c_char,
     pub align: *const c_char, pub font_size: f32, pub line_height: f32, pub max_width: f32, pub max_height: f32,
 }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct smr_text_run { pub glyphs: *const smr_glyph, pub n_glyphs: u32, pub atlas: *const u8, pub atlas_w: u32, pub atlas_h: u32 }
 pub type smr_text_measure_fn =
     Option<unsafe extern "C" fn(user: *mut c_void, params: *const smr_text_params, widest_line: *mut f32, line_count: *mut u32) -> c_int>;
 #[repr(C)] #[derive(Clone, Copy)]

@@ -40,5 +40,15 @@ def collect(root):
     return out
 
 
+def lib_identity():
+    """Which library's kernels the counters belong to: bench.py quotes a traffic file only for the library it is timing (smelter_amd/build.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from smelter_amd import build as B
+    lib = os.environ.get("SMR_LIB") or B.LIB
+    return {"lib_kernels_sha256": B.kernels_sha256(lib), "lib": os.path.relpath(lib, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))}
+
+
 if __name__ == "__main__":
-    print(json.dumps(collect(sys.argv[1]), indent=1))
+    out = collect(sys.argv[1])
+    out["_identity"] = lib_identity()
+    print(json.dumps(out, indent=1))
