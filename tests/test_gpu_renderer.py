@@ -467,7 +467,7 @@ def test_c_example_runs(tmp_path):
     assert p.returncode == 0, p.stderr
     assert "rendered 1280x720 from 4 inputs" in p.stdout
     if os.path.isdir("/usr/share/fonts/truetype"):  # the labels: laid out, rasterised and drawn by the library itself — no Python, no caller-side shaper
-        assert "4 text nodes drawn" in p.stdout and 'text node' in p.stdout and "R\u00e9gie".encode().decode("unicode_escape") in p.stdout
+        assert "4 text nodes drawn" in p.stdout and "R\u00e9gie" in p.stdout
     data = np.fromfile(out, np.uint8)
     assert data.size == 1280 * 720 * 3 // 2 and data[: 1280 * 720].std() > 10
 
