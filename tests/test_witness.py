@@ -1,0 +1,234 @@
+"""An INDEPENDENT witness for the pictures no reference-held vector pins (the PNG snapshots of the layout / resample /
+border / shadow scenes live in an un-vendored submodule): f64 NumPy written here from the reference's shader sources, sharing no function
+with oracle/smr_oracle.c — closed-form Lanczos3 weights (resample.wgsl:31-87), the IEC 61966-2-1 transfer functions as formulas (not the
+oracle's tables), rounded-rectangle distance, edge / border / shadow smoothsteps and the parent-mask product (apply_layouts.wgsl:246-377),
+premultiplied OVER on an 8-bit sRGB target (common_pipeline.rs:125).  The oracle is asserted to be within 1 LSB of the witness on every
+byte; the GPU tests then hold the kernels to the oracle.  What this does NOT pin: the last bit where the reference's own f32 arithmetic, its
+f16 intermediate and its sampler's sub-texel weights decide a rounding — the witness computes the exact-arithmetic picture."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from smelter_amd import synth
+
+
+# ---- transfer functions (IEC 61966-2-1), f64
+def srgb_to_linear(c):
+    c = np.asarray(c, np.float64)
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+def linear_to_srgb(x):
+    x = np.clip(np.asarray(x, np.float64), 0.0, 1.0)
+    return np.where(x <= 0.0031308, x * 12.92, 1.055 * x ** (1.0 / 2.4) - 0.055)
+
+
+def to_byte(x):
+    return np.floor(np.clip(x, 0.0, 1.0) * 255.0 + 0.5).astype(np.int64)
+
+
+# ---- Lanczos3, closed form (resample.wgsl:31-87: kernel stretched by max(scale, 1), window [ceil(center - 3k), +ceil(6k)], clamp to edge, / sum)
+def lanczos_matrix(src_len, dst_len, scale, offset=0.0):
+    k = max(scale, 1.0)
+    m = np.zeros((dst_len, src_len), np.float64)
+    for o in range(dst_len):
+        center = offset + (o + 0.5) * scale - 0.5
+        first = int(np.ceil(center - 3.0 * k))
+        taps = int(np.ceil(2.0 * 3.0 * k)) + 1
+        ws = np.zeros(taps)
+        for t in range(taps):
+            x = (first + t - center) / k
+            if abs(x) < 1e-5:
+                ws[t] = 1.0
+            elif abs(x) < 3.0:
+                ws[t] = 3.0 * np.sin(np.pi * x) * np.sin(np.pi * x / 3.0) / (np.pi * np.pi * x * x)
+        ws /= ws.sum()
+        for t in range(taps):
+            m[o, min(max(first + t, 0), src_len - 1)] += ws[t]
+    return m
+
+
+def witness_resample(node_rgba8, dw, dh):
+    """Opaque RGBA8 sRGB node -> dw x dh sRGB bytes: decode, Lanczos3 on both axes in linear light (exact arithmetic: the passes commute), encode."""
+    h, w = node_rgba8.shape[:2]
+    lin = srgb_to_linear(node_rgba8[..., :3] / 255.0)
+    mh, mv = lanczos_matrix(w, dw, w / dw), lanczos_matrix(h, dh, h / dh)
+    out = np.einsum("yj,jic->yic", mv, np.einsum("xi,jic->jxc", mh, lin))
+    return to_byte(linear_to_srgb(out))
+
+
+@pytest.mark.parametrize("sw,sh,dw,dh", [(504, 168, 168, 56), (630, 210, 420, 140), (320, 200, 400, 125)])
+def test_lanczos_of_the_multiscale_grid_is_within_one_lsb_of_the_closed_form(sw, sh, dw, dh):
+    """The reference's filter-quality input (TestInput::new_multiscale_grid, harness/input.rs:116-151: 2-pixel lines at periods 21 .. 3) at
+    the 3:1 downscale of rescaler.rs:813-859, at 1.5:1 (BASELINE configs[2]'s ratio) and at a mixed up / down scale: orc.resample — f32,
+    sin / cos by rotation, RGBA16F between the passes — against the exact-arithmetic picture."""
+    y, u, v = synth.multiscale_grid(sw, sh)
+    node = orc.planar_yuv_to_rgba(y, u, v, sw, sh)
+    kind, tile = orc.resample(node, (0.0, 0.0, float(sw), float(sh)), dw, dh)
+    assert kind > 0
+    want = witness_resample(node, dw, dh)
+    d = np.abs(tile[..., :3].astype(np.int64) - want)
+    assert d.max() <= 1, (d.max(), np.argwhere(d > 1)[:4].tolist())
+    assert (d == 0).mean() > 0.97
+    assert (tile[..., 3] == 255).all()
+    assert want.std() > 20  # the grid is really there: lines and flats, not a constant
+
+
+# ---- compositor (apply_layouts.wgsl:246-377), one colour / shadow layout at a time, f64
+def rounded_rect_sdf(dx, dy, w, h, radius):
+    """roundedRectSDF (:246-256): dist = (dx, dy) from the centre, radius = (tl, tr, br, bl); the radius is picked by the sign of dist:
+    x < 0 -> (tl, bl) else (tr, br); y < 0 -> the second of the pair."""
+    rx = np.where(dx < 0.0, radius[0], radius[1])
+    ry = np.where(dx < 0.0, radius[3], radius[2])
+    r = np.where(dy < 0.0, ry, rx)
+    qx, qy = np.abs(dx) - w / 2.0 + r, np.abs(dy) - h / 2.0 + r
+    return np.minimum(np.maximum(qx, qy), 0.0) + np.hypot(np.maximum(qx, 0.0), np.maximum(qy, 0.0)) - r
+
+
+def smoothstep(e0, e1, x):
+    t = np.clip((x - e0) / (e1 - e0), 0.0, 1.0)
+    return t * t * (3.0 - 2.0 * t)
+
+
+def shader_colour(rgba8):
+    """convert_to_shader_color (wgpu/utils.rs:51-61): a = A / 255, rgb = a * srgb_to_linear(C / 255)"""
+    a = rgba8[3] / 255.0
+    return np.array([a * srgb_to_linear(rgba8[k] / 255.0) for k in range(3)] + [a])
+
+
+def witness_fragments(W, H, kind, left, top, width, height, radius, colour, border_width=0.0, border_colour=None, blur=0.0, masks=()):
+    """Fragment-stage output (premultiplied linear RGBA, f64) of one colour (kind 1) or box-shadow (kind 2) layout on a W x H target; rows
+    are y-down pixel rows.  The quad (grown by blur on each side for a shadow, :216-229) covers a pixel iff its centre lies inside;
+    center_position is the centre-relative position in the rect's y-UP frame (:197-198)."""
+    ys, xs = np.mgrid[0:H, 0:W]
+    px, py = xs + 0.5, ys + 0.5
+    g = blur if kind == 2 else 0.0
+    inside = (px >= left - g) & (px < left + width + g) & (py >= top - g) & (py < top + height + g)
+    cx, cy = px - (left + width / 2.0), (top + height / 2.0) - py
+    edge = -rounded_rect_sdf(cx, cy, width, height, radius)
+    mask_alpha = np.ones((H, W))
+    for (mr, mtop, mleft, mw, mh) in masks:  # dist = mask centre - fragment position, in y-DOWN pixels (:272-277)
+        sdf = rounded_rect_sdf(mleft + mw / 2.0 - px, mtop + mh / 2.0 - py, mw, mh, mr)
+        mask_alpha = mask_alpha * smoothstep(-0.5, 0.5, -sdf)
+    colour = np.asarray(colour, np.float64)
+    if kind == 0:  # a texture layout (here: of a uniform texture, so the sampler does not enter): `colour` is the decoded sample
+        if border_width < 1.0:
+            frag = colour[None, None, :] * (smoothstep(-0.5, 0.5, edge) * mask_alpha)[..., None]
+        else:  # the inner edge sits half a pixel further out than a colour layout's (:306-317 vs :340-351); mask_alpha < 0.01 draws nothing (:303-304)
+            bc = np.asarray(border_colour, np.float64)
+            t = smoothstep(border_width - 0.5, border_width + 0.5, edge)[..., None]
+            inner = (bc[None, None, :] * (1.0 - t) + colour[None, None, :] * t) * mask_alpha[..., None]
+            outer = bc[None, None, :] * (smoothstep(-0.5, 0.5, edge) * mask_alpha)[..., None]
+            frag = np.where((edge > border_width / 2.0)[..., None], inner, outer)
+            frag = np.where((mask_alpha < 0.01)[..., None], 0.0, frag)
+    elif kind == 2:
+        frag = colour[None, None, :] * (smoothstep(-blur / 2.0, blur / 2.0, edge) * mask_alpha)[..., None]
+    elif border_width < 1.0:
+        frag = colour[None, None, :] * (smoothstep(-0.5, 0.5, edge) * mask_alpha)[..., None]
+    else:
+        bc = np.asarray(border_colour, np.float64)
+        t = smoothstep(border_width, border_width + 1.0, edge)[..., None]
+        inner = (bc[None, None, :] * (1.0 - t) + colour[None, None, :] * t) * mask_alpha[..., None]
+        outer = bc[None, None, :] * (smoothstep(-0.5, 0.5, edge) * mask_alpha)[..., None]
+        frag = np.where((edge > border_width / 2.0)[..., None], inner, outer)
+    return np.where(inside[..., None], frag, 0.0)
+
+
+def witness_over(target8, frag):
+    """premultiplied OVER on an Rgba8UnormSrgb target (common_pipeline.rs:125): the stored bytes are decoded, blended in linear light, encoded."""
+    dst = np.concatenate([srgb_to_linear(target8[..., :3] / 255.0), target8[..., 3:] / 255.0], -1)
+    out = frag + dst * (1.0 - frag[..., 3:4])
+    return np.concatenate([to_byte(linear_to_srgb(out[..., :3])), to_byte(out[..., 3:])], -1)
+
+
+def _check(W, H, specs):
+    """specs: dicts for witness_fragments (+ rgba8 colours); draws them in order with the witness and with orc.apply_layouts."""
+    target = np.zeros((H, W, 4), np.int64)
+    layouts, sources = [], []
+    for s in specs:
+        col = shader_colour(s["rgba"])
+        if s["kind"] == 0:  # a texture of one premultiplied sRGB colour: the hardware decodes rgb, alpha is linear
+            tex = np.tile(np.array(s["rgba"], np.uint8), (int(s["height"]) + 2, int(s["width"]) + 2, 1))
+            col = np.array([srgb_to_linear(s["rgba"][k] / 255.0) for k in range(3)] + [s["rgba"][3] / 255.0])
+            sources.append(tex)
+        bcol = shader_colour(s.get("border_rgba", (0, 0, 0, 0)))
+        frag = witness_fragments(W, H, s["kind"], s["left"], s["top"], s["width"], s["height"], s.get("radius", (0.0,) * 4), col,
+                                 s.get("border_width", 0.0), bcol, s.get("blur", 0.0), s.get("masks", ()))
+        target = witness_over(target, frag)
+        layouts.append(orc.Layout(top=s["top"], left=s["left"], width=s["width"], height=s["height"], type=s["kind"],
+                                  source_index=len(sources) - 1 if s["kind"] == 0 else 0xFFFFFFFF,
+                                  crop=(0.0, 0.0, float(int(s["width"]) + 2), float(int(s["height"]) + 2)) if s["kind"] == 0 else (0.0,) * 4,
+                                  border_radius=tuple(s.get("radius", (0.0,) * 4)), color=orc.color_to_shader(s["rgba"], True),
+                                  border_color=orc.color_to_shader(s.get("border_rgba", (0, 0, 0, 0)), True), border_width=s.get("border_width", 0.0),
+                                  blur_radius=s.get("blur", 0.0),
+                                  masks=[orc.Mask(radius=tuple(m[0]), top=m[1], left=m[2], width=m[3], height=m[4]) for m in s.get("masks", ())]))
+    got = orc.apply_layouts(W, H, layouts, sources, srgb=True).astype(np.int64)
+    d = np.abs(got - target)
+    assert d.max() <= 1, (int(d.max()), np.argwhere(d > 1)[:4].tolist(), got[tuple(np.argwhere(d > 1)[0][:2])].tolist() if (d > 1).any() else None)
+    assert (d == 0).mean() > 0.985
+    return got, target
+
+
+def test_straight_edges_at_quarter_half_and_three_quarter_pixel_offsets():
+    """A pixel is covered iff its centre is inside the quad (a centre ON the left / top edge is inside: the top-left rule), and inside it the
+    edge's smoothstep(-.5, .5, d) of the centre's distance d gives a known number: edge a quarter pixel right of a pixel boundary -> the first
+    column's centre is 1/4 inside: t = 3/4, t^2 (3 - 2 t) = 27/32; edge through the pixel centres -> d = 0: 1/2; edge three quarters in -> that
+    column's centre is outside (nothing drawn), the next one's is 3/4 inside: saturated."""
+    W, H = 48, 40
+    for off, first_col, cov in ((0.25, 10, 27.0 / 32.0), (0.5, 10, 0.5), (0.75, 11, 1.0)):
+        got, want = _check(W, H, [dict(kind=1, left=10.0 + off, top=6.0 + off, width=20.0, height=17.0, rgba=(255, 255, 255, 255))])
+        assert abs(float(smoothstep(-0.5, 0.5, np.float64(first_col + 0.5 - (10.0 + off)))) - cov) < 1e-12
+        row = 20
+        assert want[row, first_col, 3] == int(np.floor(cov * 255.0 + 0.5)) and want[row, first_col - 1, 3] == 0 and want[row, first_col + 1, 3] == 255
+        assert abs(int(got[row, first_col, 3]) - int(want[row, first_col, 3])) <= 1 and got[row, first_col - 1, 3] == 0
+        # ... and the same on the top edge (rows), and white stays white where the coverage is full
+        assert want[first_col - 4, 20, 3] == int(np.floor(cov * 255.0 + 0.5)) and want[first_col - 5, 20, 3] == 0
+        assert (want[20, 20] == 255).all() and (got[20, 20] == 255).all()
+
+
+def test_rounded_corners_borders_and_a_shadow_match_the_closed_forms():
+    W, H = 96, 80
+    _check(W, H, [
+        dict(kind=2, left=14.0, top=12.0, width=60.0, height=44.0, radius=(12.0 + 4.0,) * 4, blur=8.0, rgba=(0, 0, 0, 160)),   # box shadow: radius += blur / 2 (flatten.rs:354)
+        dict(kind=1, left=10.5, top=8.25, width=60.0, height=44.0, radius=(12.0, 4.0, 20.0, 0.0), rgba=(40, 120, 220, 255)),     # four different radii
+        dict(kind=1, left=30.0, top=30.0, width=50.5, height=40.25, radius=(9.0,) * 4, rgba=(250, 200, 40, 200), border_width=3.0,
+             border_rgba=(255, 255, 255, 255)),                                                                               # colour with a border, translucent
+        dict(kind=1, left=2.0, top=60.0, width=40.0, height=14.0, rgba=(255, 0, 0, 128), border_width=1.0, border_rgba=(0, 255, 0, 255)),  # the thinnest border
+    ])
+
+
+def test_a_textures_border_sits_half_a_pixel_further_out_and_vanishes_under_a_closed_mask():
+    """Texture layouts: inner border edge smoothstep(bw - .5, bw + .5, d) (a colour layout's is smoothstep(bw, bw + 1, d)), and with a border
+    the fragment is dropped where the parent masks leave less than 1 % (apply_layouts.wgsl:303-304) — a uniform premultiplied texture, so the
+    sampler's arithmetic does not enter."""
+    W, H = 72, 56
+    mask = [((10.0,) * 4, 6.0, 8.0, 40.0, 36.0)]
+    got, want = _check(W, H, [
+        dict(kind=0, left=4.25, top=3.5, width=52.0, height=40.0, radius=(11.0,) * 4, rgba=(128, 64, 32, 160), border_width=4.0, border_rgba=(255, 255, 255, 255), masks=mask),
+        dict(kind=0, left=30.0, top=28.0, width=36.0, height=24.0, radius=(6.0,) * 4, rgba=(10, 200, 90, 255), border_width=0.0),
+    ])
+    assert want[5, 60, 3] == 0 and want[20, 20, 3] > 0  # outside the mask nothing, inside the texture
+
+
+def test_shadow_falloff_at_known_distances():
+    """smoothstep(-blur / 2, blur / 2, d) on a straight edge: at d = 0 the shadow is at half strength, a quarter of the blur inside 27/32,
+    a quarter outside 5/32; beyond half the blur it is 0 / full — and the quad grown by the blur carries it on both sides of the edge."""
+    W, H, blur = 64, 48, 8.0
+    got, want = _check(W, H, [dict(kind=2, left=16.0, top=12.0, width=32.0, height=24.0, blur=blur, rgba=(0, 0, 0, 255))])
+    row = 24
+    for col, d in ((16 - 4, -4.5 + 1.0), (16 - 2, -1.5), (16 + 1, 1.5), (16 + 5, 5.5)):
+        cov = float(smoothstep(-blur / 2.0, blur / 2.0, np.float64((col + 0.5) - 16.0)))
+        assert want[row, col, 3] == int(np.floor(cov * 255.0 + 0.5))
+        del d
+    assert want[row, 16 - 5, 3] == 0 and want[row, 16 + 4, 3] == 255 and want[row, 7, 3] == 0  # outside blur / 2, inside, outside the grown quad
+    assert (np.abs(got - want) <= 1).all()
+
+
+def test_a_product_of_twenty_parent_masks():
+    """mask_alpha = prod smoothstep(-.5, .5, -sdf_i) over nested, shrinking, rounded parents (the most the reference draws with: 20)."""
+    W, H = 80, 64
+    masks = [((6.0 + 0.25 * i,) * 4, 2.0 + 0.6 * i, 3.0 + 0.45 * i, 74.0 - 0.9 * i, 60.0 - 1.2 * i) for i in range(20)]
+    got, want = _check(W, H, [dict(kind=1, left=0.0, top=0.0, width=80.0, height=64.0, rgba=(255, 180, 60, 255), masks=masks),
+                              dict(kind=1, left=20.25, top=10.5, width=30.0, height=30.0, radius=(15.0,) * 4, rgba=(20, 20, 240, 180), masks=masks[:7])])
+    assert 0 < want[..., 3].min() + 1 and want[32, 40, 3] == 255 and want[0, 0, 3] == 0
+    assert len(np.unique(want[..., 3])) > 20  # partial coverages along the innermost masks' edges
