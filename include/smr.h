@@ -169,12 +169,8 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *                            Within 1 LSB of the reference END TO END on every content class.
  *       SMR_INGEST_VALU_F32  exact f32 everywhere: bit-identical to the pass-per-launch kernels (smr_frame_to_rgba + smr_resample)
  *       SMR_INGEST_MFMA_F16, SMR_INGEST_MFMA_F16_NODE  aliases of AUTO (names of earlier revisions, kept for callers)
- *       SMR_INGEST_MFMA_F16_FUSED  opt-in: no node texture for planar 4:2:0 / NV12 frames — the matrix-core kernel converts on the fly with a
- *                            folded-FMA form of the BT.709 matrix that is within ONE CODE of planar_yuv_to_rgba.wgsl but not equal to it
- *                            (2e-5 of the node bytes differ on limited-range content).  Each stage is within 1 LSB; end to end a flipped bright
- *                            texel seen through the linear-light filter at a dark output can show as 2..4 codes on adversarial content (3 bytes
- *                            in 7.4 million on white noise), camera-like content stays within 1 LSB.  One pass over the inputs less
- *                            (HBM traffic), not faster on the whole since round 4.
+ *       (5, the conversion fused into the resampler with a folded-FMA BT.709 matrix — within one code per stage but not within 1 LSB end to end on
+ *        adversarial content — is not part of the ABI any more: laboratory builds only, -DSMR_LAB)
  *       (3, round 2's workgroup-pipelined kernel k_ingest_mfma, was retired in round 4: smr_ctx_set_option rejects it)
  *     The matrix-core resampler keeps every quantisation point of the reference (u8 node texture, f16 between the passes,
  *     layout/resampler.rs:25-28, u8 sRGB tile); its operands are f16 pairs (texels and the weights of both passes), accumulated in f32: within
@@ -186,20 +182,26 @@ SMR_API int smr_sync(smr_ctx *ctx);                 /* device.poll(wait) — ren
  *                               algorithmic bytes, at the price of vector-ALU time in a kernel that is instruction-bound: DESIGN.md); 0 (default): always through
  *                               the RGBA8 tile.  Same output bytes either way. */
 typedef enum smr_ingest_impl {
-    SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, /* 3: retired */ SMR_INGEST_MFMA_F16_NODE = 4, SMR_INGEST_MFMA_F16_FUSED = 5
+    SMR_INGEST_AUTO = 0, SMR_INGEST_VALU_F32 = 1, SMR_INGEST_MFMA_F16 = 2, /* 3: retired */ SMR_INGEST_MFMA_F16_NODE = 4 /* 5: laboratory builds only */
 } smr_ingest_impl;
 /*   SMR_OPT_CONVERT_IMPL        which kernels smr_frame_to_rgba (InputTexture::convert_to_node_texture) runs — all of them produce the same bytes:
  *       SMR_CONVERT_AUTO       the block converters: k_yuv420_to_rgba (4:2:0 planar / NV12: a thread per 4 x 4 block, shared chroma work) and
  *                              k_yuv_to_rgba_batch (4:2:2, 4:4:4, packed YUV, BGRA / ARGB), the pass kernels for what those leave (default)
  *       SMR_CONVERT_GENERAL    one kernel per WGSL pass, one launch per frame, coordinates and divisions as the shader writes them (tests: the
- *                              block converters are held to these bit for bit; SMR_CONVERT_GENERAL=1 in the environment selects it at creation)
+ *                              block converters are held to these bit for bit)
  *       SMR_CONVERT_BLOCK_4X2  k_yuv_to_rgba_batch for 4:2:0 frames too (round 3's converter; A/B) */
 typedef enum smr_convert_impl { SMR_CONVERT_AUTO = 0, SMR_CONVERT_GENERAL = 1, SMR_CONVERT_BLOCK_4X2 = 2 } smr_convert_impl;
 /*   SMR_OPT_COMPACT_NODES       1 (default): the node texture of a 4:2:0 frame that only the matrix-core resampler reads is written as RGB12 — 12 bytes
  *                               per four pixels (R x 4, G x 4, B x 4; alpha is 1 for every Y'CbCr frame and is not stored): a quarter less traffic on
  *                               either side of the intermediate the default route is bound by; 0: always RGBA8.  Same codes, same tiles bit for bit. */
+/*   SMR_OPT_FUSED_KERNELS       1 (default): smr_render_layouts / smr_ingest_resample* run the fused kernels (waves A and B); 0: one general kernel per pass
+ *                               of the reference (convert, resample passes, apply_layouts, rgba_to_yuv) — what the tests hold the fused kernels to.
+ *   SMR_OPT_COMPOSE_SELECT      1 (default): compositor tiles in which every pixel is a plain copy from the topmost layer that holds it (the seams of a
+ *                               grid of opaque 1:1 layers) are copied; 0: they take the compositing path.  Same output bytes either way.
+ * No option is read from the environment: a product build of the library calls getenv nowhere (laboratory builds, -DSMR_LAB, read their A/B knobs there). */
 typedef enum smr_option {
-    SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3, SMR_OPT_COMPACT_NODES = 4
+    SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3, SMR_OPT_COMPACT_NODES = 4,
+    SMR_OPT_FUSED_KERNELS = 5, SMR_OPT_COMPOSE_SELECT = 6
 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */
@@ -213,7 +215,7 @@ SMR_API int smr_profile_reset(smr_ctx *ctx);
 /* Which kernels a context has launched since it was created (always counted, no events): the tests assert the path a resample plan x
  * input format takes; a host can watch for scenes that leave the fast paths. */
 typedef enum smr_kernel_id {
-    SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave with the fused conversion (SMR_INGEST_MFMA_F16_FUSED: planar 4:2:0, NV12) */
+    SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave with the fused conversion (laboratory builds only: always 0 in a product build) */
     SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an RGBA8 / box-reduced RGBA16F node texture (every frame after smr_frame_to_rgba; surfaces) */
     SMR_KERNEL_INGEST_MFMA_WG = 2,   /* (retired: always 0) */
     SMR_KERNEL_INGEST_VALU = 3,      /* k_ingest_resample: fused conversion + Lanczos, every pass in f32 */

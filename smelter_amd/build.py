@@ -18,6 +18,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # WGSL source (and the oracle); hot loops that want FMA say so with __builtin_fmaf.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+if os.environ.get("SMR_LAB"):  # a laboratory build: A/B knobs from the environment, the fused-conversion builds of k_ingest_wave (tools/variant.sh -DSMR_LAB is the usual way)
+    FLAGS.append("-DSMR_LAB")
 if os.environ.get("SMR_ABLATION_BUILDS"):  # profiling only: extra instantiations of the ingest kernel with phases compiled out
     FLAGS.append("-DSMR_ABLATION_BUILDS")
 

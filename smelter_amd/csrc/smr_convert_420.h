@@ -60,12 +60,12 @@ struct ConvBatch {
 };
 
 #ifndef CV_ABL
-#define CV_ABL 0  // profiling builds (tools/variant_convert.sh): 1 no stores | 2 no chroma loads | 4 no luma loads | 8 no per-pixel arithmetic
+#define CV_ABL 0  // laboratory builds (tools/variant.sh NAME -DCV_ABL=n): 1 no stores | 2 no chroma loads | 4 no luma loads | 8 no per-pixel arithmetic
 #endif
 
 #ifdef __HIPCC__
 
-// CV_TIMING (tools/variant_convert.sh timing -DCV_TIMING): lane 0 of every wave stamps the shader clock at the phase boundaries of its run —
+// CV_TIMING (tools/variant.sh timing -DCV_TIMING): lane 0 of every wave stamps the shader clock at the phase boundaries of its run —
 // each stamp behind an explicit wait for what the phase requested — into g_cv_stamps[wave][...]; tools/r05/conv_timing.py reads them back.
 #if defined(CV_TIMING) && !defined(SMR_EMU)
 #define CV_STAMP(st, i, waits) do { asm volatile(waits ::: "memory"); if ((st) && (threadIdx.x & 63) == 0) (st)[i] = __builtin_readcyclecounter(); asm volatile("" ::: "memory"); } while (0)

@@ -155,6 +155,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         return SMR_ERR_INTERNAL;
     }
     memcpy(ctx->h_tables, tables, sizeof(tables));
+#ifdef SMR_LAB  // A/B knobs of laboratory builds (tools/variant.sh -DSMR_LAB): a product build reads nothing from the environment
     if (const char *e = getenv("SMR_INGEST_IMPL")) {  // tools / A-B runs: "valu" or "mfma"; smr_ctx_set_ingest_impl overrides
         if (!strcmp(e, "valu")) ctx->ingest_impl = SMR_INGEST_VALU_F32;
         else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
@@ -178,6 +179,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         const int v = atoi(e);
         if (v == 4 || v == 8) ctx->compose_slices = v;
     }
+#endif
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&ctx->d_lut16, sizeof(lut16)) != hipSuccess ||
@@ -229,6 +231,8 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     switch (option) {
     case SMR_OPT_INGEST_IMPL:
         if (value < 0 || value > SMR_INGEST_MFMA_F16_FUSED || value == 3) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
+        if (value == SMR_INGEST_MFMA_F16_FUSED && !SMR_LAB_BUILD)
+            return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: ingest implementation 5 (fused conversion) exists in laboratory builds only (-DSMR_LAB)");
         ctx->ingest_impl = (u32)value;
         return SMR_OK;
     case SMR_OPT_CONVERT_IMPL:
@@ -237,6 +241,12 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
         return SMR_OK;
     case SMR_OPT_COMPACT_NODES:
         ctx->compact_nodes = value != 0;
+        return SMR_OK;
+    case SMR_OPT_FUSED_KERNELS:
+        ctx->fused_disabled = value != 0 ? 0 : 1;
+        return SMR_OK;
+    case SMR_OPT_COMPOSE_SELECT:
+        ctx->compose_select = value != 0;
         return SMR_OK;
     case SMR_OPT_DIRECT_OUTPUT:
         ctx->direct_output = value != 0;

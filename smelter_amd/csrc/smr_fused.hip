@@ -31,13 +31,14 @@
 
 namespace {
 
-bool fused_disabled(smr_ctx *ctx) {
-    if (ctx->fused_disabled < 0) {
-        const char *e = getenv("SMR_DISABLE_FUSED");
-        ctx->fused_disabled = (e && e[0] && e[0] != '0') ? 1 : 0;
+bool fused_disabled(smr_ctx *ctx) {  // SMR_OPT_FUSED_KERNELS
+#ifdef SMR_LAB
+    if (!ctx->ablate_read) {
         const char *a = getenv("SMR_ABLATE");
         ctx->ablate = a ? atoi(a) : 0;
+        ctx->ablate_read = true;
     }
+#endif
     return ctx->fused_disabled == 1;
 }
 

@@ -1379,6 +1379,9 @@ int make_wave_job_rgba_transposed(smr_ctx *ctx, const SurfView &src, const smr_r
 //         its two always-zero weight fragments skipped | the north-star target's class (windows of <= 8 k-steps, pass-2 windows of 3:
 //         scales around 3);  each plain | direct output (2048) | NV12-capable (4096) | both
 typedef void (*WaveKernel)(const WArgs, const float *, const u32 *);
+// (the builds that read the PLANES and convert on the fly — the fused conversion, ingest implementation 5 — exist in laboratory builds only:
+//  a product build instantiates the node-texture builds below and nothing else)
+#ifdef SMR_LAB
 constexpr WaveKernel W_KERNELS[] = {k_ingest_wave<0, 0, 0>,    k_ingest_wave<4, 2, 0>,    k_ingest_wave<4, 2, 1>,    k_ingest_wave<8, 3, 0>,
                                     k_ingest_wave<0, 0, 2048>, k_ingest_wave<4, 2, 2048>, k_ingest_wave<4, 2, 2049>, k_ingest_wave<8, 3, 2048>,
                                     k_ingest_wave<0, 0, 4096>, k_ingest_wave<4, 2, 4096>, k_ingest_wave<4, 2, 4097>, k_ingest_wave<8, 3, 4096>,
@@ -1387,6 +1390,7 @@ constexpr int W_NKERNELS = (int)(sizeof(W_KERNELS) / sizeof(W_KERNELS[0]));
 // scales around 2 (windows of 5 .. 8 k-steps, pass-2 windows of 2: what the narrow class and the 4K class leave between them —
 // a 4x4 grid of 1080p inputs on a 4K output, tiles in mid-transition): plain | direct output | NV12-capable | both
 constexpr WaveKernel W_KERNELS_82[] = {k_ingest_wave<8, 2, 0>, k_ingest_wave<8, 2, 2048>, k_ingest_wave<8, 2, 4096>, k_ingest_wave<8, 2, 6144>};
+#endif
 // RGBA8 node textures as the source: the same four classes
 constexpr WaveKernel W_KERNELS_RGBA[] = {k_ingest_wave<0, 0, 8192>, k_ingest_wave<4, 2, 8192>, k_ingest_wave<4, 2, 8193>, k_ingest_wave<8, 3, 8192>};
 // ... RGB12 node textures (the default route of 4:2:0 frames), plain and with direct output
@@ -1406,14 +1410,21 @@ constexpr WaveKernel W_KERNELS_RGBA_ALPHA[] = {k_ingest_wave<0, 0, 8192 + 65536>
 constexpr WaveKernel W_KERNEL_RGBA_82 = k_ingest_wave<8, 2, 8192>, W_KERNEL_RGB12_82 = k_ingest_wave<8, 2, 8192 + 131072>;
 constexpr WaveKernel W_KERNEL_RGBA16F = k_ingest_wave<0, 0, 8192 + 16384>, W_KERNEL_RGBA16F_ALPHA = k_ingest_wave<0, 0, 8192 + 16384 + 65536>;
 // ... and single-axis plans (generic build): planar | NV12-capable | RGBA8 node texture
+#ifdef SMR_LAB
 constexpr WaveKernel W_KERNELS_SA[] = {k_ingest_wave<0, 0, 32768>, k_ingest_wave<0, 0, 32768 + 4096>, k_ingest_wave<0, 0, 32768 + 8192>,
                                        k_ingest_wave<0, 0, 32768 + 8192 + 65536>};
+#else
+constexpr WaveKernel W_KERNELS_SA[] = {nullptr, nullptr, k_ingest_wave<0, 0, 32768 + 8192>, k_ingest_wave<0, 0, 32768 + 8192 + 65536>};
+#endif
 
 int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false,
                 bool alpha = false, bool rgb12 = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
-        std::vector<WaveKernel> all(W_KERNELS, W_KERNELS + W_NKERNELS);
+        std::vector<WaveKernel> all;
+#ifdef SMR_LAB
+        all.insert(all.end(), W_KERNELS, W_KERNELS + W_NKERNELS);
         all.insert(all.end(), W_KERNELS_82, W_KERNELS_82 + 4);
+#endif
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
         all.insert(all.end(), W_KERNELS_RGBA_DIRECT, W_KERNELS_RGBA_DIRECT + 4);
         all.insert(all.end(), W_KERNELS_RGB12, W_KERNELS_RGB12 + 4);
@@ -1425,6 +1436,7 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         all.push_back(W_KERNEL_RGBA16F_ALPHA);
         all.insert(all.end(), W_KERNELS_SA, W_KERNELS_SA + 4);
         for (WaveKernel k : all) {
+            if (!k) continue;
             SMR_HIP(ctx, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             hipFuncAttributes fa;
             SMR_HIP(ctx, hipFuncGetAttributes(&fa, (const void *)k));
@@ -1462,6 +1474,10 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         }
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
         const int sa_i = rgba ? (alpha ? 3 : 2) : (any_nv ? 1 : 0);
+#ifndef SMR_LAB
+        if (!rgba) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: the plane-source (fused conversion) builds exist in laboratory builds only");
+        constexpr WaveKernel W_KERNELS_82[4] = {nullptr, nullptr, nullptr, nullptr}, W_KERNELS[16] = {};
+#endif
         const WaveKernel kern = node82 ? (rgb12 ? W_KERNEL_RGB12_82 : W_KERNEL_RGBA_82)
                                 : cls82 ? W_KERNELS_82[(direct ? 1 : 0) + (any_nv ? 2 : 0)]
                                 : sa ? W_KERNELS_SA[sa_i]

@@ -1,6 +1,7 @@
 // smr_internal.h — shared host/device definitions of libsmr_hip (gfx950 only).
 #pragma once
 
+
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
@@ -12,6 +13,17 @@
 #include <vector>
 
 #include "smr.h"
+
+// Laboratory builds (-DSMR_LAB: tools/variant.sh, SMR_LAB=1 python -m smelter_amd.build): the A/B knobs read from the environment at context
+// creation, the fused-conversion builds of k_ingest_wave (ingest implementation 5: within one code per stage, NOT within 1 LSB end to end on
+// adversarial content, hence not in include/smr.h) and the kernels' ablation / timing hooks.  A product build has none of them.
+constexpr int SMR_INGEST_MFMA_F16_FUSED = 5;
+#ifdef SMR_LAB
+constexpr bool SMR_LAB_BUILD = true;
+#else
+constexpr bool SMR_LAB_BUILD = false;
+#endif
+
 
 typedef uint8_t u8;
 typedef uint16_t u16;
@@ -153,8 +165,9 @@ struct smr_ctx {
     int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (profiling): cap on resident k_ingest_wave workgroups per CU, 0 = as many as fit
     bool debug_ingest = false;   // SMR_DEBUG_INGEST: print the launch geometry
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
-    int fused_disabled = -1;  // -1 = read SMR_DISABLE_FUSED on first use
-    int ablate = 0;           // SMR_ABLATE (profiling experiments only)
+    int fused_disabled = 0;   // SMR_OPT_FUSED_KERNELS = 0: the general pass-per-launch kernels instead of waves A / B (tests)
+    int ablate = 0;           // SMR_ABLATE (laboratory builds: profiling experiments only)
+    bool ablate_read = false;
     bool compose_select = true;  // SMR_COMPOSE_SELECT=0 (tests, profiling): no TC_SELECT tiles — seams between opaque 1:1 layers take the compositing path
     int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
     std::vector<u32> compose_bitmap;  // compose_predict's scratch

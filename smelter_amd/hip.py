@@ -200,7 +200,7 @@ class Comm:
         if self.handle:
             self.lib.smr_comm_destroy(self.handle)
             self.handle = None
-OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES = 0, 1, 2, 3, 4
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES, OPT_FUSED_KERNELS, OPT_COMPOSE_SELECT = 0, 1, 2, 3, 4, 5, 6
 
 
 class Context:
@@ -257,6 +257,23 @@ class Context:
     def set_compact_nodes(self, on: bool):
         """SMR_OPT_COMPACT_NODES: node textures only the matrix-core resampler reads as RGB12 instead of RGBA8 (default on)."""
         self.set_option(OPT_COMPACT_NODES, 1 if on else 0)
+
+    def set_fused_kernels(self, on: bool):
+        """SMR_OPT_FUSED_KERNELS: waves A / B (default) or one general kernel per pass of the reference (what the tests hold the fused kernels to)."""
+        self.set_option(OPT_FUSED_KERNELS, 1 if on else 0)
+
+    def set_compose_select(self, on: bool):
+        """SMR_OPT_COMPOSE_SELECT: seam tiles of a grid of opaque 1:1 layers as per-pixel copies (default) or through the compositing path."""
+        self.set_option(OPT_COMPOSE_SELECT, 1 if on else 0)
+
+    def lab_build(self) -> bool:
+        """True for a laboratory build of the library (-DSMR_LAB): the fused-conversion route (INGEST_MFMA_F16_FUSED) exists only there."""
+        try:
+            self.set_option(OPT_INGEST_IMPL, INGEST_MFMA_F16_FUSED)
+        except SmrError:
+            return False
+        self.set_option(OPT_INGEST_IMPL, INGEST_AUTO)
+        return True
 
     def set_direct_output(self, on: bool):
         """SMR_OPT_DIRECT_OUTPUT: let the resampling kernel write Y'CbCr for the compositor's copy tiles of a scene at rest (default off)."""

@@ -19,6 +19,16 @@ from tests import convert_model, refpipe, scenes  # (convert_model: the opt-in f
 pytestmark = pytest.mark.gpu
 
 
+def _impl_or_skip(c, hip, impl):
+    """The fused-conversion route (ingest implementation 5) exists in laboratory builds of the library only (-DSMR_LAB): a product build
+    refuses it, and the tests of that route skip."""
+    try:
+        c.set_ingest_impl(impl)
+    except hip.SmrError:
+        c.close()
+        pytest.skip("fused conversion: laboratory builds only (-DSMR_LAB)")
+
+
 @pytest.fixture(scope="module")
 def hip():
     from smelter_amd import hip as h
@@ -29,7 +39,7 @@ def hip():
 def ctx(hip, request):
     c = hip.Context(0)
     c.impl = request.param
-    c.set_ingest_impl({"valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_AUTO, "fused": hip.INGEST_MFMA_F16_FUSED}[request.param])
+    _impl_or_skip(c, hip, {"valu": hip.INGEST_VALU_F32, "mfma": hip.INGEST_AUTO, "fused": hip.INGEST_MFMA_F16_FUSED}[request.param])
     yield c
     c.close()
 
@@ -75,12 +85,8 @@ def _assert_matches_unfused(ctx, got, ref, what, identical=0.99, noise=False):
 
 @pytest.fixture(scope="module")
 def ctx_unfused(hip):
-    os.environ["SMR_DISABLE_FUSED"] = "1"
     c = hip.Context(0)
-    # force the env read now
-    t = c.surface(2, 2)
-    c.render_layouts([], [], 2, 2, out_rgba=t)
-    del os.environ["SMR_DISABLE_FUSED"]
+    c.set_fused_kernels(False)  # SMR_OPT_FUSED_KERNELS = 0: one general kernel per pass of the reference
     yield c
     c.close()
 
@@ -579,7 +585,7 @@ def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih
     c_on, c_off = hip.Context(0), hip.Context(0)
     try:
         for c in (c_on, c_off):  # (direct output is a build of the matrix-core kernel: one per source kind)
-            c.set_ingest_impl(hip.INGEST_MFMA_F16_FUSED if route == "fused_conversion" else hip.INGEST_AUTO)
+            _impl_or_skip(c, hip, hip.INGEST_MFMA_F16_FUSED if route == "fused_conversion" else hip.INGEST_AUTO)
             c.set_compact_nodes(route == "rgb12_node")
         c_on.set_direct_output(True)
         c_off.set_direct_output(False)
@@ -628,13 +634,12 @@ def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih
 @pytest.mark.parametrize("geom", [(640, 360, 1920, 1080, 16), (482, 274, 1000, 562, 5), (320, 180, 3840, 2160, 9)], ids=["4x4", "ragged", "3x3_4k"])
 def test_seam_tiles_copy_from_the_topmost_layer(hip, monkeypatch, geom, fmt_name):
     """A grid of video tiles that abut: the seams run through the compositor's 128 x 16 tiles, where every pixel still is a plain copy
-    from one layer (TC_SELECT).  Bit for bit what the compositing path makes of those tiles (SMR_COMPOSE_SELECT=0), on every output route."""
+    from one layer (TC_SELECT).  Bit for bit what the compositing path makes of those tiles (SMR_OPT_COMPOSE_SELECT = 0), on every output route."""
     iw, ih, W, H, n = geom
     layouts, res = scenes.cfg2_scene(iw, ih, W, H, n)
     fmt = {"planar": hip.FRAME_PLANAR_YUV420, "nv12": hip.FRAME_NV12, "rgba": hip.FRAME_RGBA}[fmt_name]
-    monkeypatch.setenv("SMR_COMPOSE_SELECT", "0")
     c_off = hip.Context(0)
-    monkeypatch.delenv("SMR_COMPOSE_SELECT")
+    c_off.set_compose_select(False)  # SMR_OPT_COMPOSE_SELECT = 0: the seam tiles through the compositing path
     c_on = hip.Context(0)
     try:
         planes, _ = _inputs(c_on, hip, n, iw, ih)
@@ -713,7 +718,9 @@ def test_full_size_white_noise_within_one_lsb(hip):
             de = np.abs(t.download().astype(np.int16) - want_o.astype(np.int16))
             assert de.max() <= 1, f"impl {impl}: max {de.max()}, {(de > 1).sum()} bytes off by more than 1 END TO END"
             assert (de == 0).mean() >= ident, f"impl {impl}: {(de == 0).mean():.5f} identical"
-        # the opt-in fused conversion: per stage, and an explicit end-to-end bound against the oracle
+        if not c.lab_build():
+            return  # (what follows holds the fused-conversion route — ingest implementation 5, laboratory builds only — to its own statement)
+        # the fused conversion: per stage, and an explicit end-to-end bound against the oracle
         node_k = convert_model.node_codes(y, u, v)
         dn = np.abs(node_k.astype(np.int16) - node_o.astype(np.int16))
         assert dn.max() <= 1 and (dn == 0).mean() >= 0.9999, f"node texture: max {dn.max()}, {(dn == 0).mean():.6f} identical"
@@ -777,14 +784,16 @@ def test_tile_class_cache_survives_alternating_and_evicted_layout_lists(hip):
 def test_a_scene_at_rest_reuses_its_parameter_pack_with_new_pixels(hip, monkeypatch):
     """smr_pack_commit queues no copy when the packed layout list equals the previous frame's byte for byte (a scene that does not
     move): the device copy of that frame is read again.  The pixels are new every frame — same device frames, new uploads — and a
-    different list in between must not be served from the stale copy.  Every frame equals the frame of a context that never reuses."""
+    different list in between must not be served from the stale copy.  Every frame equals the frame of a context that never gets to reuse (another list is rendered in front of every frame)."""
     iw, ih, W, H = 480, 270, 960, 540
     lay_a, res_a = scenes.cfg3_scene(iw, ih, W, H, 4)
     lay_b = [Layout_shift(l, 16, 8) for l in lay_a]
     frames_px = [[scenes.test_input(i, iw, ih, noise_seed=100 * t + i) for i in range(4)] for t in range(4)]
     sequence = [(lay_a, 0), (lay_a, 1), (lay_a, 2), (lay_b, 2), (lay_b, 3), (lay_a, 3), (lay_a, 0)]
 
-    def run(c):
+    lay_other = [Layout_shift(l, 3, 5) for l in lay_a]  # a third list: rendered in between, the next frame's pack never equals its predecessor's
+
+    def run(c, never_reuse=False):
         _, label_host = _label_surfaces(c, 1)
         lt = c.surface_from(label_host)
         dev = [c.frame(hip.FRAME_PLANAR_YUV420, iw, ih) for _ in range(4)]
@@ -799,6 +808,8 @@ def test_a_scene_at_rest_reuses_its_parameter_pack_with_new_pixels(hip, monkeypa
                     k += 1
                 else:
                     srcs.append(lt)
+            if never_reuse:
+                _render(c, hip, lay_other, srcs, W, H)
             outs.append(_render(c, hip, lay, srcs, W, H))
         return outs
 
@@ -807,10 +818,9 @@ def test_a_scene_at_rest_reuses_its_parameter_pack_with_new_pixels(hip, monkeypa
         got = run(c)
     finally:
         c.close()
-    monkeypatch.setenv("SMR_NO_PACK_REUSE", "1")
     f = hip.Context(0)
     try:
-        want = run(f)
+        want = run(f, never_reuse=True)
     finally:
         f.close()
     for step, (g, w_) in enumerate(zip(got, want)):
@@ -849,7 +859,7 @@ def test_vertical_first_plans_run_on_the_transposed_frame(hip, geom, fmt_name, i
     _, want = orc.resample(orc.planar_yuv_to_rgba(y, u, v, iw, ih), crop, dw, dh, omp=True)
     c = hip.Context(0)
     try:
-        c.set_ingest_impl(hip.INGEST_AUTO if impl == "auto" else hip.INGEST_MFMA_F16_FUSED)
+        _impl_or_skip(c, hip, hip.INGEST_AUTO if impl == "auto" else hip.INGEST_MFMA_F16_FUSED)
         f = c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, [y, u, v]) if fmt_name == "planar" else c.frame(hip.FRAME_NV12, iw, ih, [y, np.stack([u, v], axis=-1)])
         t = c.surface(dw, dh)
         c.profile_reset()

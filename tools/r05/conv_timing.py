@@ -1,4 +1,4 @@
-"""Where a wave of k_yuv420_to_rgba spends its life: reads the cycle stamps of the timing build (tools/variant_convert.sh timing -DCV_TIMING;
+"""Where a wave of k_yuv420_to_rgba spends its life: reads the cycle stamps of the timing build (tools/variant.sh timing -DCV_TIMING;
 run with SMR_LIB=smelter_amd/variants/libsmr_hip.timing.so) for one launch over 8 x 1920x1080 frames (or --4k) and prints, per phase,
 the distribution over waves, when waves start and end relative to the launch's first wave, and how many waves are alive over time.
     SMR_LIB=... [SMR_CONVERT_WG_PER_CU=k] python tools/r05/conv_timing.py [--4k]"""

@@ -1,15 +1,23 @@
 #!/bin/bash
-# A/B builds of the fused kernels:  tools/variant.sh NAME [-DFLAG ...]   (here, no GPU needed)
-# compiles smr_fused.hip with the extra flags and links smelter_amd/variants/libsmr_hip.NAME.so from it and the other objects of
-# the normal build; on the GPU box  tools/ab.sh NAME...  benches each one (SMR_LIB picks the library).
+# Laboratory builds of the library (here, no GPU needed):  tools/variant.sh NAME [-DFLAG ...]
+# Compiles every HIP source with -DSMR_LAB (the A/B knobs read from the environment at context creation, the fused-conversion builds of
+# k_ingest_wave, ablation / timing hooks) plus the extra flags — e.g. -DCV_TIMING, -DCV_ABL=7, -DSMR_WAVE_TIMING=1 — and links
+# smelter_amd/variants/libsmr_hip.NAME.so with the host objects of the normal build.  On the GPU box SMR_LIB=<that file> picks it
+# (tools/ab.sh NAME... benches several).  A product build (python -m smelter_amd.build) has none of this.
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 python -m smelter_amd.build >/dev/null
-mkdir -p smelter_amd/variants
-obj=smelter_amd/variants/smr_fused.$name.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function \
-  -I include -I smelter_amd/csrc "$@" -x hip -c smelter_amd/csrc/smr_fused.hip -o $obj
-others=$(ls smelter_amd/build/*.o | grep -v 'smr_fused.hip.o')
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o smelter_amd/variants/libsmr_hip.$name.so $obj $others
+dir=smelter_amd/variants/$name.d
+mkdir -p $dir
+pids=()
+for src in smelter_amd/csrc/*.hip; do
+  obj=$dir/$(basename $src).o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wno-unused-function \
+    -I include -I smelter_amd/csrc -DSMR_LAB "$@" -x hip -c $src -o $obj &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+host=$(ls smelter_amd/build/*.cpp.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o smelter_amd/variants/libsmr_hip.$name.so $dir/*.o $host -ldl
 echo smelter_amd/variants/libsmr_hip.$name.so
