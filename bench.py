@@ -94,9 +94,34 @@ def make_inputs(ctx, hip, frame_sets, input_ids):
     return ring
 
 
+_BOOK = [None, False]
+
+
+def font_book():
+    """The library's own text pipeline (smr_fontbook_*: C++ TrueType reader, layout, rasteriser) over the machine's TrueType fonts; None where
+    there are none (the labels then come from synth.label_glyphs' procedural 5x7 font — same node size, same per-frame work)."""
+    if not _BOOK[1]:
+        _BOOK[1] = True
+        try:
+            from smelter_amd import text as T
+            _BOOK[0] = T.NativeFontBook.system()
+        except Exception:
+            _BOOK[0] = None
+    return _BOOK[0]
+
+
+def label_run():
+    """(atlas, glyphs) of a tile's label: the Text node of scene_json() — "CAM 3 LIVE", 24 px, fixed 176 x 32 — as the font book rasterises it."""
+    book = font_book()
+    if book is None:
+        from smelter_amd import synth
+        return synth.label_glyphs("CAM 3 LIVE", 3)
+    glyphs, atlas = book.rasterise("CAM 3 LIVE", LABEL_W, LABEL_H, 24.0)
+    return atlas, glyphs
+
+
 def make_label(ctx):
-    from smelter_amd import synth
-    atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
+    atlas, glyphs = label_run()
     t = ctx.surface(LABEL_W, LABEL_H)
     ctx.blit_glyphs(t, (0.0, 0.0, 0.0, 0.0), glyphs, atlas)  # transparent background (text_renderer.rs default)
     return t
@@ -110,7 +135,7 @@ def cpu_baseline(layouts, res):
     from smelter_amd import synth
     orc.build()
     planes = [synth.test_input(i, IN_W, IN_H, noise_seed=1234 + i) for i in range(N_IN)]
-    atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
+    atlas, glyphs = label_run()
     label = orc.blit_glyphs(LABEL_W, LABEL_H, orc.color_to_shader((0, 0, 0, 0), True), glyphs, atlas)
     cores = orc.num_threads(omp=True)
 
@@ -377,7 +402,7 @@ def main():
             c.set_ingest_impl(ingest_impl)
             c.set_convert_impl(convert_impl)
             c.set_direct_output(args.direct_output)
-        atlas, glyphs = synth.label_glyphs("CAM 3 LIVE", 3)
+        atlas, glyphs = label_run()
 
         def make_renderer(c, extra=()):
             r = Renderer(c, stream_fallback_timeout_s=3600.0, lanes=extra)  # the synthetic ring carries no timestamps
@@ -385,8 +410,10 @@ def main():
                 r.register_input(f"input_{i}")
             if ANIMATED:
                 r.register_shader("soften")
+            if font_book() is not None:
+                r.set_fontbook(font_book())  # the renderer lays out, rasterises and draws its Text nodes itself (once per update_scene)
             for node in r.update_scene("out", OUT_W, OUT_H, scene_json()):
-                if node.kind == _ffi.NODE_TEXT:
+                if node.kind == _ffi.NODE_TEXT and font_book() is None:
                     r.set_text("out", node.index, glyphs, atlas)
             return r
         r_pipe, r_one = make_renderer(lanes[0], lanes[1:]), make_renderer(lanes[0])

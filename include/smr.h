@@ -229,6 +229,10 @@ SMR_API int smr_debug_kernel_launches(const smr_ctx *ctx, uint32_t kernel, uint6
 
 /* ---- surfaces (NodeTexture / wgpu::Texture; state/node_texture.rs:11-163) -------- */
 SMR_API int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, smr_surface **out);
+/* Device memory the caller owns (a decoder's output, a torch tensor) as a surface, in place.  The allocation must cover pitch * h bytes —
+ * every row backed out to the full pitch, the LAST ONE TOO: the block kernels read whole dwords, up to a dword past a row's last texel
+ * (never past the pitch).  pitch >= w * bytes per texel; rows and the base 4-byte aligned for the block converters, 16-byte aligned for the
+ * matrix-core resampler's node textures (other alignments take the general kernels). */
 SMR_API int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
                              smr_surface **out);
 SMR_API void smr_surface_destroy(smr_ctx *ctx, smr_surface *s);
@@ -534,6 +538,8 @@ SMR_API int smr_renderer_add_lane(smr_renderer *r, smr_ctx *ctx);
 SMR_API int smr_renderer_sync(smr_renderer *r);
 
 SMR_API uint32_t smr_abi_version(void);
+/* bit 0: a laboratory build (-DSMR_LAB: environment knobs, the fused-conversion route, profiling hooks); 0 for a product build */
+SMR_API uint32_t smr_build_flags(void);
 SMR_API uint32_t smr_sizeof_layout(void);
 
 #ifdef __cplusplus

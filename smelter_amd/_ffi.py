@@ -47,7 +47,7 @@ EXPORTS = [
     "smr_comm_last_error", "smr_gather_tiles",
     "smr_fontbook_create", "smr_fontbook_destroy", "smr_fontbook_last_error", "smr_fontbook_add_file", "smr_fontbook_add_memory",
     "smr_fontbook_add_dir", "smr_fontbook_count", "smr_fontbook_measure", "smr_fontbook_rasterise", "smr_renderer_set_fontbook",
-    "smr_abi_version", "smr_sizeof_layout",
+    "smr_abi_version", "smr_build_flags", "smr_sizeof_layout",
 ]
 NO_RESOLUTION = 0xFFFFFFFF
 NODE_INPUT_STREAM, NODE_LAYOUT, NODE_TEXT, NODE_IMAGE, NODE_SHADER = 0, 1, 2, 3, 4
@@ -241,6 +241,7 @@ def load():
         "smr_fontbook_rasterise": ([P, C.POINTER(TextParams), U, U, C.POINTER(F), C.POINTER(TextRun)], I),
         "smr_renderer_set_fontbook": ([P, P], I),
         "smr_abi_version": ([], U),
+        "smr_build_flags": ([], U),
         "smr_sizeof_layout": ([], U),
     }
     for name, (args, res) in sig.items():

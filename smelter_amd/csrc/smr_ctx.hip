@@ -122,6 +122,7 @@ static void drain_profile(smr_ctx *ctx) {
 extern "C" {
 
 uint32_t smr_abi_version(void) { return 1; }
+uint32_t smr_build_flags(void) { return SMR_LAB_BUILD ? 1u : 0u; }
 uint32_t smr_ctx_mode(const smr_ctx *ctx) { return ctx ? ctx->mode : 0u; }
 uint32_t smr_sizeof_layout(void) { return (uint32_t)sizeof(smr_layout); }
 

@@ -522,12 +522,25 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         rc = launch_wave(ctx, wjobs, direct_dev);
         if (rc != SMR_OK) return rc;
     }
+    // node-texture jobs go out class by class: launch_wave picks ONE build for a launch, and a scene that mixes classes (a main tile at 1.5x
+    // beside thumbnails at 3x) would otherwise run all of them on the generic build (the RGB12 generic build is slower than RGBA8's)
+    auto by_class = [&](std::vector<WJob> &jobs, bool rgb12) -> int {
+        std::vector<WJob> group[5];
+        for (const WJob &J : jobs) {
+            const int k = (J.NKS <= 4 && J.KV == 2) ? (J.k01 ? 1 : 0) : (J.NKS <= 8 && J.KV == 3) ? 2 : (J.NKS <= 8 && J.KV == 2) ? 3 : 4;
+            group[k].push_back(J);
+        }
+        for (auto &g : group)
+            if (!g.empty())
+                if (int r = launch_wave(ctx, g, direct_dev, true, false, false, false, rgb12)) return r;
+        return SMR_OK;
+    };
     if (!wjobs_rgb12.empty()) {
-        rc = launch_wave(ctx, wjobs_rgb12, direct_dev, true, false, false, false, true);
+        rc = by_class(wjobs_rgb12, true);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_rgba.empty()) {
-        rc = launch_wave(ctx, wjobs_rgba, direct_dev, true);
+        rc = by_class(wjobs_rgba, false);
         if (rc != SMR_OK) return rc;
     }
     if (!wjobs_rgba_alpha.empty()) {

@@ -20,6 +20,11 @@ from ._ffi import (SHADER_CIRCLE_LAYOUT, SHADER_COLOR_BY_TEXTURE_COUNT, SHADER_F
 STAGE_NAMES = {0: "ingest", 1: "resample", 2: "layouts", 3: "output", 4: "fused_ingest_resample", 5: "fused_compose_output"}
 
 
+def lab_build() -> bool:
+    """smr_build_flags() & 1: a laboratory build of the library (tools/variant.sh, SMR_LIB=...)."""
+    return bool(_ffi.load().smr_build_flags() & 1)
+
+
 class SmrError(RuntimeError):
     """Mirrors RenderSceneError::WgpuError(WgpuError::{Validation, OutOfMemory, Internal}(String))."""
 
@@ -268,12 +273,7 @@ class Context:
 
     def lab_build(self) -> bool:
         """True for a laboratory build of the library (-DSMR_LAB): the fused-conversion route (INGEST_MFMA_F16_FUSED) exists only there."""
-        try:
-            self.set_option(OPT_INGEST_IMPL, INGEST_MFMA_F16_FUSED)
-        except SmrError:
-            return False
-        self.set_option(OPT_INGEST_IMPL, INGEST_AUTO)
-        return True
+        return lab_build()
 
     def set_direct_output(self, on: bool):
         """SMR_OPT_DIRECT_OUTPUT: let the resampling kernel write Y'CbCr for the compositor's copy tiles of a scene at rest (default off)."""

@@ -35,7 +35,13 @@ def hip():
     return h
 
 
-@pytest.fixture(scope="module", params=["valu", "mfma", "fused"])
+def _routes():
+    """The routes of wave A a build of the library has: the fused conversion exists in laboratory builds only (smr_build_flags)."""
+    from smelter_amd import hip as h
+    return ["valu", "mfma"] + (["fused"] if h.lab_build() else [])
+
+
+@pytest.fixture(scope="module", params=_routes())
 def ctx(hip, request):
     c = hip.Context(0)
     c.impl = request.param
@@ -572,7 +578,7 @@ DIRECT_CASES = [
 ]
 
 
-@pytest.mark.parametrize("route", ["rgb12_node", "rgba8_node", "fused_conversion"])
+@pytest.mark.parametrize("route", ["rgb12_node", "rgba8_node"] + (["fused_conversion"] if "fused" in _routes() else []))
 @pytest.mark.parametrize("fmt_name", ["planar", "nv12"])
 @pytest.mark.parametrize("name,mk,iw,ih,W,H", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
 def test_direct_output_of_a_scene_at_rest_is_bit_identical(hip, name, mk, iw, ih, W, H, fmt_name, route):
@@ -840,7 +846,7 @@ def Layout_shift(l, dx, dy):
     return m
 
 
-@pytest.mark.parametrize("impl", ["auto", "fused"])
+@pytest.mark.parametrize("impl", ["auto"] + (["fused"] if "fused" in _routes() else []))
 @pytest.mark.parametrize("fmt_name", ["planar", "nv12"])
 @pytest.mark.parametrize("geom", [(1920, 1080, 1279, 719), (640, 360, 427, 239), (322, 182, 255, 143)], ids=["1080p", "360p", "ragged"])
 def test_vertical_first_plans_run_on_the_transposed_frame(hip, geom, fmt_name, impl):
