@@ -322,16 +322,16 @@ __global__ __launch_bounds__(BLOCK) void k_rgba_to_chroma(SurfView src, SurfView
 
 // 4:2:0 frames (planar or NV12, limited or full range) the 4 x 4 block converter takes (smr_convert_420.h): one launch for up to 16 frames.
 //
-// The launch is PERSISTENT and its work is cut into EQUAL SHARES: as many workgroups as the device holds at once (the host sizes the grid
-// and, through the dynamic LDS request, how many a CU admits — so every SIMD gets the same number of waves), and wave w computes the w-th
-// share of the launch's unit sequence (ConvBatch: block rows fastest, then column blocks, then jobs): a vertical run of blocks in one
-// column block, or the end of one and the start of the next.  Why (wave stamps, profiles/r05_convert_waves.txt): the kernel is bound by
-// vector-instruction issue — a SIMD's waves finish one after the other, oldest first, at ~3.9 cycles per vector instruction and 2.0 GHz —
-// so its time is the busiest SIMD's instruction count.  A grid of one block row per wave (4 608 workgroups) paid the table build + barrier
-// 4 608 times (a quarter of a wave's life) and ran 2.4 rounds of waves with a tail; a grid of fixed runs put 5, 6 or 7 workgroups on a CU as
-// the dispatcher saw fit (CUs finished between 14 and 20 us).  Equal shares on an even placement end together, and a share's blocks are
-// vertical neighbours: cv420_run keeps the chroma rows they share.  (A ticket counter instead of fixed shares was measured first: one word
-// serves ~90 atomics per microsecond — 150 us for this launch's 8 640 tickets.)
+// The launch is PERSISTENT and its work is cut into EQUAL SHARES: as many workgroups as the device holds at once (the host sizes the grid),
+// and wave w computes the w-th share of the launch's unit sequence (ConvBatch: block rows fastest, then column blocks, then jobs): a
+// vertical run of blocks in one column block, or the end of one and the start of the next — cv420_run keeps the chroma rows neighbouring
+// blocks share and requests block P + 1 before it computes block P; the tables are built once per resident workgroup instead of once per
+// 16 rows.  What it bought, measured (profiles/r05_convert_waves.txt): 8 % fewer vector instructions per launch (9.65 M against 10.47 M), the
+// same 22 - 23 us in the kernel trace as round 4's grid of one block per thread (22.8 us) — the wave stamps show why: the kernel is bound by
+// the issue of its vector instructions (a SIMD's waves finish one after the other, oldest first; no traffic at all: as slow), mostly the
+// byte extracts, packs, conversions and table-address arithmetic around the float arithmetic — and ~2 % more frames per second with two
+// frames in flight.  (A ticket counter instead of fixed shares was measured first: one word serves ~90 atomics per microsecond — 150 us
+// for this launch's 8 640 tickets.)
 #ifdef CV_TIMING
 __device__ unsigned long long g_cv_stamps[32768][10];  // per wave of the last launch: entry (shader clock), tables built, first task: loads in, window converted, first block done; queue dry, stores done; [7] / [8] = realtime at entry / exit, [9] = XCC_ID << 32 | HW_ID
 extern "C" __attribute__((visibility("default"))) int smr_debug_convert_stamps(unsigned long long *out, unsigned n_waves) {
@@ -532,12 +532,14 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
                 Q.B.first_unit[j + 1] = Q.B.first_unit[j] + cols * rows;
             }
             const u32 total = Q.B.first_unit[Q.nb];
-            // as many workgroups as stay resident together: convert_wg_per_cu per CU — the dynamic LDS request caps what a CU admits at that
-            // number, so the grid spreads evenly and every SIMD holds the same number of waves — and never more waves than units
+            // as many workgroups as stay resident together (6 per CU at 77 registers: convert_wg_per_cu), never more waves than units.  A dynamic LDS
+            // request that caps a CU at exactly that number (an even spread: every SIMD the same number of waves) was measured and is no
+            // faster in the kernel trace (6 per CU: 23.1 us capped, 22.0 us uncapped, 4 per CU: 23.3 / 23.7 — profiles/r05_convert_waves.txt)
+            // while it keeps other launches' workgroups off the CU; the knob remains for laboratory builds (SMR_CONVERT_LDS_PAD)
             const u32 per_cu = (u32)(ctx->convert_wg_per_cu < 1 ? 1 : ctx->convert_wg_per_cu > 6 ? 6 : ctx->convert_wg_per_cu);
             u32 blocks = (u32)ctx->cu_count * per_cu;
             if (blocks > (total + 3u) / 4u) blocks = (total + 3u) / 4u;
-            const u32 lds_pad = ctx->convert_lds_pad ? ctx->convert_lds_pad : (160u * 1024u / per_cu - 2048u) & ~255u;
+            const u32 lds_pad = ctx->convert_lds_pad;
             if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
             else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
         }

@@ -651,12 +651,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
         const int px0 = (tile - ty * tiles_x) * B_TILE_W + bx, py0 = ty * B_TILE_H + by;
         if (px0 < W && py0 < H) {
             u32 a[8];
-            // (four pixels at a time: their texel fetches overlap; the second row reuses the code)
-            // (both rows unrolled: 14 KB more code, same time — profiles/r03_compose_ab.txt, variant s8)
-#pragma unroll 1
-            for (int r = 0; r < 2; r++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) a[r * 4 + q] = composite_sampled_opaque(L, px0 + q, py0 + r, srgb_and_ablate & 1, s_tab, s_tab + 256);
+            composite_sampled_opaque_block(L, px0, py0, srgb_and_ablate & 1, s_tab, s_tab + 256, a);  // (column / row halves of the sample positions once each)
             store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
         }
     }

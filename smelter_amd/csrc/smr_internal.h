@@ -155,8 +155,8 @@ struct smr_ctx {
     u32 ingest_impl = 0;         // smr_ingest_impl
     bool wave_node82 = true;     // SMR_WAVE_NODE82=0 (A/B): node textures at scales around 2 on the generic build of k_ingest_wave instead of the <8, 2> class
     bool rgb12_cls82 = false;    // SMR_RGB12_CLS82=1 (A/B): RGB12 node textures for that class too
-    int convert_wg_per_cu = 4;   // SMR_CONVERT_WG_PER_CU (A/B): resident workgroups per CU of the persistent converter launch
-    u32 convert_lds_pad = 0;     // SMR_CONVERT_LDS_PAD (A/B): extra dynamic LDS per workgroup of the block converter, i.e. a cap on its resident workgroups per CU
+    int convert_wg_per_cu = 6;   // SMR_CONVERT_WG_PER_CU (laboratory builds): resident workgroups per CU of the persistent converter launch
+    u32 convert_lds_pad = 0;     // SMR_CONVERT_LDS_PAD (laboratory builds): extra dynamic LDS per workgroup of the block converter, i.e. a cap on its resident workgroups per CU
     u32 convert_impl = 0;        // smr_convert_impl (SMR_OPT_CONVERT_IMPL; SMR_CONVERT_GENERAL in the environment sets 1 at creation)
     bool mfma_attr_set = false;  // hipFuncSetAttribute is per device: kept per ctx, not per process
     bool wave_attr_set = false;

@@ -323,4 +323,76 @@ __device__ __forceinline__ u32 composite_sampled_opaque(const DevLayout &L, int 
     return out;
 }
 
+// The same for a 4 x 2 block of pixels (columns px0 .. px0 + 3, rows py0, py0 + 1) of such a tile.  The layer is unrotated, so everything a
+// sample position's x half is made of — varying, texture coordinate, texel pair, 8-bit sub-texel weight — depends on the pixel's column
+// alone and the y half on its row alone: four column records and two row records serve the eight pixels (per pixel the coordinate
+// arithmetic was done twice over: ~40 of its ~100 vector instructions).  The expressions are composite_sampled_opaque's, value for value.
+struct SampledAxis {
+    u32 o0, o1;  // byte offsets of the two texels (x: 4 * column; y: row * pitch)
+    float f, g;  // weight of the second texel (8-bit sub-texel fraction) and 1 - f
+};
+__device__ __forceinline__ SampledAxis sampled_axis_x(const DevLayout &L, int px) {
+    const float fx = (float)px + 0.5f;
+    const float lx = fx - L.cx;  // (DL_UNROTATED: 1 * dx + 0 * dy == dx exactly)
+    const float u01 = div_cr(lx, L.qw, L.rqw) + 0.5f;
+    const float tu = div_cr(L.crop[1] + u01 * L.crop[2], (float)L.tex_w, L.rtw);
+    const float sx = tu * (float)L.src.w - 0.5f;
+    const float fx0 = floorf(sx);
+    SampledAxis a;
+    a.f = subtexel(sx - fx0);
+    a.g = 1.0f - a.f;
+    a.o0 = 4u * (u32)clampi((int)fx0, 0, L.src.w - 1);
+    a.o1 = 4u * (u32)clampi((int)fx0 + 1, 0, L.src.w - 1);
+    return a;
+}
+__device__ __forceinline__ SampledAxis sampled_axis_y(const DevLayout &L, int py) {
+    const float fy = (float)py + 0.5f;
+    const float ly = -(fy - L.cy);
+    const float v01 = 0.5f - div_cr(ly, L.qh, L.rqh);
+    const float tv = div_cr(L.crop[0] + v01 * L.crop[3], (float)L.tex_h, L.rth);
+    const float sy = tv * (float)L.src.h - 0.5f;
+    const float fy0 = floorf(sy);
+    SampledAxis a;
+    a.f = subtexel(sy - fy0);
+    a.g = 1.0f - a.f;
+    // (row offsets as 24-bit multiplies: rows and pitches are below 2^24, a surface below 4 GiB)
+    a.o0 = (u32)__umul24((u32)clampi((int)fy0, 0, L.src.h - 1), L.src.pitch);
+    a.o1 = (u32)__umul24((u32)clampi((int)fy0 + 1, 0, L.src.h - 1), L.src.pitch);
+    return a;
+}
+__device__ __forceinline__ void composite_sampled_opaque_block(const DevLayout &L, int px0, int py0, int srgb, const float *__restrict__ dec,
+                                                               const float *__restrict__ thr, u32 (&out)[8]) {
+    SampledAxis X[4], Y[2];
+#pragma unroll
+    for (int q = 0; q < 4; q++) X[q] = sampled_axis_x(L, px0 + q);
+#pragma unroll
+    for (int r = 0; r < 2; r++) Y[r] = sampled_axis_y(L, py0 + r);
+    const u8 *base = L.src.ptr;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {  // (four pixels at a time: their texel fetches overlap)
+        u32 ta[4], tb[4], tc[4], td[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ta[q] = *(const u32 *)(base + (Y[r].o0 + X[q].o0)); tb[q] = *(const u32 *)(base + (Y[r].o0 + X[q].o1));
+            tc[q] = *(const u32 *)(base + (Y[r].o1 + X[q].o0)); td[q] = *(const u32 *)(base + (Y[r].o1 + X[q].o1));
+        }
+        const float fy = Y[r].f, gy = Y[r].g;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float fx = X[q].f, gx = X[q].g;
+            u32 o = 0xff000000u;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                const u32 ba = (ta[q] >> (8 * ch)) & 0xffu, bb = (tb[q] >> (8 * ch)) & 0xffu, bc = (tc[q] >> (8 * ch)) & 0xffu, bd = (td[q] >> (8 * ch)) & 0xffu;
+                float a, b, c, d;
+                if (srgb) { a = dec[ba]; b = dec[bb]; c = dec[bc]; d = dec[bd]; }
+                else { a = (float)ba / 255.0f; b = (float)bb / 255.0f; c = (float)bc / 255.0f; d = (float)bd / 255.0f; }
+                const float v = (a * gx + b * fx) * gy + (c * gx + d * fx) * fy;
+                o |= (srgb ? srgb_encode8(v, thr) : unorm8(v)) << (8 * ch);
+            }
+            out[r * 4 + q] = o;
+        }
+    }
+}
+
 #endif  // __HIPCC__
