@@ -198,10 +198,14 @@ typedef enum smr_convert_impl { SMR_CONVERT_AUTO = 0, SMR_CONVERT_GENERAL = 1, S
  *                               of the reference (convert, resample passes, apply_layouts, rgba_to_yuv) — what the tests hold the fused kernels to.
  *   SMR_OPT_COMPOSE_SELECT      1 (default): compositor tiles in which every pixel is a plain copy from the topmost layer that holds it (the seams of a
  *                               grid of opaque 1:1 layers) are copied; 0: they take the compositing path.  Same output bytes either way.
+ *   SMR_OPT_SHARED_DEVICE       1: other contexts run kernels on this device at the same time (a renderer's lanes: frames in flight).  The matrix-core
+ *                               resampler then occupies two waves per SIMD instead of all it could hold (it is as fast from two: its time is a
+ *                               dependency chain), which leaves a SIMD's remaining registers to the other lane's converter / compositor waves:
+ *                               +2 % frames per second with two lanes, -3 % with one.  0 (default).  smr_renderer_add_lane sets it on every lane.
  * No option is read from the environment: a product build of the library calls getenv nowhere (laboratory builds, -DSMR_LAB, read their A/B knobs there). */
 typedef enum smr_option {
     SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3, SMR_OPT_COMPACT_NODES = 4,
-    SMR_OPT_FUSED_KERNELS = 5, SMR_OPT_COMPOSE_SELECT = 6
+    SMR_OPT_FUSED_KERNELS = 5, SMR_OPT_COMPOSE_SELECT = 6, SMR_OPT_SHARED_DEVICE = 7
 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */

@@ -589,6 +589,8 @@ SMR_API int smr_renderer_add_lane(smr_renderer *r, smr_ctx *ctx) {
         if (c == ctx) return fail(r, -1, "smr_renderer_add_lane: this context is a lane already");
     if (smr_ctx_mode(ctx) != smr_ctx_mode(r->ctx)) return fail(r, -1, "smr_renderer_add_lane: the lane's context has another rendering mode");
     r->lane_ctx.push_back(ctx);
+    // frames in flight: every lane's kernels run beside another lane's from now on
+    for (smr_ctx *c : r->lane_ctx) (void)smr_ctx_set_option(c, SMR_OPT_SHARED_DEVICE, 1);
     return 0;
 }
 

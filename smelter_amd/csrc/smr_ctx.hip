@@ -249,6 +249,9 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     case SMR_OPT_COMPOSE_SELECT:
         ctx->compose_select = value != 0;
         return SMR_OK;
+    case SMR_OPT_SHARED_DEVICE:
+        ctx->shared_device = value != 0;
+        return SMR_OK;
     case SMR_OPT_DIRECT_OUTPUT:
         ctx->direct_output = value != 0;
         return SMR_OK;

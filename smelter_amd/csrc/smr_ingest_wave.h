@@ -1506,7 +1506,8 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             ctx->mfma_occupancy.push_back({1000 + ki, lds, per_cu});
         }
         const int reserve = ctx->ingest_reserve_cus >= 0 && ctx->ingest_reserve_cus < ctx->cu_count ? ctx->ingest_reserve_cus : 0;
-        const int wg_cap = ctx->ingest_wg_per_cu > 0 ? ctx->ingest_wg_per_cu : 64;
+        // (SMR_OPT_SHARED_DEVICE: four workgroups = two waves per SIMD, the rest of the register file for the other lanes' kernels)
+        const int wg_cap = ctx->ingest_wg_per_cu > 0 ? ctx->ingest_wg_per_cu : ctx->shared_device ? 4 : 64;
         const long long slots = (long long)(per_cu > wg_cap ? wg_cap : per_cu) * (ctx->cu_count - reserve) * W_WAVES;  // resident waves
         // pieces per column pair: the same number of tile rows per wave for every job, rounded so that the launch fits the resident set
         double rows_per_wave = (double)tile_rows / (double)slots;

@@ -162,7 +162,8 @@ struct smr_ctx {
     bool wave_attr_set = false;
     bool valu_attr_set = false;
     int ingest_reserve_cus = -1; // SMR_INGEST_RESERVE_CUS (profiling), read once per ctx
-    int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (profiling): cap on resident k_ingest_wave workgroups per CU, 0 = as many as fit
+    int ingest_wg_per_cu = 0;    // SMR_INGEST_WG_PER_CU (laboratory builds): cap on resident k_ingest_wave workgroups per CU, 0 = as many as fit
+    bool shared_device = false;  // SMR_OPT_SHARED_DEVICE: other contexts' kernels run beside this one's (k_ingest_wave then takes two waves per SIMD)
     bool debug_ingest = false;   // SMR_DEBUG_INGEST: print the launch geometry
     int cu_count = 256;       // compute units of the device (MI355X: 256), sizes the fused ingest grid
     int fused_disabled = 0;   // SMR_OPT_FUSED_KERNELS = 0: the general pass-per-launch kernels instead of waves A / B (tests)

@@ -205,7 +205,7 @@ class Comm:
         if self.handle:
             self.lib.smr_comm_destroy(self.handle)
             self.handle = None
-OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES, OPT_FUSED_KERNELS, OPT_COMPOSE_SELECT = 0, 1, 2, 3, 4, 5, 6
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES, OPT_FUSED_KERNELS, OPT_COMPOSE_SELECT, OPT_SHARED_DEVICE = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class Context:

@@ -23,6 +23,7 @@ for GROUP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_AN
 done
 cd $R
 python tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
+python tools/traffic_json.py $OUT > $OUT/traffic.json 2>/dev/null   # (with the library's device-code hash: bench.py quotes it only for that library)
 # (the per-dispatch traces are large and gpurun_out/ is capped at 64 MiB: keep the summaries)
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
 cat $OUT/summary.txt

@@ -17,7 +17,7 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 # counters first: the bench line quotes them only if they carry this library's hash
 bash tools/prof.sh r05 --inflight 1 --no-target > $O/prof.log 2>&1
 cp gpurun_out/prof_r05/summary.txt $O/rocprofv3_summary.txt; cp gpurun_out/prof_r05/stats/*/*kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || find gpurun_out/prof_r05/stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-python tools/traffic_json.py gpurun_out/prof_r05 > $O/traffic.json
+cp gpurun_out/prof_r05/traffic.json $O/traffic.json
 python tools/issue_json.py $O/rocprofv3_summary.txt > $O/issue.json
 cp $O/traffic.json profiles/r05_traffic.json; cp $O/issue.json profiles/r05_issue.json   # (for the bench runs below, on this box)
 for G in FETCH_SIZE WRITE_SIZE; do
