@@ -355,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
     s_nlut[threadIdx.x & 255] = unorm_of_byte(threadIdx.x & 255u);
     __syncthreads();
     CV_STAMP(st, 1, "s_nop 0");
-    cv420_share<NV>(B, cv_uniform(blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6)), gridDim.x * (BLOCK / 64u), lane, s_ylut, s_nlut, st);
+    cv420_share<NV>(B, blockIdx.x, cv_uniform(threadIdx.x >> 6), gridDim.x, lane, s_ylut, s_nlut, st);
 #ifdef CV_TIMING
     st = g_cv_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 32767u];
 #endif
@@ -523,22 +523,18 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;  // (per launch)
         if (k == 0) hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 7) / 8), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
         else {
-            // the unit sequence (k_yuv420_to_rgba's header): block rows fastest, then column blocks, then jobs
-            Q.B.n = (int)Q.nb;
-            Q.B.first_unit[0] = 0;
-            for (u32 j = 0; j < Q.nb; j++) {
-                const u32 cols = ((u32)Q.B.j[j].dst.w + 255u) / 256u, rows = ((u32)Q.B.j[j].dst.h + 3u) / 4u;
-                Q.B.rows[j] = rows;
-                Q.B.first_unit[j + 1] = Q.B.first_unit[j] + cols * rows;
-            }
-            const u32 total = Q.B.first_unit[Q.nb];
             // as many workgroups as stay resident together (6 per CU at 77 registers: convert_wg_per_cu), never more waves than units.  A dynamic LDS
             // request that caps a CU at exactly that number (an even spread: every SIMD the same number of waves) was measured and is no
             // faster in the kernel trace (6 per CU: 23.1 us capped, 22.0 us uncapped, 4 per CU: 23.3 / 23.7 — profiles/r05_convert_waves.txt)
             // while it keeps other launches' workgroups off the CU; the knob remains for laboratory builds (SMR_CONVERT_LDS_PAD)
             const u32 per_cu = (u32)(ctx->convert_wg_per_cu < 1 ? 1 : ctx->convert_wg_per_cu > 6 ? 6 : ctx->convert_wg_per_cu);
+            u32 total = 0;
+            for (u32 j = 0; j < Q.nb; j++) total += (((u32)Q.B.j[j].dst.w + 255u) / 256u) * (((u32)Q.B.j[j].dst.h + 3u) / 4u);
             u32 blocks = (u32)ctx->cu_count * per_cu;
             if (blocks > (total + 3u) / 4u) blocks = (total + 3u) / 4u;
+            // the partition (smr_convert_420.h): bands of block rows dealt to the XCDs, equal shares per wave inside an XCD
+            const u32 bands = cv420_plan(Q.B, (int)Q.nb, blocks * 4u);
+            if (blocks < (bands < 8u ? bands : 8u)) blocks = bands < 8u ? bands : 8u;  // (every XCD that owns a band runs a workgroup)
             const u32 lds_pad = ctx->convert_lds_pad;
             if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
             else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);

@@ -51,13 +51,55 @@ struct ConvJob {
 constexpr int MAX_CONV_JOBS = 16;
 struct ConvBatch {
     ConvJob j[MAX_CONV_JOBS];
-    // k_yuv420_to_rgba: the launch's work as ONE sequence of units — a unit = 64 column groups (256 pixels) x one block row (4 rows) of one
-    // job, what a wave computes per cv420_run step; job j owns units [first_unit[j], first_unit[j + 1]), block rows fastest inside a column
-    // block (rows[j] of them per column block) — cut into equal contiguous shares, one per wave of the launch
+    // k_yuv420_to_rgba: the launch's work in UNITS — a unit = 64 column groups (256 pixels) x one block row (4 rows) of one job, what a wave
+    // computes per cv420_run step — dealt to the XCDs in BANDS (cv420_plan): a band = `band` consecutive block rows of a job across all its
+    // column blocks, band g of the launch (jobs one after the other) belongs to XCD g % 8.  Inside an XCD the units are ordered band by band,
+    // column block by column block, block rows fastest, and cut into equal contiguous shares, one per wave the XCD runs (workgroup b runs on
+    // XCD b % 8 — observed, used for locality only: the partition is arithmetic on blockIdx and complete whatever the placement).
+    // Why bands: a column block's chroma window reaches a byte or two into its neighbours' cache lines; neighbours on different XCDs made
+    // every L2 fetch three lines for one (counters: 62 MB for 24.9 MB of planes with shares dealt without regard to the XCDs).
     int n;
-    u32 first_unit[MAX_CONV_JOBS + 1];
-    u32 rows[MAX_CONV_JOBS];
+    u32 band;                                  // block rows per band
+    u32 rows[MAX_CONV_JOBS];                   // block rows of job j
+    u32 cols[MAX_CONV_JOBS];                   // column blocks of job j
+    u32 band0[MAX_CONV_JOBS];                  // launch-wide index of job j's first band
+    u32 first_unit[8][MAX_CONV_JOBS + 1];      // per XCD x: job j owns units [first_unit[x][j], first_unit[x][j + 1]) of x's sequence
 };
+
+// Fills the partition tables of a launch of n jobs (j[].dst.w / .h set) that will run `waves` waves in all; returns the number of bands
+// (the launch needs at least min(8, bands) workgroups: every XCD that owns units must run a wave).
+inline u32 cv420_plan(ConvBatch &B, int n, u32 waves) {
+    B.n = n;
+    u32 total = 0;
+    for (int j = 0; j < n; j++) {
+        B.cols[j] = ((u32)B.j[j].dst.w + 255u) / 256u;
+        B.rows[j] = ((u32)B.j[j].dst.h + 3u) / 4u;
+        total += B.cols[j] * B.rows[j];
+    }
+    // Band height: every share of a band runs on the band's XCD whatever its length, so a band may be much taller than a share — and the
+    // taller, the fewer chroma rows two XCDs both fetch (a band's window reaches one chroma row into the bands above and below: 2 rows per
+    // band of 2 * band).  Against that, the XCDs' totals differ by up to one band: sixteen bands per XCD and more keeps that under a
+    // sixteenth (8 x 1080p: bands of 16 block rows, 17 per XCD, 6 % of the chroma rows fetched twice).
+    (void)waves;
+    u32 cols_max = 1;
+    for (int j = 0; j < n; j++) cols_max = B.cols[j] > cols_max ? B.cols[j] : cols_max;
+    const u32 band = total / (128u * cols_max);
+    B.band = band < 1u ? 1u : (band > 64u ? 64u : band);
+    u32 g = 0;
+    for (int x = 0; x < 8; x++) B.first_unit[x][0] = 0;
+    for (int j = 0; j < n; j++) {
+        B.band0[j] = g;
+        const u32 bands = (B.rows[j] + B.band - 1u) / B.band;
+        u32 units[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (u32 b = 0; b < bands; b++) {
+            const u32 h = B.rows[j] - b * B.band < B.band ? B.rows[j] - b * B.band : B.band;
+            units[(g + b) & 7u] += B.cols[j] * h;
+        }
+        for (int x = 0; x < 8; x++) B.first_unit[x][j + 1] = B.first_unit[x][j] + units[x];
+        g += bands;
+    }
+    return g;
+}
 
 #ifndef CV_ABL
 #define CV_ABL 0  // laboratory builds (tools/variant.sh NAME -DCV_ABL=n): 1 no stores | 2 no chroma loads | 4 no luma loads | 8 no per-pixel arithmetic
@@ -249,7 +291,8 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
 //     gathers and horizontal lerps are kept — half of the chroma work of every block after the run's first;
 //   * block P + 1's luma dwords and its two new chroma rows are requested BEFORE block P's rows are computed and stored, so they arrive
 //     while the wave's vector ALU is busy (a one-block thread loads, waits, computes, stores: its waves all wait at the same time);
-//     the last block's "next" loads go to clamped rows and are dropped (unconditional: the compiler can count what is outstanding).
+//     the run's last block requests nothing (the loop is peeled: inside it the requests are unconditional, so the compiler can count
+//     what is outstanding).
 template <bool NV, bool RGB12, bool FULL>
 __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int nb, const float *ylut, const float *nlut, unsigned long long *st = nullptr) {
     const int Pend = min(P0 + nb, (J.dst.h + 3) >> 2);
@@ -267,13 +310,16 @@ __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int n
         for (int j = 0; j < 4; j++) cv420_hrow<NV>(raw[j], W, nlut, H[j]);
         CV_STAMP(st, 3, "s_waitcnt lgkmcnt(0)");  // its chroma window is converted
     }
-    for (int P = P0;;) {
+    // every block but the run's last requests its successor before it is computed; the last one requests nothing (its successor belongs to
+    // another wave, which fetched it at ITS start — microseconds ago: by now the lines have left the L2 and the request would go to memory
+    // again: + 9 MB of fetch per 8 x 1080p launch when the loop requested unconditionally)
+    int P = P0;
+    for (; P + 1 < Pend; P++) {
         u32 ynext[4];
         cv420_load_luma(J, g, P + 1, ynext);
         const Cv420Raw<NV> n2 = cv420_load_chroma<NV>(J, W, 2 * P + 3), n3 = cv420_load_chroma<NV>(J, W, 2 * P + 4);
         cv420_rows<RGB12, FULL>(J, g, P, yrow, H, ylut);
         if (P == P0) CV_STAMP(st, 4, "s_nop 0");  // the first block's rows are computed, its stores issued
-        if (++P >= Pend) break;
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
@@ -283,6 +329,8 @@ __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int n
 #pragma unroll
         for (int r = 0; r < 4; r++) yrow[r] = ynext[r];
     }
+    cv420_rows<RGB12, FULL>(J, g, P, yrow, H, ylut);
+    if (P == P0) CV_STAMP(st, 4, "s_nop 0");
 }
 
 // A job's geometry as VALUES in scalar registers.  Read in place (B.j[j].dst.pitch ...) the compiler treats the kernel-argument segment as
@@ -309,32 +357,43 @@ __device__ __forceinline__ ConvJob cv420_job_in_registers(const ConvJob &j) {
     return J;
 }
 
-// Wave w of `waves` computes the w-th of `waves` equal contiguous shares of the launch's unit sequence (ConvBatch): total / waves units,
-// the first total % waves waves one more — one vertical run of blocks, or the end of a column block and the start of the next (in the
-// next job, too).  ylut: the limited-range luma table; nlut: byte / 255, which is also the full-range luma table.
+// Wave `wave` (0 .. 3) of workgroup `block` of a launch of `grid` workgroups: XCD x = block % 8 runs the workgroups x, x + 8, ...; its
+// waves cut x's unit sequence (ConvBatch) into equal contiguous shares — total / waves units, the first total % waves waves one more.  A
+// share is a vertical run of blocks inside one (band, column block) cell, or the end of a cell and the start of the next (in the next
+// band or job, too).  ylut: the limited-range luma table; nlut: byte / 255, which is also the full-range luma table.
 template <bool NV>
-__device__ __forceinline__ void cv420_share(const ConvBatch &B, u32 w, u32 waves, u32 lane, const float *ylut, const float *nlut, unsigned long long *st = nullptr) {
-    const u32 total = B.first_unit[B.n];
+__device__ __forceinline__ void cv420_share(const ConvBatch &B, u32 block, u32 wave, u32 grid, u32 lane, const float *ylut, const float *nlut,
+                                            unsigned long long *st = nullptr) {
+    const u32 x = block & 7u;
+    const u32 waves = ((grid - x + 7u) >> 3) * 4u, w = (block >> 3) * 4u + wave;  // of this XCD
+    const u32 total = B.first_unit[x][B.n];
     const u32 share = total / waves, extra = total - share * waves;
     u32 lo = w * share + (w < extra ? w : extra);
     const u32 hi = lo + share + (w < extra ? 1u : 0u);
     int j = 0;
     while (lo < hi) {  // (uniform: one or two runs per share, more only across tiny jobs)
 #pragma unroll 1
-        while (lo >= B.first_unit[j + 1]) j++;
+        while (lo >= B.first_unit[x][j + 1]) j++;
         const ConvJob J = cv420_job_in_registers(B.j[j]);
-        const u32 local = lo - B.first_unit[j], rows = B.rows[j];
-        const u32 col = local / rows, P0 = local - col * rows;
-        const u32 nrun = hi - lo < rows - P0 ? hi - lo : rows - P0;
+        const u32 rows = B.rows[j], cols = B.cols[j], band = B.band;
+        // x's bands of job j: b0, b0 + 8, ...; all but the job's last band (which, if x owns it, is the last of them) hold cols * band units
+        const u32 b0 = (x - B.band0[j]) & 7u;
+        const u32 local = lo - B.first_unit[x][j];
+        const u32 t = local / (cols * band), b = b0 + 8u * t;
+        const u32 in_band = local - t * cols * band;
+        const u32 band_rows = rows - b * band < band ? rows - b * band : band;
+        const u32 col = in_band / band_rows, r = in_band - col * band_rows;
+        const u32 nrun = hi - lo < band_rows - r ? hi - lo : band_rows - r;
         const int g = (int)(col * 64u + lane);
         if (4 * g < J.dst.w) {
+            const int P0 = (int)(b * band + r);
             // (uniform branches: a job is one frame; range and node format are template parameters — as run-time flags they cost a scalar branch per pixel)
             if (J.rgb12) {
-                if (J.full) cv420_run<NV, true, true>(J, g, (int)P0, (int)nrun, nlut, nlut, st);
-                else cv420_run<NV, true, false>(J, g, (int)P0, (int)nrun, ylut, nlut, st);
+                if (J.full) cv420_run<NV, true, true>(J, g, P0, (int)nrun, nlut, nlut, st);
+                else cv420_run<NV, true, false>(J, g, P0, (int)nrun, ylut, nlut, st);
             } else {
-                if (J.full) cv420_run<NV, false, true>(J, g, (int)P0, (int)nrun, nlut, nlut, st);
-                else cv420_run<NV, false, false>(J, g, (int)P0, (int)nrun, ylut, nlut, st);
+                if (J.full) cv420_run<NV, false, true>(J, g, P0, (int)nrun, nlut, nlut, st);
+                else cv420_run<NV, false, false>(J, g, P0, (int)nrun, ylut, nlut, st);
             }
         }
         st = nullptr;  // (timing builds: only the share's first run is stamped phase by phase)

@@ -84,7 +84,7 @@ extern "C" int emu_convert_420(const u8 *y, const u8 *u, const u8 *v, int w, int
 }
 
 // What a launch of k_yuv420_to_rgba computes: `n` frames of one kind (all planar or all NV12; widths / heights / ranges / node formats per
-// frame) as ONE unit sequence cut into `waves` equal shares (cv420_share), every lane of every wave emulated in turn.
+// frame) partitioned the way the host does (cv420_plan: bands dealt to the XCDs, equal shares per wave) over `waves` WORKGROUPS, every lane of every wave emulated in turn.
 // ys / us / vs / outs: n pointers; ws / hs / fulls / rgb12s: n ints.  Output layout per frame as emu_convert_420_run.
 extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *const *us, const u8 *const *vs, const int *ws, const int *hs, int nv12,
                                       const int *fulls, const int *rgb12s, int waves, u8 *const *outs) {
@@ -106,20 +106,22 @@ extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *cons
         J.yp = py[i].view; J.up = pu[i].view; J.vp = nv12 ? pu[i].view : pv[i].view;
         J.dst.ptr = dst[i].data(); J.dst.pitch = dpitch[i]; J.dst.w = w; J.dst.h = h;
         J.full = fulls[i]; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0; J.rgb12 = rgb12s[i];
-        const u32 cols = ((u32)w + 255u) / 256u, rows = ((u32)h + 3u) / 4u;  // (the host's arithmetic: smr_frames_to_rgba_batch)
-        B.rows[i] = rows;
-        B.first_unit[i + 1] = B.first_unit[i] + cols * rows;
     }
+    // `waves` = workgroups here (four waves each), as the host launches them: the partition is the host's own (cv420_plan)
+    u32 grid = (u32)waves;
+    const u32 bands = cv420_plan(B, n, grid * 4u);
+    if (grid < (bands < 8u ? bands : 8u)) grid = bands < 8u ? bands : 8u;  // (as smr_frames_to_rgba_batch does: every XCD that owns a band runs a workgroup)
     float ylut[256], nlut[256];
     for (u32 b = 0; b < 256; b++) {
         ylut[b] = cv420_luma_of_byte(b, false);
         nlut[b] = unorm_of_byte(b);
     }
-    for (u32 w = 0; w < (u32)waves; w++)
-        for (u32 lane = 0; lane < 64; lane++) {
-            if (nv12) cv420_share<true>(B, w, (u32)waves, lane, ylut, nlut);
-            else cv420_share<false>(B, w, (u32)waves, lane, ylut, nlut);
-        }
+    for (u32 blk = 0; blk < grid; blk++)
+        for (u32 wv = 0; wv < 4; wv++)
+            for (u32 lane = 0; lane < 64; lane++) {
+                if (nv12) cv420_share<true>(B, blk, wv, grid, lane, ylut, nlut);
+                else cv420_share<false>(B, blk, wv, grid, lane, ylut, nlut);
+            }
     for (int i = 0; i < n; i++) {
         const int w = ws[i], h = hs[i];
         if (rgb12s[i]) {

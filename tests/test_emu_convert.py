@@ -123,11 +123,12 @@ def test_runs_of_blocks_equal_the_oracle_bit_for_bit(emu, w, h, variant, nb):
 
 
 @pytest.mark.parametrize("nv", [0, 1])
-@pytest.mark.parametrize("waves", [1, 3, 7, 64, 1000])
+@pytest.mark.parametrize("waves", [1, 3, 8, 9, 13, 64, 1000])
 def test_a_launch_cut_into_equal_shares_writes_the_oracles_bytes(emu, nv, waves):
-    """k_yuv420_to_rgba's partition (cv420_share): frames of different sizes, ranges and node formats in ONE unit sequence, cut into
-    `waves` equal contiguous shares — shares that start and end anywhere inside a column of blocks, straddle column blocks and frames,
-    more waves than units — every byte of every frame the oracle's."""
+    """k_yuv420_to_rgba's partition (cv420_plan + cv420_share): frames of different sizes, ranges and node formats in one launch of `waves`
+    workgroups — bands of block rows dealt to the eight XCDs, every XCD's units cut into equal contiguous shares per wave: shares that start
+    and end anywhere inside a column of blocks, straddle column blocks, bands and frames, more waves than units, XCDs with one workgroup and
+    with many — every byte of every frame the oracle's (and none written twice differently: a unit missed or doubled would show)."""
     rng = np.random.default_rng(17 * waves + nv)
     sizes = [(264, 38), (8, 2), (516, 26), (64, 130), (20, 6)]
     fulls = [0, 0, 0, 0, 0] if nv else [0, 1, 0, 1, 1]
