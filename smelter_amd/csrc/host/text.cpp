@@ -756,6 +756,7 @@ GlyphBitmap rasterise_glyph(Font &font, uint32_t gid, double scale, double fx, d
             min_y = std::min(min_y, q.y); max_y = std::max(max_y, q.y);
         }
     }
+    if (!(min_x > -1e6 && max_x < 1e6 && min_y > -1e6 && max_y < 1e6)) return out;  // (a size no node can hold: MAX_NODE_RESOLUTION is 7682 x 4320; also NaN)
     const int left = (int)std::floor(min_x), top = (int)std::floor(min_y);
     const int w = (int)std::ceil(max_x) - left + 1, h = (int)std::ceil(max_y) - top + 1;
     if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 26)) return out;
