@@ -133,3 +133,35 @@ def test_bad_fonts_and_bad_text_are_errors_not_crashes(tmp_path):
             assert native.lib.smr_fontbook_measure(native.handle, C.byref(p), C.byref(w), C.byref(n)) == 1
     finally:
         native.close()
+
+
+def test_corrupted_fonts_never_crash_the_reader():
+    """Fonts are untrusted input (Renderer::register_font takes bytes from the API): every table read is bounds-checked.  A real face with
+    random bytes overwritten — header, table directory, cmap, loca, glyf, GPOS alike — is refused or renders something, never crashes."""
+    if not FONT_DIRS:
+        pytest.skip("no TrueType fonts on this machine")
+    src = sorted(os.path.join(FONT_DIRS[-1], f) for f in os.listdir(FONT_DIRS[-1]) if f.endswith(".ttf"))[0]
+    data = bytearray(open(src, "rb").read())
+    rng = np.random.default_rng(2024)
+    loaded = 0
+    for trial in range(150):
+        d = bytearray(data)
+        if trial % 3 == 0:  # the table directory and the headers
+            lo, hi = 0, 1024
+        elif trial % 3 == 1:
+            lo, hi = 0, len(d)
+        else:  # one dense burst somewhere
+            lo = int(rng.integers(0, len(d) - 4096)); hi = lo + 4096
+        for _ in range(int(rng.integers(1, 64))):
+            d[int(rng.integers(lo, hi))] = int(rng.integers(0, 256))
+        book = T.NativeFontBook()
+        try:
+            book.add_font_bytes(bytes(d))
+            loaded += 1
+            book.measure("Hamburgefonstiv AVATAR To. éà", 23.0, "Word", 90.0)
+            book.rasterise("Hamburgefonstiv AVATAR To. éà 世", 120, 60, 23.0, wrap="Glyph")
+        except ValueError:
+            pass
+        finally:
+            book.close()
+    assert loaded > 20  # (most mutations leave a loadable face: the layout and the rasteriser ran on damaged tables too)
