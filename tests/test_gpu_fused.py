@@ -920,3 +920,52 @@ def test_compact_node_textures_give_the_same_tiles(hip, geom, fmt_name):
         assert d.max() <= 1 and (d == 0).mean() >= 0.999, (int(d.max()), float((d == 0).mean()))
     finally:
         c.close()
+
+
+def test_one_call_with_many_frames_of_assorted_sizes(hip):
+    """Twenty inputs of different sizes, formats and ranges in ONE smr_render_layouts call: the converter's launches (sixteen frames, then four;
+    planar and NV12 apart) deal bands of each frame's block rows to the XCDs and equal shares to their waves — frames of a few rows, widths that
+    are no multiple of 256, heights of 2 mod 4, a 4K frame beside an 8 x 2 one.  Every tile within 1 LSB of the oracle's converter + resampler +
+    compositor, and the same picture as the pass-per-launch kernels make."""
+    from oracle import scene as S
+    sizes = [(1920, 1080), (8, 2), (12, 6), (260, 38), (516, 26), (64, 130), (20, 6), (1280, 720), (1924, 1082), (3840, 2160),
+             (256, 16), (252, 18), (1024, 4), (4, 1024), (640, 362), (332, 250), (960, 540), (8, 8), (2048, 858), (1440, 1080)]
+    sizes = [(max(w, 8), h) for w, h in sizes]  # (the block converter takes widths from 8; narrower frames take the pass kernels)
+    W, H = 1920, 1080
+    root = S.Tiles(children=[S.InputStream(i) for i in range(len(sizes))], background_color=(8, 8, 8, 255))
+    layouts = S.scene_layouts(root, W, H, sizes)
+    rng = np.random.default_rng(77)
+    planes, kinds = [], []
+    for i, (w, h) in enumerate(sizes):
+        y, u, v = scenes.test_input(i, w, h, noise_seed=900 + i)
+        kind = ("nv12", "j420", "420")[i % 3]
+        planes.append((y, u, v)); kinds.append(kind)
+    del rng
+
+    def frames_of(c):
+        out = []
+        for (w, h), (y, u, v), kind in zip(sizes, planes, kinds):
+            if kind == "nv12":
+                out.append(c.frame(hip.FRAME_NV12, w, h, [y, np.stack([u, v], axis=-1)]))
+            else:
+                out.append(c.frame(hip.FRAME_PLANAR_YUVJ420 if kind == "j420" else hip.FRAME_PLANAR_YUV420, w, h, [y, u, v]))
+        return out
+    c, g = hip.Context(0), hip.Context(0)
+    g.set_fused_kernels(False)
+    try:
+        got = _render(c, hip, layouts, frames_of(c), W, H)
+        ref = _render(g, hip, layouts, frames_of(g), W, H)
+        nodes = []
+        for (w, h), (y, u, v), kind in zip(sizes, planes, kinds):
+            nodes.append(orc.nv12_to_rgba(y, np.stack([u, v], axis=-1), w, h) if kind == "nv12"
+                         else orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if kind == "j420" else orc.YUV420))
+        # the node textures themselves, frame by frame (single-frame launches of the same kernel): the oracle's bytes
+        for f, node in zip(frames_of(c), nodes):
+            assert np.array_equal(c.frame_to_rgba(f).download(), node)
+        want, _ = refpipe.render_yuv420(layouts, nodes, W, H, omp=True)
+        for a, b, w_, pl in zip(got, ref, want, "YUV"):
+            assert refpipe.max_diff(a, w_) <= 1, f"plane {pl}: {refpipe.max_diff(a, w_)} LSB off the oracle"
+            assert refpipe.max_diff(a, b) <= 1 and refpipe.exact_fraction(a, b) >= 0.99, f"plane {pl}: fused vs pass-per-launch"
+    finally:
+        c.close()
+        g.close()
