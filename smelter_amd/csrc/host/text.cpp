@@ -140,7 +140,8 @@ bool Font::parse(std::string &err) {
     descent = (double)-i16(hhea.off + 6);
     n_hmetrics_ = u16(hhea.off + 34);
     n_glyphs_ = u16(maxp.off + 4);
-    if (upem <= 0.0 || !n_hmetrics_ || !n_glyphs_) { err = "degenerate font header"; return false; }
+    // (unitsPerEm: 16 .. 16384 by the OpenType specification — what ttf-parser, the reference's reader, insists on as well)
+    if (upem < 16.0 || upem > 16384.0 || !n_hmetrics_ || !n_glyphs_) { err = "degenerate font header"; return false; }
     if (has(tag("OS/2"))) {
         const Table os2 = table(tag("OS/2"));
         weight = (int)u16(os2.off + 4);
@@ -225,7 +226,7 @@ uint32_t Font::glyph_of(uint32_t cp) const {
         const size_t ends = o + 14, starts = ends + segx2 + 2, deltas = starts + segx2, ranges = deltas + segx2;
         uint32_t lo = 0, hi = segs;  // first segment whose endCode >= cp
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) / 2;
+            const uint32_t mid = lo + (hi - lo) / 2;
             if (u16(ends + 2 * (size_t)mid) < cp) lo = mid + 1; else hi = mid;
         }
         if (lo >= segs || u16(starts + 2 * (size_t)lo) > cp) break;
@@ -244,10 +245,12 @@ uint32_t Font::glyph_of(uint32_t cp) const {
     }
     case 12:
     case 13: {
-        const uint32_t groups = u32(o + 12);
+        uint32_t groups = u32(o + 12);  // (no more groups than the file has bytes for: a corrupt count does not get to steer the search)
+        const size_t room = d_.size() > o + 16 ? (d_.size() - o - 16) / 12 : 0;
+        if ((size_t)groups > room) groups = (uint32_t)room;
         uint32_t lo = 0, hi = groups;  // first group whose endCharCode >= cp
         while (lo < hi) {
-            const uint32_t mid = (lo + hi) / 2;
+            const uint32_t mid = lo + (hi - lo) / 2;
             if (u32(o + 16 + 12 * (size_t)mid + 4) < cp) lo = mid + 1; else hi = mid;
         }
         if (lo < groups && u32(o + 16 + 12 * (size_t)lo) <= cp)
@@ -683,7 +686,16 @@ std::vector<Line> layout(Font &font, const std::string &utf8, double font_size, 
     return layout_cp(font, cps, font_size, wrap, max_width, kerning);
 }
 
+// what a caller may hand in: a finite font size in (0, 1e5] (the scene front-end only lets positive sizes through; 1e5 pixels is an order of
+// magnitude beyond MAX_NODE_RESOLUTION), a finite line height
+static bool sane_sizes(const smr_text_params &p, std::string &err) {
+    if (!(p.font_size > 0.0f && p.font_size <= 1e5f)) { err = "font_size must be a finite number in (0, 100000]"; return false; }
+    if (!(p.line_height == p.line_height) || std::fabs(p.line_height) > 1e6f) { err = "line_height must be a finite number"; return false; }
+    return true;
+}
+
 bool measure(FontBook &book, const smr_text_params &p, float &widest, uint32_t &count, std::string &err) {
+    if (!sane_sizes(p, err)) return false;
     Font *font = book.match(p.font_family ? p.font_family : "", p.weight ? p.weight : "Normal", p.style ? p.style : "Normal");
     if (!font) { err = "the font book is empty"; return false; }
     std::vector<uint32_t> cps;
@@ -756,10 +768,11 @@ GlyphBitmap rasterise_glyph(Font &font, uint32_t gid, double scale, double fx, d
             min_y = std::min(min_y, q.y); max_y = std::max(max_y, q.y);
         }
     }
-    if (!(min_x > -1e6 && max_x < 1e6 && min_y > -1e6 && max_y < 1e6)) return out;  // (a size no node can hold: MAX_NODE_RESOLUTION is 7682 x 4320; also NaN)
+    // (a size no node can hold: MAX_NODE_RESOLUTION is 7682 x 4320; NaN; contours without a point leave the extents at +-infinity)
+    if (!(min_x <= max_x && min_y <= max_y && min_x > -1e6 && max_x < 1e6 && min_y > -1e6 && max_y < 1e6)) return out;
     const int left = (int)std::floor(min_x), top = (int)std::floor(min_y);
     const int w = (int)std::ceil(max_x) - left + 1, h = (int)std::ceil(max_y) - top + 1;
-    if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 26)) return out;
+    if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 24)) return out;  // (a 4 000 pixel glyph is 16 M pixels: nothing a node shows is larger)
     std::vector<double> acc((size_t)w * h + 4, 0.0);
     for (const Contour &c : pts) {
         const size_t n = c.size();
@@ -782,6 +795,7 @@ GlyphBitmap rasterise_glyph(Font &font, uint32_t gid, double scale, double fx, d
 
 bool rasterise(FontBook &book, const smr_text_params &p, uint32_t width, uint32_t height, const float color[4], TextRun &out, std::string &err) {
     out.glyphs.clear(); out.atlas.clear(); out.atlas_w = out.atlas_h = 0;
+    if (!sane_sizes(p, err)) return false;
     Font *font = book.match(p.font_family ? p.font_family : "", p.weight ? p.weight : "Normal", p.style ? p.style : "Normal");
     if (!font) { err = "the font book is empty"; return false; }
     std::vector<uint32_t> cps;
@@ -817,6 +831,7 @@ bool rasterise(FontBook &book, const smr_text_params &p, uint32_t width, uint32_
     };
     std::vector<Use> order;
     for (const Placed &g : placed) {
+        if (!(std::fabs(g.x) < 1e9 && std::fabs(g.base) < 1e9)) continue;  // (far outside any node; keeps the pen's pixel an int)
         const double fx = g.x - std::floor(g.x), fy = g.base - std::floor(g.base);
         char key[96];
         snprintf(key, sizeof(key), "%u/%.3f/%.3f", g.gid, fx, fy);  // round(f, 3): the correctly rounded three-decimal value

@@ -342,6 +342,9 @@ extern "C" __attribute__((visibility("default"))) int smr_debug_convert_stamps(u
 template <bool NV>
 __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
     __shared__ float s_ylut[256], s_nlut[256];
+#ifdef SMR_PRIO_CONVERT
+    __builtin_amdgcn_s_setprio(SMR_PRIO_CONVERT);
+#endif
 #ifdef CV_TIMING
     unsigned long long *st = g_cv_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 32767u];
     if ((threadIdx.x & 63) == 0) { st[7] = __builtin_amdgcn_s_memrealtime(); st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0; }

@@ -564,6 +564,9 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
                                                         int tiles_x, int tiles, const TileClass *__restrict__ tc, const TileList *__restrict__ full,
                                                         int n_banded, int slices) {
     const int tid = threadIdx.x;
+#if defined(SMR_PRIO_COMPOSE) && !defined(SMR_EMU)
+    __builtin_amdgcn_s_setprio(SMR_PRIO_COMPOSE);
+#endif
     __shared__ __attribute__((aligned(16))) float s_tab[SMR_TABLE_FLOATS];  // decode / encode tables (whoever needs them loads them)
     // The first `slices * n_banded` workgroups take the tiles that need compositing (TileList; the host sized the grid from the
     // list's length when it knows it, from its own prediction otherwise), band by band — they are latency-bound and would be the

@@ -992,6 +992,9 @@ __global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (20
 #endif
     const int tid = threadIdx.x;
     const int wave = dev_readfirstlane(tid >> 6);
+#if defined(SMR_PRIO_WAVE) && !defined(SMR_EMU)
+    __builtin_amdgcn_s_setprio(SMR_PRIO_WAVE);
+#endif
 #if SMR_WAVE_STAGGER && !defined(SMR_EMU)
     if (__builtin_amdgcn_s_getreg(((4 - 1) << 11) | 4) & 1u) __builtin_amdgcn_s_sleep(SMR_WAVE_STAGGER);  // HW_ID.wave_id (this wave's slot in its SIMD)
 #endif

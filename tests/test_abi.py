@@ -36,6 +36,21 @@ def test_struct_layouts_agree(lib):
     assert lib.smr_abi_version() == 1
 
 
+def test_product_build_reads_nothing_from_the_environment(lib):
+    """A product build (what build() makes, what everything is measured on) holds no A/B knob: smr_build_flags() is 0 and the library does
+    not even import getenv — the knobs of laboratory builds (tools/variant.sh, -DSMR_LAB) are compiled out, not switched off."""
+    import subprocess
+    from smelter_amd import build
+    if os.environ.get("SMR_LIB") or os.environ.get("SMR_LAB"):
+        pytest.skip("a laboratory build was asked for")
+    lib.smr_build_flags.restype = C.c_uint32
+    assert lib.smr_build_flags() == 0
+    undefined = subprocess.run(["nm", "-D", "--undefined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    imported = {line.split()[-1].split("@")[0] for line in undefined.splitlines() if line.strip()}
+    assert not ({"getenv", "secure_getenv"} & imported), imported & {"getenv", "secure_getenv"}
+    assert "hipLaunchKernel" in imported or any(n.startswith("hip") for n in imported), "nm listed no HIP imports: wrong file?"
+
+
 def test_no_gpu_means_loud_failure(lib):
     import torch
     if torch.cuda.is_available():

@@ -131,6 +131,24 @@ def test_bad_fonts_and_bad_text_are_errors_not_crashes(tmp_path):
             p.max_width = p.max_height = 100.0
             w, n = C.c_float(), C.c_uint32()
             assert native.lib.smr_fontbook_measure(native.handle, C.byref(p), C.byref(w), C.byref(n)) == 1
+            # sizes no node can have are refused before any arithmetic is done with them (found by tests/san/host_fuzz.cpp under UBSan:
+            # a pen position of a 1e30-pixel font cast to int)
+            for bad in (0.0, -3.0, float("nan"), float("inf"), 1e6, 1e30):
+                with pytest.raises(ValueError, match="font_size"):
+                    native.measure("x", bad)
+                with pytest.raises(ValueError, match="font_size"):
+                    native.rasterise("x", 10, 10, bad)
+            with pytest.raises(ValueError, match="line_height"):
+                native.rasterise("x", 10, 10, 12.0, line_height=float("nan"))
+            # unitsPerEm outside 16 .. 16384 (OpenType; ttf-parser refuses such a face too): with 1 unit per em every glyph would be
+            # thousands of pixels wide
+            tables = {data[12 + 16 * i:16 + 16 * i]: int.from_bytes(data[20 + 16 * i:24 + 16 * i], "big") for i in range(int.from_bytes(data[4:6], "big"))}
+            head = tables[b"head"]
+            for upem in (0, 1, 15, 16385, 65535):
+                d = bytearray(data)
+                d[head + 18:head + 20] = upem.to_bytes(2, "big")
+                with pytest.raises(ValueError, match="degenerate font header"):
+                    native.add_font_bytes(bytes(d))
     finally:
         native.close()
 
