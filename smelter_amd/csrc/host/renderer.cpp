@@ -114,8 +114,12 @@ int enter_lane(smr_renderer *r, Output &o, size_t lane) {
     if (l.node_surface.size() != n) { l.node_surface.assign(n, nullptr); l.scaled_image.assign(n, nullptr); }
     if (!l.have_frames) {
         int rc = gpu(r, smr_frame_create(r->ctx, o.format, o.w, o.h, &l.frames[0]), "output frame");
-        if (rc >= 0) rc = gpu(r, smr_frame_create(r->ctx, o.format, o.w, o.h, &l.frames[1]), "output frame");
         if (rc < 0) return rc;
+        rc = gpu(r, smr_frame_create(r->ctx, o.format, o.w, o.h, &l.frames[1]), "output frame");
+        if (rc < 0) {  // (both or neither: the next attempt starts from nothing)
+            smr_frame_destroy(r->ctx, &l.frames[0]);
+            return rc;
+        }
         l.have_frames = true;
     }
     return 0;
@@ -142,8 +146,8 @@ static void flatten_shader_param(const Json &j, std::vector<uint8_t> &out) {
     if (!ty || !v) return;
     auto put = [&](const void *p) { const uint8_t *b = (const uint8_t *)p; out.insert(out.end(), b, b + 4); };
     if (ty->str == "f32") { float f = (float)v->num; put(&f); }
-    else if (ty->str == "u32") { uint32_t u = (uint32_t)v->num; put(&u); }
-    else if (ty->str == "i32") { int32_t n = (int32_t)v->num; put(&n); }
+    else if (ty->str == "u32") { uint32_t u = as_u32(v->num); put(&u); }
+    else if (ty->str == "i32") { int32_t n = as_i32(v->num); put(&n); }
     else if (v->kind == Json::Array) for (const Json &e : v->arr) flatten_shader_param(e, out);
 }
 
@@ -168,7 +172,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
     case Kind::Image: {
         auto it = r->images.find(c.ref_id);
         if (it == r->images.end()) return 0;
-        const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+        const uint32_t w = as_u32(c.leaf_size.width), h = as_u32(c.leaf_size.height);
         if (w == it->second.w && h == it->second.h) {
             out.kind = SMR_SOURCE_SURFACE; out.surface = it->second.surface; out.w = w; out.h = h;
             return 0;
@@ -186,7 +190,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
     case Kind::Text: {
         if (o.text_surface[idx]) {
             out.kind = SMR_SOURCE_SURFACE; out.surface = o.text_surface[idx];
-            out.w = (uint32_t)c.leaf_size.width; out.h = (uint32_t)c.leaf_size.height;
+            out.w = as_u32(c.leaf_size.width); out.h = as_u32(c.leaf_size.height);
         }
         return 0;
     }
@@ -201,7 +205,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
     if (g.kind == Kind::Shader) {
         auto it = r->shaders.find(c.ref_id);
         if (it == r->shaders.end()) return fail(r, -1, "Shader \"" + c.ref_id + "\" does not exist. You have to register it first before using it in the scene definition.");
-        const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+        const uint32_t w = as_u32(c.leaf_size.width), h = as_u32(c.leaf_size.height);
         if (w == 0 || h == 0) return 0;
         int rc = ensure_surface(r, o.l->node_surface[idx], w, h);
         if (rc < 0) return rc;
@@ -419,7 +423,7 @@ SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id,
 static int set_text_run(smr_renderer *r, Output &o, int node, const float bg[4], const smr_glyph *glyphs, uint32_t n, const uint8_t *atlas,
                         uint32_t atlas_w, uint32_t atlas_h) {
     const Stateful &c = *o.scene.nodes()[node].component;
-    const uint32_t w = (uint32_t)c.leaf_size.width, h = (uint32_t)c.leaf_size.height;
+    const uint32_t w = as_u32(c.leaf_size.width), h = as_u32(c.leaf_size.height);
     if (!w || !h) return 0;  // (a zero-sized text node is the 1x1 transparent texture: text_renderer.rs:77-85)
     int rc = ensure_surface(r, o.text_surface[node], w, h);
     if (rc < 0) return rc;
@@ -449,7 +453,7 @@ static int draw_text_nodes(smr_renderer *r, const std::string &output_id, Output
         float bg[4];
         convert_to_shader_color(t.background, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, bg);
         smr_text_run run;
-        if (smr_fontbook_rasterise(r->fontbook, &p, (uint32_t)c.leaf_size.width, (uint32_t)c.leaf_size.height, color, &run) != 0)
+        if (smr_fontbook_rasterise(r->fontbook, &p, as_u32(c.leaf_size.width), as_u32(c.leaf_size.height), color, &run) != 0)
             return fail(r, -1, std::string("text node: ") + smr_fontbook_last_error(r->fontbook));
         const int rc = set_text_run(r, o, i, bg, run.glyphs, run.n_glyphs, run.atlas, run.atlas_w, run.atlas_h);
         if (rc < 0) return rc;
@@ -541,7 +545,7 @@ SMR_API int smr_renderer_node_info(smr_renderer *r, const char *output_id, int n
     out->parent = g.parent;
     out->n_children = (uint32_t)g.children.size();
     const Size sz = g.has_forced_size ? g.forced_size : c.leaf_size;
-    out->width = (uint32_t)sz.width; out->height = (uint32_t)sz.height;
+    out->width = as_u32(sz.width); out->height = as_u32(sz.height);
     out->ref_id = c.ref_id.c_str(); out->id = c.id.c_str();
     out->payload = c.kind == Kind::Text ? c.text.c_str() : "";
     return 0;

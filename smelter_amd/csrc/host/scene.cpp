@@ -686,7 +686,7 @@ bool should_render(const RenderLayout &l, const std::vector<std::optional<Size>>
     if (l.content == 0) {
         if (l.index < res.size() && res[l.index]) {
             // Resolution is usize in the reference: the size went through `as usize`
-            if (l.crop.left > (float)(size_t)res[l.index]->width || l.crop.top > (float)(size_t)res[l.index]->height) return false;
+            if (l.crop.left > (float)as_usize(res[l.index]->width) || l.crop.top > (float)as_usize(res[l.index]->height)) return false;
         }
         if (l.crop.top + l.crop.height < 0.0f || l.crop.left + l.crop.width < 0.0f) return false;
         return true;

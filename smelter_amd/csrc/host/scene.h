@@ -16,6 +16,12 @@
 
 namespace smr_host {
 
+// Rust's `as usize` / `as u32` / `as i32` on a float — saturating, NaN -> 0: what every `Resolution { width: x as usize, .. }` and every
+// ShaderParam conversion of the reference does.  (A plain C++ cast of an out-of-range float is undefined behaviour.)
+inline size_t as_usize(double v) { return !(v > 0.0) ? 0 : v >= 18446744073709551615.0 ? SIZE_MAX : (size_t)v; }
+inline uint32_t as_u32(double v) { return !(v > 0.0) ? 0u : v >= 4294967295.0 ? UINT32_MAX : (uint32_t)v; }
+inline int32_t as_i32(double v) { return v != v ? 0 : v <= -2147483648.0 ? INT32_MIN : v >= 2147483647.0 ? INT32_MAX : (int32_t)v; }
+
 struct RGBA { uint8_t r = 0, g = 0, b = 0, a = 0; bool operator==(const RGBA &o) const { return r == o.r && g == o.g && b == o.b && a == o.a; } };
 struct Size { float width = 0, height = 0; };
 struct BorderRadius {

@@ -514,12 +514,12 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             return nullptr;
         }
         // the reference divides the usize dimensions before the float conversion (integer aspect ratio)
-        size_t iw = (size_t)it->second.width, ih = (size_t)it->second.height;
+        size_t iw = as_usize(it->second.width), ih = as_usize(it->second.height);
         float aspect = ih ? (float)(iw / ih) : 0.0f;
         size_t rw, rh;
-        if (w && h) { rw = (size_t)std::round(*w); rh = (size_t)std::round(*h); }
-        else if (w) { rw = (size_t)std::round(*w); rh = (size_t)std::round(*w / aspect); }
-        else if (h) { rw = (size_t)std::round(*h * aspect); rh = (size_t)std::round(*h); }
+        if (w && h) { rw = as_usize(std::round(*w)); rh = as_usize(std::round(*h)); }
+        else if (w) { rw = as_usize(std::round(*w)); rh = as_usize(std::round(*w / aspect)); }
+        else if (h) { rw = as_usize(std::round(*h * aspect)); rh = as_usize(std::round(*h)); }
         else { rw = iw; rh = ih; }
         s->leaf_size = {(float)rw, (float)rh};
         return s;
@@ -587,13 +587,13 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             uint32_t lines = 0;
             if (c.measure(c.measure_user, &tp, &widest, &lines) != 0) { fail(c, "the text shaper failed to lay out \"" + s->text + "\""); return nullptr; }
             // get_text_resolution (text_renderer.rs:348-368)
-            const size_t tw = (size_t)std::ceil(widest > 0.0f ? widest : 0.0f);
-            const size_t th = (size_t)((float)lines * std::ceil(line_height) + *fs / 5.0f);
-            s->leaf_size = {(float)(w ? (size_t)*w : tw), (float)th};
+            const size_t tw = as_usize(std::ceil(widest > 0.0f ? widest : 0.0f));
+            const size_t th = as_usize((float)lines * std::ceil(line_height) + *fs / 5.0f);
+            s->leaf_size = {(float)(w ? as_usize(*w) : tw), (float)th};
             s->shader_param = j;
             return s;
         }
-        s->leaf_size = {(float)(size_t)*w, (float)(size_t)*h};  // Resolution { width as usize, height as usize }
+        s->leaf_size = {(float)as_usize(*w), (float)as_usize(*h)};  // Resolution { width as usize, height as usize }
         s->shader_param = j;                                    // colours / font properties for the caller's shaper
         return s;
     }
@@ -609,7 +609,7 @@ std::unique_ptr<Stateful> build(const Json &j, BuildCtx &c) {
             fail(c, "missing field `resolution`");
             return nullptr;
         }
-        s->leaf_size = {(float)(size_t)rw->num, (float)(size_t)rh->num};
+        s->leaf_size = {(float)as_usize(rw->num), (float)as_usize(rh->num)};
         Json param;
         if (const Json *p = j.get("shader_param")) {
             s->shader_param = *p;
@@ -760,8 +760,8 @@ bool Scene::node_layouts(int node, int64_t pts_ns, const std::vector<std::option
     g.cache.valid = false;
     // SizedLayoutComponent::resolution (scene/layout.rs:245-257)
     Position p = root.position(pts_ns);
-    w = (uint32_t)(size_t)(p.width ? *p.width : g.forced_size.width);
-    h = (uint32_t)(size_t)(p.height ? *p.height : g.forced_size.height);
+    w = as_u32(p.width ? *p.width : g.forced_size.width);
+    h = as_u32(p.height ? *p.height : g.forced_size.height);
     root.update_state(child_resolutions, 0);
     NestedLayout nested = root.layout(g.forced_size, pts_ns);
     std::vector<RenderLayout> flat = nested.flatten(child_resolutions, w, h);

@@ -73,8 +73,8 @@ SMR_API int smr_scene_node_info(const smr_scene *scene_c, int node, smr_scene_no
     out->parent = g.parent;
     out->n_children = (uint32_t)g.children.size();
     Size sz = g.has_forced_size ? g.forced_size : c.leaf_size;
-    out->width = (uint32_t)(size_t)sz.width;
-    out->height = (uint32_t)(size_t)sz.height;
+    out->width = as_u32(sz.width);
+    out->height = as_u32(sz.height);
     out->ref_id = c.ref_id.c_str();  // owned by the component tree: valid until the next successful update
     out->id = c.id.c_str();
     out->payload = c.kind == Kind::Text ? c.text.c_str() : "";

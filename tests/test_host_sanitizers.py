@@ -1,9 +1,13 @@
-"""The host side of the library (scene engine + text pipeline, smelter_amd/csrc/host) under AddressSanitizer + UBSan.
+"""The host side of the library (scene engine, text pipeline, renderer: smelter_amd/csrc/host) under AddressSanitizer + UBSan.
 
-tests/san/host_fuzz.cpp is compiled by g++ together with the host sources (no HIP involved: they are plain C++17) and drives them through
-the C ABI with the reference's own scenes, mutated scenes and corrupted fonts.  A rejected input is an answer; a memory error, undefined
-behaviour or a hang fails the test.  (What it found when it was written: an empty-contour glyph whose extents stayed at infinity, pen
-positions of absurd font sizes cast to int, a cmap-12 group count above 2^31 that sent the binary search round in circles.)"""
+tests/san/host_fuzz.cpp is compiled by g++ together with the host sources (no HIP involved: they are plain C++17) and drives the scene
+engine and the text pipeline through the C ABI with the reference's own scenes, mutated scenes and corrupted fonts.
+tests/san/renderer_fuzz.cpp does the same to the renderer (registry, update_scene, render-graph walk, lanes, text nodes), linked against
+tests/san/null_device.cpp — a stand-in for the GPU half of the ABI that checks and reads every argument, counts the surfaces it hands
+out and fails allocations on request.  A rejected input is an answer; a memory error, undefined behaviour, a leaked device surface or a
+hang fails the test.  (What they found when they were written: an empty-contour glyph whose extents stayed at infinity, pen positions
+of absurd font sizes cast to int, a cmap-12 group count above 2^31 that sent the binary search round in circles, an output frame
+leaked when the second of a lane's two frames could not be allocated, float -> integer casts of hostile node sizes.)"""
 import json
 import os
 import shutil
@@ -16,9 +20,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HOST = os.path.join(ROOT, "smelter_amd", "csrc", "host")
 BUILD = os.path.join(HERE, "san", "_build")
-SOURCES = [os.path.join(HERE, "san", "host_fuzz.cpp")] + [os.path.join(HOST, f) for f in
-                                                         ("scene.cpp", "scene_build.cpp", "scene_capi.cpp", "text.cpp", "text_capi.cpp")]
-FLAGS = ["-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+HOST_SOURCES = [os.path.join(HOST, f) for f in ("scene.cpp", "scene_build.cpp", "scene_capi.cpp", "text.cpp", "text_capi.cpp")]
+PROGRAMS = {  # executable -> its sources beyond HOST_SOURCES
+    "host_fuzz": [os.path.join(HERE, "san", "host_fuzz.cpp")],
+    "renderer_fuzz": [os.path.join(HERE, "san", "renderer_fuzz.cpp"), os.path.join(HERE, "san", "null_device.cpp"), os.path.join(HOST, "renderer.cpp")],
+}
+SOURCES = HOST_SOURCES + [p for v in PROGRAMS.values() for p in v]
+SANITIZE = "-fsanitize=address,undefined,float-cast-overflow"
+FLAGS = ["-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", SANITIZE, "-fno-sanitize-recover=undefined,float-cast-overflow",
          "-I", os.path.join(ROOT, "include"), "-I", HOST]
 FONT_DIRS = ["/usr/share/fonts/truetype/dejavu", "/root/reference/smelter-render/fonts"]
 
@@ -37,22 +46,24 @@ def harness():
     probe = os.path.join(BUILD, "probe.cpp")
     with open(probe, "w") as f:
         f.write("int main() { return 0; }\n")
-    if subprocess.run([gxx, "-fsanitize=address,undefined", probe, "-o", os.path.join(BUILD, "probe")], capture_output=True).returncode != 0:
+    if subprocess.run([gxx, SANITIZE, probe, "-o", os.path.join(BUILD, "probe")], capture_output=True).returncode != 0:
         pytest.skip("this g++ has no sanitizer runtimes")
-    exe = os.path.join(BUILD, "host_fuzz")
-    if os.path.exists(exe) and os.path.getmtime(exe) >= _newest_dependency():
-        return exe
+    exes = {name: os.path.join(BUILD, name) for name in PROGRAMS}
+    newest = _newest_dependency()
+    if all(os.path.exists(e) and os.path.getmtime(e) >= newest for e in exes.values()):
+        return exes
 
     def compile_one(src):
         obj = os.path.join(BUILD, os.path.basename(src) + ".o")
         r = subprocess.run([gxx] + FLAGS + ["-c", src, "-o", obj], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         return obj
-    with ThreadPoolExecutor(max_workers=6) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([gxx, "-fsanitize=address,undefined"] + objs + ["-o", exe], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
-    return exe
+    with ThreadPoolExecutor(max_workers=9) as ex:
+        objs = dict(zip(SOURCES, ex.map(compile_one, SOURCES)))
+    for name, own in PROGRAMS.items():
+        r = subprocess.run([gxx, SANITIZE] + [objs[p] for p in HOST_SOURCES + own] + ["-o", exes[name]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    return exes
 
 
 @pytest.fixture(scope="module")
@@ -92,7 +103,7 @@ def _run(exe, corpus_dir, iterations, seed, timeout):
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_scene_engine_and_text_pipeline_survive_hostile_input(harness, corpus, seed):
     corpus_dir, n_scenes, n_fonts = corpus
-    got = _run(harness, corpus_dir, 4000, seed, timeout=600)
+    got = _run(harness["host_fuzz"], corpus_dir, 4000, seed, timeout=600)
     assert got["corpus_scenes"] == n_scenes
     # every scene of the corpus runs twice (alone; as an update of a scene that lives on): what the reference accepts must be accepted
     assert got["corpus_ok"] >= n_scenes, got
@@ -103,8 +114,23 @@ def test_scene_engine_and_text_pipeline_survive_hostile_input(harness, corpus, s
         assert got["fonts_ok"] > n_fonts and got["fonts_rejected"] > 50, got                  # corrupted fonts: some load, some are refused
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_renderer_survives_hostile_hosts_and_a_failing_device(harness, corpus, seed):
+    """smr_renderer_* on the null device: scenes (also mutated) on three outputs, frames of every format — fresh, stale, missing, for
+    unknown inputs — on one to three lanes, registrations coming and going, glyph runs, a font book, device allocations that fail.  The
+    null device refuses what the library would refuse and aborts on what would corrupt memory; every surface it handed out must be back
+    when a renderer is destroyed."""
+    corpus_dir, n_scenes, n_fonts = corpus
+    got = _run(harness["renderer_fuzz"], corpus_dir, 12000, seed, timeout=600)
+    assert got["updates_ok"] > 1000 and got["updates_refused"] > 500, got
+    assert got["renders_ok"] > 4000 and got["frames_out"] > got["renders_ok"], got     # several outputs per render
+    assert got["renders_refused"] > 50 and got["injected_failures"] > 100, got          # the error paths ran
+    assert got["text_runs"] > 10, got
+
+
 def test_replay_modes(harness, corpus, tmp_path):
     """--scene / --font replay one input (what HOST_FUZZ_TRACE leaves behind after an abort)."""
+    harness = harness["host_fuzz"]
     corpus_dir = corpus[0]
     scene = sorted(f for f in os.listdir(corpus_dir) if f.endswith(".json"))[0]
     r = subprocess.run([harness, "--scene", os.path.join(corpus_dir, scene)], capture_output=True, text=True, timeout=120)
