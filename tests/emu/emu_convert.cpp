@@ -12,6 +12,7 @@ thread_local dim3 threadIdx, blockIdx;
 dim3 gridDim, blockDim;
 
 #include "emu_device.h"
+#include "emu_guard.h"
 EmuBlock *emu_blk = nullptr;
 thread_local unsigned char *emu_smem = nullptr;
 void __syncthreads() {}
@@ -21,17 +22,32 @@ void __syncthreads() {}
 namespace {
 
 struct Plane {
-    std::vector<u8> buf;
+    GuardBuf buf;
     SurfView view;
 };
-// rows on a 256-byte pitch like smr_surface_create's, padding filled with a byte no plane contains by accident
-Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill) {
+// rows on a 256-byte pitch like smr_surface_create's, padding filled with a byte no plane contains by accident; with emu_set_guard(.., 1)
+// on the smallest pitch conv_420_ok (smr_convert.hip) lets through: `min_row` bytes (what the last block's window loads reach), dword-aligned
+Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill, u32 min_row = 0) {
     Plane p;
-    const u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
-    p.buf.assign((size_t)pitch * h + 64, fill);
-    for (int y = 0; y < h; y++) memcpy(p.buf.data() + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
-    p.view.ptr = p.buf.data(); p.view.pitch = pitch; p.view.w = w; p.view.h = h;
+    u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
+    if (emu_min_pitch) {
+        pitch = (u32)(((size_t)w * bpp + 3) & ~(size_t)3);
+        if (pitch < min_row) pitch = (min_row + 3u) & ~3u;
+    }
+    p.buf.alloc((size_t)pitch * h, fill, 4);
+    for (int y = 0; y < h; y++) memcpy(p.buf.ptr + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
+    p.view.ptr = p.buf.ptr; p.view.pitch = pitch; p.view.w = w; p.view.h = h;
     return p;
+}
+// conv_420_ok's `need`: the last block's chroma window starts at column cw - 3; its bytes begin in the dword at ((cw - 3) [* 2]) & ~3 and
+// the loads reach 8 (12) bytes from there
+u32 chroma_need(int w, int nv12) {
+    const u32 cw = (u32)w / 2;
+    return nv12 ? ((2u * (cw - 3u)) & ~3u) + 12u : ((cw - 3u) & ~3u) + 8u;
+}
+u32 node_pitch(int w, int rgb12) {
+    if (emu_min_pitch) return rgb12 ? (u32)((3 * w + 15) & ~15) : (u32)w * 4;
+    return rgb12 ? (u32)((3 * w + 255) & ~255) : (u32)w * 4;
 }
 
 }  // namespace
@@ -41,13 +57,15 @@ Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill) {
 // nb = 0: one cv420_block call per block; nb >= 1: cv420_run over runs of nb block rows (what k_yuv420_to_rgba's waves execute)
 extern "C" int emu_convert_420_run(const u8 *y, const u8 *u, const u8 *v, int w, int h, int nv12, int full, int rgb12, int nb, u8 *out) {
     if (w % 4 || w < 8 || h % 2 || h < 2) return -1;
-    Plane py = make_plane(y, w, h, 1, 0x5a), pu = make_plane(u, w / 2, h / 2, nv12 ? 2 : 1, 0xa5), pv = nv12 ? Plane() : make_plane(v, w / 2, h / 2, 1, 0x3c);
-    const u32 dpitch = rgb12 ? (u32)((3 * w + 255) & ~255) : (u32)w * 4;
-    std::vector<u8> dst((size_t)dpitch * h + 64, 0);
+    const u32 need = chroma_need(w, nv12);
+    Plane py = make_plane(y, w, h, 1, 0x5a), pu = make_plane(u, w / 2, h / 2, nv12 ? 2 : 1, 0xa5, need), pv = nv12 ? Plane() : make_plane(v, w / 2, h / 2, 1, 0x3c, need);
+    const u32 dpitch = node_pitch(w, rgb12);
+    GuardBuf dst;
+    dst.alloc((size_t)dpitch * h, 0, 16);
     ConvJob J;
     memset(&J, 0, sizeof(J));
     J.yp = py.view; J.up = pu.view; J.vp = nv12 ? pu.view : pv.view;
-    J.dst.ptr = dst.data(); J.dst.pitch = dpitch; J.dst.w = w; J.dst.h = h;
+    J.dst.ptr = dst.ptr; J.dst.pitch = dpitch; J.dst.w = w; J.dst.h = h;
     J.full = full; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0; J.rgb12 = rgb12;
     float ylut[256], nlut[256];
     for (u32 b = 0; b < 256; b++) {
@@ -72,9 +90,9 @@ extern "C" int emu_convert_420_run(const u8 *y, const u8 *u, const u8 *v, int w,
 #undef EMU_CV
         }
     if (rgb12) {
-        for (int r = 0; r < h; r++) memcpy(out + (size_t)r * 3 * w, dst.data() + (size_t)r * dpitch, (size_t)3 * w);
+        for (int r = 0; r < h; r++) memcpy(out + (size_t)r * 3 * w, dst.ptr + (size_t)r * dpitch, (size_t)3 * w);
     } else {
-        memcpy(out, dst.data(), (size_t)w * 4 * h);
+        memcpy(out, dst.ptr, (size_t)w * 4 * h);
     }
     return 0;
 }
@@ -90,7 +108,7 @@ extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *cons
                                       const int *fulls, const int *rgb12s, int waves, u8 *const *outs) {
     if (n < 1 || n > MAX_CONV_JOBS || waves < 1) return -1;
     std::vector<Plane> py(n), pu(n), pv(n);
-    std::vector<std::vector<u8>> dst(n);
+    std::vector<GuardBuf> dst(n);
     std::vector<u32> dpitch(n);
     ConvBatch B;
     memset(&B, 0, sizeof(B));
@@ -98,13 +116,14 @@ extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *cons
     for (int i = 0; i < n; i++) {
         const int w = ws[i], h = hs[i];
         if (w % 4 || w < 8 || h % 2 || h < 2) return -1;
-        py[i] = make_plane(ys[i], w, h, 1, 0x5a); pu[i] = make_plane(us[i], w / 2, h / 2, nv12 ? 2 : 1, 0xa5);
-        if (!nv12) pv[i] = make_plane(vs[i], w / 2, h / 2, 1, 0x3c);
-        dpitch[i] = rgb12s[i] ? (u32)((3 * w + 255) & ~255) : (u32)w * 4;
-        dst[i].assign((size_t)dpitch[i] * h + 64, 0);
+        const u32 need = chroma_need(w, nv12);
+        py[i] = make_plane(ys[i], w, h, 1, 0x5a); pu[i] = make_plane(us[i], w / 2, h / 2, nv12 ? 2 : 1, 0xa5, need);
+        if (!nv12) pv[i] = make_plane(vs[i], w / 2, h / 2, 1, 0x3c, need);
+        dpitch[i] = node_pitch(w, rgb12s[i]);
+        dst[i].alloc((size_t)dpitch[i] * h, 0, 16);
         ConvJob &J = B.j[i];
         J.yp = py[i].view; J.up = pu[i].view; J.vp = nv12 ? pu[i].view : pv[i].view;
-        J.dst.ptr = dst[i].data(); J.dst.pitch = dpitch[i]; J.dst.w = w; J.dst.h = h;
+        J.dst.ptr = dst[i].ptr; J.dst.pitch = dpitch[i]; J.dst.w = w; J.dst.h = h;
         J.full = fulls[i]; J.nv = nv12; J.sx = 1; J.sy = 1; J.packed = 0; J.rgb12 = rgb12s[i];
     }
     // `waves` = workgroups here (four waves each), as the host launches them: the partition is the host's own (cv420_plan)
@@ -125,9 +144,9 @@ extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *cons
     for (int i = 0; i < n; i++) {
         const int w = ws[i], h = hs[i];
         if (rgb12s[i]) {
-            for (int r = 0; r < h; r++) memcpy(outs[i] + (size_t)r * 3 * w, dst[i].data() + (size_t)r * dpitch[i], (size_t)3 * w);
+            for (int r = 0; r < h; r++) memcpy(outs[i] + (size_t)r * 3 * w, dst[i].ptr + (size_t)r * dpitch[i], (size_t)3 * w);
         } else {
-            memcpy(outs[i], dst[i].data(), (size_t)w * 4 * h);
+            memcpy(outs[i], dst[i].ptr, (size_t)w * 4 * h);
         }
     }
     return 0;

@@ -6,6 +6,7 @@
 // machines without a GPU; arithmetic follows the instruction semantics, except that the MFMA sums its 32 products in order.
 #include <pthread.h>
 
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -15,6 +16,7 @@ thread_local dim3 threadIdx, blockIdx;
 dim3 gridDim, blockDim;
 
 #include "emu_device.h"
+#include "emu_guard.h"
 EmuBlock *emu_blk = nullptr;
 thread_local unsigned char *emu_smem = nullptr;
 void __syncthreads() { pthread_barrier_wait(&emu_blk->bar); }
@@ -50,20 +52,24 @@ void run_grid(unsigned blocks, unsigned threads, size_t lds, F kernel) {
 }
 
 struct Plane {
-    std::vector<u8> buf;
+    std::shared_ptr<GuardBuf> buf;  // (shared: the node-texture builds alias the three plane views)
     SurfView view;
 };
-Plane make_plane(const u8 *tight, int w, int h, int bpp) {
+// rows on the allocator's 256-byte pitch; with emu_set_guard(.., 1) a NODE texture (min_row != 0) sits on the smallest pitch
+// can_fuse_wave_rgba lets through: 16-byte multiples that hold the row rounded up to four texels
+Plane make_plane(const u8 *tight, int w, int h, int bpp, u32 min_row = 0) {
     Plane p;
-    const u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
-    p.buf.assign((size_t)pitch * h + 64, bpp == 8 ? 0xff : 0xcd);  // (row padding: arbitrary bytes; as f16 texels 0xffff is a NaN)
-    for (int y = 0; y < h; y++) memcpy(p.buf.data() + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
-    p.view.ptr = p.buf.data(); p.view.pitch = pitch; p.view.w = w; p.view.h = h;
+    u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
+    if (emu_min_pitch && min_row) pitch = (min_row + 15u) & ~15u;
+    p.buf = std::make_shared<GuardBuf>();
+    p.buf->alloc((size_t)pitch * h, bpp == 8 ? 0xff : 0xcd, 16);  // (row padding: arbitrary bytes; as f16 texels 0xffff is a NaN)
+    for (int y = 0; y < h; y++) memcpy(p.buf->ptr + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
+    p.view.ptr = p.buf->ptr; p.view.pitch = pitch; p.view.w = w; p.view.h = h;
     return p;
 }
 
 struct Band {
-    std::vector<u8> mem;
+    GuardBuf mem;
     void *meta;
     uint4 *frag;
     int K, nks, n_units;
@@ -76,8 +82,8 @@ Band build_band(float scale, float offset, int n_dst, int n_src, int axis) {
     B.n_units = axis == 2 ? (n_tiles + 1) / 2 : n_tiles;
     const size_t meta_bytes = ((size_t)B.n_units * (axis != 3 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
     const size_t frags = axis != 3 ? (size_t)B.n_units * 2 * B.K * 2 : (size_t)B.n_units * B.K * 2;
-    B.mem.assign(meta_bytes + frags * 64 * sizeof(uint4) + 32, 0);
-    u8 *base = (u8 *)(((uintptr_t)B.mem.data() + 15) & ~(uintptr_t)15);
+    B.mem.alloc(meta_bytes + frags * 64 * sizeof(uint4), 0, 16);
+    u8 *base = B.mem.ptr;
     B.meta = base;
     B.frag = (uint4 *)(base + meta_bytes);
     WWBatch args;
@@ -136,11 +142,14 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     const bool rgb12 = nv12 == 6;              // y = the node texture as RGB12 (12 bytes per four pixels; sw a multiple of 4): the 8192 + 131072 builds
     const bool rgba = nv12 == 2 || f16 || alpha || rgb12;   // y = the RGBA8 node texture (alpha 255), u / v ignored: the kernel's 8192 builds
     if (rgba) nv12 = 0;
-    Plane py = rgb12 ? make_plane(y, 3 * sw, sh, 1) : make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1);
+    const u32 sw4 = ((u32)sw + 3u) & ~3u;  // (a node's rows hold whole groups of four texels)
+    Plane py = rgb12 ? make_plane(y, 3 * sw, sh, 1, 3 * sw4) : make_plane(y, sw, sh, f16 ? 8 : rgba ? 4 : 1, rgba ? sw4 * (f16 ? 8u : 4u) : 0u);
     if (rgb12) py.view.w = sw;
     Plane pu = rgba ? py : (nv12 ? make_plane(u, sw / 2, sh / 2, 2) : make_plane(u, sw / 2, sh / 2, 1));
     Plane pv = (nv12 || rgba) ? pu : make_plane(v, sw / 2, sh / 2, 1);
-    std::vector<u8> tile((size_t)(((size_t)dw * 4 + 255) & ~(size_t)255) * dh + 64, 0x5a);
+    const u32 tile_pitch = emu_min_pitch ? (u32)(((size_t)dw * 4 + 15) & ~(size_t)15) : (u32)(((size_t)dw * 4 + 255) & ~(size_t)255);
+    GuardBuf tile;
+    tile.alloc((size_t)tile_pitch * dh, 0x5a, 16);
     const bool single = specialised == 3;  // one tile per unit (axis 4 bands): windows too wide for a pair; generic builds
     if (single) specialised = 0;
     Band bh = build_band(scale_h, off_h, dw, sw, single ? 4 : 2), bv = build_band(scale_v, off_v, dh, sh, 3);
@@ -156,8 +165,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     WJob &J = args.jobs[0];
     J.yp = py.view; J.up = pu.view; J.vp = nv12 ? pu.view : pv.view;
     if (nv12) { J.up.w = sw / 2; J.vp = J.up; }
-    J.dst.ptr = (u8 *)(((uintptr_t)tile.data() + 15) & ~(uintptr_t)15);
-    J.dst.pitch = (u32)(((size_t)dw * 4 + 255) & ~(size_t)255); J.dst.w = dw; J.dst.h = dh;
+    J.dst.ptr = tile.ptr;
+    J.dst.pitch = tile_pitch; J.dst.w = dw; J.dst.h = dh;
     J.src_w = sw; J.src_h = sh;
     J.conv = m_conv_constants(full_range != 0);
     J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.NKS = bh.K; J.n_pairs = bh.n_units;

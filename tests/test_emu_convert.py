@@ -5,6 +5,7 @@ kernel itself to the WGSL-pass kernels and to the oracle on the device."""
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -25,7 +26,7 @@ def emu():
     out_dir = os.path.join(EMU, "_build")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libsmr_emu_convert.so")
-    srcs = [os.path.join(EMU, "emu_convert.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_convert_420.h"),
+    srcs = [os.path.join(EMU, "emu_convert.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(EMU, "emu_guard.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_convert_420.h"),
             os.path.join(ROOT, "smelter_amd/csrc/smr_convert_dev.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
         cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function", "-I", os.path.join(EMU, "shim"),
@@ -38,6 +39,8 @@ def emu():
     PP8, PI = C.POINTER(P8), C.POINTER(C.c_int)
     h.emu_convert_420_shares.argtypes = [C.c_int, PP8, PP8, PP8, PI, PI, C.c_int, PI, PI, C.c_int, PP8]
     orc.build()
+    if os.environ.get("SMR_EMU_GUARD"):  # the inner run of test_converter_never_leaves_its_planes: planes of exactly pitch * h bytes against an unmapped page
+        h.emu_set_guard(int(os.environ["SMR_EMU_GUARD"]), 1)
     return h
 
 
@@ -153,3 +156,18 @@ def test_a_launch_cut_into_equal_shares_writes_the_oracles_bytes(emu, nv, waves)
         if r12:
             got = np.concatenate([got.reshape(h, w // 4, 3, 4).transpose(0, 1, 3, 2).reshape(h, w, 3), np.full((h, w, 1), 255, np.uint8)], -1)
         assert np.array_equal(got, want), (w, h, waves, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_converter_never_leaves_its_planes(emu, mode):
+    """The memory contract of include/smr.h (smr_surface_wrap): an allocation covers pitch * h bytes and no kernel touches a byte outside it.
+    The tests above once more in a child process, with every plane and node texture exactly pitch * h bytes — on the SMALLEST pitch the host
+    code lets through (conv_420_ok: the reach of the last block's dword loads) — ending at (mode 1) or starting behind (mode 2) an unmapped
+    page: a load or store outside the allocation kills the child.  Prefetches included: a run requests nothing behind its last block."""
+    if os.environ.get("SMR_EMU_GUARD"):
+        pytest.skip("this is the inner run")
+    env = dict(os.environ, SMR_EMU_GUARD=str(mode))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "block_converter or runs_of_blocks or equal_shares"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, f"guard mode {mode}: rc {r.returncode} (-11 = a kernel left its planes)\n{r.stdout[-3000:]}\n{r.stderr[-2000:]}"
+    assert " passed" in r.stdout

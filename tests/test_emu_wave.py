@@ -26,7 +26,7 @@ def emu():
     out_dir = os.path.join(EMU, "_build")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libsmr_emu.so")
-    srcs = [os.path.join(EMU, "emu_wave.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_wave.h"),
+    srcs = [os.path.join(EMU, "emu_wave.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(EMU, "emu_guard.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_wave.h"),
             os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_common.h")]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
         cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function", "-I", os.path.join(EMU, "shim"),
@@ -38,6 +38,8 @@ def emu():
                                   C.c_int, C.c_int, C.POINTER(C.c_int)]
     h.emu_check_encode.restype = C.c_longlong
     orc.build()
+    if os.environ.get("SMR_EMU_GUARD"):  # the inner run of test_resampler_never_leaves_its_surfaces
+        h.emu_set_guard(int(os.environ["SMR_EMU_GUARD"]), 1)
     return h
 
 
@@ -334,3 +336,21 @@ def test_emulated_single_tile_units_for_wide_windows(emu, kind):
     assert info[1] <= 8, list(info)
     d = np.abs(got.astype(np.int16) - want.astype(np.int16))
     assert d.max() <= 1 and (d == 0).mean() >= 0.9995, (d.max(), (d == 0).mean())
+
+
+def test_resampler_never_leaves_its_surfaces(emu):
+    """The memory contract of include/smr.h (smr_surface_wrap) for k_ingest_wave's node-texture builds (RGBA8, RGB12, alpha, RGBA16F, single
+    axis, single-tile units): the tests above once more in child processes with node textures, tiles and weight bands of exactly pitch * h
+    bytes — node and tile on the SMALLEST pitch can_fuse_wave_rgba lets through (16-byte multiples holding the row rounded up to four
+    texels) — ending at (mode 1) or starting behind (mode 2) an unmapped page: a 16-byte load of the last texel group that reached past the
+    row's pitch, a window clamped a row too late, a store beyond the tile would kill the child."""
+    import sys
+    if os.environ.get("SMR_EMU_GUARD"):
+        pytest.skip("this is the inner run")
+    children = {mode: subprocess.Popen([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
+                                        "not one_gather and not matches_the_oracle"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                       env=dict(os.environ, SMR_EMU_GUARD=str(mode)), cwd=ROOT) for mode in (1, 2)}
+    for mode, child in children.items():
+        out, err = child.communicate(timeout=1500)
+        assert child.returncode == 0, f"guard mode {mode}: rc {child.returncode} (-11 = the kernel left its surfaces)\n{out[-3000:]}\n{err[-2000:]}"
+        assert " passed" in out
