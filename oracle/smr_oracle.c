@@ -17,12 +17,12 @@
  * un-vendored submodule) is held to an INDEPENDENT witness instead — f64 NumPy written from the shader sources in
  * tests/test_witness.py, sharing no function with this file: closed-form Lanczos3 of the reference's multiscale grid (3:1, 1.5:1,
  * mixed), straight-edge coverage at 1/4, 1/2, 3/4-pixel offsets, rounded corners with four radii, colour and texture borders,
- * box-shadow falloff, a product of 20 parent masks, premultiplied OVER on the 8-bit sRGB target: this file is within 1 LSB of
- * the witness on every byte of those pictures.  STILL "PARITY UNPINNED", to the last bit: where the reference's own f32
- * arithmetic, its RGBA16F intermediate and its sampler's sub-texel weights decide a rounding (wgpu / Vulkan leave them
- * implementation-defined; the choices made here are listed below), rotated layouts and bilinear sampling of non-uniform
- * textures at fractional positions (pinned by the oracle <-> Pillow / oracle <-> kernel agreement only), and every TEXT pixel
- * (glyphon / cosmic-text / swash are not in the reference tree).  The <= 1 LSB contract of BASELINE.json is therefore
+ * box-shadow falloff, a product of 20 parent masks, premultiplied OVER on the 8-bit sRGB target, rotated rects / shadows /
+ * borders (the vertex stage in exact arithmetic), a smooth texture sampled through a crop at fractional positions, under
+ * non-uniform scale and rotation: this file is within 1 LSB of the witness on every byte of those pictures.  STILL "PARITY
+ * UNPINNED", to the last bit: where the reference's own f32 arithmetic, its RGBA16F intermediate and its sampler's sub-texel
+ * weights decide a rounding (wgpu / Vulkan leave them implementation-defined; the choices made here are listed below), and
+ * every TEXT pixel (glyphon / cosmic-text / swash are not in the reference tree).  The <= 1 LSB contract of BASELINE.json is therefore
  * a statement about this restatement, not a bit-identity with a wgpu run.
  *
  * Arithmetic conventions:

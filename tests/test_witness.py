@@ -2,7 +2,8 @@
 border / shadow scenes live in an un-vendored submodule): f64 NumPy written here from the reference's shader sources, sharing no function
 with oracle/smr_oracle.c — closed-form Lanczos3 weights (resample.wgsl:31-87), the IEC 61966-2-1 transfer functions as formulas (not the
 oracle's tables), rounded-rectangle distance, edge / border / shadow smoothsteps and the parent-mask product (apply_layouts.wgsl:246-377),
-premultiplied OVER on an 8-bit sRGB target (common_pipeline.rs:125).  The oracle is asserted to be within 1 LSB of the witness on every
+premultiplied OVER on an 8-bit sRGB target (common_pipeline.rs:125), the vertex stage's rotation and texture-coordinate transforms with an
+exact-weight bilinear sampler (:127-229).  The oracle is asserted to be within 1 LSB of the witness on every
 byte; the GPU tests then hold the kernels to the oracle.  What this does NOT pin: the last bit where the reference's own f32 arithmetic, its
 f16 intermediate and its sampler's sub-texel weights decide a rounding — the witness computes the exact-arithmetic picture."""
 import numpy as np
@@ -232,3 +233,129 @@ def test_a_product_of_twenty_parent_masks():
                               dict(kind=1, left=20.25, top=10.5, width=30.0, height=30.0, radius=(15.0,) * 4, rgba=(20, 20, 240, 180), masks=masks[:7])])
     assert 0 < want[..., 3].min() + 1 and want[32, 40, 3] == 255 and want[0, 0, 3] == 0
     assert len(np.unique(want[..., 3])) > 20  # partial coverages along the innermost masks' edges
+
+
+# ---- rotated quads and a sampled (non-uniform) texture: the vertex stage of apply_layouts.wgsl:127-229 in exact arithmetic
+def witness_fragments_rotated(W, H, kind, left, top, width, height, rot_deg, radius, colour=None, border_width=0.0, border_colour=None, blur=0.0,
+                              texture8=None, crop=None):
+    """One layout rotated by rot_deg.  vertices_transformation_matrix (:127-157): the unit quad scaled to the rect's half size, rotated by
+    [[c, -s], [s, c]] in the y-UP pixel frame, moved to the rect's centre.  A pixel centre (px, py) (y down) is at (dx, dy) = (px - cx, cy - py)
+    from that centre in the y-up frame; its position in the rect's own frame — what the varying `center_position` (:197, 210, 227)
+    interpolates to — is R(-angle) (dx, dy); the pixel is drawn iff that lies inside the (shadow: blur-grown) rect.  tex_coords (:160-173,
+    190-196): u = x / w + 1/2, v = 1/2 - y / h, through the crop into texel space; textureSample = bilinear at (u dim - 1/2), clamp to edge,
+    on the sRGB-decoded texels (Rgba8UnormSrgb view) — exact weights here, 8-bit sub-texel weights in hardware: the textures used are smooth."""
+    ys, xs = np.mgrid[0:H, 0:W]
+    px, py = xs + 0.5, ys + 0.5
+    g = blur if kind == 2 else 0.0
+    qw, qh = width + 2.0 * g, height + 2.0 * g
+    a = np.deg2rad(rot_deg)
+    c, s = np.cos(a), np.sin(a)
+    dx, dy = px - (left + width / 2.0), (top + height / 2.0) - py
+    lx, ly = c * dx + s * dy, -s * dx + c * dy
+    inside = (np.abs(lx) < qw / 2.0) & (np.abs(ly) < qh / 2.0)  # (generic angles: no centre sits on an edge)
+    edge = -rounded_rect_sdf(lx, ly, width, height, radius)
+    if kind == 0:
+        th, tw = texture8.shape[:2]
+        ctop, cleft, cw, ch = crop
+        u, v = lx / qw + 0.5, 0.5 - ly / qh
+        sx, sy = (cleft + u * cw) - 0.5, (ctop + v * ch) - 0.5   # (u' dim - 1/2 with u' = (crop_left + u crop_w) / dim)
+        x0, y0 = np.floor(sx), np.floor(sy)
+        fx, fy = sx - x0, sy - y0
+        lin = np.concatenate([srgb_to_linear(texture8[..., :3] / 255.0), texture8[..., 3:] / 255.0], -1)
+        def tap(xi, yi):
+            return lin[np.clip(yi, 0, th - 1).astype(int), np.clip(xi, 0, tw - 1).astype(int)]
+        sample = (tap(x0, y0) * ((1 - fx) * (1 - fy))[..., None] + tap(x0 + 1, y0) * (fx * (1 - fy))[..., None] +
+                  tap(x0, y0 + 1) * ((1 - fx) * fy)[..., None] + tap(x0 + 1, y0 + 1) * (fx * fy)[..., None])
+        if border_width < 1.0:
+            frag = sample * smoothstep(-0.5, 0.5, edge)[..., None]
+        else:
+            bc = np.asarray(border_colour, np.float64)
+            t = smoothstep(border_width - 0.5, border_width + 0.5, edge)[..., None]
+            inner = bc[None, None, :] * (1.0 - t) + sample * t
+            outer = bc[None, None, :] * smoothstep(-0.5, 0.5, edge)[..., None]
+            frag = np.where((edge > border_width / 2.0)[..., None], inner, outer)
+    elif kind == 2:
+        frag = np.asarray(colour, np.float64)[None, None, :] * smoothstep(-blur / 2.0, blur / 2.0, edge)[..., None]
+    elif border_width < 1.0:
+        frag = np.asarray(colour, np.float64)[None, None, :] * smoothstep(-0.5, 0.5, edge)[..., None]
+    else:
+        bc, col = np.asarray(border_colour, np.float64), np.asarray(colour, np.float64)
+        t = smoothstep(border_width, border_width + 1.0, edge)[..., None]
+        inner = bc[None, None, :] * (1.0 - t) + col[None, None, :] * t
+        outer = bc[None, None, :] * smoothstep(-0.5, 0.5, edge)[..., None]
+        frag = np.where((edge > border_width / 2.0)[..., None], inner, outer)
+    return np.where(inside[..., None], frag, 0.0)
+
+
+def _check_rotated(W, H, specs, exact_share=0.97):
+    target = np.zeros((H, W, 4), np.int64)
+    layouts, sources = [], []
+    for s in specs:
+        tex = s.get("texture")
+        if tex is not None:
+            sources.append(tex)
+        frag = witness_fragments_rotated(W, H, s["kind"], s["left"], s["top"], s["width"], s["height"], s.get("rot", 0.0), s.get("radius", (0.0,) * 4),
+                                         shader_colour(s["rgba"]) if "rgba" in s else None, s.get("border_width", 0.0),
+                                         shader_colour(s.get("border_rgba", (0, 0, 0, 0))), s.get("blur", 0.0), tex, s.get("crop"))
+        target = witness_over(target, frag)
+        layouts.append(orc.Layout(top=s["top"], left=s["left"], width=s["width"], height=s["height"], rotation_degrees=s.get("rot", 0.0), type=s["kind"],
+                                  source_index=len(sources) - 1 if tex is not None else 0xFFFFFFFF, crop=tuple(s.get("crop", (0.0,) * 4)),
+                                  border_radius=tuple(s.get("radius", (0.0,) * 4)), color=orc.color_to_shader(s.get("rgba", (0, 0, 0, 0)), True),
+                                  border_color=orc.color_to_shader(s.get("border_rgba", (0, 0, 0, 0)), True), border_width=s.get("border_width", 0.0),
+                                  blur_radius=s.get("blur", 0.0)))
+    got = orc.apply_layouts(W, H, layouts, sources, srgb=True).astype(np.int64)
+    d = np.abs(got - target)
+    assert d.max() <= 1, (int(d.max()), np.argwhere(d > 1)[:6].tolist())
+    assert (d == 0).mean() > exact_share, float((d == 0).mean())
+    return got, target
+
+
+def _smooth_texture(w, h, alpha=False):
+    """sRGB bytes that change by at most three codes per texel (so the sampler's 8-bit sub-texel weights stay far below one code);
+    with `alpha`: a premultiplied texture whose alpha falls from 255 to 90 across it."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    t = np.stack([40 + 2 * xx, 215 - 3 * yy, 90 + xx + yy, np.full_like(xx, 255)], -1).astype(np.float64)
+    if alpha:
+        a = 255.0 - 165.0 * (xx + yy) / (w + h - 2)
+        t = np.stack([t[..., 0] * a / 255.0 * 0.9, t[..., 1] * a / 255.0 * 0.9, t[..., 2] * a / 255.0 * 0.9, a], -1)
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+
+def test_rotated_rects_shadows_and_borders_match_the_closed_forms():
+    """Rotation (LayoutNode's rotation_degrees: view.rs `rotation`, apply_layouts.wgsl:94-106, 127-157): four different corner radii under
+    17.3 degrees — the corner a radius belongs to turns with the rect —, a bordered translucent rect under -64 degrees over it, a shadow
+    under 120 degrees.  The quad's coverage, the SDF in the rect's own frame and the blend against the exact-arithmetic picture."""
+    W, H = 120, 100
+    specs = [
+        dict(kind=2, left=30.0, top=28.0, width=60.0, height=36.0, rot=120.0, radius=(10.0,) * 4, blur=10.0, rgba=(0, 0, 0, 200)),
+        dict(kind=1, left=22.5, top=20.25, width=70.0, height=44.0, rot=17.3, radius=(16.0, 3.0, 21.0, 0.0), rgba=(40, 120, 220, 255)),
+        dict(kind=1, left=48.0, top=30.0, width=52.5, height=38.25, rot=-64.0, radius=(9.0,) * 4, rgba=(250, 200, 40, 190), border_width=3.0,
+             border_rgba=(255, 255, 255, 255)),
+    ]
+    got, want = _check_rotated(W, H, specs)
+    # the picture is really a rotated one: the same rects unrotated cover other pixels, and turned the other way round yet others
+    def witness_only(specs):
+        target = np.zeros((H, W, 4), np.int64)
+        for s in specs:
+            target = witness_over(target, witness_fragments_rotated(W, H, s["kind"], s["left"], s["top"], s["width"], s["height"], s["rot"], s["radius"],
+                                                                    shader_colour(s["rgba"]), s.get("border_width", 0.0),
+                                                                    shader_colour(s.get("border_rgba", (0, 0, 0, 0))), s.get("blur", 0.0)))
+        return target
+    assert np.array_equal(witness_only(specs), want)
+    flat, mirrored = witness_only([dict(s, rot=0.0) for s in specs]), witness_only([dict(s, rot=-s["rot"]) for s in specs])
+    assert ((want[..., 3] > 0) != (flat[..., 3] > 0)).mean() > 0.04 and ((want[..., 3] > 0) != (mirrored[..., 3] > 0)).mean() > 0.04
+    assert len(np.unique(want[..., 3])) > 40
+
+
+def test_a_sampled_texture_scaled_cropped_and_rotated_matches_the_closed_form():
+    """textureSample through the crop (texture_coord_transformation_matrix, :160-173): a smooth 80 x 48 texture's 64.5 x 37 crop drawn 90 x 50
+    (non-uniform scale, fractional position — what a layout in transition samples), the same under -32 degrees with rounded corners and a
+    border, and a premultiplied texture with an alpha ramp: bilinear in linear light on decoded texels, exact weights."""
+    W, H = 128, 96
+    tex = _smooth_texture(80, 48)
+    _check_rotated(W, H, [dict(kind=0, left=11.3, top=7.6, width=90.0, height=50.0, texture=tex, crop=(5.25, 9.5, 64.5, 37.0))], exact_share=0.9)
+    _check_rotated(W, H, [dict(kind=0, left=20.0, top=22.0, width=84.0, height=48.0, rot=-32.0, radius=(12.0, 0.0, 7.0, 20.0), texture=tex,
+                               crop=(0.0, 0.0, 80.0, 48.0), border_width=2.0, border_rgba=(255, 255, 0, 255))], exact_share=0.9)
+    _check_rotated(W, H, [dict(kind=1, left=0.0, top=0.0, width=128.0, height=96.0, rgba=(30, 60, 90, 255)),
+                          dict(kind=0, left=16.5, top=12.25, width=96.0, height=64.0, rot=8.0, texture=_smooth_texture(64, 40, alpha=True),
+                               crop=(0.0, 0.0, 64.0, 40.0))], exact_share=0.9)
