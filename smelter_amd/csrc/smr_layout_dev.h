@@ -10,6 +10,9 @@
 //   * sqrt(m*m) == m, and (x - e0) / 1 == x - e0.
 #pragma once
 
+#include <algorithm>
+#include <cmath>
+
 #include "smr_internal.h"
 
 constexpr int LAYOUT_TILE_W = 32;
@@ -69,6 +72,127 @@ struct PackedLayouts {
     void *extra_dev = nullptr;
     size_t copy_bytes = 0;
 };
+
+// One layout of the POD list in the compact device form (rotation, quad and bounding box precomputed on the host in f32, as the vertex stage
+// does per draw: apply_layouts.wgsl:127-157; the classification helpers of the fused compositor).  Host code: smr_pack_layouts and — so that
+// the compositor kernels can be run on the CPU against the oracle — the lane emulator of tests/emu.  `thr`: the context's sRGB encode
+// thresholds (tables + 256); `hm` / `mo`: the mask array and the next free entry in it.
+inline void smr_pack_one_layout(const smr_layout &L, const SurfView *src_views, const int *src_kind, u32 n_sources, int out_w, int out_h, bool srgb,
+                                const float *thr, DevLayout &D, DevMask *hm, u32 &mo) {
+    const float DEG = 0.017453292519943295f;
+    memset(&D, 0, sizeof(D));
+    D.top = L.top; D.left = L.left; D.width = L.width; D.height = L.height;
+    for (int k = 0; k < 4; k++) {
+        D.radius[k] = L.border_radius[k];
+        D.color[k] = L.color[k];
+        D.border_color[k] = L.border_color[k];
+        D.crop[k] = L.crop[k];
+    }
+    D.type = L.type;
+    D.border_width = L.border_width;
+    D.blur = L.blur_radius;
+    D.masks_off = mo;
+    D.masks_len = L.masks_len > SMR_MAX_MASKS ? SMR_MAX_MASKS : L.masks_len;
+    for (u32 m = 0; m < D.masks_len; m++) {
+        const smr_mask &K = L.masks[m];
+        DevMask &DM = hm[mo++];
+        memset(&DM, 0, sizeof(DM));
+        for (int k = 0; k < 4; k++) DM.radius[k] = K.radius[k];
+        DM.top = K.top; DM.left = K.left; DM.width = K.width; DM.height = K.height;
+        // solid region of smoothstep(-.5, .5, -sdf): the rect inset by .5 minus the four corner squares of side max radius
+        // (+ rounding slack unless every quantity is a multiple of 1/2 below 2^15: then each f32 operation of the SDF is exact)
+        const float mr = fmaxf(fmaxf(K.radius[0], K.radius[1]), fmaxf(K.radius[2], K.radius[3]));
+        auto hi = [](float v) { return v * 2.0f == floorf(v * 2.0f) && fabsf(v) < 32768.0f; };
+        const bool mexact = hi(K.radius[0]) && hi(K.radius[1]) && hi(K.radius[2]) && hi(K.radius[3]) && hi(K.left) && hi(K.top) &&
+                            hi(K.width) && hi(K.height);
+        const float mslack = mexact ? 0.0f : 0.015625f;
+        DM.inset = 0.5f + mslack;
+        DM.corner = (mr + mslack > DM.inset) ? mr + mslack : 0.0f;
+    }
+    float qleft = L.left, qtop = L.top, qw = L.width, qh = L.height;
+    if (L.type == 2) {  // box shadow quad grown by blur on each side (apply_layouts.wgsl:216-229)
+        qleft = L.left - L.blur_radius; qtop = L.top - L.blur_radius;
+        qw = L.width + 2.0f * L.blur_radius; qh = L.height + 2.0f * L.blur_radius;
+    }
+    D.qw = qw; D.qh = qh;
+    D.cx = qleft + qw / 2.0f; D.cy = qtop + qh / 2.0f;
+    float ang = L.rotation_degrees * DEG;
+    D.cs = cosf(ang); D.sn = sinf(ang);
+    D.src_kind = 0;
+    D.tex_w = 1; D.tex_h = 1;
+    D.src_index = -1;
+    if (L.type == 0 && L.source_index < n_sources && src_kind[L.source_index] != 0) {
+        D.src = src_views[L.source_index];
+        D.src_kind = src_kind[L.source_index];
+        D.tex_w = D.src.w; D.tex_h = D.src.h;
+        D.src_index = (int)L.source_index;
+    }
+    D.rqw = 1.0f / D.qw; D.rqh = 1.0f / D.qh;
+    D.rtw = 1.0f / (float)D.tex_w; D.rth = 1.0f / (float)D.tex_h;
+    // ---- classification helpers for the fused compose kernel
+    D.flags = (D.cs == 1.0f && D.sn == 0.0f) ? DL_UNROTATED : 0;
+    // Solid region: inside the rect inset by m >= radius on every side the SDF is <= -m, i.e. edge_distance >= m.
+    // m must also reach the point where every smoothstep saturates at exactly 1:
+    //   no border: smoothstep(-.5,.5,ed) -> ed >= .5;  texture border: smoothstep(bw-.5,bw+.5,ed) -> ed >= bw+.5;
+    //   colour border: smoothstep(bw,bw+1,ed) -> ed >= bw+1;  shadow: smoothstep(-b/2,b/2,ed) -> ed >= b/2.
+    float rmax = fmaxf(fmaxf(L.border_radius[0], L.border_radius[1]), fmaxf(L.border_radius[2], L.border_radius[3]));
+    float need = 0.5f;
+    if (L.type == 2) need = fmaxf(L.blur_radius / 2.0f, 0.5f);  // >= .5 keeps the region inside the half-open quad coverage
+    else if (L.border_width >= 1.0f) need = L.border_width + (L.type == 0 ? 0.5f : 1.0f);
+    // Outside the four corner squares (side = max radius) the SDF is the plain distance to the nearest straight edge
+    // (smr_layout_dev.h, rect_solid_box), so only those squares and the `need` band along the edges are not solid.
+    auto half_int = [](float v) { return v * 2.0f == floorf(v * 2.0f) && fabsf(v) < 32768.0f; };
+    const bool exact = half_int(L.border_radius[0]) && half_int(L.border_radius[1]) && half_int(L.border_radius[2]) &&
+                       half_int(L.border_radius[3]) && half_int(L.left) && half_int(L.top) && half_int(L.width) && half_int(L.height) &&
+                       half_int(need) && half_int(qleft) && half_int(qw) && half_int(qtop) && half_int(qh);
+    const float slack = exact ? 0.0f : 0.015625f;  // 1/64 px for f32 rounding in the SDF
+    D.inset = need + slack;
+    D.corner = (rmax + slack > D.inset) ? rmax + slack : 0.0f;
+    if (L.type == 0 && D.src_kind != 0 && (D.flags & DL_UNROTATED) && L.crop[0] == 0.0f && L.crop[1] == 0.0f &&
+        L.crop[2] == (float)D.tex_w && L.crop[3] == (float)D.tex_h && L.width == (float)D.tex_w && L.height == (float)D.tex_h &&
+        L.left == floorf(L.left) && L.top == floorf(L.top) && fabsf(L.left) < 65536.0f && fabsf(L.top) < 65536.0f) {
+        D.flags |= DL_ALIGNED;
+        D.ix = (int)L.left;
+        D.iy = (int)L.top;
+    }
+    if (L.type != 0 && L.color[3] == 1.0f) {
+        D.flags |= DL_COLOR_OPAQUE;
+                auto enc = [&](float x) -> u32 {
+            if (srgb) {
+                if (!(x > 0.0f)) return 0u;
+                return (u32)(std::upper_bound(thr + 1, thr + 256, x) - (thr + 1));  // #{i in 1..255 : thr[i] <= x}
+            }
+            x = !(x > 0.0f) ? 0.0f : (x > 1.0f ? 1.0f : x);
+            return (u32)(int)(x * 255.0f + 0.5f);
+        };
+        D.solid_px = enc(L.color[0]) | (enc(L.color[1]) << 8) | (enc(L.color[2]) << 16) | (255u << 24);
+    }
+    const bool finite = std::isfinite(qleft) && std::isfinite(qtop) && std::isfinite(qw) && std::isfinite(qh) && std::isfinite(D.cs) &&
+                        std::isfinite(D.sn);
+    if (!(qw > 0.0f) || !(qh > 0.0f) || L.type > 2 || !finite) {
+        // (a quad with a NaN / infinite corner rasterises to nothing; it must not reach the float -> int conversions below)
+        D.bx0 = D.by0 = 0; D.bx1 = D.by1 = -1;  // never binned
+    } else if (D.flags & DL_UNROTATED) {
+        // pixel x is covered iff qleft <= x + .5 < qleft + qw (layout_covers), i.e. qleft - .5 <= x < qleft + qw - .5.
+        // Tight bounds matter: a one-pixel margin makes every neighbour of a tile-aligned rect "touch" the next tile column.
+        // 1/64 px of slack unless the quad is on half-integers (then the coverage arithmetic is exact in f32).
+        const float s = (half_int(qleft) && half_int(qtop) && half_int(qw) && half_int(qh)) ? 0.0f : 0.015625f;
+        auto clampi_h = [](float v, int lo, int hi) { return v < (float)lo ? lo : (v > (float)hi ? hi : (int)v); };
+        D.bx0 = clampi_h(ceilf(qleft - 0.5f - s), 0, out_w);
+        D.bx1 = clampi_h(ceilf(qleft + qw - 0.5f + s), 0, out_w);
+        D.by0 = clampi_h(ceilf(qtop - 0.5f - s), 0, out_h);
+        D.by1 = clampi_h(ceilf(qtop + qh - 0.5f + s), 0, out_h);
+    } else {
+        float ex = fabsf(D.cs) * qw / 2.0f + fabsf(D.sn) * qh / 2.0f;
+        float ey = fabsf(D.sn) * qw / 2.0f + fabsf(D.cs) * qh / 2.0f;
+        auto clampi_h = [](float v, int lo, int hi) { return v < (float)lo ? lo : (v > (float)hi ? hi : (int)v); };
+        D.bx0 = clampi_h(floorf(D.cx - ex - 1.0f), 0, out_w);
+        D.bx1 = clampi_h(ceilf(D.cx + ex + 1.0f), 0, out_w);
+        D.by0 = clampi_h(floorf(D.cy - ey - 1.0f), 0, out_h);
+        D.by1 = clampi_h(ceilf(D.cy + ey + 1.0f), 0, out_h);
+    }
+
+}
 
 int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfView *src_views, const int *src_kind,
                      u32 n_sources, int out_w, int out_h, size_t extra_bytes, PackedLayouts *out);

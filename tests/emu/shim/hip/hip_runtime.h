@@ -49,3 +49,19 @@ typedef void *hipEvent_t;
 typedef int hipError_t;
 enum { hipSuccess = 0 };
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+
+// what the compositor kernels use beyond the above (tests/emu/emu_compose.cpp): LDS / global atomics between a workgroup's host threads,
+// the 24-bit multiply, count-leading-zeros, and the scalar broadcast (callers pass wave-uniform values)
+template <typename T>
+static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+template <typename T>
+static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+template <typename T>
+static inline T atomicMax(T *p, T v) {
+    T old = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return old;
+}
+static inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
+#define __builtin_amdgcn_readfirstlane(x) (x)
