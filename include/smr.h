@@ -384,7 +384,10 @@ SMR_API int smr_fontbook_add_memory(smr_fontbook *book, const uint8_t *data, siz
 SMR_API int smr_fontbook_add_dir(smr_fontbook *book, const char *dir);                       /* every *.ttf below dir, by path; returns how many, < 0 if none */
 SMR_API uint32_t smr_fontbook_count(const smr_fontbook *book);
 /* lays params->text out at font_size with params->wrap inside max_width; widest line (pixels) and line count — the signature of
- * smr_text_measure_fn with `user` = the font book */
+ * smr_text_measure_fn with `user` = the font book.  Refused (SMR_ERR_INVALID, message in smr_fontbook_last_error): text that is not UTF-8,
+ * font_size outside (0, 100000] or not finite, a line_height that is not finite; smr_fontbook_add_* refuse a face whose tables do not
+ * hold together (directory, head / hhea / maxp / hmtx / cmap / loca / glyf bounds, unitsPerEm outside 16 .. 16384).  Fonts and text
+ * are untrusted input: tests/san drives this API with corrupted faces under AddressSanitizer. */
 SMR_API int smr_fontbook_measure(void *book, const smr_text_params *params, float *widest_line, uint32_t *line_count);
 /* the glyph run of a Text node of width x height pixels for smr_blit_glyphs / smr_renderer_set_text; `color` = straight RGBA 0..1 */
 SMR_API int smr_fontbook_rasterise(smr_fontbook *book, const smr_text_params *params, uint32_t width, uint32_t height, const float color[4],
