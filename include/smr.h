@@ -221,7 +221,7 @@ SMR_API int smr_profile_reset(smr_ctx *ctx);
 typedef enum smr_kernel_id {
     SMR_KERNEL_INGEST_WAVE = 0,      /* k_ingest_wave with the fused conversion (laboratory builds only: always 0 in a product build) */
     SMR_KERNEL_INGEST_WAVE_RGBA = 1, /* k_ingest_wave on an RGBA8 / box-reduced RGBA16F node texture (every frame after smr_frame_to_rgba; surfaces) */
-    SMR_KERNEL_INGEST_MFMA_WG = 2,   /* (retired: always 0) */
+    SMR_KERNEL_FRAME_TO_RGBA_420 = 2, /* k_yuv420_to_rgba, the 4:2:0 planar / NV12 block converter: its launches (counted by FRAME_TO_RGBA as well) */
     SMR_KERNEL_INGEST_VALU = 3,      /* k_ingest_resample: fused conversion + Lanczos, every pass in f32 */
     SMR_KERNEL_RESAMPLE_GENERAL = 4, /* smr_resample on a node texture: box pre-reduction and one or two Lanczos pass kernels */
     SMR_KERNEL_FRAME_TO_RGBA = 5,    /* the input converters (InputTexture::convert_to_node_texture): launches — a block-converter launch takes up to 16 frames */
@@ -236,7 +236,11 @@ SMR_API int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t fo
 /* Device memory the caller owns (a decoder's output, a torch tensor) as a surface, in place.  The allocation must cover pitch * h bytes —
  * every row backed out to the full pitch, the LAST ONE TOO: the block kernels read whole dwords, up to a dword past a row's last texel
  * (never past the pitch).  pitch >= w * bytes per texel; rows and the base 4-byte aligned for the block converters, 16-byte aligned for the
- * matrix-core resampler's node textures (other alignments take the general kernels). */
+ * matrix-core resampler's node textures (other alignments take the general kernels).  One more thing for wrapped 4:2:0 / NV12 CHROMA
+ * planes: the block converter also reads (and ignores) the dword after the last block's chroma window, so a plane whose rows FILL their pitch
+ * (bytes per row a multiple of the pitch: 720p or 4K NV12 on a 256-byte pitch, planar frames 512 / 1024 / 2048 / 4096 wide) is converted by the
+ * general kernel — same bytes, slower — unless the pitch leaves 4 bytes after the row.  Planes the library allocates never take that detour:
+ * every allocation of smr_surface_create / smr_frame_create ends with 16 spare bytes. */
 SMR_API int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
                              smr_surface **out);
 SMR_API void smr_surface_destroy(smr_ctx *ctx, smr_surface *s);

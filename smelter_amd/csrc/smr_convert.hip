@@ -481,7 +481,9 @@ static bool conv_batchable(const smr_ctx *ctx, const smr_frame *in) {
 }
 
 // k_yuv420_to_rgba's frames (cv420_block, smr_convert_420.h): 4:2:0 planar / NV12, width a multiple of 4 from 8, even height, every plane
-// dword-aligned with rows that can be read one dword past a block's chroma window (every surface this library allocates: 256-byte pitch)
+// dword-aligned with chroma rows that can be read up to a dword past the last block's window.  The bytes of that dword are never used (the
+// window's last column is the plane's edge, repeated), but they are read: a plane the library allocated may be read past a row's end — the
+// next row, or the 16 bytes every allocation ends with (SMR_SURFACE_TAIL) — a wrapped one only inside its pitch.
 static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) {
     if (ctx->convert_impl != SMR_CONVERT_AUTO) return false;
     const bool nv = in->format == SMR_FRAME_NV12;
@@ -492,7 +494,8 @@ static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) {
     const u32 cw = in->width / 2;
     // the last block's window starts at chroma column cw - 3: its bytes begin in the dword at ((cw - 3) [* 2]) & ~3 and the loads reach 8 (12) bytes from there
     const u32 need = nv ? ((2u * (cw - 3u)) & ~3u) + 12u : ((cw - 3u) & ~3u) + 8u;
-    if (in->planes[1]->pitch < need || (!nv && in->planes[2]->pitch < need)) return false;
+    auto reach_ok = [&](const smr_surface *s) { return s->pitch >= need || (s->owned && s->pitch >= (nv ? 2u * cw : cw)); };
+    if (!reach_ok(in->planes[1]) || (!nv && !reach_ok(in->planes[2]))) return false;
     return in->planes[0]->pitch >= in->width;
 }
 
@@ -524,6 +527,7 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         if (!Q.nb) return SMR_OK;
         StageScope scope(ctx, SMR_STAGE_INGEST);
         ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA]++;  // (per launch)
+        if (k != 0) ctx->kernel_launches[SMR_KERNEL_FRAME_TO_RGBA_420]++;
         if (k == 0) hipLaunchKernelGGL(k_yuv_to_rgba_batch, dim3((unsigned)((Q.mw + 255) / 256), (unsigned)((Q.mh + 7) / 8), Q.nb), dim3(BLOCK), 0, ctx->stream, Q.B);
         else {
             // as many workgroups as stay resident together (6 per CU at 77 registers: convert_wg_per_cu), never more waves than units.  A dynamic LDS

@@ -62,7 +62,7 @@ smr_surface *smr_cached_surface(smr_ctx *ctx, size_t slot, u32 w, u32 h, u32 fmt
     // place while the new size fits its allocation (work on the stream is ordered, the previous frame is done with it by then)
     const u32 bpp = bytes_per_px(fmt);
     const size_t pitch = ((size_t)w * bpp + 255) & ~(size_t)255;
-    if (s && bpp && w && h && w <= 7682 * 2 && h <= 4320 * 2 && pitch * h <= s->capacity) {
+    if (s && bpp && w && h && w <= 7682 * 2 && h <= 4320 * 2 && pitch * h + SMR_SURFACE_TAIL <= s->capacity) {
         s->w = w; s->h = h; s->fmt = fmt; s->pitch = pitch;
         return s;
     }
@@ -348,7 +348,7 @@ static int surface_create_with(smr_ctx *ctx, u32 w, u32 h, u32 format, size_t he
     s->fmt = format;
     s->pitch = ((size_t)w * bpp + 255) & ~(size_t)255;
     s->owned = true;
-    s->capacity = s->pitch * h + headroom;
+    s->capacity = s->pitch * h + headroom + SMR_SURFACE_TAIL;
     hipError_t e = hipMalloc(&s->ptr, s->capacity);
     if (e != hipSuccess) {
         delete s;

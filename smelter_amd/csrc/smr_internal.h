@@ -47,12 +47,17 @@ enum {
     SMR_STAGE_FUSED_COMPOSE = 5,
 };
 
+// Every allocation of the library ends with this many spare bytes: the 4:2:0 block converter reads (and ignores) up to a dword past the last
+// chroma row's end when a row's bytes fill its pitch exactly (smr_convert.hip, conv_420_ok).
+constexpr size_t SMR_SURFACE_TAIL = 16;
+
 struct smr_surface {
     void *ptr = nullptr;
     size_t pitch = 0;
     u32 w = 0, h = 0, fmt = 0;
     bool owned = false;
     size_t capacity = 0;  // bytes behind ptr when owned (cached scratch surfaces are re-described in place while they fit)
+
 };
 
 // Device-side view of a surface.

@@ -146,7 +146,7 @@ def pack_layouts(layouts) -> "C.Array":
 
 INGEST_AUTO, INGEST_VALU_F32, INGEST_MFMA_F16, INGEST_MFMA_F16_NODE, INGEST_MFMA_F16_FUSED = 0, 1, 2, 4, 5  # (3: retired)
 CONVERT_AUTO, CONVERT_GENERAL, CONVERT_BLOCK_4X2 = 0, 1, 2
-KERNEL_NAMES = ("ingest_wave", "ingest_wave_rgba", "ingest_mfma_wg", "ingest_valu", "resample_general", "frame_to_rgba", "compose_output", "apply_layouts")
+KERNEL_NAMES = ("ingest_wave", "ingest_wave_rgba", "frame_to_rgba_420", "ingest_valu", "resample_general", "frame_to_rgba", "compose_output", "apply_layouts")
 COMM_ID_BYTES = 128
 
 

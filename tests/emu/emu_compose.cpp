@@ -28,25 +28,31 @@ void __syncthreads() { pthread_barrier_wait(&emu_blk->bar); }
 
 namespace {
 
+// A launch: `threads` host threads — one per lane — live for the whole grid and run its workgroups one after the other (a barrier between
+// two workgroups: the LDS statics and the EmuBlock are the workgroup's).
 template <typename F>
 void run_grid(unsigned blocks, unsigned threads, F kernel) {
     gridDim = dim3(blocks);
     blockDim = dim3(threads);
-    for (unsigned b = 0; b < blocks; b++) {
-        auto blk = std::make_unique<EmuBlock>();
-        pthread_barrier_init(&blk->bar, nullptr, threads);
-        emu_blk = blk.get();
-        std::vector<std::thread> ts;
-        ts.reserve(threads);
-        for (unsigned t = 0; t < threads; t++)
-            ts.emplace_back([&, t] {
-                threadIdx = dim3(t);
+    auto blk = std::make_unique<EmuBlock>();
+    pthread_barrier_t step;
+    pthread_barrier_init(&blk->bar, nullptr, threads);
+    pthread_barrier_init(&step, nullptr, threads);
+    emu_blk = blk.get();
+    std::vector<std::thread> ts;
+    ts.reserve(threads);
+    for (unsigned t = 0; t < threads; t++)
+        ts.emplace_back([&, t] {
+            threadIdx = dim3(t);
+            for (unsigned b = 0; b < blocks; b++) {
                 blockIdx = dim3(b);
                 kernel();
-            });
-        for (auto &t : ts) t.join();
-        pthread_barrier_destroy(&blk->bar);
-    }
+                pthread_barrier_wait(&step);
+            }
+        });
+    for (auto &t : ts) t.join();
+    pthread_barrier_destroy(&blk->bar);
+    pthread_barrier_destroy(&step);
 }
 
 struct Surface {

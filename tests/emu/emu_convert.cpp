@@ -34,7 +34,9 @@ Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill, u32 min_row = 
         pitch = (u32)(((size_t)w * bpp + 3) & ~(size_t)3);
         if (pitch < min_row) pitch = (min_row + 3u) & ~3u;
     }
-    p.buf.alloc((size_t)pitch * h, fill, 4);
+    // (a plane the library allocates ends with SMR_SURFACE_TAIL spare bytes and may be read past a row's end — conv_420_ok's rule for owned
+    //  surfaces; a wrapped one, emu_min_pitch, is exactly pitch * h bytes and is only let through with a pitch that holds the reach)
+    p.buf.alloc((size_t)pitch * h + (emu_min_pitch ? 0 : SMR_SURFACE_TAIL), fill, 4);
     for (int y = 0; y < h; y++) memcpy(p.buf.ptr + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
     p.view.ptr = p.buf.ptr; p.view.pitch = pitch; p.view.w = w; p.view.h = h;
     return p;

@@ -39,8 +39,13 @@ struct GuardBuf {
         release();
         size = bytes;
         if (!emu_guard_mode) {
+#ifdef SMR_EMU_ASAN  // (an instrumented build: the exact size, AddressSanitizer's red zones around it)
+            if (posix_memalign((void **)&ptr, 256, bytes ? bytes : 1)) abort();
+            memset(ptr, fill, bytes);
+#else
             if (posix_memalign((void **)&ptr, 256, bytes + 64)) abort();  // (slack: the pre-guard behaviour)
             memset(ptr, fill, bytes + 64);
+#endif
             return;
         }
         const size_t page = (size_t)sysconf(_SC_PAGESIZE);

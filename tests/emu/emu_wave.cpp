@@ -26,29 +26,40 @@ void __syncthreads() { pthread_barrier_wait(&emu_blk->bar); }
 
 namespace {
 
+// A launch: `threads` host threads — one per lane — live for the whole grid and run its workgroups one after the other (a barrier between
+// two workgroups: the LDS block and the EmuBlock are the workgroup's).
 template <typename F>
 void run_grid(unsigned blocks, unsigned threads, size_t lds, F kernel) {
     gridDim = dim3(blocks);
     blockDim = dim3(threads);
+#ifdef SMR_EMU_ASAN
+    std::vector<unsigned char> smem(lds ? lds : 1);  // (the dynamic LDS block at its exact size: an overrun is a report)
+#else
     std::vector<unsigned char> smem(lds + 64);
-    for (unsigned b = 0; b < blocks; b++) {
-        EmuBlock blk;
-        pthread_barrier_init(&blk.bar, nullptr, threads);
-        for (unsigned w = 0; w < (threads + 63) / 64; w++) pthread_barrier_init(&blk.waves[w].bar, nullptr, 64);
-        blk.smem = smem.data();
-        emu_blk = &blk;
-        std::vector<std::thread> ts;
-        for (unsigned t = 0; t < threads; t++)
-            ts.emplace_back([&, t] {
-                threadIdx = dim3(t);
+#endif
+    auto blk = std::make_unique<EmuBlock>();
+    pthread_barrier_t step;
+    pthread_barrier_init(&blk->bar, nullptr, threads);
+    pthread_barrier_init(&step, nullptr, threads);
+    for (unsigned w = 0; w < (threads + 63) / 64; w++) pthread_barrier_init(&blk->waves[w].bar, nullptr, 64);
+    blk->smem = smem.data();
+    emu_blk = blk.get();
+    std::vector<std::thread> ts;
+    ts.reserve(threads);
+    for (unsigned t = 0; t < threads; t++)
+        ts.emplace_back([&, t] {
+            threadIdx = dim3(t);
+            emu_smem = blk->smem;
+            for (unsigned b = 0; b < blocks; b++) {
                 blockIdx = dim3(b);
-                emu_smem = blk.smem;
                 kernel();
-            });
-        for (auto &t : ts) t.join();
-        pthread_barrier_destroy(&blk.bar);
-        for (unsigned w = 0; w < (threads + 63) / 64; w++) pthread_barrier_destroy(&blk.waves[w].bar);
-    }
+                pthread_barrier_wait(&step);
+            }
+        });
+    for (auto &t : ts) t.join();
+    pthread_barrier_destroy(&blk->bar);
+    pthread_barrier_destroy(&step);
+    for (unsigned w = 0; w < (threads + 63) / 64; w++) pthread_barrier_destroy(&blk->waves[w].bar);
 }
 
 struct Plane {

@@ -25,17 +25,8 @@ CLASSES = ["clear", "colour", "texture", "full", "skip", "sampled", "select"]
 def emu():
     if not os.path.exists(CLANG):
         pytest.skip("no clang++ to build the emulator with")
-    out_dir = os.path.join(EMU, "_build")
-    os.makedirs(out_dir, exist_ok=True)
-    lib = os.path.join(out_dir, "libsmr_emu_compose.so")
-    csrc = os.path.join(ROOT, "smelter_amd/csrc")
-    srcs = [os.path.join(EMU, "emu_compose.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(EMU, "emu_guard.h"), os.path.join(EMU, "shim/hip/hip_runtime.h")] + \
-           [os.path.join(csrc, f) for f in ("smr_fused_compose.h", "smr_layout_dev.h", "smr_convert_dev.h", "smr_internal.h", "smr_tables.h")]
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
-        cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function", "-I", os.path.join(EMU, "shim"),
-               "-I", EMU, "-I", csrc, "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0], "-lpthread"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
+    from tests import emu_build
+    lib = emu_build.build("smr_emu_compose", "emu_compose.cpp", ("smr_fused_compose.h", "smr_layout_dev.h", "smr_convert_dev.h", "smr_tables.h"))
     h = C.CDLL(lib)
     h.emu_compose.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(P8), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int,
                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P8, P8, P8, C.POINTER(C.c_int)]

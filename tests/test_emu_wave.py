@@ -23,16 +23,8 @@ P8 = C.POINTER(C.c_uint8)
 def emu():
     if not os.path.exists(CLANG):
         pytest.skip("no clang++ to build the emulator with")
-    out_dir = os.path.join(EMU, "_build")
-    os.makedirs(out_dir, exist_ok=True)
-    lib = os.path.join(out_dir, "libsmr_emu.so")
-    srcs = [os.path.join(EMU, "emu_wave.cpp"), os.path.join(EMU, "emu_device.h"), os.path.join(EMU, "emu_guard.h"), os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_wave.h"),
-            os.path.join(ROOT, "smelter_amd/csrc/smr_ingest_common.h")]
-    if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
-        cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function", "-I", os.path.join(EMU, "shim"),
-               "-I", EMU, "-I", os.path.join(ROOT, "smelter_amd/csrc"), "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0], "-lpthread"]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
+    from tests import emu_build
+    lib = emu_build.build("smr_emu", "emu_wave.cpp", ("smr_ingest_wave.h", "smr_ingest_common.h", "smr_tables.h"))
     h = C.CDLL(lib)
     h.emu_ingest_wave.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, P8, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.POINTER(C.c_int)]

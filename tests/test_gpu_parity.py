@@ -101,6 +101,30 @@ def test_batched_converter_equals_the_general_kernel(ctx, hip, w, h, variant):
             assert np.array_equal(fast, orc.nv12_to_rgba(y, c, w, h)), (variant, w, h, content)
 
 
+@pytest.mark.parametrize("variant,w,h", [("nv12", 1280, 720), ("nv12", 3840, 16), ("nv12", 256, 18), ("420", 2048, 16), ("420", 512, 34), ("j420", 1024, 6), ("420", 4096, 8)])
+def test_chroma_rows_that_fill_their_pitch_take_the_block_converter(ctx, hip, variant, w, h):
+    """k_yuv420_to_rgba reads (and ignores) up to a dword past the last block's chroma window.  Where a chroma row's bytes are a multiple of
+    256 — 720p and 4K NV12, planar frames 512 / 1024 / 2048 / 4096 wide — that dword lies past the row's pitch: in the next row, or, for
+    the last row, in the spare bytes every allocation of the library ends with (SMR_SURFACE_TAIL).  Such frames used to fall back to the
+    general converter; a plane the library allocated now takes the block converter (its launch shows in SMR_KERNEL_FRAME_TO_RGBA_420) and
+    writes the oracle's bytes.  (Found by running the emulated kernel under AddressSanitizer: tests/test_emu_asan.py.)"""
+    rng = np.random.default_rng(w * 31 + h)
+    y = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    c = rng.integers(0, 256, (h // 2, w // 2, 2), dtype=np.uint8)
+    if variant == "nv12":
+        f = ctx.frame(hip.FRAME_NV12, w, h, [y, c])
+        want = orc.nv12_to_rgba(y, c, w, h)
+    else:
+        u, v = np.ascontiguousarray(c[..., 0]), np.ascontiguousarray(c[..., 1])
+        f = ctx.frame(hip.FRAME_PLANAR_YUVJ420 if variant == "j420" else hip.FRAME_PLANAR_YUV420, w, h, [y, u, v])
+        want = orc.planar_yuv_to_rgba(y, u, v, w, h, orc.YUVJ420 if variant == "j420" else orc.YUV420)
+    before = ctx.kernel_launches()
+    got = ctx.frame_to_rgba(f).download()
+    ran = {k: n - before[k] for k, n in ctx.kernel_launches().items()}
+    assert ran["frame_to_rgba_420"] == 1 and ran["frame_to_rgba"] == 1, ran
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 def test_nv12_to_rgba(ctx, hip):
     w, h = 642, 362
     rng = np.random.default_rng(5)
