@@ -6,7 +6,10 @@ again, text drawn by the library's font book at every update — while watching 
     and downloads only): no growth,
   * the picture: the frame of a scene at rest, for the same input set, has the same checksum every time it comes round,
   * the error channel: no call fails.
-python tools/soak.py [--seconds 150]          prints one JSON line"""
+python tools/soak.py [--seconds 150] [--variety]          prints one JSON line
+--variety: three lanes instead of two, 720p NV12 frames on two of the inputs (the block converter's pitch-filling rows), and a second output —
+1080p NV12 — whose scene (synth.animated_grid_scene: a grid in a cubic-bezier transition under a gaussian-blur shader layer, plus an image and
+a text node) is replaced every time as well; both outputs' pictures at rest are compared."""
 import argparse
 import json
 import os
@@ -34,17 +37,36 @@ def scenes():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=150.0)
+    ap.add_argument("--variety", action="store_true")
     args = ap.parse_args()
     import psutil
     import torch
     ctx = hip.Context(0)
-    r = Renderer(ctx, stream_fallback_timeout_s=1e9, lanes=[hip.Context(0)])  # (the ring's frames carry pts 0: never stale, however long the run)
+    r = Renderer(ctx, stream_fallback_timeout_s=1e9, lanes=[hip.Context(0) for _ in range(2 if args.variety else 1)])  # (the ring's frames carry pts 0: never stale)
     book = bench.font_book()
     if book is not None:
         r.set_fontbook(book)
     for i in range(bench.N_IN):
         r.register_input(f"input_{i}")
     ring = bench.make_inputs(ctx, hip, 4, list(range(bench.N_IN)))
+    second = None
+    if args.variety:
+        import numpy as np
+        from smelter_amd import synth
+        rng = np.random.default_rng(7)
+        for s_, row in enumerate(ring):  # inputs 6 and 7 become 1280 x 720 NV12
+            for i in (6, 7):
+                y = rng.integers(16, 236, (720, 1280), dtype=np.uint8)
+                uv = rng.integers(16, 241, (360, 640, 2), dtype=np.uint8)
+                row[i] = ctx.frame(hip.FRAME_NV12, 1280, 720, [y, uv])
+        r.register_shader("soften")
+        r.register_image("logo", rng.integers(0, 256, (90, 160, 4), dtype=np.uint8))
+        def second_scene(k):
+            sc2 = synth.animated_grid_scene(bench.N_IN, k, 480, 270, 300, 2.5)
+            sc2["children"].append({"type": "view", "width": 200, "height": 120, "right": 20, "bottom": 20, "children": [
+                {"type": "image", "image_id": "logo"}, {"type": "text", "text": f"scene {k % 2}", "font_size": 28.0, "color": "#FFFF00FF"}]})
+            return sc2
+        second = second_scene
     sets = [r.make_frame_set({f"input_{i}": row[i] for i in range(bench.N_IN)}) for row in ring]
     sc = scenes()
     ns = 1_000_000_000 // 60
@@ -54,17 +76,23 @@ def main():
     r.update_scene("out", bench.OUT_W, bench.OUT_H, sc[0])
 
     def picture():
-        """the frame of a scene at rest for input set 0 (rendered now, on whichever lane is next)"""
+        """the frames of the scenes at rest for input set 0 (rendered now, on whichever lane is next): every output's planes"""
         nonlocal frame
-        r.render_packed(frame * ns, sets[0])
+        n = r.render_packed(frame * ns, sets[0])
         frame += 1
-        out = r.output(0)
-        y, u, v = out.download()
-        return zlib.crc32(v.tobytes(), zlib.crc32(u.tobytes(), zlib.crc32(y.tobytes()))), (y, u, v)
+        planes = []
+        for k in range(n):
+            planes += list(r.output(k).download())
+        c = 0
+        for p_ in planes:
+            c = zlib.crc32(p_.tobytes(), c)
+        return c, tuple(planes)
 
     # warm-up: both scenes seen, both lanes own their surfaces
     for k in range(2):
         r.update_scene("out", bench.OUT_W, bench.OUT_H, sc[k])
+        if second:
+            r.update_scene("second", 1920, 1080, second(k), hip.FRAME_NV12)
         for _ in range(120):
             r.render_packed(frame * ns, sets[frame % 4])
             frame += 1
@@ -103,6 +131,8 @@ def main():
         checks += 1
         which ^= 1
         r.update_scene("out", bench.OUT_W, bench.OUT_H, sc[which])
+        if second:
+            r.update_scene("second", 1920, 1080, second(which), hip.FRAME_NV12)
         updates += 1
         r.sync()
         min_free = min(min_free, torch.cuda.mem_get_info()[0])
@@ -115,7 +145,7 @@ def main():
               "input_reregistrations": reregistrations, "picture_checks": checks, "distinct_pictures": len(first),
               "device_memory_growth_MB": round((free0 - min_free) / 2**20, 2), "host_rss_growth_MB": round((max_rss - rss0) / 2**20, 2),
               "host_rss_growth_last_two_thirds_MB": round((max_rss - (rss_third or rss0)) / 2**20, 2),
-              "font_book": book is not None, "picture_mismatches": len(mismatches), "first_mismatches": mismatches[:6]}
+              "font_book": book is not None, "variety": bool(args.variety), "lanes": 3 if args.variety else 2, "outputs": 2 if second else 1, "picture_mismatches": len(mismatches), "first_mismatches": mismatches[:6]}
     print(json.dumps(result))
     assert result["device_memory_growth_MB"] < 64 and result["host_rss_growth_last_two_thirds_MB"] < 32 and not mismatches, result
 
