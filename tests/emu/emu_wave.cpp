@@ -227,6 +227,12 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 8192>(args, tables, lut16); });
         else if (spec82) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 8192>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 8192>(args, tables, lut16); });
+#ifdef SMR_EMU_ASAN  // (the instrumented library holds the node-texture builds — what a product build launches — and the single-axis ones: half
+                     //  the compile time; the plane-source builds of laboratory libraries stay with the plain emulator)
+    } else {
+        return -3;
+    }
+#else
     } else if (spec && bh.k01) {
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 4097>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 1>(args, tables, lut16); });
@@ -243,6 +249,7 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 4096>(args, tables, lut16); });
         else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 0>(args, tables, lut16); });
     }
+#endif
     for (int yy = 0; yy < dh; yy++) memcpy(dst + (size_t)yy * dw * 4, J.dst.ptr + (size_t)yy * J.dst.pitch, (size_t)dw * 4);
     return 0;
 }

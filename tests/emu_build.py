@@ -1,7 +1,7 @@
 """Builds the lane emulator's libraries (tests/emu/*.cpp: the kernel sources of smelter_amd/csrc compiled for the CPU with SMR_EMU) — test
 infrastructure.  SMR_EMU_ASAN=1 (the inner runs of tests/test_emu_asan.py, under LD_PRELOAD of the compiler's AddressSanitizer runtime)
 builds them instrumented: LDS arrays (function-local statics here), the dynamic LDS block, register arrays and every host-side buffer get
-red zones."""
+red zones, and undefined behaviour in the kernels' index arithmetic (misaligned vector loads, shifts, signed overflow) aborts."""
 import os
 import subprocess
 
@@ -21,8 +21,31 @@ def asan_runtime():
     return path if r.returncode == 0 and os.path.isabs(path) and os.path.exists(path) else None
 
 
-def build(name, source, deps=()):
-    """-> path of tests/emu/_build/lib<name>[_asan].so, rebuilt when its source, a kernel header or an emulator header is newer."""
+LIBS = {  # name -> (source, kernel headers it compiles)
+    "smr_emu_convert": ("emu_convert.cpp", ("smr_convert_420.h", "smr_convert_dev.h")),
+    "smr_emu": ("emu_wave.cpp", ("smr_ingest_wave.h", "smr_ingest_common.h", "smr_tables.h")),
+    "smr_emu_compose": ("emu_compose.cpp", ("smr_fused_compose.h", "smr_layout_dev.h", "smr_convert_dev.h", "smr_tables.h")),
+}
+
+
+def build(name, source=None, deps=None):
+    """-> path of tests/emu/_build/lib<name>[_asan].so, rebuilt when its source, a kernel header or an emulator header is newer.  The first
+    call of a plain (not instrumented) run builds every library that is out of date, side by side: the resampler alone takes half a minute."""
+    if source is None:
+        source, deps = LIBS[name]
+    if not os.environ.get("SMR_EMU_ASAN"):
+        from concurrent.futures import ThreadPoolExecutor
+        others = [n for n in LIBS if n != name]
+        with ThreadPoolExecutor(max_workers=3) as ex:
+            futures = [ex.submit(_build_one, n, *LIBS[n]) for n in others]
+            lib = _build_one(name, source, deps)
+            for f in futures:
+                f.result()
+        return lib
+    return _build_one(name, source, deps)
+
+
+def _build_one(name, source, deps=()):
     asan = bool(os.environ.get("SMR_EMU_ASAN"))
     out_dir = os.path.join(EMU, "_build")
     os.makedirs(out_dir, exist_ok=True)
@@ -31,7 +54,7 @@ def build(name, source, deps=()):
             os.path.join(CSRC, "smr_internal.h")] + [os.path.join(CSRC, d) for d in deps]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
         flags = ["-std=c++17", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function"]
-        flags += ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-shared-libasan", "-DSMR_EMU_ASAN=1"] if asan else ["-O2"]
+        flags += ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libasan", "-DSMR_EMU_ASAN=1"] if asan else ["-O2"]
         cmd = [CLANG] + flags + ["-I", os.path.join(EMU, "shim"), "-I", EMU, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0], "-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr

@@ -1,4 +1,4 @@
-"""The three kernels of the default route on the lane emulator, INSTRUMENTED: tests/emu built with -fsanitize=address (tests/emu_build.py,
+"""The three kernels of the default route on the lane emulator, INSTRUMENTED: tests/emu built with -fsanitize=address,undefined (tests/emu_build.py,
 SMR_EMU_ASAN) and the parity tests rerun in child processes under the compiler's AddressSanitizer runtime.  What guard pages
 (emu_guard.h) cannot see, red zones do: an index past an LDS array (function-local statics here) or past the dynamic LDS block, a
 register array indexed out of range, a read one element past a weight band — the emulated "device" buffers at their exact sizes.
@@ -37,4 +37,4 @@ def test_emulated_kernels_under_address_sanitizer():
         out, _ = child.communicate(timeout=2400)
         report = out[out.index("ERROR: AddressSanitizer"):][:4000] if "ERROR: AddressSanitizer" in out else out[-2500:]
         assert child.returncode == 0, f"{mod}: rc {child.returncode}\n{report}"
-        assert " passed" in out and "AddressSanitizer" not in out, f"{mod}\n{report}"
+        assert " passed" in out and "AddressSanitizer" not in out and "runtime error" not in out, f"{mod}\n{report}"

@@ -331,8 +331,8 @@ def test_emulated_single_tile_units_for_wide_windows(emu, kind):
 
 
 def test_resampler_never_leaves_its_surfaces(emu):
-    """The memory contract of include/smr.h (smr_surface_wrap) for k_ingest_wave's node-texture builds (RGBA8, RGB12, alpha, RGBA16F, single
-    axis, single-tile units): the tests above once more in child processes with node textures, tiles and weight bands of exactly pitch * h
+    """The memory contract of include/smr.h (smr_surface_wrap) for k_ingest_wave's node-texture builds (RGBA8 and RGB12 side by side, alpha, RGBA16F, single
+    axis, single-tile units): those tests once more in child processes with node textures, tiles and weight bands of exactly pitch * h
     bytes — node and tile on the SMALLEST pitch can_fuse_wave_rgba lets through (16-byte multiples holding the row rounded up to four
     texels) — ending at (mode 1) or starting behind (mode 2) an unmapped page: a 16-byte load of the last texel group that reached past the
     row's pitch, a window clamped a row too late, a store beyond the tile would kill the child."""
@@ -340,7 +340,7 @@ def test_resampler_never_leaves_its_surfaces(emu):
     if os.environ.get("SMR_EMU_GUARD"):
         pytest.skip("this is the inner run")
     children = {mode: subprocess.Popen([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
-                                        "not one_gather and not matches_the_oracle"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                        "rgb12 or alpha or rgba16f or single_tile or single_axis"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                        env=dict(os.environ, SMR_EMU_GUARD=str(mode)), cwd=ROOT) for mode in (1, 2)}
     for mode, child in children.items():
         out, err = child.communicate(timeout=1500)
