@@ -61,28 +61,75 @@ def build(force: bool = False) -> str:
     return LIB
 
 
-def kernels_sha256(lib: str = LIB) -> str:
-    """Identity of the library's DEVICE code: sha256 of its .hip_fatbin section (the gfx950 code objects of every kernel).  Profiles that
-    quote per-kernel counters record it (tools/traffic_json.py, tools/issue_json.py); bench.py refuses to quote a profile whose hash is not
-    the hash of the library it is timing."""
-    import hashlib
+def _elf_sections(data: bytes) -> dict:
     import struct
-    with open(lib, "rb") as f:
-        data = f.read()
     if data[:4] != b"\x7fELF" or data[4] != 2:
-        raise ValueError(f"{lib}: not an ELF64 file")
+        raise ValueError("not an ELF64 image")
     shoff, = struct.unpack_from("<Q", data, 0x28)
     shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+
     def sect(i):
         name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
         return name, off, size
     _n, stroff, _strsize = sect(shstrndx)
+    out = {}
     for i in range(shnum):
         name, off, size = sect(i)
         end = data.index(b"\0", stroff + name)
-        if data[stroff + name:end] == b".hip_fatbin":
-            return hashlib.sha256(data[off:off + size]).hexdigest()
-    raise ValueError(f"{lib}: no .hip_fatbin section")
+        out[data[stroff + name:end].decode()] = (off, size)
+    return out
+
+
+def fatbin_sha256(lib: str = LIB) -> str:
+    """sha256 of the library's .hip_fatbin section as it is.  NOT an identity of the device code across checkouts: the offload bundles carry
+    a compilation-unit id derived from the source file's absolute path (the same sources built in another directory hash differently)."""
+    import hashlib
+    with open(lib, "rb") as f:
+        data = f.read()
+    off, size = _elf_sections(data)[".hip_fatbin"]
+    return hashlib.sha256(data[off:off + size]).hexdigest()
+
+
+def kernels_sha256(lib: str = LIB) -> str:
+    """Identity of the library's DEVICE code: sha256 over the machine code (.text) and the kernel descriptors / constants (.rodata) of every
+    gfx950 code object in its .hip_fatbin section, in order — what the GPU executes, and nothing that depends on where the sources were built
+    (the same sources give the same value in any directory; `fatbin_sha256` does not).  Profiles that quote per-kernel counters record it
+    (tools/traffic_json.py, tools/issue_json.py); bench.py refuses to quote a profile whose hash is not the hash of the library it is timing."""
+    import hashlib
+    import struct
+    with open(lib, "rb") as f:
+        data = f.read()
+    secs = _elf_sections(data)
+    if ".hip_fatbin" not in secs:
+        raise ValueError(f"{lib}: no .hip_fatbin section")
+    off, size = secs[".hip_fatbin"]
+    fb = data[off:off + size]
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    h = hashlib.sha256()
+    pos, objects = 0, 0
+    while True:
+        pos = fb.find(magic, pos)
+        if pos < 0:
+            break
+        n, = struct.unpack_from("<Q", fb, pos + len(magic))
+        p = pos + len(magic) + 8
+        for _ in range(n):
+            eoff, esize, tlen = struct.unpack_from("<QQQ", fb, p)
+            p += 24
+            triple = fb[p:p + tlen]
+            p += tlen
+            if b"amdgcn" in triple and esize:
+                elf = fb[pos + eoff:pos + eoff + esize]
+                es = _elf_sections(elf)
+                for name in (".text", ".rodata"):
+                    if name in es:
+                        h.update(name.encode())
+                        h.update(elf[es[name][0]:es[name][0] + es[name][1]])
+                objects += 1
+        pos += len(magic)
+    if not objects:
+        raise ValueError(f"{lib}: no gfx code object in .hip_fatbin (a compressed bundle?)")
+    return h.hexdigest()
 
 
 if __name__ == "__main__":

@@ -69,3 +69,25 @@ def test_watchdog_ends_a_stuck_rank_with_an_error_line_and_rc_3():
             "for i in range(12):\n    w.beat('step'); time.sleep(0.2)\nw.stop(); time.sleep(1.0); print('done')" % ROOT)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=25)
     assert p.returncode == 0 and p.stdout.strip() == "done"
+
+
+def test_device_code_identity_does_not_depend_on_the_build_directory(tmp_path):
+    """kernels_sha256 — what ties committed counter profiles to a library — hashes the code objects' machine code and descriptors, not the
+    fatbin as a whole: the offload bundles carry a compilation-unit id derived from the source's absolute path, so the same sources built in
+    two directories differ in fatbin_sha256 and must not differ in kernels_sha256 (a checkout elsewhere still matches profiles/)."""
+    import shutil
+    hipcc = B.HIPCC
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    got = []
+    for name in ("here", "somewhere/else/entirely"):
+        d = tmp_path / name
+        shutil.copytree(os.path.join(ROOT, "smelter_amd", "csrc"), d / "csrc", ignore=shutil.ignore_patterns("host"))
+        shutil.copytree(os.path.join(ROOT, "include"), d / "include")
+        obj, lib = str(d / "m.o"), str(d / "libm.so")
+        flags = [f for f in B.FLAGS if not f.startswith(ROOT) and f != "-I"] + ["-I", str(d / "include"), "-I", str(d / "csrc")]
+        subprocess.run([hipcc] + flags + ["-x", "hip", "-c", str(d / "csrc" / "smr_misc.hip"), "-o", obj], check=True, capture_output=True)
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj], check=True, capture_output=True)
+        got.append((B.kernels_sha256(lib), B.fatbin_sha256(lib)))
+    assert got[0][0] == got[1][0], got
+    assert got[0][1] != got[1][1], "the fatbin no longer depends on the path: kernels_sha256 could be simplified again"
