@@ -6,7 +6,7 @@ host bytes in and out.  There is no CPU implementation behind these classes.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence
+from typing import Tuple, List, Optional, Sequence
 
 import numpy as np
 
@@ -328,6 +328,23 @@ class Context:
     def surface_from(self, arr, fmt: int = PX_RGBA8) -> Surface:
         a = np.asarray(arr)
         return self.surface(a.shape[1], a.shape[0], fmt).upload(a)
+
+    def wrapped_frame(self, fmt: int, w: int, h: int, planes: Sequence[Tuple[int, int]]) -> DeviceFrame:
+        """A frame over device memory the caller owns (a decoder's output, torch tensors): `planes` = (device pointer, pitch in bytes) per
+        plane, in the order of smr_frame.planes; each is wrapped in place (smr_surface_wrap: nothing is copied, nothing is owned)."""
+        f = DeviceFrame.__new__(DeviceFrame)
+        f.ctx, f.fmt, f.w, f.h = self, fmt, w, h
+        f.c = _ffi.Frame()
+        f.c.format, f.c.width, f.c.height = fmt, w, h
+        shapes = f.plane_shapes()
+        assert len(shapes) == len(planes), "one (pointer, pitch) pair per plane"
+        f.surfaces = []
+        for i, ((dptr, pitch), shape) in enumerate(zip(planes, shapes)):
+            pf = PX_RGBA8 if len(shape) == 3 and shape[2] == 4 else PX_RG8 if len(shape) == 3 else PX_R8
+            s = self.wrap(dptr, pitch, shape[1], shape[0], pf)
+            f.surfaces.append(s)  # (kept alive with the frame)
+            f.c.planes[i] = s.handle.value if hasattr(s.handle, "value") else s.handle
+        return f
 
     def frame(self, fmt: int, w: int, h: int, planes: Optional[Sequence[np.ndarray]] = None) -> DeviceFrame:
         f = DeviceFrame(self, fmt, w, h)
