@@ -236,11 +236,10 @@ SMR_API int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t fo
 /* Device memory the caller owns (a decoder's output, a torch tensor) as a surface, in place.  The allocation must cover pitch * h bytes —
  * every row backed out to the full pitch, the LAST ONE TOO: the block kernels read whole dwords, up to a dword past a row's last texel
  * (never past the pitch).  pitch >= w * bytes per texel; rows and the base 4-byte aligned for the block converters, 16-byte aligned for the
- * matrix-core resampler's node textures (other alignments take the general kernels).  One more thing for wrapped 4:2:0 / NV12 CHROMA
- * planes: the block converter also reads (and ignores) the dword after the last block's chroma window, so a plane whose rows FILL their pitch
- * (bytes per row a multiple of the pitch: 720p or 4K NV12 on a 256-byte pitch, planar frames 512 / 1024 / 2048 / 4096 wide) is converted by the
- * general kernel — same bytes, slower — unless the pitch leaves 4 bytes after the row.  Planes the library allocates never take that detour:
- * every allocation of smr_surface_create / smr_frame_create ends with 16 spare bytes. */
+ * matrix-core resampler's node textures (other alignments take the general kernels).  Wrapped 4:2:0 / NV12 chroma planes whose rows FILL
+ * their pitch (a decoder's tight surfaces: pitch == bytes per row) are converted by a build of the block converter that requests nothing behind
+ * a row's last column (k_yuv420_to_rgba_tight: the same bytes, ~2 % more instructions); with 4 spare bytes of pitch, or allocated by the
+ * library (every allocation of smr_surface_create / smr_frame_create ends with 16 spare bytes), a plane takes the plain one. */
 SMR_API int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
                              smr_surface **out);
 SMR_API void smr_surface_destroy(smr_ctx *ctx, smr_surface *s);

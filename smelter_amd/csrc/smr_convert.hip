@@ -369,6 +369,39 @@ __global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
 #endif
 }
 
+// The same for frames with a chroma plane whose rows fill its pitch and that the library did not allocate (conv_420_ok: a wrapped decoder
+// surface with tight rows): cv420_load_chroma's TIGHT build requests nothing behind a window's last column.  A kernel of its own, so that the
+// plain one stays the instruction stream it was measured as.
+template <bool NV>
+__global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba_tight(const ConvBatch B) {
+    __shared__ float s_ylut[256], s_nlut[256];
+#ifdef SMR_PRIO_CONVERT
+    __builtin_amdgcn_s_setprio(SMR_PRIO_CONVERT);
+#endif
+#ifdef CV_TIMING
+    unsigned long long *st = g_cv_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 32767u];
+    if ((threadIdx.x & 63) == 0) { st[7] = __builtin_amdgcn_s_memrealtime(); st[1] = st[2] = st[3] = st[4] = st[5] = st[6] = 0; }
+    CV_STAMP(st, 0, "s_nop 0");
+#else
+    unsigned long long *st = nullptr;
+#endif
+    const u32 lane = threadIdx.x & 63u;
+    // both ranges' luma tables: a wave's share may touch several jobs (the full-range luma value of a byte is byte / 255 itself: s_nlut)
+    s_ylut[threadIdx.x & 255] = cv420_luma_of_byte(threadIdx.x & 255u, false);
+    s_nlut[threadIdx.x & 255] = unorm_of_byte(threadIdx.x & 255u);
+    __syncthreads();
+    CV_STAMP(st, 1, "s_nop 0");
+    cv420_share<NV, true>(B, blockIdx.x, cv_uniform(threadIdx.x >> 6), gridDim.x, lane, s_ylut, s_nlut, st);
+#ifdef CV_TIMING
+    st = g_cv_stamps[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 32767u];
+#endif
+    CV_STAMP(st, 5, "s_nop 0");                // the queue is dry, the last stores are issued
+    CV_STAMP(st, 6, "s_waitcnt vmcnt(0)");     // ... and acknowledged
+#ifdef CV_TIMING
+    if ((threadIdx.x & 63) == 0) { st[8] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); st[9] = ((unsigned long long)xcc << 32) | hw; }
+#endif
+}
+
 // rgba_to_yuv.wgsl's three passes (k_rgba_to_y + k_rgba_to_chroma) in one launch for even-sized frames: a thread owns a 4 x 2 pixel block,
 // reads its eight texels once and writes the luma dwords and its share of the chroma planes.  Same values bit for bit: channels are
 // byte / 255 (unorm_of_byte), a chroma sample of a subsampled axis sits exactly between two texels (sub-texel fraction 128 / 256 for
@@ -481,23 +514,27 @@ static bool conv_batchable(const smr_ctx *ctx, const smr_frame *in) {
 }
 
 // k_yuv420_to_rgba's frames (cv420_block, smr_convert_420.h): 4:2:0 planar / NV12, width a multiple of 4 from 8, even height, every plane
-// dword-aligned with chroma rows that can be read up to a dword past the last block's window.  The bytes of that dword are never used (the
-// window's last column is the plane's edge, repeated), but they are read: a plane the library allocated may be read past a row's end — the
-// next row, or the 16 bytes every allocation ends with (SMR_SURFACE_TAIL) — a wrapped one only inside its pitch.
-static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) {
-    if (ctx->convert_impl != SMR_CONVERT_AUTO) return false;
+// dword-aligned.  The plain kernel reads up to a dword past the last block's window; the bytes of that dword are never used (the window's
+// last column is the plane's edge, repeated), but they are read: a plane the library allocated may be read past a row's end — the next row,
+// or the 16 bytes every allocation ends with (SMR_SURFACE_TAIL) — a wrapped one only inside its pitch.  A wrapped plane whose pitch does not
+// hold that reach (tight rows: a decoder's pitch == bytes per row) takes k_yuv420_to_rgba_tight, which requests nothing behind a window's last
+// column.  -> 0: not a frame for the block converter | 1: the plain kernel | 2: the tight one
+static int conv_420_mode(const smr_ctx *ctx, const smr_frame *in) {
+    if (ctx->convert_impl != SMR_CONVERT_AUTO) return 0;
     const bool nv = in->format == SMR_FRAME_NV12;
-    if (in->format != SMR_FRAME_PLANAR_YUV420 && in->format != SMR_FRAME_PLANAR_YUVJ420 && !nv) return false;
-    if (in->width % 4 || in->width < 8 || in->height % 2 || in->height < 2 || in->width > 16384 || in->height > 16384) return false;
+    if (in->format != SMR_FRAME_PLANAR_YUV420 && in->format != SMR_FRAME_PLANAR_YUVJ420 && !nv) return 0;
+    if (in->width % 4 || in->width < 8 || in->height % 2 || in->height < 2 || in->width > 16384 || in->height > 16384) return 0;
     auto dwords = [](const smr_surface *s) { return s && (s->pitch & 3u) == 0 && (((uintptr_t)s->ptr) & 3) == 0; };
-    if (!dwords(in->planes[0]) || !dwords(in->planes[1]) || (!nv && !dwords(in->planes[2]))) return false;
+    if (!dwords(in->planes[0]) || !dwords(in->planes[1]) || (!nv && !dwords(in->planes[2]))) return 0;
     const u32 cw = in->width / 2;
     // the last block's window starts at chroma column cw - 3: its bytes begin in the dword at ((cw - 3) [* 2]) & ~3 and the loads reach 8 (12) bytes from there
     const u32 need = nv ? ((2u * (cw - 3u)) & ~3u) + 12u : ((cw - 3u) & ~3u) + 8u;
-    auto reach_ok = [&](const smr_surface *s) { return s->pitch >= need || (s->owned && s->pitch >= (nv ? 2u * cw : cw)); };
-    if (!reach_ok(in->planes[1]) || (!nv && !reach_ok(in->planes[2]))) return false;
-    return in->planes[0]->pitch >= in->width;
+    const u32 row = nv ? 2u * cw : cw;
+    if (in->planes[0]->pitch < in->width || in->planes[1]->pitch < row || (!nv && in->planes[2]->pitch < row)) return 0;
+    auto reach_ok = [&](const smr_surface *s) { return s->pitch >= need || s->owned; };
+    return reach_ok(in->planes[1]) && (nv || reach_ok(in->planes[2])) ? 1 : 2;
 }
+static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) { return conv_420_mode(ctx, in) != 0; }
 
 bool smr_conv_rgb12_ok(const smr_ctx *ctx, const smr_frame *in) { return in && conv_420_ok(ctx, in) && 3u * in->width <= 7682u * 2u; }
 
@@ -521,7 +558,7 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         u32 nb = 0;
         int mw = 0, mh = 0;
     };
-    Queue q[3];  // 0: k_yuv_to_rgba_batch | 1: k_yuv420_to_rgba planar | 2: ... NV12
+    Queue q[5];  // 0: k_yuv_to_rgba_batch | 1: k_yuv420_to_rgba planar | 2: ... NV12 | 3, 4: k_yuv420_to_rgba_tight planar, NV12
     auto flush = [&](int k) -> int {
         Queue &Q = q[k];
         if (!Q.nb) return SMR_OK;
@@ -544,7 +581,9 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
             if (blocks < (bands < 8u ? bands : 8u)) blocks = bands < 8u ? bands : 8u;  // (every XCD that owns a band runs a workgroup)
             const u32 lds_pad = ctx->convert_lds_pad;
             if (k == 1) hipLaunchKernelGGL(k_yuv420_to_rgba<false>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
-            else hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
+            else if (k == 2) hipLaunchKernelGGL(k_yuv420_to_rgba<true>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
+            else if (k == 3) hipLaunchKernelGGL(k_yuv420_to_rgba_tight<false>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
+            else hipLaunchKernelGGL(k_yuv420_to_rgba_tight<true>, dim3(blocks), dim3(BLOCK), lds_pad, ctx->stream, Q.B);
         }
         Q.nb = 0; Q.mw = 0; Q.mh = 0;
         SMR_HIP(ctx, hipGetLastError());
@@ -552,7 +591,7 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
     };
     auto flush_all = [&]() -> int {
         int rc = SMR_OK;
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < 5; k++)
             if (int r = flush(k)) rc = rc ? rc : r;
         return rc;
     };
@@ -560,7 +599,8 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
         const bool c12 = rgb12 && rgb12[i];
         const bool aligned16 = c12 || ((((uintptr_t)nodes[i]->ptr) & 15) == 0 && (nodes[i]->pitch & 15u) == 0);  // (the block kernels store 16 B)
         const bool nv = in[i]->format == SMR_FRAME_NV12;
-        const int k = !aligned16 ? -1 : conv_420_ok(ctx, in[i]) ? (nv ? 2 : 1) : conv_batchable(ctx, in[i]) ? 0 : -1;
+        const int mode = conv_420_mode(ctx, in[i]);
+        const int k = !aligned16 ? -1 : mode ? (nv ? 2 : 1) + (mode == 2 ? 2 : 0) : conv_batchable(ctx, in[i]) ? 0 : -1;
         if (k < 0) {
             if (int rc = smr_frame_to_rgba_general(ctx, in[i], nodes[i])) {
                 (void)flush_all();

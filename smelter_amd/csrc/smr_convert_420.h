@@ -133,6 +133,7 @@ struct Cv420Win {
     u32 sh;         // ... and the byte's offset inside that dword
     u32 right_fix;  // v_perm selector: the window's last column repeats the one before it at the plane's right edge
     bool left;      // the window starts left of the plane: columns 0 1 2 3 -> 0 0 1 2
+    u32 lim;        // TIGHT builds: offset of the last dword that holds a column of the plane (0, 4 or 8 from base): nothing behind it is loaded
 };
 template <bool NV>
 __device__ __forceinline__ Cv420Win cv420_window(const ConvJob &J, int g) {
@@ -142,6 +143,9 @@ __device__ __forceinline__ Cv420Win cv420_window(const ConvJob &J, int g) {
     const int nvalid = cw - first;  // window columns 0 .. nvalid - 1 exist (>= 3: the last block's window starts at cw - 3)
     Cv420Win W;
     W.base = (u32)base; W.sh = (u32)(byte0 - base); W.right_fix = nvalid >= 4 ? 0x03020100u : 0x02020100u; W.left = first < 0;
+    // the last column the loaded window can hold is min(first_ld + 3, cw - 1): its last byte decides which dwords are worth loading
+    const int last_col = first_ld + 3 < cw - 1 ? first_ld + 3 : cw - 1;
+    W.lim = (u32)(((NV ? 2 * last_col + 1 : last_col) - base) & ~3);
     return W;
 }
 
@@ -150,7 +154,10 @@ template <bool NV>
 struct Cv420Raw {
     u32 d[NV ? 3 : 4];
 };
-template <bool NV>
+// TIGHT: a plane whose rows fill its pitch with nothing behind the last row (a wrapped decoder surface): the dwords behind the window's last
+// column — read and ignored by the plain build, in the next row or the allocation's tail — are not requested; the dword before them is loaded
+// again instead (its bytes land where the ignored ones would).  Same results, two more vector instructions per load; a kernel of its own.
+template <bool NV, bool TIGHT = false>
 __device__ __forceinline__ Cv420Raw<NV> cv420_load_chroma(const ConvJob &J, const Cv420Win &W, int crow) {
     const int ch = J.dst.h >> 1;
     const int cy = min(max(crow, 0), ch - 1);
@@ -160,10 +167,12 @@ __device__ __forceinline__ Cv420Raw<NV> cv420_load_chroma(const ConvJob &J, cons
 #pragma unroll
         for (int k = 0; k < (NV ? 3 : 4); k++) R.d[k] = 0x01020304u * (u32)(crow + k) + W.base;
     } else if (NV) {
-        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + 4); R.d[2] = *(const u32 *)(ur + 8);
+        const u32 o1 = TIGHT ? (W.lim < 4u ? W.lim : 4u) : 4u, o2 = TIGHT ? (W.lim < 8u ? W.lim : 8u) : 8u;
+        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + o1); R.d[2] = *(const u32 *)(ur + o2);
     } else {
         const u8 *vr = J.vp.ptr + cv_mad24((u32)cy, J.vp.pitch, W.base);
-        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + 4); R.d[2] = *(const u32 *)vr; R.d[3] = *(const u32 *)(vr + 4);
+        const u32 o1 = TIGHT ? (W.lim < 4u ? W.lim : 4u) : 4u;
+        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + o1); R.d[2] = *(const u32 *)vr; R.d[3] = *(const u32 *)(vr + o1);
     }
     return R;
 }
@@ -268,7 +277,7 @@ __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const
 // dword past the window, 16-byte aligned destination rows.
 // nlut: 256 floats, unorm_of_byte of every byte (the chroma bytes' byte / 255: a table gather instead of a conversion and two multiply-adds)
 // RGB12: the node texture as 12-byte groups (ConvJob::rgb12), else RGBA8 — separate instantiations: each packs its own bytes only
-template <bool NV, bool RGB12, bool FULL>
+template <bool NV, bool RGB12, bool FULL, bool TIGHT = false>
 __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, const float *ylut, const float *nlut) {
     // every load of the block is in flight before the first store (a row's luma load behind the previous row's store waited for that
     // store and for itself: four memory round trips per block instead of one)
@@ -277,7 +286,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
     const Cv420Win W = cv420_window<NV>(J, g);
     Cv420Raw<NV> raw[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) raw[j] = cv420_load_chroma<NV>(J, W, 2 * P - 1 + j);  // chroma rows 2 P - 1 .. 2 P + 2
+    for (int j = 0; j < 4; j++) raw[j] = cv420_load_chroma<NV, TIGHT>(J, W, 2 * P - 1 + j);  // chroma rows 2 P - 1 .. 2 P + 2
     float H[4][2][4];  // [window row][plane][luma column]
 #pragma unroll
     for (int j = 0; j < 4; j++) cv420_hrow<NV>(raw[j], W, nlut, H[j]);
@@ -293,7 +302,7 @@ __device__ __forceinline__ void cv420_block(const ConvJob &J, int g, int P, cons
 //     while the wave's vector ALU is busy (a one-block thread loads, waits, computes, stores: its waves all wait at the same time);
 //     the run's last block requests nothing (the loop is peeled: inside it the requests are unconditional, so the compiler can count
 //     what is outstanding).
-template <bool NV, bool RGB12, bool FULL>
+template <bool NV, bool RGB12, bool FULL, bool TIGHT = false>
 __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int nb, const float *ylut, const float *nlut, unsigned long long *st = nullptr) {
     const int Pend = min(P0 + nb, (J.dst.h + 3) >> 2);
     if (P0 >= Pend) return;
@@ -304,7 +313,7 @@ __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int n
     {
         Cv420Raw<NV> raw[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) raw[j] = cv420_load_chroma<NV>(J, W, 2 * P0 - 1 + j);
+        for (int j = 0; j < 4; j++) raw[j] = cv420_load_chroma<NV, TIGHT>(J, W, 2 * P0 - 1 + j);
         CV_STAMP(st, 2, "s_waitcnt vmcnt(0)");  // the first block's loads have arrived
 #pragma unroll
         for (int j = 0; j < 4; j++) cv420_hrow<NV>(raw[j], W, nlut, H[j]);
@@ -317,7 +326,7 @@ __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int n
     for (; P + 1 < Pend; P++) {
         u32 ynext[4];
         cv420_load_luma(J, g, P + 1, ynext);
-        const Cv420Raw<NV> n2 = cv420_load_chroma<NV>(J, W, 2 * P + 3), n3 = cv420_load_chroma<NV>(J, W, 2 * P + 4);
+        const Cv420Raw<NV> n2 = cv420_load_chroma<NV, TIGHT>(J, W, 2 * P + 3), n3 = cv420_load_chroma<NV, TIGHT>(J, W, 2 * P + 4);
         cv420_rows<RGB12, FULL>(J, g, P, yrow, H, ylut);
         if (P == P0) CV_STAMP(st, 4, "s_nop 0");  // the first block's rows are computed, its stores issued
 #pragma unroll
@@ -361,7 +370,7 @@ __device__ __forceinline__ ConvJob cv420_job_in_registers(const ConvJob &j) {
 // waves cut x's unit sequence (ConvBatch) into equal contiguous shares — total / waves units, the first total % waves waves one more.  A
 // share is a vertical run of blocks inside one (band, column block) cell, or the end of a cell and the start of the next (in the next
 // band or job, too).  ylut: the limited-range luma table; nlut: byte / 255, which is also the full-range luma table.
-template <bool NV>
+template <bool NV, bool TIGHT = false>
 __device__ __forceinline__ void cv420_share(const ConvBatch &B, u32 block, u32 wave, u32 grid, u32 lane, const float *ylut, const float *nlut,
                                             unsigned long long *st = nullptr) {
     const u32 x = block & 7u;
@@ -389,11 +398,11 @@ __device__ __forceinline__ void cv420_share(const ConvBatch &B, u32 block, u32 w
             const int P0 = (int)(b * band + r);
             // (uniform branches: a job is one frame; range and node format are template parameters — as run-time flags they cost a scalar branch per pixel)
             if (J.rgb12) {
-                if (J.full) cv420_run<NV, true, true>(J, g, P0, (int)nrun, nlut, nlut, st);
-                else cv420_run<NV, true, false>(J, g, P0, (int)nrun, ylut, nlut, st);
+                if (J.full) cv420_run<NV, true, true, TIGHT>(J, g, P0, (int)nrun, nlut, nlut, st);
+                else cv420_run<NV, true, false, TIGHT>(J, g, P0, (int)nrun, ylut, nlut, st);
             } else {
-                if (J.full) cv420_run<NV, false, true>(J, g, P0, (int)nrun, nlut, nlut, st);
-                else cv420_run<NV, false, false>(J, g, P0, (int)nrun, ylut, nlut, st);
+                if (J.full) cv420_run<NV, false, true, TIGHT>(J, g, P0, (int)nrun, nlut, nlut, st);
+                else cv420_run<NV, false, false, TIGHT>(J, g, P0, (int)nrun, ylut, nlut, st);
             }
         }
         st = nullptr;  // (timing builds: only the share's first run is stamped phase by phase)

@@ -19,6 +19,11 @@ void __syncthreads() {}
 
 #include "smr_convert_420.h"
 
+// emu_set_tight(1): the TIGHT builds (k_yuv420_to_rgba_tight: nothing behind a window's last column is requested) — and, with
+// emu_set_guard(.., 1), chroma planes on the pitch such a frame has: the row's bytes rounded up to a dword, not the plain kernel's reach
+static int emu_tight = 0;
+extern "C" void emu_set_tight(int on) { emu_tight = on; }
+
 namespace {
 
 struct Plane {
@@ -32,11 +37,11 @@ Plane make_plane(const u8 *tight, int w, int h, int bpp, u8 fill, u32 min_row = 
     u32 pitch = (u32)(((size_t)w * bpp + 255) & ~(size_t)255);
     if (emu_min_pitch) {
         pitch = (u32)(((size_t)w * bpp + 3) & ~(size_t)3);
-        if (pitch < min_row) pitch = (min_row + 3u) & ~3u;
+        if (pitch < min_row && !emu_tight) pitch = (min_row + 3u) & ~3u;
     }
     // (a plane the library allocates ends with SMR_SURFACE_TAIL spare bytes and may be read past a row's end — conv_420_ok's rule for owned
     //  surfaces; a wrapped one, emu_min_pitch, is exactly pitch * h bytes and is only let through with a pitch that holds the reach)
-    p.buf.alloc((size_t)pitch * h + (emu_min_pitch ? 0 : SMR_SURFACE_TAIL), fill, 4);
+    p.buf.alloc((size_t)pitch * h + (emu_min_pitch || emu_tight ? 0 : SMR_SURFACE_TAIL), fill, 4);
     for (int y = 0; y < h; y++) memcpy(p.buf.ptr + (size_t)y * pitch, tight + (size_t)y * w * bpp, (size_t)w * bpp);
     p.view.ptr = p.buf.ptr; p.view.pitch = pitch; p.view.w = w; p.view.h = h;
     return p;
@@ -77,7 +82,10 @@ extern "C" int emu_convert_420_run(const u8 *y, const u8 *u, const u8 *v, int w,
     for (int P = 0; 4 * P < h; P += nb ? nb : 1)
         for (int g = 0; 4 * g < w; g++) {
 #define EMU_CV(NVv, R12, FULLv) \
-    do { if (nb) cv420_run<NVv, R12, FULLv>(J, g, P, nb, ylut, nlut); else cv420_block<NVv, R12, FULLv>(J, g, P, ylut, nlut); } while (0)
+    do { \
+        if (emu_tight) { if (nb) cv420_run<NVv, R12, FULLv, true>(J, g, P, nb, ylut, nlut); else cv420_block<NVv, R12, FULLv, true>(J, g, P, ylut, nlut); } \
+        else { if (nb) cv420_run<NVv, R12, FULLv>(J, g, P, nb, ylut, nlut); else cv420_block<NVv, R12, FULLv>(J, g, P, ylut, nlut); } \
+    } while (0)
             if (full) {
                 if (nv12 && rgb12) EMU_CV(true, true, true);
                 else if (nv12) EMU_CV(true, false, true);
@@ -140,7 +148,10 @@ extern "C" int emu_convert_420_shares(int n, const u8 *const *ys, const u8 *cons
     for (u32 blk = 0; blk < grid; blk++)
         for (u32 wv = 0; wv < 4; wv++)
             for (u32 lane = 0; lane < 64; lane++) {
-                if (nv12) cv420_share<true>(B, blk, wv, grid, lane, ylut, nlut);
+                if (emu_tight) {
+                    if (nv12) cv420_share<true, true>(B, blk, wv, grid, lane, ylut, nlut);
+                    else cv420_share<false, true>(B, blk, wv, grid, lane, ylut, nlut);
+                } else if (nv12) cv420_share<true>(B, blk, wv, grid, lane, ylut, nlut);
                 else cv420_share<false>(B, blk, wv, grid, lane, ylut, nlut);
             }
     for (int i = 0; i < n; i++) {

@@ -33,6 +33,8 @@ def emu():
     orc.build()
     if os.environ.get("SMR_EMU_GUARD"):  # the inner run of test_converter_never_leaves_its_planes: planes of exactly pitch * h bytes against an unmapped page
         h.emu_set_guard(int(os.environ["SMR_EMU_GUARD"]), 1)
+    if os.environ.get("SMR_EMU_TIGHT"):  # ... of test_tight_builds_...: k_yuv420_to_rgba_tight's code, chroma planes whose pitch is the row itself
+        h.emu_set_tight(1)
     return h
 
 
@@ -156,10 +158,27 @@ def test_converter_never_leaves_its_planes(emu, mode):
     The tests above once more in a child process, with every plane and node texture exactly pitch * h bytes — on the SMALLEST pitch the host
     code lets through (conv_420_ok: the reach of the last block's dword loads) — ending at (mode 1) or starting behind (mode 2) an unmapped
     page: a load or store outside the allocation kills the child.  Prefetches included: a run requests nothing behind its last block."""
-    if os.environ.get("SMR_EMU_GUARD"):
+    if os.environ.get("SMR_EMU_GUARD") or os.environ.get("SMR_EMU_TIGHT"):
         pytest.skip("this is the inner run")
     env = dict(os.environ, SMR_EMU_GUARD=str(mode))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
                         "block_converter or runs_of_blocks or equal_shares"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, f"guard mode {mode}: rc {r.returncode} (-11 = a kernel left its planes)\n{r.stdout[-3000:]}\n{r.stderr[-2000:]}"
+    assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_tight_builds_write_the_same_bytes_and_request_nothing_behind_a_row(emu, mode):
+    """k_yuv420_to_rgba_tight — the kernel of wrapped frames whose chroma rows fill their pitch (a decoder's tight surfaces): the dwords behind a
+    window's last column are not requested.  The tests above once more with the TIGHT builds: every byte the oracle's (mode 0), and with each
+    plane an allocation of exactly pitch * h bytes at pitch = the row's bytes rounded up to a dword, ending at / starting behind an unmapped
+    page (modes 1, 2) — where the plain kernel's reach would fault."""
+    if os.environ.get("SMR_EMU_GUARD") or os.environ.get("SMR_EMU_TIGHT"):
+        pytest.skip("this is the inner run")
+    env = dict(os.environ, SMR_EMU_TIGHT="1")
+    if mode:
+        env["SMR_EMU_GUARD"] = str(mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "block_converter or runs_of_blocks or equal_shares"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, f"tight, guard mode {mode}: rc {r.returncode} (-11 = the kernel left its planes)\n{r.stdout[-3000:]}\n{r.stderr[-2000:]}"
     assert " passed" in r.stdout

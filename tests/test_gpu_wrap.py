@@ -1,7 +1,7 @@
 """smr_surface_wrap on the device: frames and node textures over memory the caller owns (here: torch tensors), in place.  The contract of
 include/smr.h — an allocation covers exactly pitch x h bytes, no kernel touches a byte outside it — with the pitches a decoder hands out:
-tight rows (pitch == bytes per row: the 4:2:0 block converter then leaves such planes to the general kernel, its last block's spare dword
-would lie past the pitch), rows with four spare bytes (the block converter), 256-byte pitches.  Every result equals the oracle's bytes /
+tight rows (pitch == bytes per row: k_yuv420_to_rgba_tight, which requests nothing behind a window's last column — the plain kernel's spare
+dword would lie past the pitch), rows with four spare bytes and 256-byte pitches (the plain block converter).  Every result equals the oracle's bytes /
 the result of the same content in a surface the library allocated; canaries behind every wrapped plane stay intact."""
 import numpy as np
 import pytest
@@ -60,12 +60,8 @@ def test_wrapped_frames_convert_to_the_oracles_node_texture(ctx, hip, variant, w
     assert np.array_equal(got, want), (variant, w, h, slack, int((got != want).sum()))
     for b, p in zip(bufs, planes):
         assert _canary_intact(b, pad(p.shape[1]) * p.shape[0])
-    # which converter ran: the block converter needs the last block's spare dword inside the pitch
-    if w % 4 == 0 and w >= 8:
-        cw = w // 2
-        row = 2 * cw if variant == "nv12" else cw
-        need = ((2 * (cw - 3)) & ~3) + 12 if variant == "nv12" else ((cw - 3) & ~3) + 8
-        assert ran["frame_to_rgba_420"] == (1 if pad(row) >= need else 0), (ran, pad(row), need)
+    # every frame the block converter's geometry admits takes it — its plain kernel or, for rows that fill their pitch, its tight one
+    assert ran["frame_to_rgba_420"] == (1 if w % 4 == 0 and w >= 8 else 0) and ran["frame_to_rgba"] == 1, ran
 
 
 def test_a_wrapped_node_texture_is_resampled_and_composited_like_an_owned_one(ctx, hip):
