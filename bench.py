@@ -103,7 +103,7 @@ def font_book():
     if not _BOOK[1]:
         _BOOK[1] = True
         try:
-            from smelter_amd import text as T
+            from smelter_amd import fontbook as T
             _BOOK[0] = T.NativeFontBook.system()
         except Exception:
             _BOOK[0] = None

@@ -233,13 +233,16 @@ SMR_API int smr_debug_kernel_launches(const smr_ctx *ctx, uint32_t kernel, uint6
 
 /* ---- surfaces (NodeTexture / wgpu::Texture; state/node_texture.rs:11-163) -------- */
 SMR_API int smr_surface_create(smr_ctx *ctx, uint32_t w, uint32_t h, uint32_t format, smr_surface **out);
-/* Device memory the caller owns (a decoder's output, a torch tensor) as a surface, in place.  The allocation must cover pitch * h bytes —
- * every row backed out to the full pitch, the LAST ONE TOO: the block kernels read whole dwords, up to a dword past a row's last texel
- * (never past the pitch).  pitch >= w * bytes per texel; rows and the base 4-byte aligned for the block converters, 16-byte aligned for the
- * matrix-core resampler's node textures (other alignments take the general kernels).  Wrapped 4:2:0 / NV12 chroma planes whose rows FILL
- * their pitch (a decoder's tight surfaces: pitch == bytes per row) are converted by a build of the block converter that requests nothing behind
- * a row's last column (k_yuv420_to_rgba_tight: the same bytes, ~2 % more instructions); with 4 spare bytes of pitch, or allocated by the
- * library (every allocation of smr_surface_create / smr_frame_create ends with 16 spare bytes), a plane takes the plain one. */
+/* Device memory the caller owns (a decoder's output, a torch tensor) as a surface, in place.  pitch >= w * bytes per texel; rows and the base
+ * 4-byte aligned for the block converters, 16-byte aligned for the matrix-core resampler's node textures (other alignments take the general
+ * kernels).  What the library READS of a wrapped surface:
+ *   - 4:2:0 / NV12 planes of a frame (the input converter): the texels of each row and nothing else — every wrapped plane, tight rows
+ *     (pitch == bytes per row) or wide ones, is converted by the build of the block converter that requests nothing behind a row's last
+ *     column (k_yuv420_to_rgba_tight: the same bytes, ~2 % more instructions), so pitch * (h - 1) + row bytes of allocation suffice;
+ *   - RGBA8 / RGBA16F surfaces handed to the resampler or the compositor: whole 16-byte groups inside a row's pitch — the allocation must
+ *     back every row out to the pitch rounded down to 16 bytes, the LAST ROW TOO.
+ * Planes the library allocates itself (smr_surface_create / smr_frame_create: every allocation ends with 16 spare bytes) take the plain
+ * converter. */
 SMR_API int smr_surface_wrap(smr_ctx *ctx, void *dptr, size_t pitch, uint32_t w, uint32_t h, uint32_t format,
                              smr_surface **out);
 SMR_API void smr_surface_destroy(smr_ctx *ctx, smr_surface *s);
@@ -524,6 +527,10 @@ SMR_API int smr_renderer_register_input(smr_renderer *r, const char *input_id);
 SMR_API int smr_renderer_unregister_input(smr_renderer *r, const char *input_id);
 SMR_API int smr_renderer_register_image(smr_renderer *r, const char *image_id, const uint8_t *rgba_straight, uint32_t width, uint32_t height);
 SMR_API int smr_renderer_register_shader(smr_renderer *r, const char *shader_id, uint32_t builtin_id);
+/* An update is refused as a whole — the previous scene stays active — for everything the scene definition can get wrong: validation errors,
+ * unknown shader ids, and (with a font book) Text nodes no run can be made of (empty font book, text that is not UTF-8, absurd sizes).  One
+ * failure is reported AFTER the new scene is in place: a device allocation that fails while the output's frames or a Text node's surface are
+ * created (SMR_ERR_OOM): the new scene is active, the nodes that could not be drawn render transparent. */
 SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, uint32_t width, uint32_t height, uint32_t output_format,
                                       const char *scene_json);
 SMR_API int smr_renderer_unregister_output(smr_renderer *r, const char *output_id);
@@ -547,6 +554,18 @@ SMR_API int smr_renderer_render(smr_renderer *r, int64_t pts_ns, const smr_input
 SMR_API int smr_renderer_add_lane(smr_renderer *r, smr_ctx *ctx);
 SMR_API int smr_renderer_sync(smr_renderer *r);
 
+/* ABI version: a host checks smr_abi_version() == SMR_ABI_VERSION when it loads the library.
+ *   1  rounds 1 - 4.
+ *   2  SMR_INGEST_MFMA_F16_FUSED (ingest implementation 5, the fused one-code-per-stage conversion) left the product enum: a product build
+ *      rejects 5, a laboratory build (smr_build_flags() & 1) keeps it under an internal name.  Kernel counter slot 2, once
+ *      SMR_KERNEL_INGEST_MFMA_WG, counts SMR_KERNEL_FRAME_TO_RGBA_420.  smr_text_params moved in front of the font-book entry points.  The
+ *      SMR_CONVERT_GENERAL / SMR_DISABLE_FUSED / SMR_COMPOSE_SELECT environment knobs are smr_ctx_set_option options in a product build
+ *      (the environment is read by laboratory builds only).
+ * The two removed names are kept as macros that do not compile, so that a source written against version 1 fails where it uses them
+ * instead of silently meaning something else. */
+#define SMR_ABI_VERSION 2
+#define SMR_INGEST_MFMA_F16_FUSED SMR_REMOVED_IN_ABI_2__the_fused_conversion_is_a_laboratory_route__use_SMR_INGEST_AUTO
+#define SMR_KERNEL_INGEST_MFMA_WG SMR_REMOVED_IN_ABI_2__slot_2_counts_SMR_KERNEL_FRAME_TO_RGBA_420
 SMR_API uint32_t smr_abi_version(void);
 /* bit 0: a laboratory build (-DSMR_LAB: environment knobs, the fused-conversion route, profiling hooks); 0 for a product build */
 SMR_API uint32_t smr_build_flags(void);

@@ -482,21 +482,43 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
         }
         Json tree;
         JsonParser jp(converted);
-        std::string missing;
+        std::string missing, text_err;
         if (jp.parse(tree, err)) {
             std::vector<const Json *> stack{&tree};
-            while (!stack.empty() && missing.empty()) {
+            while (!stack.empty() && missing.empty() && text_err.empty()) {
                 const Json *j = stack.back();
                 stack.pop_back();
                 for (const Json &a : j->arr) stack.push_back(&a);
                 for (const auto &kv : j->obj) stack.push_back(&kv.second);
                 const Json *type = j->get("type"), *sid = j->get("shader_id");
                 if (type && sid && type->str == "Shader" && !r->shaders.count(sid->str)) missing = sid->str;
+                // The renderer draws its Text nodes itself (smr_renderer_set_fontbook) once the new scene is in place; what can make that fail for
+                // reasons the scene carries — an empty font book, text that is not UTF-8, sizes no run can have — is found HERE, while the previous
+                // scene is still the active one (the reference fails an update as a whole: state.rs:177-189).  smr_fontbook_measure runs
+                // the rasteriser's own checks (text.cpp: measure / rasterise share sane_sizes, the font match and the decoder).
+                if (type && type->str == "Text" && r->fontbook) {
+                    auto str = [&](const char *k) { const Json *v = j->get(k); return v ? v->str : std::string(); };
+                    auto num = [&](const char *k, double d) { const Json *v = j->get(k); return v ? v->num : d; };
+                    const std::string text = str("text"), family = str("font_family"), style = str("style"), weight = str("weight"), wrap = str("wrap");
+                    smr_text_params p;
+                    memset(&p, 0, sizeof(p));
+                    p.text = text.c_str(); p.font_family = family.c_str(); p.style = style.c_str(); p.weight = weight.c_str(); p.wrap = wrap.c_str();
+                    p.align = "Left";
+                    p.font_size = (float)num("font_size", 0.0); p.line_height = (float)num("line_height", num("font_size", 0.0));
+                    p.max_width = 7682.0f; p.max_height = 4320.0f;
+                    float widest = 0.0f;
+                    uint32_t lines = 0;
+                    if (smr_fontbook_measure(r->fontbook, &p, &widest, &lines) != 0) text_err = std::string("text node: ") + smr_fontbook_last_error(r->fontbook);
+                }
             }
         }
         if (!missing.empty()) {
             if (o.w == 0) r->outputs.erase(output_id);
             return fail(r, -1, "Shader \"" + missing + "\" does not exist. You have to register it first before using it in the scene definition.");
+        }
+        if (!text_err.empty()) {
+            if (o.w == 0) r->outputs.erase(output_id);
+            return fail(r, -1, text_err);
         }
     }
     if (!o.scene.update(scene_json, width, height, err)) {
@@ -511,6 +533,8 @@ SMR_API int smr_renderer_update_scene(smr_renderer *r, const char *output_id, ui
     // node indices belong to the new graph: per-node surfaces are re-created on demand, text runs must be supplied again
     free_node_surfaces(r, o);
     int rc = enter_lane(r, o, 0);  // the output's first frames exist after a successful update, as before
+    // (what is left to fail below is a device allocation — the frames, a text node's surface: SMR_ERR_OOM with the NEW scene active and the
+    //  nodes that could not be drawn transparent; include/smr.h says so.  Everything the scene itself can get wrong was refused above.)
     if (rc >= 0 && r->fontbook) rc = draw_text_nodes(r, output_id, o);
     return rc;
 }

@@ -1,6 +1,6 @@
 // text.cpp — TrueType reader, line layout and exact-area glyph rasteriser behind smr_fontbook_* (text.h; reference:
 // smelter-render/src/transformations/text_renderer.rs:72-167, 236-368).  Host code only, no GPU; the run it produces is drawn by
-// smr_blit_glyphs.  Kept operation for operation in step with smelter_amd/text.py (tests/test_text_capi.py: byte-identical runs):
+// smr_blit_glyphs.  Kept operation for operation in step with tests/text_twin.py (tests/test_text_capi.py: byte-identical runs):
 // every quantity is a double, products and sums are written in the order the Python evaluates them, and this file is compiled with
 // -ffp-contract=off like everything else (smelter_amd/build.py).
 #include "text.h"
@@ -286,12 +286,16 @@ bool Font::glyph_range(uint32_t gid, size_t &off, size_t &len) const {
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // outlines: what fontTools' glyf pen protocol emits (ttLib/tables/_g_l_y_f.py Glyph.draw, pens/basePen.py DecomposingPen.addComponent,
-// pens/transformPen.py) turned into closed polylines the way text.py's Font.outline does
+// pens/transformPen.py) turned into closed polylines the way text_twin.py's Font.outline does
 // ---------------------------------------------------------------------------------------------------------------------------------
 
 void Font::draw(uint32_t gid, const std::vector<Affine> &chain, bool top_level, int depth, std::vector<Contour> &out) {
     size_t off, len;
-    if (depth > 16 || !glyph_range(gid, off, len)) return;
+    // (depth alone bounds nothing: composites that each name N composite children cost N^16 calls.  An outline gets a budget of components
+    //  and points — far above any real glyph — and a font that exceeds it is a malformed font)
+    if (depth > 16 || draw_calls_ > 4096u) return;
+    if (++draw_calls_ > 4096u) return;
+    if (!glyph_range(gid, off, len)) return;
     const int32_t n_contours = i16(off);
     if (n_contours < 0) {  // composite: every component through its transform, then through the transforms around it
         size_t p = off + 10;
@@ -319,7 +323,7 @@ void Font::draw(uint32_t gid, const std::vector<Affine> &chain, bool top_level, 
             std::vector<Affine> inner = chain;
             if (!t.identity) inner.push_back(t);
             draw(child, inner, false, depth + 1, out);
-            if (!(flags & 0x0020u) || bad_) break;  // MORE_COMPONENTS
+            if (!(flags & 0x0020u) || bad_ || draw_calls_ > 4096u) break;  // MORE_COMPONENTS
         }
         return;
     }
@@ -367,7 +371,7 @@ void Font::draw(uint32_t gid, const std::vector<Affine> &chain, bool top_level, 
         }
         pts[i] = Pt{x, y};
     }
-    auto curve = [](Contour &cur, const Pt &c, const Pt &p1) {  // one quadratic segment as 8 chords (text.py)
+    auto curve = [](Contour &cur, const Pt &c, const Pt &p1) {  // one quadratic segment as 8 chords (text_twin.py)
         const Pt p0 = cur.back();
         for (int k = 1; k < 9; k++) {
             const double t = (double)k / 8.0;
@@ -424,7 +428,9 @@ const std::vector<Contour> &Font::outline(uint32_t gid) {
     auto it = outlines_.find(gid);
     if (it != outlines_.end()) return it->second;
     std::vector<Contour> out;
+    draw_calls_ = 0;
     draw(gid, {}, true, 0, out);
+    if (draw_calls_ > 4096u) out.clear();  // (budget exceeded: no outline rather than a fraction of an absurd one)
     return outlines_.emplace(gid, std::move(out)).first->second;
 }
 
@@ -496,11 +502,11 @@ int Font::coverage_index(size_t cov, uint32_t gid) const {
             if (u16(cov + 4 + 2 * (size_t)i) == gid) return (int)i;
         return -1;
     }
-    int index = 0;  // format 2: the glyph list the ranges expand to, in range order
+    uint32_t index = 0;  // format 2: the glyph list the ranges expand to, in range order (65 535 ranges of 65 536 glyphs overflow an int: unsigned, and capped)
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t a = u16(cov + 4 + 6 * (size_t)i), b = u16(cov + 4 + 6 * (size_t)i + 2);
-        if (gid >= a && gid <= b) return index + (int)(gid - a);
-        if (b >= a) index += (int)(b - a + 1);
+        if (gid >= a && gid <= b) return index + (gid - a) < 0x7fffffffu ? (int)(index + (gid - a)) : -1;
+        if (b >= a) index = index + (b - a + 1) < 0x7fffffffu ? index + (b - a + 1) : 0x7fffffffu;
     }
     return -1;
 }
@@ -713,16 +719,19 @@ bool measure(FontBook &book, const smr_text_params &p, float &widest, uint32_t &
 // along the row turns the deltas into coverage (non-zero winding for outlines that do not self-overlap)
 // ---------------------------------------------------------------------------------------------------------------------------------
 
-static void accumulate_edge(std::vector<double> &a, int w, int h, double x0, double y0, double x1, double y1) {
+void accumulate_edge(std::vector<double> &a, int w, int h, double x0, double y0, double x1, double y1) {  // (not static: tests/san/host_fuzz.cpp --edges drives it directly)
     if (y0 == y1) return;
     double d = 1.0;
     if (y0 > y1) { std::swap(x0, x1); std::swap(y0, y1); d = -1.0; }
     const double dxdy = (x1 - x0) / (y1 - y0);
     double x = x0;
+    // x advances by dxdy * dy row by row: rounding can carry it a hair past the edge's own end (an edge that ends exactly on the bitmap's left
+    // column arrives at -1e-17: floor -> column -1, eight bytes in front of the accumulator).  An edge never leaves its own x range.
+    const double x_lo = std::min(x0, x1), x_hi = std::max(x0, x1);
     const int ya = std::max((int)std::floor(y0), 0), yb = std::min(h, (int)std::ceil(y1));
     for (int y = ya; y < yb; y++) {
         const double dy = std::min((double)y + 1.0, y1) - std::max((double)y, y0);
-        const double xn = x + dxdy * dy;
+        const double xn = std::min(std::max(x + dxdy * dy, x_lo), x_hi);
         const double s = d * dy;
         const double xa = x < xn ? x : xn, xb = x < xn ? xn : x;
         const int ia = (int)std::floor(xa), ib = (int)std::ceil(xb);

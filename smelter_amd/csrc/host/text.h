@@ -10,8 +10,8 @@
 // rasteriser.  NOT restated (stated in include/smr.h too): GSUB ligatures / contextual alternates, mark positioning, bidi, font
 // fallback, hinting — glyph SHAPES and sub-pixel positions are this file's, not glyphon's; parity for text pixels stays unpinned.
 //
-// The C++ here is the product path; smelter_amd/text.py is its Python twin (fontTools-based) and tests/test_text_capi.py holds the two
-// to each other byte for byte (glyph runs and atlases).  Everything is double precision in the order text.py evaluates it.
+// The C++ here is the product path; tests/text_twin.py is its Python twin (fontTools-based) and tests/test_text_capi.py holds the two
+// to each other byte for byte (glyph runs and atlases).  Everything is double precision in the order text_twin.py evaluates it.
 #pragma once
 
 #include <cstdint>
@@ -63,6 +63,7 @@ private:
     Table table(uint32_t tag) const;
     // bounds-checked big-endian reads: out of range reads give 0 and set bad_
     mutable bool bad_ = false;
+    uint32_t draw_calls_ = 0;  // components visited by the outline being drawn (Font::draw's budget)
     uint32_t u8(size_t o) const;
     uint32_t u16(size_t o) const;
     int32_t i16(size_t o) const;
@@ -114,6 +115,8 @@ struct GlyphBitmap {
 };
 // Exact-area coverage of one glyph at `scale` pixels per font unit, origin at the fractional pixel offset (fx, fy) of its cell.
 GlyphBitmap rasterise_glyph(Font &font, uint32_t gid, double scale, double fx, double fy);
+// one edge into the signed-area accumulator of a w x h bitmap (w * h + 1 doubles; x in [0, w - 1], any y): internal, declared for the sanitizer harness
+void accumulate_edge(std::vector<double> &a, int w, int h, double x0, double y0, double x1, double y1);
 
 struct TextRun {
     std::vector<smr_glyph> glyphs;

@@ -516,9 +516,8 @@ static bool conv_batchable(const smr_ctx *ctx, const smr_frame *in) {
 // k_yuv420_to_rgba's frames (cv420_block, smr_convert_420.h): 4:2:0 planar / NV12, width a multiple of 4 from 8, even height, every plane
 // dword-aligned.  The plain kernel reads up to a dword past the last block's window; the bytes of that dword are never used (the window's
 // last column is the plane's edge, repeated), but they are read: a plane the library allocated may be read past a row's end — the next row,
-// or the 16 bytes every allocation ends with (SMR_SURFACE_TAIL) — a wrapped one only inside its pitch.  A wrapped plane whose pitch does not
-// hold that reach (tight rows: a decoder's pitch == bytes per row) takes k_yuv420_to_rgba_tight, which requests nothing behind a window's last
-// column.  -> 0: not a frame for the block converter | 1: the plain kernel | 2: the tight one
+// or the 16 bytes every allocation ends with (SMR_SURFACE_TAIL) — a wrapped one is read inside its rows' bytes only: it takes
+// k_yuv420_to_rgba_tight, which requests nothing behind a window's last column (tight rows — a decoder's pitch == bytes per row — or wide ones).  -> 0: not a frame for the block converter | 1: the plain kernel | 2: the tight one
 static int conv_420_mode(const smr_ctx *ctx, const smr_frame *in) {
     if (ctx->convert_impl != SMR_CONVERT_AUTO) return 0;
     const bool nv = in->format == SMR_FRAME_NV12;
@@ -531,7 +530,10 @@ static int conv_420_mode(const smr_ctx *ctx, const smr_frame *in) {
     const u32 need = nv ? ((2u * (cw - 3u)) & ~3u) + 12u : ((cw - 3u) & ~3u) + 8u;
     const u32 row = nv ? 2u * cw : cw;
     if (in->planes[0]->pitch < in->width || in->planes[1]->pitch < row || (!nv && in->planes[2]->pitch < row)) return 0;
-    auto reach_ok = [&](const smr_surface *s) { return s->pitch >= need || s->owned; };
+    // (a wrapped plane with a wide pitch still ends with its last ROW for many producers — pitch * (h - 1) + row bytes, not pitch * h — and the plain
+    //  kernel's reach into that row's padding would leave the allocation: every plane the library does not own takes the tight kernel, + 2 %)
+    (void)need;
+    auto reach_ok = [&](const smr_surface *s) { return s->owned; };
     return reach_ok(in->planes[1]) && (nv || reach_ok(in->planes[2])) ? 1 : 2;
 }
 static bool conv_420_ok(const smr_ctx *ctx, const smr_frame *in) { return conv_420_mode(ctx, in) != 0; }

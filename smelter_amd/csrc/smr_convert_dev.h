@@ -2,6 +2,7 @@
 #pragma once
 
 #include "smr_internal.h"
+#include "smr_yuv_fast.h"
 
 #ifdef __HIPCC__
 
@@ -88,6 +89,31 @@ __device__ __forceinline__ u32 yuv_byte(float r, float g, float b, int plane) {
         comp = ((v + 0.5f) * 0.87843137254f) + (16.0f / 255.0f);
     }
     return (u32)(int)(comp * 255.0f + 0.5f);
+}
+
+// ---- the same bytes through the fast path (smr_yuv_fast.h: three FMAs per value, proven equal to the sequence above wherever its guard
+//      flag is clear — tools/check_yuv_fast.cpp, the complete domain) with the sequence itself behind the flag: a divergent branch that
+//      2.4 values in 10 000 take.  The callers hold the bytes as floats already (v_cvt_f32_ubyteN: extract + convert in one instruction).
+// Y' of a pixel: px = the RGBA8 bytes, fr / fg / fb = its colour bytes as floats
+__device__ __forceinline__ u32 yuv_luma_byte(u32 px, float fr, float fg, float fb) {
+    bool flag;
+    u32 y = yuvfast::convert<0>(fr, fg, fb, &flag);
+    if (flag) y = yuv_byte(unorm_of_byte(px & 0xffu), unorm_of_byte((px >> 8) & 0xffu), unorm_of_byte((px >> 16) & 0xffu), 0);
+    return y;
+}
+// (Cb | Cr << 8) of a 2x2 block: pa, pb = the upper row's pixels, pc, pd = the lower row's; sr / sg / sb = the block's byte sums as floats
+// (exact: sums of integers up to 1020 in any order).  The reference's mean is ((a + b) + (c + d)) / 4 of the byte / 255 values.
+__device__ __forceinline__ u32 yuv_chroma_bytes(u32 pa, u32 pb, u32 pc, u32 pd, float sr, float sg, float sb) {
+    bool f1, f2;
+    u32 u = yuvfast::convert<1>(sr, sg, sb, &f1), v = yuvfast::convert<2>(sr, sg, sb, &f2);
+    if (f1 || f2) {
+        const float mr = ((unorm_of_byte(pa & 0xffu) + unorm_of_byte(pb & 0xffu)) + (unorm_of_byte(pc & 0xffu) + unorm_of_byte(pd & 0xffu))) * 0.25f;
+        const float mg = ((unorm_of_byte((pa >> 8) & 0xffu) + unorm_of_byte((pb >> 8) & 0xffu)) + (unorm_of_byte((pc >> 8) & 0xffu) + unorm_of_byte((pd >> 8) & 0xffu))) * 0.25f;
+        const float mb = ((unorm_of_byte((pa >> 16) & 0xffu) + unorm_of_byte((pb >> 16) & 0xffu)) + (unorm_of_byte((pc >> 16) & 0xffu) + unorm_of_byte((pd >> 16) & 0xffu))) * 0.25f;
+        u = yuv_byte(mr, mg, mb, 1);
+        v = yuv_byte(mr, mg, mb, 2);
+    }
+    return u | (v << 8);
 }
 
 #endif

@@ -121,7 +121,7 @@ static void drain_profile(smr_ctx *ctx) {
 
 extern "C" {
 
-uint32_t smr_abi_version(void) { return 1; }
+uint32_t smr_abi_version(void) { return SMR_ABI_VERSION; }
 uint32_t smr_build_flags(void) { return SMR_LAB_BUILD ? 1u : 0u; }
 uint32_t smr_ctx_mode(const smr_ctx *ctx) { return ctx ? ctx->mode : 0u; }
 uint32_t smr_sizeof_layout(void) { return (uint32_t)sizeof(smr_layout); }
@@ -161,7 +161,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
         if (!strcmp(e, "valu")) ctx->ingest_impl = SMR_INGEST_VALU_F32;
         else if (!strcmp(e, "mfma")) ctx->ingest_impl = SMR_INGEST_MFMA_F16;
         else if (!strcmp(e, "mfma_node")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_NODE;
-        else if (!strcmp(e, "fused")) ctx->ingest_impl = SMR_INGEST_MFMA_F16_FUSED;
+        else if (!strcmp(e, "fused")) ctx->ingest_impl = SMR_INGEST_LAB_FUSED;
     }
     if (const char *e = getenv("SMR_CONVERT_GENERAL")) ctx->convert_impl = (e[0] && e[0] != '0') ? SMR_CONVERT_GENERAL : SMR_CONVERT_AUTO;  // (read once: tools)
     if (const char *e = getenv("SMR_CONVERT_LDS_PAD")) ctx->convert_lds_pad = (u32)atoi(e);
@@ -231,8 +231,8 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
     if (!ctx) return SMR_ERR_INVALID;
     switch (option) {
     case SMR_OPT_INGEST_IMPL:
-        if (value < 0 || value > SMR_INGEST_MFMA_F16_FUSED || value == 3) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
-        if (value == SMR_INGEST_MFMA_F16_FUSED && !SMR_LAB_BUILD)
+        if (value < 0 || value > SMR_INGEST_LAB_FUSED || value == 3) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: unknown ingest implementation %d", value);
+        if (value == SMR_INGEST_LAB_FUSED && !SMR_LAB_BUILD)
             return smr_fail(ctx, SMR_ERR_INVALID, "smr_ctx_set_option: ingest implementation 5 (fused conversion) exists in laboratory builds only (-DSMR_LAB)");
         ctx->ingest_impl = (u32)value;
         return SMR_OK;

@@ -10,7 +10,7 @@
 //   wave A  k_yuv420_to_rgba (smr_convert_420.h: every frame of the call in one launch, the reference's node texture bit for bit,
 //           RGB12 where only the resampler reads it) + k_ingest_wave (smr_ingest_wave.h: both Lanczos passes on the matrix cores,
 //           node textures -> dst-sized RGBA8 tiles, all inputs of the frame in one launch; the f16 intermediate lives in registers).
-//           Options: the conversion folded into k_ingest_wave (SMR_INGEST_MFMA_F16_FUSED: no node texture at all, not exact);
+//           Options: the conversion folded into k_ingest_wave (SMR_INGEST_LAB_FUSED: no node texture at all, not exact);
 //           k_ingest_resample (smr_fused_ingest.h: every pass in f32, SMR_INGEST_VALU_F32).
 //   wave B  k_compose_output (smr_fused_compose.h) — all layouts + RGBA->Y'CbCr (or an RGBA8 node target) in one launch, driven
 //           by per-tile class records (k_classify_tiles) that are kept while the layout list repeats; the RGBA8 output frame
@@ -625,7 +625,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
 }
 
 // InputTexture::convert_to_node_texture + ResampledChild::render for one input: the exact converter into a node texture and the
-// matrix-core kernel on it (the default), the fused-conversion kernel (SMR_INGEST_MFMA_F16_FUSED), the f32 kernel (SMR_INGEST_VALU_F32),
+// matrix-core kernel on it (the default), the fused-conversion kernel (SMR_INGEST_LAB_FUSED), the f32 kernel (SMR_INGEST_VALU_F32),
 // otherwise convert + general resample.  This is the per-shard step of the multi-GPU path: each GPU turns its inputs into dst-sized tiles.
 //
 // `new_call`: open a weight-cache call of its own.  The batch entry point passes false: the bands it already handed to jobs that are

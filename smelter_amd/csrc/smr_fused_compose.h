@@ -353,20 +353,21 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
         }
         return;
     }
-    // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52, as yuv_component() /
-    // unorm8() compute it, minus the operations that cannot act on bytes (smr_convert_dev.h: unorm_of_byte, yuv_byte)
+    // RGBA -> Y'CbCr on the raw (gamma-encoded) bytes: rgba_to_yuv.wgsl:26-54 / rgba_to_nv12.wgsl:24-52 — the bytes yuv_component() /
+    // unorm8() compute, through the fast path of smr_yuv_fast.h: three FMAs per value on the bytes as floats, the reference sequence itself
+    // (unorm_of_byte, yuv_byte) only where the guard flag asks for it (smr_convert_dev.h: yuv_luma_byte, yuv_chroma_bytes)
     float cr[8], cg[8], cb[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        cr[k] = unorm_of_byte(acc[k] & 0xffu);
-        cg[k] = unorm_of_byte((acc[k] >> 8) & 0xffu);
-        cb[k] = unorm_of_byte((acc[k] >> 16) & 0xffu);
+        cr[k] = (float)(acc[k] & 0xffu);
+        cg[k] = (float)((acc[k] >> 8) & 0xffu);
+        cb[k] = (float)((acc[k] >> 16) & 0xffu);
     }
     u32 yrow0 = 0, yrow1 = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        yrow0 |= yuv_byte(cr[k], cg[k], cb[k], 0) << (8 * k);
-        yrow1 |= yuv_byte(cr[4 + k], cg[4 + k], cb[4 + k], 0) << (8 * k);
+        yrow0 |= yuv_luma_byte(acc[k], cr[k], cg[k], cb[k]) << (8 * k);
+        yrow1 |= yuv_luma_byte(acc[4 + k], cr[4 + k], cg[4 + k], cb[4 + k]) << (8 * k);
     }
     if (half) {
         *(u16 *)(yp.ptr + b_off(py0, yp.pitch, px0)) = (u16)yrow0;
@@ -377,16 +378,16 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     }
     // chroma: the bilinear tap at the chroma texel centre = weights (1/2, 1/2) x (1/2, 1/2):
     //     (a * .5 + b * .5) * .5 + (c * .5 + d * .5) * .5  ==  ((a + b) + (c + d)) * .25   bit for bit
-    // (a power of two scales exactly and commutes with rounding — the operands are 0 or >= 1/255, nowhere near the subnormals)
+    // (a power of two scales exactly and commutes with rounding — the operands are 0 or >= 1/255, nowhere near the subnormals);
+    // the fast path takes the block's byte sums (exact in f32)
     u32 uv[2][2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int a = 2 * j, b = 2 * j + 1, c = 4 + 2 * j, d = 4 + 2 * j + 1;
-        const float mr = ((cr[a] + cr[b]) + (cr[c] + cr[d])) * 0.25f;
-        const float mg = ((cg[a] + cg[b]) + (cg[c] + cg[d])) * 0.25f;
-        const float mb = ((cb[a] + cb[b]) + (cb[c] + cb[d])) * 0.25f;
-        uv[j][0] = yuv_byte(mr, mg, mb, 1);
-        uv[j][1] = yuv_byte(mr, mg, mb, 2);
+        const u32 q = yuv_chroma_bytes(acc[a], acc[b], acc[c], acc[d], (cr[a] + cr[b]) + (cr[c] + cr[d]), (cg[a] + cg[b]) + (cg[c] + cg[d]),
+                                       (cb[a] + cb[b]) + (cb[c] + cb[d]));
+        uv[j][0] = q & 0xffu;
+        uv[j][1] = q >> 8;
     }
     const int cx = px0 >> 1, cy = py0 >> 1;
     if (NV == 0) {

@@ -119,25 +119,33 @@ __device__ __forceinline__ void m_convert_px(const MConv &J, u32 yy, u32 ua, u32
 // columns 0-1, the odd row's that of columns 2-3.  Returns the four luma bytes; *mine / *other = (U | V << 8) of the block this
 // lane finished / the one its neighbour finished.
 __device__ __forceinline__ u32 m_direct_yuv(const u32 px[4], bool odd, u32 *mine, u32 *other) {
-    u32 yq = 0;
-    float own_r = 0.f, own_g = 0.f, own_b = 0.f, snd_r = 0.f, snd_g = 0.f, snd_b = 0.f;
-#pragma nounroll
-    for (int p = 0; p < 2; p++) {  // (a real two-trip loop: unrolled, the twelve unpacked channels cost registers the kernels do not have)
-        const u32 pa = p ? px[2] : px[0], pb = p ? px[3] : px[1];
-        const float ar = unorm_of_byte(pa & 0xffu), ag = unorm_of_byte((pa >> 8) & 0xffu), ab = unorm_of_byte((pa >> 16) & 0xffu);
-        const float br = unorm_of_byte(pb & 0xffu), bg = unorm_of_byte((pb >> 8) & 0xffu), bb = unorm_of_byte((pb >> 16) & 0xffu);
-        const u32 y2 = yuv_byte(ar, ag, ab, 0) | (yuv_byte(br, bg, bb, 0) << 8);
-        yq |= y2 << (16 * p);
-        const float hr = ar + br, hg = ag + bg, hb = ab + bb;  // (row sums; the halvings are one exact * .25 at the end)
-        const bool mine_here = (p == 1) == odd;  // this lane finishes block p, the neighbour the other one
-        own_r = mine_here ? hr : own_r; own_g = mine_here ? hg : own_g; own_b = mine_here ? hb : own_b;
-        snd_r = mine_here ? snd_r : hr; snd_g = mine_here ? snd_g : hg; snd_b = mine_here ? snd_b : hb;
+    // fast path (smr_yuv_fast.h: yuv_luma_byte / yuv_chroma_bytes, the reference sequence behind their guard flags): luma from the bytes as floats;
+    // chroma from the block's byte sums — this lane's row sums of both blocks, the neighbour's row sums of the block this lane finishes
+    // (exact integers: either order of the sum is the same value)
+    float f[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        f[i][0] = (float)(px[i] & 0xffu); f[i][1] = (float)((px[i] >> 8) & 0xffu); f[i][2] = (float)((px[i] >> 16) & 0xffu);
     }
-    const float nb_r = __int_as_float(dev_mov_dpp_quad_swap(__float_as_int(snd_r)));
-    const float nb_g = __int_as_float(dev_mov_dpp_quad_swap(__float_as_int(snd_g)));
-    const float nb_b = __int_as_float(dev_mov_dpp_quad_swap(__float_as_int(snd_b)));
-    const float m_r = (own_r + nb_r) * 0.25f, m_g = (own_g + nb_g) * 0.25f, m_b = (own_b + nb_b) * 0.25f;
-    *mine = yuv_byte(m_r, m_g, m_b, 1) | (yuv_byte(m_r, m_g, m_b, 2) << 8);
+    u32 yq = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) yq |= yuv_luma_byte(px[i], f[i][0], f[i][1], f[i][2]) << (8 * i);
+    // this lane finishes block (odd ? 1 : 0) of its four columns and hands the row sums and pixels of the other block to its neighbour
+    const u32 own_a = odd ? px[2] : px[0], own_b = odd ? px[3] : px[1], snd_a = odd ? px[0] : px[2], snd_b = odd ? px[1] : px[3];
+    float own[3], snd[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float h0 = f[0][c] + f[1][c], h1 = f[2][c] + f[3][c];
+        own[c] = odd ? h1 : h0;
+        snd[c] = odd ? h0 : h1;
+    }
+    const float nb_r = __int_as_float(dev_mov_dpp_quad_swap(__float_as_int(snd[0])));
+    const float nb_g = __int_as_float(dev_mov_dpp_quad_swap(__float_as_int(snd[1])));
+    const float nb_b = __int_as_float(dev_mov_dpp_quad_swap(__float_as_int(snd[2])));
+    const u32 nb_a = (u32)dev_mov_dpp_quad_swap((int)snd_a), nb_bb = (u32)dev_mov_dpp_quad_swap((int)snd_b);  // (the neighbour row's pixels: the exact branch's operands)
+    // upper row first: the even lane's own pixels are the block's upper row
+    *mine = odd ? yuv_chroma_bytes(nb_a, nb_bb, own_a, own_b, own[0] + nb_r, own[1] + nb_g, own[2] + nb_b)
+                : yuv_chroma_bytes(own_a, own_b, nb_a, nb_bb, own[0] + nb_r, own[1] + nb_g, own[2] + nb_b);
     *other = (u32)dev_mov_dpp_quad_swap((int)*mine);
     return yq;
 }

@@ -1,7 +1,7 @@
 // smr_ingest_wave.h — wave A of the hot path, second generation: k_ingest_wave (included by smr_fused.hip only).
 //
 // The matrix-core resampler: an RGBA8 node texture (what the exact input converter wrote: smr_convert_420.h — the default route) or,
-// with SMR_INGEST_MFMA_F16_FUSED, a planar 4:2:0 / NV12 frame converted on the fly -> dst-sized sRGB RGBA8 tile, i.e.
+// with SMR_INGEST_LAB_FUSED, a planar 4:2:0 / NV12 frame converted on the fly -> dst-sized sRGB RGBA8 tile, i.e.
 // (planar_yuv_to_rgba.wgsl:35-58 followed by) the two Lanczos3 passes of transformations/layout/resample.wgsl:31-87 with their
 // Rgba16Float intermediate (layout/resampler.rs:25-28), both passes as banded GEMMs on v_mfma_f32_16x16x32_f16 with f16-pair
 // operands — but organised so that a wave never waits for another wave:
@@ -337,19 +337,27 @@ __host__ __device__ inline int w_band_bytes(int nks) { return 2 * nks * 2 * 64 *
 // One table gather per value instead of two (estimate byte, then the threshold above it): a bucket — 7 mantissa bits — holds at most one
 // threshold, so its entry carries the code of its lowest x and where in the bucket the code steps up.  The clamped operand decides both
 // (below 2^-13: bucket 0, code 0, no threshold; at and above 1: the last bucket's top, past its threshold): the values of srgb_encode8.
-__device__ __forceinline__ u32 w_encode8(float x, const u32 *__restrict__ enc) {
-    const float xc = dev_fmed3(x, 1.220703125e-4f, 0.99999994f);
+// Round 6: the bucket is addressed by bits [26:16] of the clamped operand (the clamp keeps bits [31:27] fixed: no subtraction), and its entry
+// is (code << 16) | (0xffff - threshold offset): adding the operand's low 16 bits carries into the code exactly when the operand lies past the
+// threshold.  Five vector instructions per value (median, shift, mask, mask, add) against ten; the sum's byte 2 is the code.
+__device__ __forceinline__ u32 w_encode_sum(float x, const u32 *__restrict__ enc) {
+    const u32 b = __float_as_uint(dev_fmed3(x, 1.220703125e-4f, 0.99999994f));  // [0x39000000, 0x3f7fffff]
 #if SMR_WAVE_ENC1
-    const u32 b = __float_as_uint(xc) - 0x39000000u;
-    const u32 e = enc[b >> 16];
-    return (e & 0xffffu) + ((b & 0xffffu) > (e >> 16) ? 1u : 0u);
+    const u32 e = (enc - 0x100)[(b >> 16) & 0x7ffu];  // (0x3900 & 0x7ff = 0x100: the table's first bucket)
+    return e + (b & 0xffffu);
 #else
     const float *thr = (const float *)enc;
     const u8 *est = (const u8 *)(thr + SMR_ENC_OFFSET_FROM_THR);
-    u32 c = est[(__float_as_uint(xc) - 0x39000000u) >> 16];
+    u32 c = est[(b - 0x39000000u) >> 16];
     c += thr[c + 1] <= x ? 1u : 0u;
-    return c;
+    return c << 16;
 #endif
+}
+__device__ __forceinline__ u32 w_encode8(float x, const u32 *__restrict__ enc) { return w_encode_sum(x, enc) >> 16; }
+// three encoded channels -> an opaque RGBA8 pixel: two byte permutes (byte 2 of each sum; selector 0x0d = 0xff)
+__device__ __forceinline__ u32 w_encode_px(float r, float g, float b, const u32 *__restrict__ enc) {
+    const u32 rg = dev_perm(w_encode_sum(g, enc), w_encode_sum(r, enc), 0x0c0c0602u);
+    return dev_perm(w_encode_sum(b, enc), rg, 0x0d060100u);
 }
 
 template <int NKS_T, int KV_T, int FL, typename Pro>
@@ -832,8 +840,8 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int y = 16 * c - 1 + 4 * lq + k - perp;
-                    const u32 px = w_encode8(acc[i][0][k], s_thr) | (w_encode8(acc[i][1][k], s_thr) << 8) | (w_encode8(acc[i][2][k], s_thr) << 16) |
-                                   (AL ? unorm8(acc[i][AL ? 3 : 0][k]) << 24 : 0xff000000u);
+                    const u32 px = AL ? (w_encode_px(acc[i][0][k], acc[i][1][k], acc[i][2][k], s_thr) & 0xffffffu) | (unorm8(acc[i][AL ? 3 : 0][k]) << 24)
+                                      : w_encode_px(acc[i][0][k], acc[i][1][k], acc[i][2][k], s_thr);
                     if (y >= y_lo && y <= y_hi && x < d_w) *(u32 *)(d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u)) = px;
                 }
             }
@@ -925,8 +933,8 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 }
 #pragma unroll
                 for (int k = 0; k < 4; k++)
-                    px[i][k] = w_encode8(o[i][0][k], s_thr) | (w_encode8(o[i][1][k], s_thr) << 8) | (w_encode8(o[i][2][k], s_thr) << 16) |
-                               (AL ? unorm8(o[i][AL ? 3 : 0][k]) << 24 : 0xff000000u);
+                    px[i][k] = AL ? (w_encode_px(o[i][0][k], o[i][1][k], o[i][2][k], s_thr) & 0xffffffu) | (unorm8(o[i][AL ? 3 : 0][k]) << 24)
+                                  : w_encode_px(o[i][0][k], o[i][1][k], o[i][2][k], s_thr);
             }
 #ifndef SMR_EMU
 #pragma unroll
@@ -1091,7 +1099,7 @@ smr_ctx::MfmaTable *find_mfma_table(smr_ctx *ctx, float scale, float offset, int
 bool mfma_plane_ok(const SurfView &p, u32 bytes) { return (p.pitch % 4) == 0 && (((uintptr_t)p.ptr) % 4) == 0 && p.pitch >= ((bytes + 3u) & ~3u); }
 // the fused colour conversion (k_ingest_wave reading Y'CbCr planes) is opt-in: its conversion is within one code of the WGSL pass, not equal
 // to it, and a linear-light filter can amplify a flipped code (include/smr.h) — the default converts exactly, then resamples the node
-inline bool fused_conversion(const smr_ctx *ctx) { return ctx->ingest_impl == SMR_INGEST_MFMA_F16_FUSED; }
+inline bool fused_conversion(const smr_ctx *ctx) { return ctx->ingest_impl == SMR_INGEST_LAB_FUSED; }
 
 // ------------------------------------------------------------------ vertical-first plans: the same kernel on the transposed problem
 // The reference filters the axis with the stronger shrink first (resampler.rs:123-145); for aspect-preserving fits that order hangs

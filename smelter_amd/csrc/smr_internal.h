@@ -17,7 +17,7 @@
 // Laboratory builds (-DSMR_LAB: tools/variant.sh, SMR_LAB=1 python -m smelter_amd.build): the A/B knobs read from the environment at context
 // creation, the fused-conversion builds of k_ingest_wave (ingest implementation 5: within one code per stage, NOT within 1 LSB end to end on
 // adversarial content, hence not in include/smr.h) and the kernels' ablation / timing hooks.  A product build has none of them.
-constexpr int SMR_INGEST_MFMA_F16_FUSED = 5;
+constexpr int SMR_INGEST_LAB_FUSED = 5;
 #ifdef SMR_LAB
 constexpr bool SMR_LAB_BUILD = true;
 #else
@@ -34,7 +34,7 @@ typedef uint32_t u32;
 #define SMR_ENC_OFFSET_FROM_THR 260
 #define SMR_ENC_ENTRIES 1664
 // lut16 block (device: ctx->d_lut16): [0,256) the decode table as (f16 hi | f16 lo << 16) | [256, 256 + SMR_ENC_ENTRIES) the encode table of the
-// matrix-core resampler: per estimate bucket (code of its lowest x) | (offset of the one threshold inside it - 1, 0xffff = none) << 16
+// matrix-core resampler: per estimate bucket (code of its lowest x) << 16 | 0xffff - (offset of the one threshold inside it - 1; 0xffff = none)
 #define SMR_LUT16_WORDS (256 + SMR_ENC_ENTRIES)
 
 #define SMR_NUM_STAGES 8

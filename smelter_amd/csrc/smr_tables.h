@@ -38,7 +38,9 @@ static inline bool smr_build_tables(float *tables, u32 *lut16) {
         if (chh - cl > 1) return false;
         enc[idx] = (u8)cl;
         // the same bucket for k_ingest_wave's one-gather encode: at most one threshold lies inside a bucket (just checked), strictly above
-        // its lowest x; code = cl + (low 16 bits of x > that threshold's low 16 bits - 1)
+        // its lowest x; code = cl + (low 16 bits of x > `above` = that threshold's low 16 bits - 1).  The entry holds cl in its upper half
+        // and 0xffff - above in its lower half: entry + (low 16 bits of x) carries into bit 16 exactly when the code steps up — one add
+        // instead of a compare and a conditional increment, and the code sits in byte 2 of the sum, where v_perm_b32 picks it up (w_encode_sum)
         u32 above = 0xffffu;
         if (chh > cl) {
             u32 tb;
@@ -46,7 +48,7 @@ static inline bool smr_build_tables(float *tables, u32 *lut16) {
             if (tb <= lo_bits || tb > hi_bits) return false;
             above = tb - lo_bits - 1u;
         }
-        lut16[256 + idx] = (u32)cl | (above << 16);
+        lut16[256 + idx] = ((u32)cl << 16) | (0xffffu - above);
     }
     for (int i = 0; i < 256; i++) {
         const _Float16 hi = (_Float16)tables[i];

@@ -74,12 +74,12 @@ class Renderer:
         self._check(self.lib.smr_renderer_register_image(self._h, image_id.encode(), px.ctypes.data, w, h))
 
     def set_text_measurer(self, measurer):
-        """The caller's text shaper for Text nodes without explicit width / height (smelter_amd.text.Shaper(...).measurer)."""
+        """The caller's text shaper for Text nodes without explicit width / height (tests.text_twin.Shaper(...).measurer)."""
         self._measurer = measurer  # keep the callback alive
         self._check(self.lib.smr_renderer_set_text_measurer(self._h, measurer if measurer is not None else _ffi.TEXT_MEASURE_FN(0), None))
 
     def set_fontbook(self, book):
-        """A smelter_amd.text.NativeFontBook (smr_fontbook): the renderer measures and draws every Text node itself at update_scene."""
+        """A smelter_amd.fontbook.NativeFontBook (smr_fontbook): the renderer measures and draws every Text node itself at update_scene."""
         self._fontbook = book  # keep it alive: the renderer does not own it
         self._check(self.lib.smr_renderer_set_fontbook(self._h, book.handle if book is not None else None))
 

@@ -61,7 +61,7 @@ class Scene:
         self._check(self._lib.smr_scene_register_image(self._h, image_id.encode(), width, height))
 
     def set_text_measurer(self, measurer):
-        """`measurer`: an _ffi.TEXT_MEASURE_FN (e.g. smelter_amd.text.Shaper(...).measurer) or None; sizes fitted Text nodes."""
+        """`measurer`: an _ffi.TEXT_MEASURE_FN (e.g. tests.text_twin.Shaper(...).measurer) or None; sizes fitted Text nodes."""
         self._measurer = measurer  # keep the callback alive
         self._check(self._lib.smr_scene_set_text_measurer(self._h, measurer if measurer is not None else _ffi.TEXT_MEASURE_FN(0), None))
 

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "smr.h"
+#include "text.h"  // (smr_text::accumulate_edge: the one internal the harness calls directly)
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint64_t rnd() {
@@ -278,6 +279,28 @@ int main(int argc, char **argv) {
         if (smr_fontbook_add_memory(book, (const uint8_t *)f.data(), f.size()) == 0) run_text(book, 50);
         else printf("rejected: %s\n", smr_fontbook_last_error(book));
         smr_fontbook_destroy(book);
+        return 0;
+    }
+    if (argc == 3 && !strcmp(argv[1], "--edges")) {  // the rasteriser's edge accumulation on edges that END on the bitmap's left / right column
+        // (x advanced row by row used to arrive a rounding error past the edge's own end: column -1 — ADVICE round 5; every accumulator here is
+        //  exactly w * h + 1 doubles, so AddressSanitizer sees the first write outside it)
+        const long n = atol(argv[2]);
+        long done = 0;
+        for (long i = 0; i < n; i++) {
+            const int w = 1 + (int)below(6), h = 1 + (int)below(4);
+            std::vector<double> acc((size_t)w * h + 1, 0.0);
+            auto u = [&]() { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); };
+            const double xmax = (double)(w - 1);  // (rasterise_glyph sizes the bitmap so that every x lies in [0, w - 1])
+            double x0 = u() * xmax, x1 = (rnd() & 1) ? 0.0 : xmax, y0 = u() * h, y1 = u() * h;
+            if (rnd() & 1) y1 = y0 + (u() - 0.5) * 1e-3;          // nearly horizontal, inside one row
+            if (rnd() & 3) { std::swap(x0, x1); std::swap(y0, y1); }
+            if (i == 0) { x0 = 0.301; y0 = 0.1; x1 = 0.0; y1 = 0.10037; }  // the advisor's case (w >= 2 there)
+            if (i == 0) { std::vector<double> a4((size_t)4 * 2 + 1, 0.0); smr_text::accumulate_edge(a4, 4, 2, x0, y0, x1, y1); done++; continue; }
+            y0 = std::min(std::max(y0, 0.0), (double)h); y1 = std::min(std::max(y1, 0.0), (double)h);
+            smr_text::accumulate_edge(acc, w, h, x0, y0, x1, y1);
+            done++;
+        }
+        printf("{\"edges\": %ld}\n", done);
         return 0;
     }
     if (argc == 3 && !strcmp(argv[1], "--scene")) {  // replay one scene

@@ -33,7 +33,7 @@ def test_struct_layouts_agree(lib):
     from oracle import oracle
     assert lib.smr_sizeof_layout() == C.sizeof(_ffi.Layout) == C.sizeof(oracle._Layout) == 744
     assert C.sizeof(_ffi.Mask) == 32
-    assert lib.smr_abi_version() == 1
+    assert lib.smr_abi_version() == 2  # include/smr.h SMR_ABI_VERSION (history there)
 
 
 def test_product_build_reads_nothing_from_the_environment(lib):

@@ -473,11 +473,12 @@ def test_c_example_runs(tmp_path):
 
 
 def test_fitted_text_is_sized_by_the_shaper_and_drawn(ctx, hip, renderer):
-    """TextDimensions::Fitted end to end: the node is sized by get_text_resolution from the caller's shaper (smelter_amd/text.py over a
+    """TextDimensions::Fitted end to end: the node is sized by get_text_resolution from the caller's shaper (tests/text_twin.py over a
     system TrueType font), the shaper's glyph run is blitted by smr_blit_glyphs, and the output equals the oracle's blit."""
     import json
 
-    from smelter_amd import _ffi, text as T
+    from smelter_amd import _ffi
+    from tests import text_twin as T
     try:
         book = T.FontBook.system()
     except FileNotFoundError:
@@ -511,7 +512,8 @@ def test_renderer_with_a_font_book_draws_its_text_nodes_itself(ctx, hip, rendere
     import json
     import math
 
-    from smelter_amd import _ffi, text as T
+    from smelter_amd import _ffi
+    from tests import text_twin as T
     try:
         book = T.NativeFontBook.system()
     except FileNotFoundError:
@@ -541,3 +543,29 @@ def test_renderer_with_a_font_book_draws_its_text_nodes_itself(ctx, hip, rendere
     with pytest.raises(Exception):  # no shaper any more: a fitted Text node is refused
         renderer.update_scene("out", W, H, json.dumps(scene(txt, "#FFFFFFFF", "#00000000")), output_format=hip.FRAME_RGBA)
     book.close()
+
+
+def test_an_update_whose_text_cannot_be_drawn_leaves_the_previous_scene_active(ctx, hip, renderer):
+    """smr_renderer_update_scene drew its Text nodes after the new scene had been committed, so an update that failed there
+    (an empty font book) reported an error with the new scene active.  The reference fails an update as a whole (state.rs:177-189): what the
+    scene itself can get wrong is now found before the commit (smr_fontbook_measure on every Text node of the converted tree) — the previous
+    scene keeps rendering, and a failed FIRST update leaves no output behind."""
+    import json
+
+    from smelter_amd import fontbook
+    empty = fontbook.NativeFontBook()  # no font in it
+    renderer.set_fontbook(empty)
+    W, H = 64, 32
+    text_scene = {"type": "view", "children": [{"type": "text", "text": "x", "font_size": 12.0, "width": 40.0, "height": 16.0}]}
+    with pytest.raises(Exception, match="font book is empty"):
+        renderer.update_scene("out", W, H, json.dumps(text_scene), output_format=hip.FRAME_RGBA)
+    assert "out" not in renderer.render(0.0, {})  # the failed first update left no output
+    red = {"type": "view", "background_color": "#FF0000FF"}
+    renderer.update_scene("out", W, H, json.dumps(red), output_format=hip.FRAME_RGBA)
+    before = np.asarray(renderer.render(0.0, {})["out"].download()[0]).copy()
+    with pytest.raises(Exception, match="font book is empty"):
+        renderer.update_scene("out", W, H, json.dumps(text_scene), output_format=hip.FRAME_RGBA)
+    after = np.asarray(renderer.render(1.0, {})["out"].download()[0])
+    assert before.reshape(H, W, 4)[0, 0].tolist() == [255, 0, 0, 255] and np.array_equal(before, after)  # still the red view
+    renderer.set_fontbook(None)
+    empty.close()

@@ -139,3 +139,13 @@ def test_replay_modes(harness, corpus, tmp_path):
     if fonts:
         r = subprocess.run([harness, "--font", os.path.join(corpus_dir, fonts[0])], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_edges_that_end_on_the_bitmap_border_stay_inside_the_accumulator(harness):
+    """x advanced row by row could arrive at -1e-17 for an edge that ends exactly on column 0 (floor -> column -1, eight bytes in
+    front of the accumulator).  A million random edges ending on the first / last column, the advisor's own case first, into accumulators of
+    exactly w * h + 1 doubles under AddressSanitizer."""
+    r = subprocess.run([harness["host_fuzz"], "--edges", "1000000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-4000:]
+    assert "runtime error" not in r.stderr, r.stderr[-4000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["edges"] == 1000000

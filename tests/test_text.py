@@ -1,12 +1,13 @@
 """a12 host side: the reference's text sizing rule in the scene engine (text_renderer.rs:282-368, through the C ABI's
-smr_text_measure_fn) and the bundled TrueType shaper / rasteriser of smelter_amd/text.py.  No GPU."""
+smr_text_measure_fn) and the bundled TrueType shaper / rasteriser of tests/text_twin.py.  No GPU."""
 import math
 import os
 
 import numpy as np
 import pytest
 
-from smelter_amd import _ffi, text as T
+from smelter_amd import _ffi
+from tests import text_twin as T
 from smelter_amd.scene import Scene, SceneError
 
 REF_FONTS = "/root/reference/smelter-render/fonts"          # Inter, bundled by the reference (only in the build container)

@@ -1,5 +1,5 @@
 """a12 / f4: the text pipeline BEHIND the C ABI (smr_fontbook_*, smelter_amd/csrc/host/text.cpp) against its Python twin
-(smelter_amd/text.py, fontTools-based): the same font matching, the same line breaks and widths, and the same glyph runs and atlases
+(tests/text_twin.py, fontTools-based): the same font matching, the same line breaks and widths, and the same glyph runs and atlases
 BYTE FOR BYTE — so everything tests/test_text.py establishes about the Python shaper (hmtx advances + GPOS kern pairs, word / glyph wrap,
 exact-area coverage) holds for the C++ one a C host links.  No GPU.  Glyph SHAPES remain unpinned against glyphon / swash (not in the
 reference tree): both implementations here are this repository's reading of the same TrueType outlines."""
@@ -10,7 +10,8 @@ import os
 import numpy as np
 import pytest
 
-from smelter_amd import _ffi, text as T
+from smelter_amd import _ffi
+from tests import text_twin as T
 from smelter_amd.scene import Scene
 
 REF_FONTS = "/root/reference/smelter-render/fonts"          # Inter, bundled by the reference (only in the build container)

@@ -1,4 +1,7 @@
-"""Host-side text shaper and rasteriser for Text nodes: the caller-side half of a12.
+"""TEST INFRASTRUCTURE — the pure-Python twin of the library's text pipeline (smelter_amd/csrc/host/text.cpp behind smr_fontbook_*), fontTools-based;
+tests/test_text_capi.py holds the two to each other byte for byte.  Not part of the product package (the binding is smelter_amd/fontbook.py).
+
+Host-side text shaper and rasteriser for Text nodes: the caller-side half of a12.
 
 The reference lays text out and rasterises it with glyphon / cosmic-text (third-party, not in the reference tree) and keeps only
 the sizing rule and the layout parameters in its own code (smelter-render/src/transformations/text_renderer.rs:282-368).  The C ABI
@@ -25,7 +28,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from . import _ffi
+from smelter_amd import _ffi
+from smelter_amd.fontbook import NativeFontBook, TextGlyph  # noqa: F401  (re-exported: the tests address both pipelines through this module)
 
 WEIGHTS = {"Thin": 100, "ExtraLight": 200, "Light": 300, "Normal": 400, "Medium": 500, "SemiBold": 600, "Bold": 700, "ExtraBold": 800,
            "Black": 900}
@@ -322,98 +326,6 @@ class Shaper:
         return glyphs, atlas
 
 
-class NativeFontBook:
-    """smr_fontbook (smelter_amd/csrc/host/text.cpp): the product's text pipeline — font database, layout, rasteriser in C++ behind
-    the C ABI.  This module's pure-Python classes above are its twin; tests/test_text_capi.py holds the two to each other byte for byte."""
-
-    def __init__(self, paths: Sequence[str] = ()):
-        self.lib = _ffi.load()
-        h = _ffi.C.c_void_p()
-        if self.lib.smr_fontbook_create(_ffi.C.byref(h)) != 0:
-            raise MemoryError("smr_fontbook_create")
-        self._h = h
-        for p in paths:
-            self.add_font(p)
-
-    def _check(self, rc: int) -> int:
-        if rc < 0:
-            raise ValueError(self.lib.smr_fontbook_last_error(self._h).decode())
-        return rc
-
-    def add_font(self, path: str):
-        self._check(self.lib.smr_fontbook_add_file(self._h, path.encode()))
-
-    def add_font_bytes(self, data: bytes):
-        self._check(self.lib.smr_fontbook_add_memory(self._h, data, len(data)))
-
-    def add_dir(self, directory: str) -> int:
-        return self._check(self.lib.smr_fontbook_add_dir(self._h, directory.encode()))
-
-    @staticmethod
-    def system() -> "NativeFontBook":
-        for d in (os.environ.get("SMR_FONT_DIR"), "/usr/share/fonts/truetype", "/usr/share/fonts"):
-            if d and os.path.isdir(d):
-                book = NativeFontBook()
-                try:
-                    book.add_dir(d)
-                    return book
-                except ValueError:
-                    book.close()
-        raise FileNotFoundError("no TrueType fonts found (set SMR_FONT_DIR)")
-
-    def __len__(self):
-        return int(self.lib.smr_fontbook_count(self._h))
-
-    @property
-    def handle(self):
-        return self._h
-
-    @staticmethod
-    def _params(text, font_size, line_height, family, weight, style, wrap, align, max_width, max_height):
-        p = _ffi.TextParams()
-        keep = [text.encode(), family.encode(), style.encode(), weight.encode(), wrap.encode(), align.encode()]
-        p.text, p.font_family, p.style, p.weight, p.wrap, p.align = keep
-        p.font_size, p.line_height, p.max_width, p.max_height = font_size, line_height, max_width, max_height
-        return p, keep
-
-    def measure(self, text: str, font_size: float, wrap: str = "None", max_width: float = 7682.0, family: str = "", weight: str = "Normal",
-                style: str = "Normal") -> Tuple[float, int]:
-        p, _keep = self._params(text, font_size, font_size, family, weight, style, wrap, "Left", max_width, 4320.0)
-        w, n = _ffi.C.c_float(), _ffi.C.c_uint32()
-        if self.lib.smr_fontbook_measure(self._h, _ffi.C.byref(p), _ffi.C.byref(w), _ffi.C.byref(n)) != 0:
-            raise ValueError(self.lib.smr_fontbook_last_error(self._h).decode())
-        return w.value, n.value
-
-    def rasterise(self, text: str, width: int, height: int, font_size: float, line_height: Optional[float] = None, family: str = "",
-                  weight: str = "Normal", style: str = "Normal", wrap: str = "None", align: str = "Left",
-                  color: Sequence[float] = (1.0, 1.0, 1.0, 1.0)):
-        """(glyphs, atlas) like Shaper.rasterise, computed by the C++ pipeline."""
-        p, _keep = self._params(text, font_size, font_size if line_height is None else line_height, family, weight, style, wrap, align,
-                                float(width), float(height))
-        col = (_ffi.C.c_float * 4)(*[float(c) for c in color])
-        run = _ffi.TextRun()
-        self._check(self.lib.smr_fontbook_rasterise(self._h, _ffi.C.byref(p), width, height, col, _ffi.C.byref(run)))
-        glyphs = [TextGlyph(g.dst_x, g.dst_y, g.w, g.h, g.atlas_x, g.atlas_y, tuple(g.color)) for g in (run.glyphs[i] for i in range(run.n_glyphs))]
-        atlas = np.ctypeslib.as_array(run.atlas, shape=(run.atlas_h, run.atlas_w)).copy()
-        return glyphs, atlas
-
-    def close(self):
-        if getattr(self, "_h", None):
-            self.lib.smr_fontbook_destroy(self._h)
-            self._h = None
-
-
-@dataclass
-class TextGlyph:  # field for field include/smr.h smr_glyph
-    dst_x: int
-    dst_y: int
-    w: int
-    h: int
-    atlas_x: int
-    atlas_y: int
-    color: Tuple[float, float, float, float]
-
-
 def rasterise_glyph(font: Font, glyph: str, scale: float, fx: float = 0.0, fy: float = 0.0) -> Tuple[np.ndarray, int, int]:
     """Exact-area coverage of one glyph at `scale` pixels per font unit, origin at the fractional pixel offset (fx, fy) of its
     cell.  Returns (u8 bitmap, left, top): the bitmap's top-left pixel sits `left` right of and `top` above the pen's pixel.
@@ -446,9 +358,10 @@ def _accumulate_edge(a: np.ndarray, w: int, h: int, x0: float, y0: float, x1: fl
         x0, y0, x1, y1, d = x1, y1, x0, y0, -1.0
     dxdy = (x1 - x0) / (y1 - y0)
     x = x0
+    x_lo, x_hi = min(x0, x1), max(x0, x1)  # (rounding must not carry x past the edge's own end: text.cpp accumulate_edge)
     for y in range(max(int(math.floor(y0)), 0), min(h, int(math.ceil(y1)))):
         dy = min(y + 1.0, y1) - max(float(y), y0)
-        xn = x + dxdy * dy
+        xn = min(max(x + dxdy * dy, x_lo), x_hi)
         s = d * dy
         xa, xb = (x, xn) if x < xn else (xn, x)
         ia, ib = int(math.floor(xa)), int(math.ceil(xb))
