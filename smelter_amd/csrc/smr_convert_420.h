@@ -41,6 +41,52 @@
 #define cv_mad24(a, b, c) ((u32)__umul24((a), (b)) + (c))  // row * pitch + offset with both factors below 2^24: one full-rate v_mad_u32_u24 (a 32 x 32 multiply is a quarter-rate v_mad_u64_u32)
 #endif
 
+// ---- the unorm8 store of a row's twelve values: floor(clamp(x, 0, 1) * 255 + 0.5) (planar_yuv_to_rgba.wgsl:57 through the Rgba8Unorm target).
+// v_cvt_pk_u8_f32 converts, saturates to [0, 255] and inserts the byte into a dword in ONE instruction — with the wave's f32 rounding mode:
+// round-to-nearest-even by default (tools/ubench/cvt_pk_u8.hip: not the reference's truncation), but under round-toward-zero exactly the
+// truncation (tools/ubench/cvt_pk_u8_mode.hip on the device: every f32 within 4 ulp of every integer and half-integer of [0, 258), a sweep of
+// [-2, 298] and the specials — 4.2 M values, no difference from trunc(clamp(x, 0, 255))).  The operands t = x * 255 + 0.5 are computed before, in the
+// default mode, WITHOUT the clamp (t <= 0.5 truncates / saturates to 0 like clamp's 0.5, t >= 255.5 saturates to 255 like clamp's 255.5; NaN
+// cannot occur); the mode is switched inside one asm block around the twelve conversions, so no other float instruction can be scheduled into
+// the switched region.  Three instructions per value (multiply, add, convert) instead of five (median, multiply, add, convert, shift-or).
+// dst[c] |= byte i of channel c for the row's pixel i: RGB12 rows are (R x 4, G x 4, B x 4) dwords; RGBA8 rows take cv_store_px.
+#ifdef SMR_EMU
+static inline u32 cv_emu_u8(float t) { return t >= 255.0f ? 255u : (t > 0.0f ? (u32)t : 0u); }
+#define CV_U8X4(d, t0, t1, t2, t3) do { (d) = cv_emu_u8(t0) | (cv_emu_u8(t1) << 8) | (cv_emu_u8(t2) << 16) | (cv_emu_u8(t3) << 24); } while (0)
+static inline void cv_row_bytes_planar(const float (&t)[3][4], u32 &r4, u32 &g4, u32 &b4) {
+    CV_U8X4(r4, t[0][0], t[0][1], t[0][2], t[0][3]); CV_U8X4(g4, t[1][0], t[1][1], t[1][2], t[1][3]); CV_U8X4(b4, t[2][0], t[2][1], t[2][2], t[2][3]);
+}
+static inline void cv_row_bytes_packed(const float (&t)[3][4], u32 (&px)[4]) {
+    for (int i = 0; i < 4; i++) px[i] = cv_emu_u8(t[0][i]) | (cv_emu_u8(t[1][i]) << 8) | (cv_emu_u8(t[2][i]) << 16) | 0xff000000u;
+}
+#else
+__device__ __forceinline__ void cv_row_bytes_planar(const float (&t)[3][4], u32 &r4, u32 &g4, u32 &b4) {
+    u32 r = 0u, g = 0u, b = 0u;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %3, 0, %0\n\tv_cvt_pk_u8_f32 %1, %7, 0, %1\n\tv_cvt_pk_u8_f32 %2, %11, 0, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 1, %0\n\tv_cvt_pk_u8_f32 %1, %8, 1, %1\n\tv_cvt_pk_u8_f32 %2, %12, 1, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %5, 2, %0\n\tv_cvt_pk_u8_f32 %1, %9, 2, %1\n\tv_cvt_pk_u8_f32 %2, %13, 2, %2\n\t"
+                 "v_cvt_pk_u8_f32 %0, %6, 3, %0\n\tv_cvt_pk_u8_f32 %1, %10, 3, %1\n\tv_cvt_pk_u8_f32 %2, %14, 3, %2\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "+v"(r), "+v"(g), "+v"(b)
+                 : "v"(t[0][0]), "v"(t[0][1]), "v"(t[0][2]), "v"(t[0][3]), "v"(t[1][0]), "v"(t[1][1]), "v"(t[1][2]), "v"(t[1][3]), "v"(t[2][0]), "v"(t[2][1]),
+                   "v"(t[2][2]), "v"(t[2][3]));
+    r4 = r; g4 = g; b4 = b;
+}
+__device__ __forceinline__ void cv_row_bytes_packed(const float (&t)[3][4], u32 (&px)[4]) {
+    u32 p0 = 0xff000000u, p1 = 0xff000000u, p2 = 0xff000000u, p3 = 0xff000000u;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 3\n\ts_nop 1\n\t"
+                 "v_cvt_pk_u8_f32 %0, %4, 0, %0\n\tv_cvt_pk_u8_f32 %1, %5, 0, %1\n\tv_cvt_pk_u8_f32 %2, %6, 0, %2\n\tv_cvt_pk_u8_f32 %3, %7, 0, %3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %8, 1, %0\n\tv_cvt_pk_u8_f32 %1, %9, 1, %1\n\tv_cvt_pk_u8_f32 %2, %10, 1, %2\n\tv_cvt_pk_u8_f32 %3, %11, 1, %3\n\t"
+                 "v_cvt_pk_u8_f32 %0, %12, 2, %0\n\tv_cvt_pk_u8_f32 %1, %13, 2, %1\n\tv_cvt_pk_u8_f32 %2, %14, 2, %2\n\tv_cvt_pk_u8_f32 %3, %15, 2, %3\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1"
+                 : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3)
+                 : "v"(t[0][0]), "v"(t[0][1]), "v"(t[0][2]), "v"(t[0][3]), "v"(t[1][0]), "v"(t[1][1]), "v"(t[1][2]), "v"(t[1][3]), "v"(t[2][0]), "v"(t[2][1]),
+                   "v"(t[2][2]), "v"(t[2][3]));
+    px[0] = p0; px[1] = p1; px[2] = p2; px[3] = p3;
+}
+#endif
+
 struct ConvJob {
     SurfView yp, up, vp, dst;
     int full, nv;  // full range (J420) | NV12 (interleaved chroma in `up`)
@@ -235,6 +281,7 @@ __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const
         const int j34 = r < 2 ? 1 : 2, j14 = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
         const u32 y4 = yrow[r];
         u32 px[4] = {0u, 0u, 0u, 0u}, r4 = 0u, g4 = 0u, b4 = 0u;
+        float t[3][4];  // x * 255 + 0.5 of the row's twelve values (cv_row_bytes_* truncates and packs them)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (CV_ABL & 8) {
@@ -255,11 +302,13 @@ __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const
             const float R = yy + 1.5748f * vm;
             const float G = yy - 0.1873f * um - 0.4681f * vm;
             const float B = yy + 1.8556f * um;
-            const u32 r8 = (u32)(int)(cv_clamp01(R) * 255.0f + 0.5f);
-            const u32 g8 = (u32)(int)(cv_clamp01(G) * 255.0f + 0.5f);
-            const u32 b8 = (u32)(int)(cv_clamp01(B) * 255.0f + 0.5f);
-            if (RGB12) { r4 |= r8 << (8 * i); g4 |= g8 << (8 * i); b4 |= b8 << (8 * i); }
-            else px[i] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+            t[0][i] = R * 255.0f + 0.5f;
+            t[1][i] = G * 255.0f + 0.5f;
+            t[2][i] = B * 255.0f + 0.5f;
+        }
+        if (!(CV_ABL & 8)) {
+            if (RGB12) cv_row_bytes_planar(t, r4, g4, b4);
+            else cv_row_bytes_packed(t, px);
         }
         if ((CV_ABL & 1) && (r4 ^ g4 ^ b4 ^ px[0] ^ px[3]) != 0x12345677u) continue;  // (never equal in practice: the values stay live)
         if (RGB12) {

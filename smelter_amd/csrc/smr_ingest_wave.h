@@ -63,6 +63,9 @@ namespace {
 #define SMR_WAVE_STAGGER 0   // A/B: waves in odd hardware slots of a SIMD start s_sleep(N) later (N x 64 cycles), so that the two waves of a SIMD are not in the
                              // same phase (LDS gathers / matrix cores / encode) at the same time
 #endif
+#ifndef SMR_DIRECT_ABL
+#define SMR_DIRECT_ABL 0  // profiling builds only: direct output without 1 its conversion arithmetic, 2 its stores
+#endif
 #ifndef SMR_WAVE_ABL
 #define SMR_WAVE_ABL 0  // profiling builds only (tools/variant.sh): 1 no LUT gathers, 2 no pass-1 MFMAs, 4 no conversion, 8 no pass 2 / encode, 16 no stores, 32 no staging
 #endif
@@ -955,8 +958,13 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                     direct = cls_now[i] == (u32)d_layer;
                     const bool odd = (l16 & 1) != 0;
                     u32 mine, other;
+#if SMR_DIRECT_ABL & 1  // (profiling builds: no conversion arithmetic)
+                    const u32 yq = px[i][0] ^ px[i][1];
+                    mine = px[i][2]; other = px[i][3];
+#else
                     const u32 yq = m_direct_yuv(px[i], odd, &mine, &other);
-                    if (direct) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);
+#endif
+                    if (direct && (!(SMR_DIRECT_ABL & 2) || yq == 0x12345678u)) m_direct_store(Dg, d_ox + x, d_oy + y, odd, yq, mine, other);  // (2: profiling, no direct stores)
                 }
                 if (!direct && y < d_h && x < d_w && (!(SMR_WAVE_ABL & 16) || px[i][0] == 0x12345678u)) {  // (16: profiling, all work but no store traffic)
                     u8 *op = d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u);  // (a tile is far below 4 GiB)

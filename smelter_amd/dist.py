@@ -251,3 +251,47 @@ class ShardedCompositor:
     def flush(self):
         prev, self.pending = self.pending, None
         self._finish(prev)
+
+
+class LocalRanks:
+    """One process, `world` ShardedCompositors — one per context, i.e. what a single renderer thread holding several GPUs (or several
+    contexts of one GPU) runs — over ONE local communicator (smr_comm_create_local: peer copies + events, smr_comm.hip).
+
+    A rank-mode communicator is called by every rank with its own half of the gather; a local one moves everything in one call.  `view(rank)`
+    is the `comm=` of rank's ShardedCompositor: it collects the ranks' halves and issues the single smr_gather_tiles when the last rank of a
+    frame has posted.  Drive the compositors in lockstep, the root LAST (its call composes frame k - 1 and then posts frame k's gather):
+
+        ranks = LocalRanks(hip.Comm.local(ctxs))
+        sc = [ShardedCompositor(ctxs[r], hip, plan, r, ..., comm=ranks.view(r)) for r in range(world)]
+        for frame in frames:
+            for r in ranks.order(plan.root): sc[r].step_pipelined(frame[r], out if r == plan.root else None)
+    """
+
+    class _View:
+        def __init__(self, parent, rank):
+            self.parent, self.rank = parent, rank
+
+        def gather(self, root, owners, src, dst):
+            self.parent._post(self.rank, root, owners, src, dst)
+
+    def __init__(self, comm):
+        self.comm, self.world = comm, comm.world
+        self.posted = {}
+
+    def view(self, rank: int):
+        return LocalRanks._View(self, rank)
+
+    def order(self, root: int = 0):
+        return [r for r in range(self.world) if r != root] + [root]
+
+    def _post(self, rank, root, owners, src, dst):
+        if rank in self.posted:
+            raise RuntimeError(f"rank {rank} posted two gathers before the others posted one: drive the compositors in lockstep")
+        self.posted[rank] = (list(src), list(dst))
+        if len(self.posted) < self.world:
+            return
+        n = len(owners)
+        src_all = [self.posted[owners[i]][0][i] for i in range(n)]
+        dst_all = [self.posted[root][1][i] for i in range(n)]
+        self.posted = {}
+        self.comm.gather(root, list(owners), src_all, dst_all)

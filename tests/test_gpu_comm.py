@@ -138,3 +138,55 @@ def test_rank_comm_across_processes(hip):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     assert "== one context" in p.stdout
+
+
+def test_sharded_pipeline_with_two_ranks_on_one_device_over_an_animated_scene(hip):
+    """The N > 1 driver on hardware as far as one GPU allows: TWO ShardedCompositors (rank 0 = root, rank 1), one context each on the same
+    device, over smr_comm_create_local — the full `step_pipelined` protocol (ingest k, compose k - 1, gather k posted; two tile sets, two
+    output frames) for 36 frames of configs[3]'s geometry (8 x 4K YUV420 inputs -> 4K, tiles 1280 x 720) while the layout list moves every
+    frame.  Every output equals, byte for byte, what ONE context renders from the same frames and that frame's layouts.
+    The per-input independence the sharding relies on: smelter-render/src/state/render_loop.rs:24-41, transformations/layout.rs:250-275."""
+    import torch
+    from dataclasses import replace
+    from smelter_amd import dist as smr_dist
+    iw, ih, W, H, n, frames_n = 3840, 2160, 3840, 2160, 8, 36
+    a, b = hip.Context(0), hip.Context(0)
+    ctxs = [a, b]
+    base, res = scenes.cfg2_scene(iw, ih, W, H, n)  # Tiles of 8 inputs on 4K: a 3 x 3 grid of 1280 x 720 tiles
+    rng = np.random.default_rng(77)
+    planes = [scenes.random_yuv420(iw, ih, rng) if i % 2 else scenes.test_input(i, iw, ih, noise_seed=500 + i) for i in range(n)]
+    frames = [[c.frame(hip.FRAME_PLANAR_YUV420, iw, ih, list(planes[i])) for i in range(n)] for c in ctxs]
+
+    def layouts_at(k):  # the grid drifts: every tile moves (integer and fractional offsets, the size stays), two tiles swap depth order
+        out = []
+        for L in base:
+            if L.type == 0:
+                dx = 0.25 * k * (1 + L.source_index % 3) - 3.0 * (L.source_index % 2)
+                dy = (k % 7) - 0.5 * (L.source_index % 4)
+                L = replace(L, left=L.left + dx, top=L.top + dy)
+            out.append(L)
+        if k % 5 == 4:
+            out[-1], out[-2] = out[-2], out[-1]
+        return out
+    comm = hip.Comm.local(ctxs)
+    ranks = smr_dist.LocalRanks(comm)
+    plan = smr_dist.ShardPlan(n_inputs=n, world=2)
+    sc = [smr_dist.ShardedCompositor(ctxs[r], hip, plan, r, layouts_at(0), res, list(range(n)), None, torch, None, comm=ranks.view(r)) for r in range(2)]
+    outs = [a.frame(hip.FRAME_PLANAR_YUV420, W, H) for _ in range(frames_n)]
+    for k in range(frames_n):
+        for r in ranks.order(plan.root):
+            sc[r].set_layouts(layouts_at(k))
+            sc[r].step_pipelined({i: frames[r][i] for i in range(n)}, outs[k] if r == plan.root else None)
+    for r in ranks.order(plan.root):
+        sc[r].flush()
+    for c in ctxs:
+        c.sync()
+    ref = a.frame(hip.FRAME_PLANAR_YUV420, W, H)
+    for k in range(frames_n):
+        a.render_layouts(layouts_at(k), frames[0], W, H, out=ref)
+        a.sync()
+        for g, w_ in zip(outs[k].download(), ref.download()):
+            assert np.array_equal(g, w_), f"frame {k}"
+    comm.close()
+    b.close()
+    a.close()
