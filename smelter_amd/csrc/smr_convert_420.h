@@ -214,11 +214,11 @@ __device__ __forceinline__ Cv420Raw<NV> cv420_load_chroma(const ConvJob &J, cons
         for (int k = 0; k < (NV ? 3 : 4); k++) R.d[k] = 0x01020304u * (u32)(crow + k) + W.base;
     } else if (NV) {
         const u32 o1 = TIGHT ? (W.lim < 4u ? W.lim : 4u) : 4u, o2 = TIGHT ? (W.lim < 8u ? W.lim : 8u) : 8u;
-        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + o1); R.d[2] = *(const u32 *)(ur + o2);
+        R.d[0] = g_ld_u32(ur); R.d[1] = g_ld_u32(ur + o1); R.d[2] = g_ld_u32(ur + o2);
     } else {
         const u8 *vr = J.vp.ptr + cv_mad24((u32)cy, J.vp.pitch, W.base);
         const u32 o1 = TIGHT ? (W.lim < 4u ? W.lim : 4u) : 4u;
-        R.d[0] = *(const u32 *)ur; R.d[1] = *(const u32 *)(ur + o1); R.d[2] = *(const u32 *)vr; R.d[3] = *(const u32 *)(vr + o1);
+        R.d[0] = g_ld_u32(ur); R.d[1] = g_ld_u32(ur + o1); R.d[2] = g_ld_u32(vr); R.d[3] = g_ld_u32(vr + o1);
     }
     return R;
 }
@@ -227,7 +227,7 @@ __device__ __forceinline__ void cv420_load_luma(const ConvJob &J, int g, int P, 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         if (CV_ABL & 4) yrow[r] = 0x10203040u * (u32)(g + r) + (u32)P;
-        else yrow[r] = *(const u32 *)(J.yp.ptr + cv_mad24((u32)min(4 * P + r, h - 1), J.yp.pitch, 4u * (u32)g));
+        else yrow[r] = g_ld_u32(J.yp.ptr + cv_mad24((u32)min(4 * P + r, h - 1), J.yp.pitch, 4u * (u32)g));
     }
 }
 
@@ -268,7 +268,10 @@ __device__ __forceinline__ void cv420_hrow(const Cv420Raw<NV> &R, const Cv420Win
 // (c - 16/255) / 0.8784 as RN(a * y_hi + RN(a * y_lo)) with y_hi + y_lo = 1 / 0.8784 to 48 bits: the IEEE quotient for EVERY f32 a in
 // [-16/255, 1] — all 636 524 221 of them checked against the division (tools/check_div_by_constant.py), as unorm_of_byte's form is
 // for the 256 bytes.  One multiply and one fused multiply-add.
-template <bool RGB12, bool FULL>
+// ALLROWS: the caller knows that all four rows of the block exist (every block of a run but its last): no branch around the stores, so the
+// compiler can count the stores in flight and wait for the NEXT block's loads — requested before them — with vmcnt(stores) instead of vmcnt(0)
+// (the memory counter counts loads and stores alike: with the branch every block waited for its own stores' round trip)
+template <bool RGB12, bool FULL, bool ALLROWS = false>
 __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const u32 yrow[4], const float H[4][2][4], const float *ylut) {
     const int h = J.dst.h;
     constexpr bool full = FULL;  // (a template parameter: as a run-time flag it was a scalar branch per pixel)
@@ -277,7 +280,7 @@ __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int y = 4 * P + r;
-        if (y >= h) break;
+        if (!ALLROWS && y >= h) break;
         const int j34 = r < 2 ? 1 : 2, j14 = r == 0 ? 0 : (r == 1 ? 2 : (r == 2 ? 1 : 3));
         const u32 y4 = yrow[r];
         u32 px[4] = {0u, 0u, 0u, 0u}, r4 = 0u, g4 = 0u, b4 = 0u;
@@ -312,10 +315,9 @@ __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const
         }
         if ((CV_ABL & 1) && (r4 ^ g4 ^ b4 ^ px[0] ^ px[3]) != 0x12345677u) continue;  // (never equal in practice: the values stay live)
         if (RGB12) {
-            u32 *d = (u32 *)(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 12u * (u32)g));
-            d[0] = r4; d[1] = g4; d[2] = b4;
+            g_st_u32x3(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 12u * (u32)g), r4, g4, b4);
         } else {
-            *(uint4 *)(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 16u * (u32)g)) = make_uint4(px[0], px[1], px[2], px[3]);
+            g_st_u32x4(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 16u * (u32)g), make_uint4(px[0], px[1], px[2], px[3]));
         }
     }
 }
@@ -376,7 +378,7 @@ __device__ __forceinline__ void cv420_run(const ConvJob &J, int g, int P0, int n
         u32 ynext[4];
         cv420_load_luma(J, g, P + 1, ynext);
         const Cv420Raw<NV> n2 = cv420_load_chroma<NV, TIGHT>(J, W, 2 * P + 3), n3 = cv420_load_chroma<NV, TIGHT>(J, W, 2 * P + 4);
-        cv420_rows<RGB12, FULL>(J, g, P, yrow, H, ylut);
+        cv420_rows<RGB12, FULL, true>(J, g, P, yrow, H, ylut);  // (P + 1 < Pend: not the frame's last block row — all four rows exist)
         if (P == P0) CV_STAMP(st, 4, "s_nop 0");  // the first block's rows are computed, its stores issued
 #pragma unroll
         for (int c = 0; c < 2; c++)

@@ -309,7 +309,7 @@ __device__ __forceinline__ float4 decode_texel(u32 raw, int srgb, const float *_
 //     to exactly 1) stores its own bytes: encode(decode(b)) == b;
 //   * `is_base`: the caller established that this layer is opaque and solid at the pixel.
 __device__ __forceinline__ u32 aligned_texel(const DevLayout &L, int px, int py) {
-    return *(const u32 *)(L.src.ptr + b_off(clampi(py - L.iy, 0, L.tex_h - 1), L.src.pitch, clampi(px - L.ix, 0, L.tex_w - 1) * 4));
+    return g_ld_u32(L.src.ptr + b_off(clampi(py - L.iy, 0, L.tex_h - 1), L.src.pitch, clampi(px - L.ix, 0, L.tex_w - 1) * 4));  // (a global load: the layer record came through LDS / scalar registers)
 }
 
 // `raw_pre`: the texel of an aligned texture layer, fetched by the caller ahead of the arithmetic (aligned_texel)
@@ -613,8 +613,8 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
             const bool tex = on[k] && c[k].kind == TC_TEXTURE;
             const u8 *r0 = tex ? c[k].base + b_off(by, c[k].pitch_or_px, bx * 4) : (const u8 *)tables;
             const u8 *r1 = tex ? r0 + c[k].pitch_or_px : (const u8 *)tables;
-            ra[k] = *(const uint4 *)r0;
-            rb[k] = *(const uint4 *)r1;
+            ra[k] = g_ld_u32x4(r0);  // (global loads: a base from a record in memory is a generic pointer to the compiler — smr_internal.h)
+            rb[k] = g_ld_u32x4(r1);
         }
 #pragma unroll
         for (int k = 0; k < B_COPY_TILES; k++) {
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
                 const int tile = t0 + k, cols = W - ((tile - (tile / tiles_x) * tiles_x) * B_TILE_W + bx);  // >= 2
 #pragma unroll
                 for (int q = 0; q < 4; q++)
-                    if (q < cols) { acc[k][q] = ((const u32 *)r0)[q]; acc[k][4 + q] = ((const u32 *)r1)[q]; }
+                    if (q < cols) { acc[k][q] = g_ld_u32(r0 + 4 * q); acc[k][4 + q] = g_ld_u32(r1 + 4 * q); }
             }
         }
     }

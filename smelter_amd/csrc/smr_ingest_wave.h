@@ -63,6 +63,9 @@ namespace {
 #define SMR_WAVE_STAGGER 0   // A/B: waves in odd hardware slots of a SIMD start s_sleep(N) later (N x 64 cycles), so that the two waves of a SIMD are not in the
                              // same phase (LDS gathers / matrix cores / encode) at the same time
 #endif
+#ifndef SMR_WAVE_DEFER_STORES
+#define SMR_WAVE_DEFER_STORES 1  // node-texture builds: a tile row's stores go out at the top of the NEXT chunk, behind its wait (A/B knob; see wave_piece)
+#endif
 #ifndef SMR_DIRECT_ABL
 #define SMR_DIRECT_ABL 0  // profiling builds only: direct output without 1 its conversion arithmetic, 2 its stores
 #endif
@@ -650,6 +653,30 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         breg[0][0][0] = breg[0][0][1] = make_uint4(0u, 0u, 0u, 0u);
     }
 
+    // Deferred tile stores (node-texture builds without direct output).  The memory counter of gfx950 counts loads AND stores, in order:
+    // the wait at the top of a chunk — for the chunk's blocks, requested a whole chunk ago — also waited for the stores of the tile row that
+    // had just been finished, i.e. for a full write round trip per tile row (the build without stores ran 3.8 us shorter).  A finished tile
+    // row's pixels therefore stay in registers (8) until that wait is over and leave right behind it: by the next wait they are a chunk old.
+    constexpr bool DEFER = RG && !DIRECT && !SA && NKS_T != 0 && (SMR_WAVE_DEFER_STORES != 0);  // (the generic builds sit at the register limit: immediate stores there)
+    u32 pend_px[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+    int pend_vt = -1;  // (uniform) the tile row waiting to be stored, -1 = none
+    auto store_rows = [&](int vt_s, const u32 (&p)[2][4]) {
+#pragma unroll
+        for (int i = 0; i < W_NTI; i++) {
+            if (klo[i] == 0xff) continue;
+            const int y = 16 * vt_s + l16, x = tx0 + 16 * i + 4 * lq;  // lane holds columns x .. x + 3 of output row y
+            if (y < d_h && x < d_w && (!(SMR_WAVE_ABL & 16) || p[i][0] == 0x12345678u)) {  // (16: profiling, all work but no store traffic)
+                u8 *op = d_ptr + dev_mad24((u32)y, d_pitch, (u32)x * 4u);  // (a tile is far below 4 GiB)
+                if (x + 3 < d_w) {
+                    *(uint4 *)op = make_uint4(p[i][0], p[i][1], p[i][2], p[i][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (x + k < d_w) ((u32 *)op)[k] = p[i][k];
+                }
+            }
+        }
+    };
     int vt = vt0;
     int2 vm = J.v_meta[vt0];
     int2 vm_next = J.v_meta[min(vt0 + 1, vt1)];  // (read a tile ahead: a scalar load the loop never waits for)
@@ -677,6 +704,10 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         //  count the loads in flight), the first tile row of a chunk is its own copy of the code (below), and everything outstanding is waited for
         //  here, at the top of the chunk, where it is old — this chunk's blocks, the next tile row's weights.)
         if (RG && SMR_WAVE_RG_EARLY_WAIT) dev_wait_vmcnt0();
+        if (DEFER && pend_vt >= 0) {  // (uniform) the tile row finished in the previous chunk
+            store_rows(pend_vt, pend_px);
+            pend_vt = -1;
+        }
         // ---- conversion + pass 1 of chunk c: k-step by k-step, straight into the accumulators of the tiles it feeds
         f32x4 acc[2][4];
 #pragma unroll
@@ -946,6 +977,15 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 for (int k = 0; k < 4; k++) asm volatile("" : "+v"(px[i][k]));  // (all the lookups in flight together: not sunk into the store branches)
 #endif
             W_MARK(6);
+            if (DEFER) {
+                if (pend_vt >= 0) store_rows(pend_vt, pend_px);  // (a second tile row of the same chunk: the older one leaves now)
+#pragma unroll
+                for (int i = 0; i < W_NTI; i++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pend_px[i][k] = px[i][k];
+                pend_vt = vt_now;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < W_NTI; i++) {
                 if (klo[i] == 0xff) continue;
@@ -988,6 +1028,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         if (c + 1 < c_last && !(SMR_WAVE_ABL & 32)) issue(c + 2);
         W_MARK(5);
     }
+    if (DEFER && pend_vt >= 0) store_rows(pend_vt, pend_px);
 #if SMR_WAVE_TIMING
     if (timing && lane == 0) {
         for (int i = 0; i < 8; i++) atomicAdd(dbg + i, tph[i]);

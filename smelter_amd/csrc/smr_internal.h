@@ -67,6 +67,31 @@ struct SurfView {
     int w, h;
 };
 
+// ---- device memory through GLOBAL instructions.  A pointer the compiler cannot trace back to a kernel argument — rebuilt from integers
+// (v_readfirstlane round trips), loaded from a record in memory or LDS, selected between two bases — is a generic pointer, and generic
+// accesses are FLAT instructions: they count in BOTH wait counters (a wait for an LDS table gather then also waits for every load still on its
+// way from memory: the prefetch of the next block buys nothing), may return out of order (the compiler waits with vmcnt(0): a loop that stores
+// waits for its own stores) and resolve their address space per access.  Every surface the kernels touch is device memory: these say so.
+#if defined(__HIPCC__) && !defined(SMR_EMU)
+typedef u32 g_u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 g_u32x3 __attribute__((ext_vector_type(3)));
+typedef u32 g_u32x4 __attribute__((ext_vector_type(4)));
+#define SMR_GLOBAL_PTR(T, p) ((__attribute__((address_space(1))) T *)(uintptr_t)(p))
+__device__ __forceinline__ u32 g_ld_u32(const void *p) { return *SMR_GLOBAL_PTR(const u32, p); }
+__device__ __forceinline__ uint2 g_ld_u32x2(const void *p) { const g_u32x2 v = *SMR_GLOBAL_PTR(const g_u32x2, p); return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint4 g_ld_u32x4(const void *p) { const g_u32x4 v = *SMR_GLOBAL_PTR(const g_u32x4, p); return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void g_st_u32(void *p, u32 v) { *SMR_GLOBAL_PTR(u32, p) = v; }
+__device__ __forceinline__ void g_st_u32x3(void *p, u32 a, u32 b, u32 c) { g_u32x3 v; v.x = a; v.y = b; v.z = c; *SMR_GLOBAL_PTR(g_u32x3, p) = v; }
+__device__ __forceinline__ void g_st_u32x4(void *p, uint4 q) { g_u32x4 v; v.x = q.x; v.y = q.y; v.z = q.z; v.w = q.w; *SMR_GLOBAL_PTR(g_u32x4, p) = v; }
+#else  // (host code and the lane emulator: plain accesses)
+static inline u32 g_ld_u32(const void *p) { return *(const u32 *)p; }
+static inline uint2 g_ld_u32x2(const void *p) { return *(const uint2 *)p; }
+static inline uint4 g_ld_u32x4(const void *p) { return *(const uint4 *)p; }
+static inline void g_st_u32(void *p, u32 v) { *(u32 *)p = v; }
+static inline void g_st_u32x3(void *p, u32 a, u32 b, u32 c) { ((u32 *)p)[0] = a; ((u32 *)p)[1] = b; ((u32 *)p)[2] = c; }
+static inline void g_st_u32x4(void *p, uint4 q) { *(uint4 *)p = q; }
+#endif
+
 // one pinned-host + device staging slot of the per-call layout parameter ring
 struct LayoutSlot {
     void *host = nullptr;

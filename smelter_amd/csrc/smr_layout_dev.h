@@ -431,8 +431,8 @@ __device__ __forceinline__ u32 composite_sampled_opaque(const DevLayout &L, int 
     const int y0 = clampi((int)fy0, 0, s.h - 1), y1 = clampi((int)fy0 + 1, 0, s.h - 1);
     // (row offsets as 24-bit multiplies: rows and pitches are below 2^24, a surface below 4 GiB — a 32 x 32 multiply is quarter rate)
     const u32 o0 = (u32)__umul24((u32)y0, s.pitch), o1 = (u32)__umul24((u32)y1, s.pitch);
-    const u32 ta = *(const u32 *)(s.ptr + (o0 + 4u * (u32)x0)), tb = *(const u32 *)(s.ptr + (o0 + 4u * (u32)x1));
-    const u32 tc = *(const u32 *)(s.ptr + (o1 + 4u * (u32)x0)), td = *(const u32 *)(s.ptr + (o1 + 4u * (u32)x1));
+    const u32 ta = g_ld_u32(s.ptr + (o0 + 4u * (u32)x0)), tb = g_ld_u32(s.ptr + (o0 + 4u * (u32)x1));  // (global loads: smr_internal.h)
+    const u32 tc = g_ld_u32(s.ptr + (o1 + 4u * (u32)x0)), td = g_ld_u32(s.ptr + (o1 + 4u * (u32)x1));
     const float gx = 1.0f - fx, gy = 1.0f - fy;
     u32 out = 0xff000000u;
 #pragma unroll
@@ -497,8 +497,8 @@ __device__ __forceinline__ void composite_sampled_opaque_block(const DevLayout &
         u32 ta[4], tb[4], tc[4], td[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            ta[q] = *(const u32 *)(base + (Y[r].o0 + X[q].o0)); tb[q] = *(const u32 *)(base + (Y[r].o0 + X[q].o1));
-            tc[q] = *(const u32 *)(base + (Y[r].o1 + X[q].o0)); td[q] = *(const u32 *)(base + (Y[r].o1 + X[q].o1));
+            ta[q] = g_ld_u32(base + (Y[r].o0 + X[q].o0)); tb[q] = g_ld_u32(base + (Y[r].o0 + X[q].o1));
+            tc[q] = g_ld_u32(base + (Y[r].o1 + X[q].o0)); td[q] = g_ld_u32(base + (Y[r].o1 + X[q].o1));
         }
         const float fy = Y[r].f, gy = Y[r].g;
 #pragma unroll
