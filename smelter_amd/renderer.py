@@ -29,15 +29,17 @@ class BorrowedFrame(DeviceFrame):
 
 
 class Renderer:
-    def __init__(self, ctx: Context, stream_fallback_timeout_s: float = 0.5, lanes: Sequence[Context] = ()):
+    def __init__(self, ctx: Context, stream_fallback_timeout_s: float = 0.5, lanes: Sequence[Context] = (), max_outputs: int = 16):
         """`lanes`: extra contexts on the same device — consecutive frames rotate through `ctx` and these, so up to
-        1 + len(lanes) frames are in flight on the GPU while the scene stays one state (smr_renderer_add_lane)."""
+        1 + len(lanes) frames are in flight on the GPU while the scene stays one state (smr_renderer_add_lane).
+        `max_outputs`: how many output frames one render call can hand back (the `cap` of smr_renderer_render)."""
         self.ctx, self.lib = ctx, ctx.lib
         h = C.c_void_p()
         if self.lib.smr_renderer_create(ctx.handle, int(stream_fallback_timeout_s * 1e9), C.byref(h)) != 0:
             raise RuntimeError("smr_renderer_create failed")
         self._h = h
-        self._outs = (_ffi.OutputFrame * 16)()
+        self._max_outputs = max(int(max_outputs), 1)
+        self._outs = (_ffi.OutputFrame * self._max_outputs)()
         self._ctx_of = {ctx.handle.value: ctx}
         for c in lanes:
             self._check(self.lib.smr_renderer_add_lane(self._h, c.handle))
@@ -137,10 +139,10 @@ class Renderer:
         """One frame for every output; returns the number of outputs (frames are read with `output`)."""
         arr, n, _ = packed
         cnt = C.c_uint32()
-        self._check(self.lib.smr_renderer_render(self._h, pts_ns, arr, n, self._outs, 16, C.byref(cnt)))
+        self._check(self.lib.smr_renderer_render(self._h, pts_ns, arr, n, self._outs, self._max_outputs, C.byref(cnt)))
         return cnt.value
 
     def render(self, pts_s: float, frames: Dict[str, DeviceFrame], frame_pts_s: Optional[Dict[str, float]] = None) -> Dict[str, BorrowedFrame]:
         packed = self.make_frame_set(frames, pts_s, frame_pts_s)
         n = self.render_packed(int(pts_s * 1e9), packed)
-        return {self._outs[i].output_id.decode(): self.output(i) for i in range(min(n, 16))}
+        return {self._outs[i].output_id.decode(): self.output(i) for i in range(min(n, self._max_outputs))}

@@ -1,8 +1,8 @@
 #!/bin/bash
 # round 6: the converter's unorm8 store through v_cvt_pk_u8_f32 under round-toward-zero — parity on the device first, then A/B against the previous commit
 cd "$(dirname "$0")/../.."
-O=gpurun_out/ab5; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_fused.py tests/test_gpu_kernel_selection.py tests/test_gpu_comm.py -q -m gpu -x 2>&1 | tail -n 5 > $O/pytest.txt
+O=gpurun_out/ab6; mkdir -p $O
+timeout 900 python -m pytest tests/test_gpu_fused.py tests/test_gpu_parity.py tests/test_gpu_wrap.py tests/test_gpu_renderer.py -q -m gpu -x 2>&1 | tail -n 3 > $O/pytest.txt
 cat $O/pytest.txt
 for n in product prev; do
   lib=smelter_amd/variants/libsmr_hip.$n.so; [ $n = product ] && lib=smelter_amd/libsmr_hip.so
@@ -14,7 +14,7 @@ for n in product prev; do
 done
 python - <<'PY'
 import json,glob
-for f in sorted(glob.glob('gpurun_out/ab5/bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/ab6/bench_*.json')):
     try:
         r=json.loads(open(f).read().strip().splitlines()[-1])
         print(f.split('/')[-1], r['value'], (r.get('value_long') or {}).get('frames_per_s'), {k:v['avg_us'] for k,v in (r.get('kernels') or {}).items()})
