@@ -400,6 +400,9 @@ def main():
     ap.add_argument("--convert", choices=["auto", "general", "block4x2"], default="auto", help="input converter kernels (SMR_OPT_CONVERT_IMPL; A/B)")
     ap.add_argument("--direct-output", action="store_true",
                     help="SMR_OPT_DIRECT_OUTPUT: the resampling kernel writes Y'CbCr for the compositor's copy tiles (A/B; default off)")
+    ap.add_argument("--plane-source", action="store_true",
+                    help="SMR_OPT_PLANE_SOURCE: the resampling kernel reads the frames' planes and converts exactly in the wave — no converter launch, no node "
+                         "texture in memory (A/B; default off: slower, DESIGN.md section 3c)")
     ap.add_argument("--no-long", action="store_true", help="skip the `value_long` loop (profiling runs: keeps traces small)")
     ap.add_argument("--long-seconds", type=float, default=12.0,
                     help="length of the `value_long` loop — the same timed loop run right after `value`, BEFORE any CPU work, long enough for an outside "
@@ -467,6 +470,7 @@ def main():
     ctx.set_ingest_impl(ingest_impl)
     ctx.set_convert_impl(convert_impl)
     ctx.set_direct_output(args.direct_output)
+    ctx.set_plane_source(args.plane_source)
     layouts, res = build_scene()
     packed = hip.pack_layouts(layouts)
     label = make_label(ctx)
@@ -497,6 +501,7 @@ def main():
             c.set_ingest_impl(ingest_impl)
             c.set_convert_impl(convert_impl)
             c.set_direct_output(args.direct_output)
+            c.set_plane_source(args.plane_source)
         atlas, glyphs = label_run()
 
         def make_renderer(c, extra=()):

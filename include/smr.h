@@ -194,6 +194,13 @@ typedef enum smr_convert_impl { SMR_CONVERT_AUTO = 0, SMR_CONVERT_GENERAL = 1, S
 /*   SMR_OPT_COMPACT_NODES       1 (default): the node texture of a 4:2:0 frame that only the matrix-core resampler reads is written as RGB12 — 12 bytes
  *                               per four pixels (R x 4, G x 4, B x 4; alpha is 1 for every Y'CbCr frame and is not stored): a quarter less traffic on
  *                               either side of the intermediate the default route is bound by; 0: always RGBA8.  Same codes, same tiles bit for bit. */
+/*   SMR_OPT_PLANE_SOURCE        1: a planar 4:2:0 / NV12 frame whose layout plan lies inside the matrix-core resampler's class windows (scales around 1.5, 2
+ *                               and 3: every input of the benchmark scenes) is read by that kernel as it is — the wave converts each chunk of its window with
+ *                               the exact converter's own block arithmetic (the node texture's bytes, bit for bit) into LDS and resamples from there: the
+ *                               reference's node texture never exists in memory (half the route's traffic, one launch fewer; the same pixels within the
+ *                               resampler's 1 LSB).  0 (default): the converter writes the node texture (RGB12 with SMR_OPT_COMPACT_NODES) and the
+ *                               resampler reads it back — faster on every measured workload: a wave converts its window's overlaps again (1.45 x) at two
+ *                               waves per SIMD, the converter kernel converts every pixel once at six. */
 /*   SMR_OPT_FUSED_KERNELS       1 (default): smr_render_layouts / smr_ingest_resample* run the fused kernels (waves A and B); 0: one general kernel per pass
  *                               of the reference (convert, resample passes, apply_layouts, rgba_to_yuv) — what the tests hold the fused kernels to.
  *   SMR_OPT_COMPOSE_SELECT      1 (default): compositor tiles in which every pixel is a plain copy from the topmost layer that holds it (the seams of a
@@ -205,7 +212,7 @@ typedef enum smr_convert_impl { SMR_CONVERT_AUTO = 0, SMR_CONVERT_GENERAL = 1, S
  * No option is read from the environment: a product build of the library calls getenv nowhere (laboratory builds, -DSMR_LAB, read their A/B knobs there). */
 typedef enum smr_option {
     SMR_OPT_INGEST_IMPL = 0, SMR_OPT_INGEST_STRIP_WIDTH = 1, SMR_OPT_DIRECT_OUTPUT = 2, SMR_OPT_CONVERT_IMPL = 3, SMR_OPT_COMPACT_NODES = 4,
-    SMR_OPT_FUSED_KERNELS = 5, SMR_OPT_COMPOSE_SELECT = 6, SMR_OPT_SHARED_DEVICE = 7
+    SMR_OPT_FUSED_KERNELS = 5, SMR_OPT_COMPOSE_SELECT = 6, SMR_OPT_SHARED_DEVICE = 7, SMR_OPT_PLANE_SOURCE = 8
 } smr_option;
 SMR_API int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value);
 SMR_API int smr_timer_start(smr_ctx *ctx);          /* hipEvent on the ctx stream */

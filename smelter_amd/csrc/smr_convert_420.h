@@ -271,8 +271,19 @@ __device__ __forceinline__ void cv420_hrow(const Cv420Raw<NV> &R, const Cv420Win
 // ALLROWS: the caller knows that all four rows of the block exist (every block of a run but its last): no branch around the stores, so the
 // compiler can count the stores in flight and wait for the NEXT block's loads — requested before them — with vmcnt(stores) instead of vmcnt(0)
 // (the memory counter counts loads and stores alike: with the branch every block waited for its own stores' round trip)
-template <bool RGB12, bool FULL, bool ALLROWS = false>
-__device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const u32 yrow[4], const float H[4][2][4], const float *ylut) {
+// SINK: where a finished row goes — sink(r, y, r4, g4, b4, px): row r of the block = frame row y, as RGB12 dwords (RGB12) or four RGBA8 pixels.
+// The default stores into the job's node texture; k_ingest_wave's plane-source builds (smr_ingest_wave.h) hand the rows to LDS instead.
+struct Cv420StoreNode {
+    const ConvJob &J;
+    int g;
+    bool rgb12;
+    __device__ __forceinline__ void operator()(int, int y, u32 r4, u32 g4, u32 b4, const u32 (&px)[4]) const {
+        if (rgb12) g_st_u32x3(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 12u * (u32)g), r4, g4, b4);
+        else g_st_u32x4(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 16u * (u32)g), make_uint4(px[0], px[1], px[2], px[3]));
+    }
+};
+template <bool RGB12, bool FULL, bool ALLROWS, typename SINK>
+__device__ __forceinline__ void cv420_rows_to(const ConvJob &J, int g, int P, const u32 yrow[4], const float H[4][2][4], const float *ylut, const SINK &sink) {
     const int h = J.dst.h;
     constexpr bool full = FULL;  // (a template parameter: as a run-time flag it was a scalar branch per pixel)
     constexpr float kc = 0.87843137254f;
@@ -314,12 +325,12 @@ __device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const
             else cv_row_bytes_packed(t, px);
         }
         if ((CV_ABL & 1) && (r4 ^ g4 ^ b4 ^ px[0] ^ px[3]) != 0x12345677u) continue;  // (never equal in practice: the values stay live)
-        if (RGB12) {
-            g_st_u32x3(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 12u * (u32)g), r4, g4, b4);
-        } else {
-            g_st_u32x4(J.dst.ptr + cv_mad24((u32)y, J.dst.pitch, 16u * (u32)g), make_uint4(px[0], px[1], px[2], px[3]));
-        }
+        sink(r, y, r4, g4, b4, px);
     }
+}
+template <bool RGB12, bool FULL, bool ALLROWS = false>
+__device__ __forceinline__ void cv420_rows(const ConvJob &J, int g, int P, const u32 yrow[4], const float H[4][2][4], const float *ylut) {
+    cv420_rows_to<RGB12, FULL, ALLROWS>(J, g, P, yrow, H, ylut, Cv420StoreNode{J, g, RGB12});
 }
 
 // One 4 x 4 block: columns 4 g .. 4 g + 3, rows 4 P .. 4 P + 3 of job J (rows past the frame's height are not stored).

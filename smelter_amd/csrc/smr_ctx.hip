@@ -166,6 +166,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_CONVERT_GENERAL")) ctx->convert_impl = (e[0] && e[0] != '0') ? SMR_CONVERT_GENERAL : SMR_CONVERT_AUTO;  // (read once: tools)
     if (const char *e = getenv("SMR_CONVERT_LDS_PAD")) ctx->convert_lds_pad = (u32)atoi(e);
     if (const char *e = getenv("SMR_COMPACT_NODES")) ctx->compact_nodes = atoi(e) != 0;  // (tools / A-B)
+    if (const char *e = getenv("SMR_PLANE_SOURCE")) ctx->plane_source = atoi(e) != 0;
     if (const char *e = getenv("SMR_INGEST_TW")) ctx->force_tw = atoi(e);  // (tools; smr_ctx_set_option overrides)
     if (const char *e = getenv("SMR_WAVE_NODE82")) ctx->wave_node82 = atoi(e) != 0;
     if (const char *e = getenv("SMR_RGB12_CLS82")) ctx->rgb12_cls82 = atoi(e) != 0;
@@ -242,6 +243,9 @@ int smr_ctx_set_option(smr_ctx *ctx, uint32_t option, int32_t value) {
         return SMR_OK;
     case SMR_OPT_COMPACT_NODES:
         ctx->compact_nodes = value != 0;
+        return SMR_OK;
+    case SMR_OPT_PLANE_SOURCE:
+        ctx->plane_source = value != 0;
         return SMR_OK;
     case SMR_OPT_FUSED_KERNELS:
         ctx->fused_disabled = value != 0 ? 0 : 1;

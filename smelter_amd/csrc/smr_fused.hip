@@ -160,6 +160,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     std::vector<smr_layout> eff(layouts, layouts + n);
     std::vector<IngestJob> jobs;
     std::vector<WJob> wjobs, wjobs_rgb12, wjobs_rgba, wjobs_rgba_alpha, wjobs_f16, wjobs_f16_alpha, wjobs_sa, wjobs_sa_rgba, wjobs_sa_rgba_alpha;
+    std::vector<WJob> wjobs_planes[2][3];  // plane-source jobs by (NV12, class): the frame's planes, converted in the kernel (the default route of 4:2:0 frames)
     std::vector<u32> wjob_layout, wjob_rgb12_layout, wjob_rgba_layout;  // layout index of each job (direct output)
     std::vector<MTransposeBack> transposed;
     ctx->weight_call++;
@@ -251,8 +252,17 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                     // (kinds 1: the node has an alpha channel — the four-channel builds)
                     std::vector<WJob> &rgba_jobs = kinds[si] == 2 ? wjobs_rgba : wjobs_rgba_alpha;
                     std::vector<WJob> &f16_jobs = kinds[si] == 2 ? wjobs_f16 : wjobs_f16_alpha;
-                    if (is_frame && kinds[si] == 2 && rgb12_node_serves(ctx, sources[si].frame, plan, tile)) {
-                        // the default route of a 4:2:0 frame: exact converter -> RGB12 node -> the matrix-core kernel
+                    int pcls = -1;
+                    if (is_frame && kinds[si] == 2 && !node_ready[si] && !ctx->direct_output && can_fuse_planes(ctx, sources[si].frame, plan, tile, &pcls)) {
+                        // the default route of a 4:2:0 frame: the matrix-core kernel on the frame's planes, exact conversion in the wave (no node texture)
+                        WJob J;
+                        int rc = make_wave_job_planes(ctx, sources[si].frame, plan, tile, &J);
+                        if (rc != SMR_OK) return rc;
+                        wjobs_planes[J.nv12][pcls].push_back(J);
+                        on_mfma = true;
+                    }
+                    if (!on_mfma && is_frame && kinds[si] == 2 && rgb12_node_serves(ctx, sources[si].frame, plan, tile)) {
+                        // SMR_OPT_PLANE_SOURCE off / direct output: exact converter -> RGB12 node -> the matrix-core kernel
                         int rc = ensure_rgb12_node(si);
                         if (rc != SMR_OK) return rc;
                         WJob J;
@@ -535,6 +545,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 if (int r = launch_wave(ctx, g, direct_dev, true, false, false, false, rgb12)) return r;
         return SMR_OK;
     };
+    for (auto &by_nv : wjobs_planes)
+        for (auto &g : by_nv)
+            if (!g.empty())
+                if (int r = launch_wave(ctx, g, nullptr, false, false, false, false, false, true)) return r;
     if (!wjobs_rgb12.empty()) {
         rc = by_class(wjobs_rgb12, true);
         if (rc != SMR_OK) return rc;
@@ -661,6 +675,13 @@ static int ingest_resample_one(smr_ctx *ctx, const smr_frame *in, const float cr
     }
     // the exact converter into the node texture, then the matrix-core kernel on it (every Y'CbCr format; two-pass plans within the kernel's
     // windows, either pass order)
+    if (!fused_disabled(ctx) && can_fuse_planes(ctx, in, plan, dst)) {  // the default route: the frame's planes, converted in the kernel
+        std::vector<WJob> wjobs(1);
+        int rc = make_wave_job_planes(ctx, in, plan, dst, &wjobs[0]);
+        if (rc != SMR_OK) return rc;
+        rc = launch_wave(ctx, wjobs, nullptr, false, false, false, false, false, true);
+        return rc == SMR_OK ? kind : rc;
+    }
     if (!fused_disabled(ctx) && ctx->ingest_impl != SMR_INGEST_VALU_F32 && rgb12_node_serves(ctx, in, plan, dst)) {
         smr_surface *cnode = smr_cached_surface(ctx, SMR_SLOT_INGEST_NODE_RGB12, 3 * in->width, in->height, SMR_PX_R8);
         if (!cnode) return SMR_ERR_OOM;
@@ -731,7 +752,7 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
     if (!ctx->srgb()) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: CpuOptimized mode has no resampler");
     if (n > 1024) return smr_fail(ctx, SMR_ERR_INVALID, "smr_ingest_resample_batch: too many inputs");
     std::vector<IngestJob> jobs;
-    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgb12;
+    std::vector<WJob> wjobs, wjobs_rgba, wjobs_rgb12, wjobs_planes[2][3];
     std::vector<const smr_frame *> conv_in;
     std::vector<smr_surface *> conv_node;
     std::vector<u8> conv_rgb12;
@@ -751,6 +772,14 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
             int rc = make_wave_job(ctx, in[i], plan, dst[i], &J);
             if (rc != SMR_OK) return rc;
             wjobs.push_back(J);
+            continue;
+        }
+        int pcls = -1;
+        if (fused && !fused_conversion(ctx) && can_fuse_planes(ctx, in[i], plan, dst[i], &pcls)) {  // the default route: no node texture
+            WJob J;
+            int rc = make_wave_job_planes(ctx, in[i], plan, dst[i], &J);
+            if (rc != SMR_OK) return rc;
+            wjobs_planes[J.nv12][pcls].push_back(J);
             continue;
         }
         if (fused && !fused_conversion(ctx) && ctx->ingest_impl != SMR_INGEST_VALU_F32 && rgb12_node_serves(ctx, in[i], plan, dst[i])) {
@@ -802,6 +831,10 @@ extern "C" int smr_ingest_resample_batch(smr_ctx *ctx, const smr_frame *const *i
         if (!wjobs_rgba.empty()) rc = launch_wave(ctx, wjobs_rgba, nullptr, true);
         if (rc != SMR_OK) return rc;
     }
+    for (auto &by_nv : wjobs_planes)
+        for (auto &g : by_nv)
+            if (!g.empty())
+                if (int rc = launch_wave(ctx, g, nullptr, false, false, false, false, false, true)) return rc;
     if (!wjobs.empty()) {
         int rc = launch_wave(ctx, wjobs);
         if (rc != SMR_OK) return rc;

@@ -31,7 +31,13 @@
 // converter, opaque surfaces) | + 16384 that texture is RGBA16F, linear light (box-pre-reduced plans) | + 65536 it has an alpha
 // channel (four channels) | 32768 single-axis plan: pass 1's f32 sums are encoded and stored directly (no f16 rounding, no pass 2) |
 // + 131072 (with 8192) the node texture is RGB12: 12 bytes per four pixels, R x 4, G x 4, B x 4 (what k_yuv420_to_rgba writes for nodes only
-// this kernel reads: alpha is 1 everywhere and not stored) — one 12-byte load per lane and k-step instead of 16.
+// this kernel reads: alpha is 1 everywhere and not stored) — one 12-byte load per lane and k-step instead of 16 |
+// 262144 (round 6, the default route of 4:2:0 frames): the source is the FRAME — planar 4:2:0 (+ 4096: NV12) — and the node texture never
+// reaches memory: at the top of a chunk the wave converts the chunk's 16 rows x window with the exact converter's own block arithmetic
+// (smr_convert_420.h: lane (bc, br) = (lane & 15, lane >> 4) owns the 4 x 4 block of block row br, block column bc — 64 blocks = the 16 x 64 texels
+// of a 4-k-step window; two blocks per lane for 8 k-steps), bit for bit k_yuv420_to_rgba's bytes, into an RGB12 chunk in LDS (3 KB per wave),
+// from which the k-steps read their blocks exactly like the RGB12 node builds read theirs from memory.  Chunks start on rows 16 c (origin 0:
+// whole 4 x 4 blocks; vertical bands of axis 5).  Half the route's memory traffic (no 50 MB node written and read back), one launch fewer.
 //
 // Work split: a workgroup = W_WAVES waves on the same column pair (they share its pass-1 band in LDS), each with its own vertical
 // piece; workgroups are ordered pair-fastest within a band of rows, so neighbouring pairs read the same source lines at the same
@@ -40,6 +46,7 @@
 #pragma once
 
 #include "smr_ingest_common.h"
+#include "smr_convert_420.h"  // the exact 4:2:0 converter's block arithmetic: the plane-source builds (FL & 262144) convert in the wave
 
 #include <cmath>
 #include <type_traits>
@@ -106,8 +113,12 @@ constexpr int W_KV_MAX = 4;               // k-steps (two chunks of 16 rows) of 
 constexpr int W_WSPAN = 136;              // >= 16 * W_NKS_MAX, >= 32 * W_KV_MAX
 
 // ------------------------------------------------------------------ geometry (host + device: one f32 sequence)
-// chunk c = source rows 16 c - 1 .. 16 c + 14 (row 0 of a chunk is an odd luma row: rows (2 p + 1, 2 p + 2) share chroma rows p, p + 1)
-__host__ __device__ inline int w_chunk_of_row(int r) { return (r + 1) >> 4; }
+// chunk c = source rows 16 c + org .. 16 c + org + 15.  org = -1 (every build but the plane-source ones): row 0 of a chunk is an odd luma row — rows
+// (2 p + 1, 2 p + 2) share chroma rows p, p + 1 (the laboratory builds' on-the-fly conversion); org = 0 (the plane-source builds, FL & 262144):
+// a chunk is four rows of the exact converter's 4 x 4 blocks (smr_convert_420.h).  The vertical bands are built per origin (axis 3 / axis 5).
+__host__ __device__ inline int w_chunk_of_row(int r, int org = -1) { return (r - org) >> 4; }
+__host__ __device__ inline bool w_axis_vertical(int axis) { return axis == 3 || axis == 5; }
+__host__ __device__ inline int w_axis_org(int axis) { return axis == 5 ? 0 : -1; }
 __host__ __device__ inline int w_posmod(int a, int n) { const int r = a % n; return r < 0 ? r + n : r; }
 __host__ __device__ inline int w_clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 __host__ __device__ inline int w_taps(float scale) {
@@ -148,12 +159,12 @@ __host__ __device__ inline WPairGeom w_pair_geometry(int pair, float scale, floa
     return g;
 }
 // A 16-row output tile of pass 2: first / last chunk that carries a weight
-__host__ __device__ inline void w_vtile_chunks(int t, float scale, float offset, int taps, int n_dst, int n_src, int *cs, int *ce) {
+__host__ __device__ inline void w_vtile_chunks(int t, float scale, float offset, int taps, int n_dst, int n_src, int *cs, int *ce, int org = -1) {
     const int o0 = 16 * t, o1 = o0 + 15 < n_dst - 1 ? o0 + 15 : n_dst - 1;
     int lo, hi;
     w_span(o0, o1, scale, offset, taps, n_src, &lo, &hi);
-    *cs = w_chunk_of_row(lo);
-    *ce = w_chunk_of_row(hi);
+    *cs = w_chunk_of_row(lo, org);
+    *ce = w_chunk_of_row(hi, org);
 }
 
 // host twin of the geometry the builder uses (same f32 sequence: lanczos_first is __host__ __device__)
@@ -181,12 +192,12 @@ inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, 
     } else {
         for (int t = 0; t < n_tiles; t++) {
             int cs, ce;
-            w_vtile_chunks(t, scale, offset, taps, n_dst, n_src, &cs, &ce);
+            w_vtile_chunks(t, scale, offset, taps, n_dst, n_src, &cs, &ce, w_axis_org(axis));
             const int need = (ce - cs + 2) / 2;
             k = need > k ? need : k;
         }
     }
-    *K = axis != 3 ? n : k;  // (axis 2 / 4: the band is dense over the unit's window)
+    *K = !w_axis_vertical(axis) ? n : k;  // (axis 2 / 4: the band is dense over the unit's window)
     *nks = n;
 }
 
@@ -198,7 +209,7 @@ inline void wave_band_geometry(float scale, float offset, int n_dst, int n_src, 
 //   (t_hi, t_lo) pair, the (w_lo, 0) fragment adds t_hi w_lo (t_lo w_lo is below 2^-22).
 // axis 3 (pass 2, per 16-row output tile):  meta int2 (first chunk, last chunk);  frag[tile][k-step p < KV][hi | lo][64 lanes]:
 //   lane l = (output row n = l & 15, q = l >> 4), element e: ring slot s = 2 p + (e >> 2), chunk cc = the chunk of the tile's window
-//   [ce - 2 KV + 1, ce] with cc mod 2 KV == s, source row 16 cc - 1 + 4 q + (e & 3).
+//   [ce - 2 KV + 1, ce] with cc mod 2 KV == s, source row 16 cc + org + 4 q + (e & 3) (org = -1; axis 5: the same with org = 0).
 struct WWBuild {
     float scale, offset;
     int taps, n_dst, n_src, axis, K, unit0;  // unit0: first workgroup of this band (units = pairs or tiles)
@@ -222,17 +233,18 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
     const int taps = B.taps, n_dst = B.n_dst, n_src = B.n_src, K = B.K;
     const int u = (int)blockIdx.x - B.unit0, lane = threadIdx.x;
     const int n16 = lane & 15, q = lane >> 4;
-    const bool horiz = B.axis != 3, single = B.axis == 4;
+    const bool horiz = !w_axis_vertical(B.axis), single = B.axis == 4;
+    const int org = w_axis_org(B.axis);
     const int n_sub = horiz ? 2 : 1;
     WPairGeom G;
     int v_cs = 0, v_ce = 0;
     if (horiz) G = w_pair_geometry(u, scale, offset, taps, n_dst, n_src, single);
-    else w_vtile_chunks(u, scale, offset, taps, n_dst, n_src, &v_cs, &v_ce);
+    else w_vtile_chunks(u, scale, offset, taps, n_dst, n_src, &v_cs, &v_ce, org);
     for (int sub = 0; sub < n_sub; sub++) {
         const int tile = horiz && !single ? 2 * u + sub : u;
         // origin of the window in source texels / rows, and its length
         const int wlo = v_ce - 2 * K + 1;  // (axis 3) first chunk of the window; may be negative: those chunks do not exist
-        const int origin = horiz ? G.base : 16 * wlo - 1;
+        const int origin = horiz ? G.base : 16 * wlo + org;
         const int span = horiz ? 16 * K : 32 * K;
         for (int i = lane; i < 16 * W_WSPAN; i += 64) {
             (&s_w[0][0])[i] = 0.0f;
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(64) void k_build_wave_weights(const WWBatch args) {
             (&s_r[0][0])[i] = (_Float16)0.0f;
         }
         __syncthreads();
-        const bool present = B.axis == 3 || G.klo[sub] >= 0;
+        const bool present = !horiz || G.klo[sub] >= 0;
         if (present && lane < 16 && 16 * tile + lane < n_dst) {
             float w[MAX_TAPS];
             float ws;
@@ -307,6 +319,7 @@ struct WJob {
     int layer, ox, oy;    // direct output: the layer this tile is blitted by (-1 = none) and its (even) position in the output frame
     int perp;             // single-axis builds (FL & 32768): output row y shows source row y + perp
     int single;           // the pass-1 band has one tile per unit (axis 4: windows too wide for a pair): unit u = output columns 16 u ..
+    int full;             // plane-source builds (FL & 262144): the frame is full range (J420)
 };
 
 constexpr int MAX_WJOBS_PER_LAUNCH = 16;
@@ -330,6 +343,8 @@ __host__ __device__ inline int w_ys(int nks) { return 4 * nks + 1; }  // staged 
 __host__ __device__ inline int w_cs(int nks) { return 2 * nks + 2; }  // staged chroma dwords per row: columns base/2 - 1 .. base/2 + 8 nks, from a 4-aligned start
 __host__ __device__ inline int w_raw_bytes(int nks) { return 4 * (16 * w_ys(nks) + 2 * 9 * w_cs(nks)); }
 __host__ __device__ inline int w_band_bytes(int nks) { return 2 * nks * 2 * 64 * 16; }
+constexpr int W_FX_TABLE_BYTES = 2048;                                                     // plane-source builds: ylut + nlut behind the band
+__host__ __device__ inline int w_fx_node_bytes(int nks) { return ((16 * (12 * nks + 1) * 4) + 15) & ~15; }  // ... and a wave's RGB12 chunk: 16 rows of 12 nks + 1 dwords
 
 #ifdef __HIPCC__
 
@@ -396,6 +411,9 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // 4 q .. 4 q + 3), held in registers — no LDS staging — and its "conversion" is the decode table alone.
     // 16384 (with 8192): that node texture is RGBA16F in linear light — what the box pre-reduction of a plan with shrink factors from 4
     // leaves (resampler.rs: downsample.wgsl into an Rgba16Float texture): the f16 texels ARE the operand's hi halves, lo = 0.
+    constexpr bool FX = (FL & 262144) != 0;  // the source is a 4:2:0 frame, converted exactly in the wave (header)
+    static_assert(!FX || (NKS_T != 0 && SMR_WAVE_PIPE && !(FL & (8192 | 16384 | 32768 | 65536 | 131072 | 2048))), "plane-source builds: class builds of the pipelined loop only");
+    constexpr int ORG = FX ? 0 : -1;  // first row of chunk 0 (w_chunk_of_row)
     constexpr bool RG = (FL & 8192) != 0, RH = RG && (FL & 16384) != 0;
     // 131072 (with 8192): the node texture as 12-byte groups of four pixels (smr_convert_420.h rgb12): lane (m, q) loads the group of texels
     // 4 q .. 4 q + 3 — a dword per channel
@@ -465,7 +483,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     }
     const u32 c_colb = nv ? 2u * (u32)c_col0c : (u32)c_col0c;
     auto issue = [&](int c) {
-        if (RG) return;  // (rg_load, block by block)
+        if (RG || FX) return;  // (rg_load, block by block; fx_issue)
         if (SMR_WAVE_ABL & 256) c = J.v_meta[vt0].x;  // profiling: always the same rows (cache hits)
         if (SMR_WAVE_ABL & 128) {                       // profiling: no global loads
 #pragma unroll
@@ -491,7 +509,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
     };
     auto land = [&]() {
-        if (RG) return;
+        if (RG || FX) return;
         if (SMR_WAVE_ABL & 64) {  // profiling: no LDS writes (one keeps the loads alive)
             u32 x = 0;
 #pragma unroll
@@ -557,7 +575,21 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         }
         return *(const uint4 *)(y_ptr + dev_mad24(row, y_pitch, 4u * col));
     };
-    // ... and its texel bytes -> decode table (entries 256 .. 511 of the LUT are the codes themselves)
+    // an RGB12 group (a dword of four codes per channel) -> decode table (entries 256 .. 511 of the LUT are the codes themselves)
+    auto decode_rgb12 = [&](u32 p0, u32 p1, u32 p2, uint4 (&a)[4]) {
+        const u32 pc[3] = {p0, p1, p2};
+        u32 o[3][4];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            o[ch][0] = dev_lds_u32(((pc[ch] << 2) & 0x3fcu) + 1024u);
+            o[ch][1] = dev_lds_u32(((pc[ch] >> 6) & 0x3fcu) + 1024u);
+            o[ch][2] = dev_lds_u32(((pc[ch] >> 14) & 0x3fcu) + 1024u);
+            o[ch][3] = dev_lds_u32(((pc[ch] >> 22) & 0x3fcu) + 1024u);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
+    };
+    // ... and its texel bytes -> decode table
     auto convert_rgba = [&](int j, uint4 (&a)[4]) {
         const uint4 t = rg[RG ? (j < RG_N ? j : 0) : 0];
         if (RH) {  // texel = (r | g << 16, b | a << 16): hi = the f16 itself, lo = 0
@@ -571,15 +603,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         const u32 px[4] = {t.x, t.y, t.z, t.w};
         u32 o[4][4];
         if (RP) {  // px[ch] = the four texels of channel ch
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                o[ch][0] = dev_lds_u32(((px[ch] << 2) & 0x3fcu) + 1024u);
-                o[ch][1] = dev_lds_u32(((px[ch] >> 6) & 0x3fcu) + 1024u);
-                o[ch][2] = dev_lds_u32(((px[ch] >> 14) & 0x3fcu) + 1024u);
-                o[ch][3] = dev_lds_u32(((px[ch] >> 22) & 0x3fcu) + 1024u);
-            }
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
+            decode_rgb12(px[0], px[1], px[2], a);
             return;
         }
 #pragma unroll
@@ -597,6 +621,62 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) a[ch] = make_uint4(o[ch][0], o[ch][1], o[ch][2], o[ch][3]);
     };
+
+    // ---- plane-source builds (FX): the chunk's 4 x 4 blocks of the exact converter.  Lane (bc, br) = (l16, lq) owns block row br of the chunk
+    //      (rows 16 c + 4 br .. + 3) and block columns bc (+ 16 for windows beyond 4 k-steps) of the pair's window; the blocks' luma dwords
+    //      and chroma window rows are requested a chunk ahead (right after the previous chunk was converted: the registers are free then)
+    //      and converted at the top of the chunk into the wave's RGB12 chunk in LDS: row r of the chunk at dword r * fx_rs, 3 dwords per group.
+    constexpr int FXB = FX ? (NKS_N + 3) / 4 : 1;  // blocks per lane and chunk
+    constexpr bool FXNV = FX && NV;                // (a launch of NV12 jobs: launch_wave groups them)
+    ConvJob CJ;
+    CJ.yp = J.yp; CJ.up = J.up; CJ.vp = J.vp;
+    CJ.dst.ptr = nullptr; CJ.dst.pitch = 0u; CJ.dst.w = J.src_w; CJ.dst.h = J.src_h;
+    CJ.full = J.full; CJ.nv = FXNV ? 1 : 0; CJ.sx = 1; CJ.sy = 1; CJ.rgb12 = 1; CJ.packed = 0;
+    Cv420Win fx_win[FXB];
+    int fx_g[FXB];
+    u32 fx_y[FXB][4];
+    Cv420Raw<FXNV> fx_c[FXB][4];
+    const u32 fx_rs = 12u * (u32)NKS + 1u;  // dwords per chunk row (+ 1: rows fall on different banks)
+    u32 *const fx_node = (u32 *)(smem + raw_off);
+    const float *const fx_ylut = (const float *)(smem + b_off + (u32)J_b_bytes), *const fx_nlut = fx_ylut + 256;
+    if (FX) {
+#pragma unroll
+        for (int sb = 0; sb < FXB; sb++) {
+            fx_g[sb] = min((base >> 2) + 16 * sb + l16, (sw >> 2) - 1);  // (columns past the row's end only ever meet zero weights: the last block again)
+            fx_win[sb] = cv420_window<FXNV>(CJ, fx_g[sb]);
+        }
+    }
+    auto fx_issue = [&](int c) {
+        if (!FX) return;
+#pragma unroll
+        for (int sb = 0; sb < FXB; sb++) {
+            if (16 * sb >= 4 * NKS) continue;  // (uniform: a narrower job of the wide class)
+            const int P = 4 * c + lq;
+            cv420_load_luma(CJ, fx_g[sb], P, fx_y[sb]);
+#pragma unroll
+            for (int k = 0; k < 4; k++) fx_c[sb][k] = cv420_load_chroma<FXNV, true>(CJ, fx_win[sb], 2 * P - 1 + k);  // (the build that reads nothing behind a row's last column)
+        }
+    };
+    auto fx_convert = [&](int c) {
+        if (!FX) return;
+#pragma unroll
+        for (int sb = 0; sb < FXB; sb++) {
+            if (16 * sb >= 4 * NKS) continue;
+            float H[4][2][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cv420_hrow<FXNV>(fx_c[sb][k], fx_win[sb], fx_nlut, H[k]);
+            u32 *const dst = fx_node + (u32)(4 * lq) * fx_rs + 3u * (u32)(16 * sb + l16);
+            const u32 rs = fx_rs;
+            const bool live = 16 * sb + l16 < 4 * NKS;  // (a narrower job of the wide class: its chunk rows hold 4 NKS groups)
+            auto sink = [=](int r, int, u32 r4, u32 g4, u32 b4, const u32 (&)[4]) {
+                if (live) { dst[(u32)r * rs] = r4; dst[(u32)r * rs + 1u] = g4; dst[(u32)r * rs + 2u] = b4; }
+            };
+            // (all four rows: rows past the frame's end repeat its last row — they only ever meet zero weights, like the columns)
+            if (CJ.full) cv420_rows_to<true, true, true>(CJ, fx_g[sb], 4 * c + lq, fx_y[sb], H, fx_nlut, sink);
+            else cv420_rows_to<true, false, true>(CJ, fx_g[sb], 4 * c + lq, fx_y[sb], H, fx_ylut, sink);
+        }
+    };
+    const u32 *const fx_rd = fx_node + (u32)l16 * fx_rs + 3u * (u32)lq;  // this lane's group of k-step 0 (k-step j: + 12 j)
 
     // ---- pass-2 state: the ring of f16 rows (two chunks per register quad) and the weights of the next tile to finish
     //      (one register vector per tile and channel, written at a uniform runtime index: register-indexed moves, not a select per slot)
@@ -657,7 +737,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // the wait at the top of a chunk — for the chunk's blocks, requested a whole chunk ago — also waited for the stores of the tile row that
     // had just been finished, i.e. for a full write round trip per tile row (the build without stores ran 3.8 us shorter).  A finished tile
     // row's pixels therefore stay in registers (8) until that wait is over and leave right behind it: by the next wait they are a chunk old.
-    constexpr bool DEFER = RG && !DIRECT && !SA && NKS_T != 0 && (SMR_WAVE_DEFER_STORES != 0);  // (the generic builds sit at the register limit: immediate stores there)
+    constexpr bool DEFER = (RG || FX) && !DIRECT && !SA && NKS_T != 0 && (SMR_WAVE_DEFER_STORES != 0);  // (the generic builds sit at the register limit: immediate stores there)
     u32 pend_px[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     int pend_vt = -1;  // (uniform) the tile row waiting to be stored, -1 = none
     auto store_rows = [&](int vt_s, const u32 (&p)[2][4]) {
@@ -688,6 +768,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             if (j < NKS) rg[j] = rg_load(c_first, j);
     }
     issue(c_first);
+    fx_issue(c_first);
     finish_prologue();
     dev_wait_vmcnt0();
     land();
@@ -703,7 +784,13 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
         //  Three things keep the waits where they cost nothing: the block loads are unconditional (the last chunk re-requests itself: the compiler can
         //  count the loads in flight), the first tile row of a chunk is its own copy of the code (below), and everything outstanding is waited for
         //  here, at the top of the chunk, where it is old — this chunk's blocks, the next tile row's weights.)
-        if (RG && SMR_WAVE_RG_EARLY_WAIT) dev_wait_vmcnt0();
+        if ((RG || FX) && SMR_WAVE_RG_EARLY_WAIT) dev_wait_vmcnt0();
+        if (FX) {  // the chunk's node texels: converted, into LDS; the next chunk's blocks requested
+            dev_wave_lds_sync();  // (every lane has read its groups of the previous chunk)
+            fx_convert(c);
+            dev_wave_lds_sync();
+            fx_issue(min(c + 1, c_last));  // (unconditional: the compiler can count the loads in flight)
+        }
         if (DEFER && pend_vt >= 0) {  // (uniform) the tile row finished in the previous chunk
             store_rows(pend_vt, pend_px);
             pend_vt = -1;
@@ -720,6 +807,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
             //      operands arrived long ago, and the tail of block j's gathers lands behind them.
             struct Raw { u32 yy, u0, u1, u2, u3, v0, v1, v2, v3; };
             auto read_raw = [&](int j, Raw &r) {
+                if (FX) { r.yy = fx_rd[12 * j]; r.u0 = fx_rd[12 * j + 1]; r.u1 = fx_rd[12 * j + 2]; return; }  // (the group's R, G, B dwords)
                 if (RG) return;
                 r.yy = yrow[4 * j];
                 r.u0 = urow[2 * j]; r.u1 = urow[2 * j + 1]; r.u2 = urow[cs + 2 * j]; r.u3 = urow[cs + 2 * j + 1];
@@ -738,6 +826,7 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
                 }
             };
             auto convert = [&](int j, const Raw &r, uint4 (&a)[4]) {
+                if (FX) { decode_rgb12(r.yy, r.u0, r.u1, a); return; }
                 if (RG) {
                     convert_rgba(j, a);
                     rg[RG ? (j < RG_N ? j : 0) : 0] = rg_load(min(c + 1, c_last), j);  // (unconditional: the compiler can then count the loads in flight — see the chunk loop)
@@ -1106,6 +1195,13 @@ __global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (20
         } else {
             for (int i = tid; i < 2 * NKS * 2 * 64; i += W_THREADS) Bs[i] = src[i];
         }
+        if (FL & 262144) {  // plane-source builds: the exact converter's tables behind the band — y' of a limited-range luma byte, byte / 255 (smr_convert_420.h)
+            float *yl = (float *)(smem + W_OFF_B + args.b_bytes), *nl = yl + 256;
+            for (int i = tid; i < 256; i += W_THREADS) {
+                yl[i] = cv420_luma_of_byte((u32)i, false);
+                nl[i] = unorm_of_byte((u32)i);
+            }
+        }
         if ((FL & 8192) && !(FL & 16384) && (FL & 65536)) {  // alpha builds: a / 255 (correctly rounded, as unorm_of_byte) as (hi | lo << 16)
             for (int i = tid; i < 256; i += W_THREADS) {
                 const float v = unorm_of_byte((u32)i);
@@ -1124,7 +1220,7 @@ __global__ __launch_bounds__(W_THREADS, (NKS_T == 4 && (FL & 8192) && !(FL & (20
     const int piece = group * W_WAVES + wave;
     const int vt0 = (int)(((long long)piece * J.n_vtiles) / J.pieces), vt1 = (int)(((long long)(piece + 1) * J.n_vtiles) / J.pieces) - 1;
     if (vt0 <= vt1)
-        wave_piece<NKS_T, KV_T, FL>(J, args.direct, pair, vt0, vt1, smem, (u32)W_OFF_B, (u32)(W_OFF_B + args.b_bytes + wave * args.raw_bytes), args.dbg,
+        wave_piece<NKS_T, KV_T, FL>(J, args.direct, pair, vt0, vt1, smem, (u32)W_OFF_B, (u32)(W_OFF_B + args.b_bytes + ((FL & 262144) ? W_FX_TABLE_BYTES : 0) + wave * args.raw_bytes), args.dbg,
                                     finish_prologue, args.b_bytes);
     else
         finish_prologue();
@@ -1204,8 +1300,8 @@ int get_wave_band(smr_ctx *ctx, float scale, float offset, int n_dst, int n_src,
             ctx->mfma_tables.emplace_back();
             victim = &ctx->mfma_tables.back();
         }
-        const size_t meta_bytes = ((size_t)n_units * (axis != 3 ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
-        const size_t frags = axis != 3 ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;  // (axis 2 / 4: K = k-steps of the widest window)
+        const size_t meta_bytes = ((size_t)n_units * (!w_axis_vertical(axis) ? sizeof(int4) : sizeof(int2)) + 15) & ~(size_t)15;
+        const size_t frags = !w_axis_vertical(axis) ? (size_t)n_units * 2 * K * 2 : (size_t)n_units * K * 2;  // (axis 2 / 4: K = k-steps of the widest window)
         const size_t need = meta_bytes + frags * 64 * sizeof(uint4);
         for (size_t i = ctx->pending_bands.size(); i-- > 0;)
             if (victim->dev && ctx->pending_bands[i].meta == victim->dev) ctx->pending_bands.erase(ctx->pending_bands.begin() + (long)i);
@@ -1308,6 +1404,45 @@ int make_wave_job(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &pla
     if (J.nv12) J.vp = J.up;
     J.layer = -1; J.ox = 0; J.oy = 0;
     J.perp = 0; J.single = 0;
+    return SMR_OK;
+}
+
+// The plane-source builds (FL & 262144): a planar 4:2:0 / NV12 frame the exact block converter takes (smr_conv_rgb12_ok: 4:2:0, width a multiple of 4
+// from 8, even height, dword-aligned planes), a two-pass horizontal-first plan without box pre-reduction, inside one of the class builds'
+// windows (vertical bands on the origin-0 chunk grid: axis 5), 16-byte aligned tile rows.  *cls: 0 <4, 2> | 1 <8, 3> | 2 <8, 2>.
+bool can_fuse_planes(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, int *cls = nullptr) {
+    if (!ctx->plane_source || ctx->ingest_impl == SMR_INGEST_VALU_F32 || !f || !smr_conv_rgb12_ok(ctx, f)) return false;
+    if (!(plan.kind == 2 && plan.levels[0] == 0 && plan.levels[1] == 0 && plan.axis[0] == 0 && plan.axis[1] == 1)) return false;
+    if (((uintptr_t)tile->ptr % 16) || (tile->pitch % 16) || f->height < 4) return false;
+    int NKS, KV, unused;
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2)) NKS = t->K;
+    else wave_band_geometry(plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &NKS, &unused);
+    if (const smr_ctx::MfmaTable *t = find_mfma_table(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 5)) KV = t->K;
+    else wave_band_geometry(plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 5, &KV, &unused);
+    const int c = (NKS <= 4 && KV == 2) ? 0 : (NKS <= 8 && KV == 3) ? 1 : (NKS <= 8 && KV == 2) ? 2 : -1;
+    if (cls) *cls = c;
+    return c >= 0;
+}
+int make_wave_job_planes(smr_ctx *ctx, const smr_frame *f, const smr_resample_plan &plan, const smr_surface *tile, WJob *out) {
+    WaveBand bh, bv;
+    int rc = get_wave_band(ctx, plan.scale[0], plan.offset[0], (int)tile->w, (int)f->width, 2, &bh);
+    if (rc != SMR_OK) return rc;
+    rc = get_wave_band(ctx, plan.scale[1], plan.offset[1], (int)tile->h, (int)f->height, 5, &bv);
+    if (rc != SMR_OK) return rc;
+    WJob &J = *out;
+    memset(&J, 0, sizeof(J));
+    J.yp = view_of(f->planes[0]); J.up = view_of(f->planes[1]); J.vp = f->planes[2] ? view_of(f->planes[2]) : J.up;
+    J.dst = view_of(tile);
+    J.src_w = (int)f->width; J.src_h = (int)f->height;
+    J.conv = m_conv_constants(true);  // (unused by these builds)
+    J.h_meta = (const int4 *)bh.meta; J.h_frag = bh.frag; J.NKS = bh.K; J.n_pairs = bh.n_units;
+    J.k01 = bh.k01 ? 1 : 0;
+    J.n_htiles = ((int)tile->w + 15) / 16;
+    J.v_meta = (const int2 *)bv.meta; J.v_frag = bv.frag; J.KV = bv.K; J.n_vtiles = bv.n_units;
+    J.pieces = W_WAVES;
+    J.nv12 = f->format == SMR_FRAME_NV12 ? 1 : 0;
+    J.full = f->format == SMR_FRAME_PLANAR_YUVJ420 ? 1 : 0;
+    J.layer = -1;
     return SMR_OK;
 }
 
@@ -1458,6 +1593,11 @@ constexpr WaveKernel W_KERNELS_RGB12[] = {k_ingest_wave<0, 0, 8192 + 131072>, k_
                                           k_ingest_wave<8, 3, 8192 + 131072>};
 constexpr WaveKernel W_KERNELS_RGB12_DIRECT[] = {k_ingest_wave<0, 0, 8192 + 131072 + 2048>, k_ingest_wave<4, 2, 8192 + 131072 + 2048>,
                                                  k_ingest_wave<4, 2, 8193 + 131072 + 2048>, k_ingest_wave<8, 3, 8192 + 131072 + 2048>};
+// ... plane-source builds (262144: the frame's planes, converted exactly in the wave — the default route of 4:2:0 frames): <4, 2> | <4, 2> without its two
+// always-zero fragments | <8, 3> | <8, 2>; planar and (+ 4096) NV12
+constexpr WaveKernel W_KERNELS_PLANES[] = {k_ingest_wave<4, 2, 262144>, k_ingest_wave<4, 2, 262145>, k_ingest_wave<8, 3, 262144>, k_ingest_wave<8, 2, 262144>};
+constexpr WaveKernel W_KERNELS_PLANES_NV[] = {k_ingest_wave<4, 2, 262144 + 4096>, k_ingest_wave<4, 2, 262145 + 4096>, k_ingest_wave<8, 3, 262144 + 4096>,
+                                              k_ingest_wave<8, 2, 262144 + 4096>};
 // ... with direct output (2048: the tile's copy-class pixels leave as Y'CbCr, smr_fused.hip)
 constexpr WaveKernel W_KERNELS_RGBA_DIRECT[] = {k_ingest_wave<0, 0, 8192 + 2048>, k_ingest_wave<4, 2, 8192 + 2048>, k_ingest_wave<4, 2, 8193 + 2048>,
                                                 k_ingest_wave<8, 3, 8192 + 2048>};
@@ -1478,7 +1618,7 @@ constexpr WaveKernel W_KERNELS_SA[] = {nullptr, nullptr, k_ingest_wave<0, 0, 327
 #endif
 
 int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = nullptr, bool rgba = false, bool f16 = false, bool sa = false,
-                bool alpha = false, bool rgb12 = false) {
+                bool alpha = false, bool rgb12 = false, bool planes = false) {
     if (!ctx->wave_attr_set) {  // per device, hence per ctx
         std::vector<WaveKernel> all;
 #ifdef SMR_LAB
@@ -1487,6 +1627,8 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
 #endif
         all.insert(all.end(), W_KERNELS_RGBA, W_KERNELS_RGBA + 4);
         all.insert(all.end(), W_KERNELS_RGBA_DIRECT, W_KERNELS_RGBA_DIRECT + 4);
+        all.insert(all.end(), W_KERNELS_PLANES, W_KERNELS_PLANES + 4);
+        all.insert(all.end(), W_KERNELS_PLANES_NV, W_KERNELS_PLANES_NV + 4);
         all.insert(all.end(), W_KERNELS_RGB12, W_KERNELS_RGB12 + 4);
         all.insert(all.end(), W_KERNELS_RGB12_DIRECT, W_KERNELS_RGB12_DIRECT + 4);
         all.insert(all.end(), W_KERNELS_RGBA_ALPHA, W_KERNELS_RGBA_ALPHA + 4);
@@ -1525,8 +1667,10 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
             tile_rows += (long long)J.n_pairs * J.n_vtiles;
         }
         if (f16 || sa) cls432 = cls83 = cls82 = false;  // (one generic build)
+        if (planes && !(cls432 || cls83 || cls82)) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: a plane-source job outside the class builds");
+        const bool planes82 = planes && cls82 && !cls432;
         const bool node82 = cls82 && !cls432 && rgba && !alpha && !direct && ctx->wave_node82;  // (node textures: its own two builds)
-        if (rgba || cls432) cls82 = false;
+        if (!planes && (rgba || cls432)) cls82 = false;
         int ki = cls432 ? (k01 ? 2 : 1) : (cls83 ? 3 : 0);
         if (!rgba && !sa) {
             if (direct) ki += 4;
@@ -1535,26 +1679,29 @@ int launch_wave(smr_ctx *ctx, std::vector<WJob> &jobs, const MDirect *direct = n
         const int cls_nks = cls432 ? 4 : 0;  // (the wide class lays its LDS out for the jobs' own k-step counts)
         const int sa_i = rgba ? (alpha ? 3 : 2) : (any_nv ? 1 : 0);
 #ifndef SMR_LAB
-        if (!rgba) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: the plane-source (fused conversion) builds exist in laboratory builds only");
+        if (!rgba && !planes) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: the one-code-per-stage conversion builds exist in laboratory builds only");
         constexpr WaveKernel W_KERNELS_82[4] = {nullptr, nullptr, nullptr, nullptr}, W_KERNELS[16] = {};
 #endif
-        const WaveKernel kern = node82 ? (rgb12 ? W_KERNEL_RGB12_82 : W_KERNEL_RGBA_82)
+        const int planes_i = cls432 ? (k01 ? 1 : 0) : (planes82 ? 3 : 2);
+        const WaveKernel kern = planes ? (any_nv ? W_KERNELS_PLANES_NV[planes_i] : W_KERNELS_PLANES[planes_i])
+                                : node82 ? (rgb12 ? W_KERNEL_RGB12_82 : W_KERNEL_RGBA_82)
                                 : cls82 ? W_KERNELS_82[(direct ? 1 : 0) + (any_nv ? 2 : 0)]
                                 : sa ? W_KERNELS_SA[sa_i]
                                    : f16 ? (alpha ? W_KERNEL_RGBA16F_ALPHA : W_KERNEL_RGBA16F)
                                          : alpha ? W_KERNELS_RGBA_ALPHA[ki]
                                                  : rgb12 ? (direct ? W_KERNELS_RGB12_DIRECT[ki] : W_KERNELS_RGB12[ki])
                                                          : rgba ? (direct ? W_KERNELS_RGBA_DIRECT[ki] : W_KERNELS_RGBA[ki]) : W_KERNELS[ki];
-        if (node82) ki = rgb12 ? 710 : 700;  // (occupancy cache keys)
+        if (planes) ki = 800 + planes_i + (any_nv ? 4 : 0);
+        else if (node82) ki = rgb12 ? 710 : 700;  // (occupancy cache keys)
         else if (cls82) ki = 500 + (direct ? 1 : 0) + (any_nv ? 2 : 0);
         else if (sa) ki = 300 + sa_i;
         else if (rgba) ki += f16 ? (alpha ? 250 : 200) : alpha ? 400 : rgb12 ? (direct ? 650 : 600) : (direct ? 150 : 100);
-        ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;
+        ctx->kernel_launches[rgba ? SMR_KERNEL_INGEST_WAVE_RGBA : SMR_KERNEL_INGEST_WAVE]++;  // (slot 0: the builds that read the frame's planes)
         // (the narrow class keeps its pass-1 band in registers: no LDS for it)
         args.b_bytes = (cls_nks && SMR_WAVE_PIPE && SMR_WAVE_B_REGS) ? 0 : w_band_bytes(cls_nks ? cls_nks : nks_max);
         // (node-texture builds stage nothing: the area behind the band only holds the alpha builds' 1 KB table)
-        args.raw_bytes = rgba ? (alpha ? 1024 / W_WAVES : 0) : (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;
-        const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
+        args.raw_bytes = planes ? w_fx_node_bytes(cls_nks ? cls_nks : nks_max) : rgba ? (alpha ? 1024 / W_WAVES : 0) : (w_raw_bytes(cls_nks ? cls_nks : nks_max) + 15) & ~15;
+        const size_t lds = (size_t)W_OFF_B + args.b_bytes + (planes ? W_FX_TABLE_BYTES : 0) + (size_t)W_WAVES * args.raw_bytes;
         if (lds > 160 * 1024) return smr_fail(ctx, SMR_ERR_INTERNAL, "k_ingest_wave: %zu B of LDS", lds);
         // as many waves as are resident at once (registers and LDS), one piece each: every wave starts and ends with the launch
         int per_cu = 0;

@@ -203,6 +203,7 @@ struct smr_ctx {
     int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
     std::vector<u32> compose_bitmap;  // compose_predict's scratch
     int ingest_min_rows = 0;     // SMR_INGEST_MIN_ROWS (profiling): least tile rows per wave of k_ingest_wave (0: the default, 1)
+    bool plane_source = false;   // SMR_OPT_PLANE_SOURCE (off by default: measured slower): 4:2:0 frames inside the matrix-core kernel's class windows are converted in the kernel itself (exactly: smr_convert_420.h's blocks through LDS) — no node texture in memory
     bool compact_nodes = true;   // SMR_OPT_COMPACT_NODES: node textures that only the matrix-core resampler reads are RGB12 (12 bytes per four pixels), not RGBA8
     bool direct_output = false;  // SMR_OPT_DIRECT_OUTPUT: wave A writes Y'CbCr for the compositor's copy tiles of a scene at rest
     std::vector<uint8_t> class_key_scratch;

@@ -205,7 +205,7 @@ class Comm:
         if self.handle:
             self.lib.smr_comm_destroy(self.handle)
             self.handle = None
-OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES, OPT_FUSED_KERNELS, OPT_COMPOSE_SELECT, OPT_SHARED_DEVICE = 0, 1, 2, 3, 4, 5, 6, 7
+OPT_INGEST_IMPL, OPT_INGEST_STRIP_WIDTH, OPT_DIRECT_OUTPUT, OPT_CONVERT_IMPL, OPT_COMPACT_NODES, OPT_FUSED_KERNELS, OPT_COMPOSE_SELECT, OPT_SHARED_DEVICE, OPT_PLANE_SOURCE = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 
 class Context:
@@ -274,6 +274,11 @@ class Context:
     def lab_build(self) -> bool:
         """True for a laboratory build of the library (-DSMR_LAB): the fused-conversion route (INGEST_MFMA_F16_FUSED) exists only there."""
         return lab_build()
+
+    def set_plane_source(self, on: bool):
+        """SMR_OPT_PLANE_SOURCE: 4:2:0 frames are converted inside the matrix-core resampler (exactly, through LDS; default on) or by the converter
+        kernel into a node texture in memory (off) — the same pixels."""
+        self.set_option(OPT_PLANE_SOURCE, 1 if on else 0)
 
     def set_direct_output(self, on: bool):
         """SMR_OPT_DIRECT_OUTPUT: let the resampling kernel write Y'CbCr for the compositor's copy tiles of a scene at rest (default off)."""

@@ -148,6 +148,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
         if (!smr_build_tables(tables, lut16)) return -9;
         have_tables = true;
     }
+    const bool planes = nv12 == 7 || nv12 == 8;  // the plane-source builds (262144): planar (7) / NV12 (8) frame, converted exactly in the wave; class builds only
+    if (planes) nv12 = nv12 == 8 ? 1 : 0;
     const bool f16 = nv12 == 3 || nv12 == 5;   // y = an RGBA16F node texture (linear light): the 8192 + 16384 build (5: with an alpha channel)
     const bool alpha = nv12 == 4 || nv12 == 5; // y = a premultiplied node texture with an alpha channel: the + 65536 builds
     const bool rgb12 = nv12 == 6;              // y = the node texture as RGB12 (12 bytes per four pixels; sw a multiple of 4): the 8192 + 131072 builds
@@ -163,13 +165,14 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     tile.alloc((size_t)tile_pitch * dh, 0x5a, 16);
     const bool single = specialised == 3;  // one tile per unit (axis 4 bands): windows too wide for a pair; generic builds
     if (single) specialised = 0;
-    Band bh = build_band(scale_h, off_h, dw, sw, single ? 4 : 2), bv = build_band(scale_v, off_v, dh, sh, 3);
+    Band bh = build_band(scale_h, off_h, dw, sw, single ? 4 : 2), bv = build_band(scale_v, off_v, dh, sh, planes ? 5 : 3);
     if (info) { info[0] = bh.nks; info[1] = bh.K; info[2] = bv.K; }
     if (bh.K > W_NKS_MAX || bv.K > W_KV_MAX) return -1;
     const bool cls432 = bh.K <= 4 && bv.K == 2, cls83 = bh.K <= 8 && bv.K == 3, cls82 = !cls432 && bh.K <= 8 && bv.K == 2;
     const bool sa = specialised == 2;  // single-axis plan: scale_v = 1, off_v = the perpendicular crop offset; the 32768 builds
     if (sa) specialised = 0;
     if (specialised && !cls432 && !cls83 && !cls82) return -2;
+    if (planes && !(specialised && (cls432 || cls83 || cls82))) return -2;
 
     WArgs args;
     memset(&args, 0, sizeof(args));
@@ -189,6 +192,8 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     J.nv12 = nv12;
     J.layer = -1;
     J.single = single ? 1 : 0;
+    J.full = full_range != 0;
+    J.k01 = bh.k01 ? 1 : 0;
     args.wg_prefix[0] = 0;
     args.wg_prefix[1] = J.n_pairs * (p / W_WAVES);
     args.n_jobs = 1;
@@ -196,13 +201,25 @@ extern "C" int emu_ingest_wave(const u8 *y, const u8 *u, const u8 *v, int sw, in
     const bool spec = specialised && cls432, spec83 = specialised && !cls432 && cls83, spec82 = specialised && !cls432 && !cls83 && cls82;
     const int cls_nks = spec ? 4 : 0;
     args.b_bytes = w_band_bytes(cls_nks ? cls_nks : bh.K);
-    args.raw_bytes = (w_raw_bytes(cls_nks ? cls_nks : bh.K) + 15) & ~15;
+    args.raw_bytes = planes ? w_fx_node_bytes(cls_nks ? cls_nks : bh.K) : (w_raw_bytes(cls_nks ? cls_nks : bh.K) + 15) & ~15;
     args.direct = nullptr;
-    const size_t lds = (size_t)W_OFF_B + args.b_bytes + (size_t)W_WAVES * args.raw_bytes;
+    const size_t lds = (size_t)W_OFF_B + args.b_bytes + (planes ? W_FX_TABLE_BYTES : 0) + (size_t)W_WAVES * args.raw_bytes;
     const int total = args.wg_prefix[1];
     if (info) info[3] = total;
     const unsigned blocks = (unsigned)((total + 7) & ~7);
-    if (sa) {
+    if (planes) {
+        if (nv12) {
+            if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 262145 + 4096>(args, tables, lut16); });
+            else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 262144 + 4096>(args, tables, lut16); });
+            else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 262144 + 4096>(args, tables, lut16); });
+            else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 262144 + 4096>(args, tables, lut16); });
+        } else {
+            if (spec && bh.k01) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 262145>(args, tables, lut16); });
+            else if (spec) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<4, 2, 262144>(args, tables, lut16); });
+            else if (spec83) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 3, 262144>(args, tables, lut16); });
+            else run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<8, 2, 262144>(args, tables, lut16); });
+        }
+    } else if (sa) {
         if (alpha) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 8192 + 65536>(args, tables, lut16); });
         else if (rgba) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 8192>(args, tables, lut16); });
         else if (nv12) run_grid(blocks, W_THREADS, lds, [&] { k_ingest_wave<0, 0, 32768 + 4096>(args, tables, lut16); });

@@ -23,7 +23,7 @@ def asan_runtime():
 
 LIBS = {  # name -> (source, kernel headers it compiles)
     "smr_emu_convert": ("emu_convert.cpp", ("smr_convert_420.h", "smr_convert_dev.h", "smr_yuv_fast.h")),
-    "smr_emu": ("emu_wave.cpp", ("smr_ingest_wave.h", "smr_ingest_common.h", "smr_tables.h", "smr_convert_dev.h", "smr_yuv_fast.h")),
+    "smr_emu": ("emu_wave.cpp", ("smr_ingest_wave.h", "smr_ingest_common.h", "smr_tables.h", "smr_convert_dev.h", "smr_yuv_fast.h", "smr_convert_420.h")),
     "smr_emu_compose": ("emu_compose.cpp", ("smr_fused_compose.h", "smr_layout_dev.h", "smr_convert_dev.h", "smr_yuv_fast.h", "smr_tables.h")),
 }
 

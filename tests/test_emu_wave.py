@@ -24,7 +24,7 @@ def emu():
     if not os.path.exists(CLANG):
         pytest.skip("no clang++ to build the emulator with")
     from tests import emu_build
-    lib = emu_build.build("smr_emu", "emu_wave.cpp", ("smr_ingest_wave.h", "smr_ingest_common.h", "smr_tables.h"))
+    lib = emu_build.build("smr_emu")
     h = C.CDLL(lib)
     h.emu_ingest_wave.argtypes = [P8, P8, P8, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, P8, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.POINTER(C.c_int)]
@@ -169,6 +169,55 @@ def test_emulated_kernel_on_an_rgb12_node_texture(emu, src, dst, crop, pieces, s
     assert np.array_equal(got, ref), int((got != ref).sum())
     d = np.abs(got.astype(np.int16) - want.astype(np.int16))
     assert d.max() <= 1 and (d == 0).mean() >= 0.9995 and (got[..., 3] == 255).all(), (d.max(), (d == 0).mean())
+
+
+# (source, tile, crop, pieces, white noise, NV12, full range)
+PLANE_CASES = [
+    ((96, 60), (64, 40), None, 2, True, False, False),        # the benchmark's class (scale 1.5): <4, 2>, zero fragments skipped
+    ((192, 120), (128, 80), None, 5, True, False, False),     # several pairs, pieces that cut between tiles
+    ((192, 120), (128, 80), None, 3, False, True, False),     # NV12
+    ((96, 60), (64, 40), None, 1, True, False, True),         # full range (J420)
+    ((200, 120), (64, 40), (10.0, 20.0, 96.0, 60.0), 2, True, False, False),  # crop: windows inside the frame
+    ((256, 144), (128, 72), None, 3, True, False, False),     # scale 2: <8, 2>, two blocks per lane
+    ((384, 216), (128, 72), None, 3, True, False, False),     # scale 3: <8, 3>, the north-star target's class
+    ((384, 216), (128, 72), None, 2, True, True, False),      # ... NV12
+    ((100, 62), (66, 41), None, 2, True, False, False),       # a width that is no multiple of 16, a height that is no multiple of 4
+]
+
+
+@pytest.mark.parametrize("src,dst,crop,pieces,noise,nv12,full", PLANE_CASES)
+def test_emulated_kernel_on_the_frames_planes_converts_exactly(emu, src, dst, crop, pieces, noise, nv12, full):
+    """The 262144 builds — the default route of 4:2:0 frames since round 6: the kernel reads the frame's planes and converts each chunk of its
+    window in the wave with the exact converter's block arithmetic (smr_convert_420.h) into LDS.  The virtual node texture is the oracle's
+    bit for bit, so — unlike the laboratory builds' one-code-per-stage conversion — there is NO conversion term: the tile is within 1 LSB of the
+    oracle's resample of the oracle's node on white noise, and equal to the RGB12-node build's tile except where the two chunk grids (origin 0
+    here, - 1 there) sum pass 2 in another order."""
+    (sw, sh), (dw, dh) = src, dst
+    y, u, v = _planes(sw, sh, noise, seed=sw * 17 + dh)
+    crop = crop or (0.0, 0.0, float(sw), float(sh))
+    plan = orc.resample_plan(sw, sh, crop, dw, dh)
+    assert plan.kind == 2 and plan.levels == (0, 0) and tuple(plan.axis[:2]) == (0, 1)
+    if nv12:
+        uu = np.ascontiguousarray(np.stack([u, v], axis=-1))
+        node = orc.nv12_to_rgba(y, uu, sw, sh)
+    else:
+        uu = u
+        node = orc.planar_yuv_to_rgba(y, u, v, sw, sh, variant=orc.YUVJ420) if full else orc.planar_yuv_to_rgba(y, u, v, sw, sh)
+    _, want = orc.resample(node, crop, dw, dh)
+    got, ref = np.zeros((dh, dw, 4), np.uint8), np.zeros((dh, dw, 4), np.uint8)
+    info = (C.c_int * 4)()
+    tail = (plan.scale[0], plan.offset[0], plan.scale[1], plan.offset[1])
+    rc = emu.emu_ingest_wave(_p(y), _p(uu), _p(v), sw, sh, 1 if full else 0, 8 if nv12 else 7, *tail, _p(got), dw, dh, pieces, 1, info)
+    assert rc == 0, (rc, list(info))
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    assert d.max() <= 1, f"{(d > 1).sum()} bytes off by more than 1 (max {d.max()})"
+    assert (d == 0).mean() >= 0.9995, (d == 0).mean()
+    assert (got[..., 3] == 255).all()
+    if sw % 4 == 0:  # against the node route's kernel on the oracle's node as RGB12
+        packed = np.ascontiguousarray(node[..., :3].reshape(sh, sw // 4, 4, 3).transpose(0, 1, 3, 2)).reshape(sh, 3 * sw)
+        assert emu.emu_ingest_wave(_p(packed), _p(packed), _p(packed), sw, sh, 0, 6, *tail, _p(ref), dw, dh, pieces, 1, info) == 0
+        dr = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert dr.max() <= 1 and (dr == 0).mean() >= 0.9999, (dr.max(), (dr == 0).mean())
 
 
 @pytest.mark.parametrize("src,dst,pieces", [((96, 60), (64, 40), 2), ((130, 74), (69, 40), 3), ((100, 56), (64, 36), 1)])

@@ -922,6 +922,52 @@ def test_compact_node_textures_give_the_same_tiles(hip, geom, fmt_name):
         c.close()
 
 
+@pytest.mark.parametrize("fmt_name", ["planar", "nv12", "j420"])
+@pytest.mark.parametrize("geom", [(1920, 1080, 1280, 720), (640, 360, 426, 240), (1280, 720, 640, 360), (3840, 2160, 1280, 720), (328, 182, 216, 120)],
+                         ids=["1080p", "360p", "half", "4k", "ragged"])
+def test_plane_source_route_converts_exactly_inside_the_resampler(hip, geom, fmt_name):
+    """SMR_OPT_PLANE_SOURCE (opt-in): k_ingest_wave reads the frame's planes and converts each chunk of its window in the wave with the exact
+    converter's block arithmetic — no converter launch, no node texture in memory.  The virtual node is the oracle's bit for bit, so on white
+    noise the tile is within 1 LSB of the oracle's converter + resampler, and equal to the node route's tile except where the two chunk grids
+    sum pass 2 in another order (never more than one code)."""
+    iw, ih, dw, dh = geom
+    crop = (0.0, 0.0, float(iw), float(ih))
+    rng = np.random.default_rng(iw * 3 + dh)
+    y = rng.integers(0, 256, (ih, iw), dtype=np.uint8)
+    u = rng.integers(0, 256, (ih // 2, iw // 2), dtype=np.uint8)
+    v = rng.integers(0, 256, (ih // 2, iw // 2), dtype=np.uint8)
+    if fmt_name == "nv12":
+        node = orc.nv12_to_rgba(y, np.stack([u, v], axis=-1), iw, ih)
+    else:
+        node = orc.planar_yuv_to_rgba(y, u, v, iw, ih, orc.YUVJ420 if fmt_name == "j420" else orc.YUV420, omp=True)
+    _, want = orc.resample(node, crop, dw, dh, omp=True)
+    c = hip.Context(0)
+    try:
+        if fmt_name == "nv12":
+            f = c.frame(hip.FRAME_NV12, iw, ih, [y, np.stack([u, v], axis=-1)])
+        else:
+            f = c.frame(hip.FRAME_PLANAR_YUVJ420 if fmt_name == "j420" else hip.FRAME_PLANAR_YUV420, iw, ih, [y, u, v])
+        tiles = []
+        for on in (True, False):
+            c.set_plane_source(on)
+            t = c.surface(dw, dh)
+            before = c.kernel_launches()
+            c.ingest_resample(f, crop, t)
+            ran = {k: v_ - before[k] for k, v_ in c.kernel_launches().items()}
+            if on:
+                assert ran["ingest_wave"] == 1 and ran["frame_to_rgba"] == 0 and ran["ingest_wave_rgba"] == 0, ran  # one launch, no converter
+            else:
+                assert ran["ingest_wave"] == 0 and ran["frame_to_rgba"] == 1, ran
+            tiles.append(t.download())
+        for t in tiles:
+            d = np.abs(t.astype(np.int16) - want.astype(np.int16))
+            assert d.max() <= 1 and (d == 0).mean() >= 0.999, (int(d.max()), float((d == 0).mean()))
+        dr = np.abs(tiles[0].astype(np.int16) - tiles[1].astype(np.int16))
+        assert dr.max() <= 1 and (dr == 0).mean() >= 0.9999, (int(dr.max()), float((dr == 0).mean()))
+    finally:
+        c.close()
+
+
 def test_one_call_with_many_frames_of_assorted_sizes(hip):
     """Twenty inputs of different sizes, formats and ranges in ONE smr_render_layouts call: the converter's launches (sixteen frames, then four;
     planar and NV12 apart) deal bands of each frame's block rows to the XCDs and equal shares to their waves — frames of a few rows, widths that
