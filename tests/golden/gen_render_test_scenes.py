@@ -24,7 +24,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-FILES = ["view", "rescaler", "tiles", "tiles_transitions", "transition"]
+FILES = ["view", "rescaler", "tiles", "tiles_transitions", "transition", "simple", "text", "shader", "image"]
 
 # ----------------------------------------------------------------------------------------------- tokens
 TOK = re.compile(r"""
@@ -124,6 +124,37 @@ class P:
             if self.at("fn"):
                 out.append(self.fn())
                 continue
+            if self.at("struct"):  # a plain data struct of the test file: its literals evaluate to dicts, nothing to record
+                self.eat()
+                self.eat()
+                depth = 0
+                while True:
+                    v = self.eat()[1]
+                    depth += v == "{"
+                    depth -= v == "}"
+                    if depth == 0 and v in ("}", ";"):
+                        break
+                continue
+            if self.at("impl"):  # methods of such a struct: ("impl", Type, [fns])
+                self.eat()
+                ty = self.eat()[1]
+                self.eat("{")
+                fns = []
+                while not self.at("}"):
+                    if self.at("pub"):
+                        self.eat()
+                        continue
+                    if self.at("#"):
+                        self.eat("#")
+                        self.eat("[")
+                        while not self.at("]"):
+                            self.eat()
+                        self.eat("]")
+                        continue
+                    fns.append(self.fn())
+                self.eat("}")
+                out.append(("impl", ty, fns))
+                continue
             raise SyntaxError(f"item? {self.peek()}")
         return out
 
@@ -140,6 +171,11 @@ class P:
             if self.at("mut"):
                 self.eat()
             pname = self.eat()[1]
+            if pname == "self" and not self.at(":"):
+                params.append(pname)
+                if self.at(","):
+                    self.eat()
+                continue
             self.eat(":")
             self.skip_type((",", ")"))
             params.append(pname)
@@ -155,6 +191,16 @@ class P:
         self.eat("{")
         stmts = []
         while not self.at("}"):
+            if self.at("const"):
+                self.eat()
+                name = self.eat()[1]
+                self.eat(":")
+                self.skip_type(("=",))
+                self.eat("=")
+                e = self.expr()
+                self.eat(";")
+                stmts.append(("let", name, e))
+                continue
             if self.at("let"):
                 self.eat()
                 if self.at("mut"):
@@ -335,7 +381,7 @@ class P:
             return ("if", c, a, b)
         if v == "match":
             raise SyntaxError("match is not supported")
-        if v in ("vec!", "format!", "assert!", "assert_eq!", "println!", "matches!"):
+        if v in ("vec!", "format!", "assert!", "assert_eq!", "println!", "matches!", "include_str!"):
             self.eat()
             open_ = self.eat()[1]
             close = {"[": "]", "(": ")", "{": "}"}[open_]
@@ -395,6 +441,7 @@ class Runner:
     def __init__(self, module, name):
         self.module, self.name = module, name
         self.inputs, self.resolution, self.mode, self.steps = [], [640, 360], "gpu_optimized", []
+        self.renderers = []  # with_renderers: {"id", "kind": "shader" | "image", "wgsl": file name | "image_type", "source"}
         self.unsupported = None
 
 
@@ -431,6 +478,7 @@ BUILTINS = {
     ("Some",): lambda x: x,
     ("Box", "new"): lambda x: x,
     ("Arc", "new"): lambda x: x,
+    ("Arc", "from"): lambda x: x,
     ("Duration", "from_millis"): lambda x: ms(float(x)),
     ("Duration", "from_secs"): lambda x: ms(1000.0 * x),
     ("Duration", "from_secs_f64"): lambda x: ms(1000.0 * x),
@@ -445,7 +493,10 @@ BUILTINS = {
     ("ComponentId",): lambda s: s,
     ("RendererId",): lambda s: s,
     ("Ok",): lambda x=None: x,
+    ("integration_tests_root",): lambda: {"__path__": ""},
+    ("submodule_root_path",): lambda: {"__path__": "snapshot_tests_submodule"},
 }
+IMPLS = {}  # struct name -> {method name: fn item} of the file being evaluated
 
 
 def ev(n, env):
@@ -547,6 +598,8 @@ def ev(n, env):
     if k == "macro":
         if n[1] == "vec!":
             return [ev(e, env) for e in n[2]]
+        if n[1] == "include_str!":
+            return {"__include_str__": ev(n[2][0], env)}
         if n[1] == "format!":
             fmt = ev(n[2][0], env)
             rest = [ev(e, env) for e in n[2][1:]]
@@ -577,7 +630,17 @@ def method(o, name, args, env):
         elif name == "with_rendering_mode":
             o.mode = "cpu_optimized" if "Cpu" in unit(args[0]) else "gpu_optimized"
         elif name == "with_renderers":
-            o.unsupported = "registers renderers (image / shader / web)"
+            for rid, spec in args[0]:
+                kind, inner = spec["__enum__"], spec["args"][0]
+                if kind.endswith("Shader"):
+                    o.renderers.append({"id": rid, "kind": "shader", "wgsl": os.path.basename(inner["source"]["__include_str__"])})
+                elif kind.endswith("Image"):
+                    src = inner["src"]
+                    where = src.get("url") or src.get("path")
+                    o.renderers.append({"id": rid, "kind": "image", "image_type": unit(inner["image_type"]).split("::")[-1].lower(),
+                                        "source": where if isinstance(where, str) else os.path.basename(str(where.get("__path__", where)))})
+                else:
+                    o.unsupported = f"registers a {kind} renderer"
         elif name == "update_scene":
             o.steps.append({"update": component(args[0])})
         elif name in ("snapshot", "render"):
@@ -587,6 +650,11 @@ def method(o, name, args, env):
         else:
             raise Unsupported(f"TestRunner::{name}")
         return o
+    if isinstance(o, dict) and "__path__" in o and name == "join":
+        return {"__path__": (o["__path__"] + "/" if o["__path__"] else "") + args[0]}
+    if isinstance(o, dict) and o.get("__struct__") in IMPLS and name in IMPLS[o["__struct__"]]:
+        it = IMPLS[o["__struct__"]][name]
+        return ev(it[3], {**env, **dict(zip(it[2], [o] + list(args)))})
     if name in ("into", "clone", "to_string", "to_owned", "collect", "iter", "into_iter", "cloned", "copied", "unwrap", "as_str", "to_vec", "as_ref"):
         return o
     if name == "map":
@@ -759,7 +827,64 @@ def component(c):
         if c.get("transition") is not None:
             out["transition"] = transition(c["transition"])
         return out
+    if s == "TextComponent":
+        out = {"type": "text", "text": c["text"], "font_size": float(c["font_size"])}
+        if c.get("id") is not None:
+            out["id"] = c["id"]
+        d = c.get("dimensions")
+        if d is not None:
+            kind = d["__struct__"].split("::")[-1] if "__struct__" in d else unit(d).split("::")[-1]
+            if kind == "Fixed":
+                out["width"], out["height"] = float(d["width"]), float(d["height"])
+            elif kind == "FittedColumn":
+                out["width"] = float(d["width"])
+                if d.get("max_height") is not None:
+                    out["max_height"] = float(d["max_height"])
+            else:
+                for k in ("max_width", "max_height"):
+                    if d.get(k) is not None:
+                        out[k] = float(d[k])
+        if "line_height" in c:
+            out["line_height"] = float(c["line_height"])
+        if "color" in c:
+            out["color"] = color(c["color"])
+        if "background_color" in c:
+            out["background_color"] = color(c["background_color"])
+        if "font_family" in c:
+            out["font_family"] = c["font_family"]
+        for k in ("style", "align", "wrap", "weight"):
+            if k in c:
+                out[k] = snake(c[k])
+        return out
+    if s == "ImageComponent":
+        out = {"type": "image", "image_id": c["image_id"]}
+        if c.get("id") is not None:
+            out["id"] = c["id"]
+        for k in ("width", "height"):
+            if c.get(k) is not None:
+                out[k] = float(c[k])
+        return out
+    if s == "ShaderComponent":
+        out = {"type": "shader", "shader_id": c["shader_id"], "resolution": {"width": int(c["size"]["width"]), "height": int(c["size"]["height"])}}
+        if c.get("id") is not None:
+            out["id"] = c["id"]
+        if c.get("children"):
+            out["children"] = [component(k) for k in c["children"]]
+        if c.get("shader_param") is not None:
+            out["shader_param"] = shader_param(c["shader_param"])
+        return out
     raise Unsupported(f"{s} component")
+
+
+def shader_param(p):
+    kind, args = p["__enum__"].split("::")[-1], p["args"]
+    if kind in ("F32", "U32", "I32"):
+        return {"type": kind.lower(), "value": float(args[0]) if kind == "F32" else int(args[0])}
+    if kind == "List":
+        return {"type": "list", "value": [shader_param(x) for x in args[0]]}
+    if kind == "Struct":
+        return {"type": "struct", "value": [dict(shader_param(f["value"]), field_name=f["field_name"]) for f in args[0]]}
+    raise Unsupported(f"ShaderParam::{kind}")
 
 
 # ----------------------------------------------------------------------------------------------- driver
@@ -777,9 +902,12 @@ def extract(reference):
                 except Exception as ex:
                     if it[1] != "TESTS":  # (the TESTS tables name generated statics)
                         print(f"  {mod}: const {it[1]} not evaluated: {ex!r}", file=sys.stderr)
+        IMPLS.clear()
         for it in items:
             if it[0] == "fn":
                 fns[it[1]] = it
+            if it[0] == "impl":
+                IMPLS.setdefault(it[1], {}).update({f[1]: f for f in it[2]})
         for name, it in fns.items():
             env[name] = (lambda it: lambda *a: ev(it[3], {**env, **dict(zip(it[2], a))}))(it)
         is_test = re.compile(r"#\[render_test[^\]]*\]\s*fn\s+(\w+)")
@@ -794,8 +922,11 @@ def extract(reference):
                 r = runners[0]
                 if r.unsupported:
                     raise Unsupported(r.unsupported)
-                tests.append({"module": mod, "name": name, "resolution": r.resolution, "mode": r.mode,
-                              "inputs": [{k: i[k] for k in ("id", "index", "width", "height", "kind")} for i in r.inputs], "steps": r.steps})
+                t = {"module": mod, "name": name, "resolution": r.resolution, "mode": r.mode,
+                     "inputs": [{k: i[k] for k in ("id", "index", "width", "height", "kind")} for i in r.inputs], "steps": r.steps}
+                if r.renderers:
+                    t["renderers"] = r.renderers
+                tests.append(t)
             except Unsupported as ex:
                 skipped.append((mod, name, str(ex)))
             except Exception as ex:  # a construct the interpreter does not know: reported, never silently dropped

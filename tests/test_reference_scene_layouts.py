@@ -21,7 +21,20 @@ from tests import scene_json
 from tests.test_scene_engine import assert_same_layouts
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CORPUS = json.load(open(os.path.join(ROOT, "tests", "golden", "render_test_scenes.json")))["tests"]
+# (the layout scenes of the corpus — trees of View / Rescaler / Tiles over input streams; the 33 scenes with Text / Image / Shader nodes are rendered
+#  node by node in tests/test_gpu_reference_scenes.py)
+def _only_layout_components(test):
+    """True for the corpus scenes that are trees of View / Rescaler / Tiles over input streams (110 of the reference's 143 render tests)."""
+    def ok(c):
+        if c["type"] == "input_stream":
+            return True
+        if c["type"] not in ("view", "rescaler", "tiles"):
+            return False
+        return all(ok(k) for k in c.get("children", [])) and ("child" not in c or ok(c["child"]))
+    return all(ok(s["update"]) for s in test["steps"] if "update" in s)
+
+
+CORPUS = [t for t in json.load(open(os.path.join(ROOT, "tests", "golden", "render_test_scenes.json")))["tests"] if _only_layout_components(t)]
 BY_NAME = {(t["module"], t["name"]): t for t in CORPUS}
 
 
