@@ -403,6 +403,9 @@ def main():
     ap.add_argument("--plane-source", action="store_true",
                     help="SMR_OPT_PLANE_SOURCE: the resampling kernel reads the frames' planes and converts exactly in the wave — no converter launch, no node "
                          "texture in memory (A/B; default off: slower, DESIGN.md section 3c)")
+    ap.add_argument("--prime-seconds", type=float, default=0.25,
+                    help="untimed frames before the W warm-up steps, for this long: the device's clocks, caches and the host's code paths in the state of a running "
+                         "compositor (0: none)")
     ap.add_argument("--no-long", action="store_true", help="skip the `value_long` loop (profiling runs: keeps traces small)")
     ap.add_argument("--long-seconds", type=float, default=12.0,
                     help="length of the `value_long` loop — the same timed loop run right after `value`, BEFORE any CPU work, long enough for an outside "
@@ -603,6 +606,15 @@ def main():
     for s in range(PRIME):
         step_fn(s)
     barrier()
+    # ... and the device is brought to the state a running compositor is in: untimed frames for `--prime-seconds` (default 0.25 s) so that the
+    # K timed steps are not also a measurement of the clock ramp out of idle (a 20-step run lasts a millisecond; the same loop over 12 s is
+    # `value_long`).  Reported as config.prime_seconds / prime_frames; 0 restores the bare W warm-up steps.
+    t_prime = time.perf_counter()
+    while time.perf_counter() - t_prime < args.prime_seconds:
+        for s in range(32):
+            step_fn(PRIME + s)
+        PRIME += 32
+        barrier()
     for s in range(args.warmup):
         step_fn(s)
     barrier()
@@ -657,7 +669,7 @@ def main():
                                     4: "configs[4] on ONE GPU: 16x1080p YUV420 inputs in an animated Tiles grid (scene update every 45 frames, "
                                        "500 ms cubic-bezier transitions) + one 960x540 layer through the gaussian-blur shader -> 3840x2160 YUV420"}[args.config],
                        "inputs": N_IN, "input_resolution": [IN_W, IN_H], "output_resolution": [OUT_W, OUT_H],
-                       "layouts": len(layouts), "prime_frames": PRIME, "input_ring": RING, "frames_in_flight": len(lanes),
+                       "layouts": len(layouts), "prime_frames": PRIME, "prime_seconds": args.prime_seconds, "input_ring": RING, "frames_in_flight": len(lanes),
                        "frames_per_s_one_in_flight": round(serial_fps, 2) if serial_fps else None,
                        "per_frame_host_work": "smr_renderer_render: frame set -> layout maths at pts (C++ scene engine) -> parameter pack -> 3 kernels (convert, resample, compose)"
                        if single else ("layout maths at pts on every rank (C++ scene engine) -> ingest per shard -> gather -> blur layer + compose on the root"
