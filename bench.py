@@ -248,7 +248,7 @@ def roofline_block(args, stages, kernel_bytes, knames, ms_per_step, algo_bytes=N
     dom_us = stages[dom]["avg_us"]
     ach = ALGO_BYTES_PER_FRAME / (sum_us * 1e-6) / 1e9
     traffic, ident = None, None
-    tname = {2: "r05_traffic.json", 3: "r05_traffic_configs3.json"}.get(args.config)  # the committed counter passes: default workload, target
+    tname = {2: "r06_traffic.json", 3: "r06_traffic_configs3.json"}.get(args.config)  # the committed counter passes: default workload, target
     per_kernel_traffic = None
     if tname and args.ingest == "auto":
         data, ident = quoted_profile(tname)
@@ -271,23 +271,27 @@ def roofline_block(args, stages, kernel_bytes, knames, ms_per_step, algo_bytes=N
              "pipelined_frame": {"us": round(ms_per_step * 1e3, 3), "frac": round(ALGO_BYTES_PER_FRAME / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                                  "what": "frame bytes / ms_per_step of the timed loop (frames in flight overlap)"},
              "wave_a_us": round(sum(stages[k]["avg_us"] for k in wave_a), 3),
-             "limiter": ("vector-instruction issue, not HBM.  Evidence: cycle stamps of the converter's waves (profiles/r05_convert_waves.txt) — a SIMD's waves "
-                         "finish one after the other, oldest first, at ~3.9 cycles per vector instruction and 2.05 GHz; with every load and store compiled out the "
-                         "kernel is as slow (19.1 vs 20.9 us); the float arithmetic runs near its rate (2.3 cycles per instruction), the byte extracts, packs, "
-                         "conversions and table-address arithmetic around it at ~4.  The resampler's memory skeleton runs at copy bandwidth underneath its "
-                         "arithmetic (profiles/r04_wave_ablation.txt); two frames in flight share the same issue slots.  DESIGN.md section 3")
+             "limiter": ("latency under memory load, between the two roofs: alone, every kernel runs at 40 - 80 % of its vector-issue rate and a third of the copy bandwidth; with two "
+                         "frames in flight the frame period follows the WAITS, not the instruction or byte counts — a converter without its per-pixel arithmetic (- 55 % of its "
+                         "instructions) gains 2 %, one without its stores 3 %, while deferring the resampler's tile stores behind the next chunk's wait and turning the converter's "
+                         "and compositor's FLAT accesses into GLOBAL ones (counted waits instead of vmcnt(0)) gained 6.5 % with no instruction or byte removed "
+                         "(profiles/r06_sensitivity.txt).  `issue_frac` prices the frame's instructions at the guide's peak issue rate, `frac` its algorithmic bytes at 8 TB/s: "
+                         "both far from 1 — DESIGN.md section 3")
              if args.ingest == "auto" else "see DESIGN.md section 3"}
     if args.config == 2 and args.ingest == "auto":
-        iss, ident2 = quoted_profile("r05_issue.json")
+        iss, ident2 = quoted_profile("r06_issue.json")
         if iss:
             fl = iss["floors_us_per_frame"]
+            guide = min(v["floor_us_pipes_overlapped"] for v in fl.values())
+            block["issue_frac"] = round(guide / (ms_per_step * 1e3), 4)  # the instruction-issue roof beside the HBM one: floor at the guide's peak rate / pipelined frame time
             block["issue"] = {"valu_wave_instructions_per_frame": iss["per_frame"]["valu_wave_instructions"],
                               "mfma_wave_instructions_per_frame": iss["per_frame"]["mfma_wave_instructions"],
                               "floors_us_per_frame": {k: v["floor_us_pipes_overlapped"] for k, v in fl.items()},
                               "frame_us": round(ms_per_step * 1e3, 2),
                               "frame_over_floor": {k: round(ms_per_step * 1e3 / v["floor_us_pipes_overlapped"], 2) for k, v in fl.items()},
+                              "issue_frac": {k: round(v["floor_us_pipes_overlapped"] / (ms_per_step * 1e3), 4) for k, v in fl.items()},
                               "reading": iss.get("reading"),
-                              "source": "profiles/r05_issue.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA of this command on this device code; vector and "
+                              "source": "profiles/r06_issue.json (rocprofv3 --pmc SQ_INSTS_VALU / SQ_INSTS_MFMA of this command on this device code; vector and "
                                         "matrix pipes overlap: floor = the larger)"}
         else:
             block["issue"] = {"stale": True, "why": ident2.get("why")}
@@ -380,8 +384,64 @@ def capacity_mode(args):
                       "vs_baseline": None, "probes": probes}))
 
 
+def same_device_mode(args):
+    """The N > 1 code path as far as ONE GPU can run it: `--same-device N` drives N ShardedCompositors — rank r = its own context (HIP stream) on
+    device 0 — through the pipelined protocol of `--gpus N` (ingest k on every rank, gather k posted, root composes k - 1) over a local
+    communicator (smr_comm_create_local: device-to-device copies + events instead of RCCL over xGMI).  It exercises the sharded driver, the
+    double-buffered tile sets and the stream ordering on hardware; it says NOTHING about multi-GPU scaling — all ranks share one GPU's CUs and
+    HBM, so the value is expected near the one-GPU figure.  Informational; the scaling curve (SCALE_rNN.json) is the driver's."""
+    global IN_W, IN_H, OUT_W, OUT_H, N_IN, ALGO_BYTES_PER_FRAME
+    IN_W, IN_H, OUT_W, OUT_H, N_IN = 3840, 2160, 3840, 2160, 8  # configs[3]
+    ALGO_BYTES_PER_FRAME = N_IN * yuv420_bytes(IN_W, IN_H) + yuv420_bytes(OUT_W, OUT_H)
+    import torch
+    from smelter_amd import dist as smr_dist
+    from smelter_amd import hip
+    world = args.same_device
+    ctxs = [hip.Context(0) for _ in range(world)]
+    layouts, res = build_scene()
+    label = make_label(ctxs[0])
+    plan = smr_dist.ShardPlan(n_inputs=N_IN, world=world)
+    RING_SD = 3
+    rings = [make_inputs(ctxs[r], hip, RING_SD, plan.inputs_of(r)) for r in range(world)]
+    slots = [i for i, r in enumerate(res) if r == (IN_W, IN_H)]
+    comm = hip.Comm.local(ctxs)
+    ranks = smr_dist.LocalRanks(comm)
+    sc = [smr_dist.ShardedCompositor(ctxs[r], hip, plan, r, layouts, res, slots, label if r == plan.root else None, torch, None, comm=ranks.view(r)) for r in range(world)]
+    outs = [ctxs[plan.root].frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2)]
+
+    def step(k):
+        for r in ranks.order(plan.root):
+            sc[r].step_pipelined(rings[r][k % RING_SD], outs[k % 2] if r == plan.root else None)
+
+    def barrier():
+        for r in ranks.order(plan.root):
+            sc[r].flush()
+        for c in ctxs:
+            c.sync()
+    for k in range(4 + args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "composited frames/sec, 8x4K -> 4K sharded over N contexts of ONE device (code-path evidence, not a scaling point)", "value": round(args.steps / dt, 2),
+                      "unit": "frames/s", "n_gpus": 1, "ranks_on_one_device": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 5),
+                      "higher_is_better": True, "data": "synthetic", "dtype": "u8 in / u8 out (f32 conversion, f16-pair matrix-core resampler)",
+                      "config": {"workload": "configs[3]: 8x4K YUV420 inputs, input i on rank i mod N, tiles gathered by device-to-device copies (smr_comm_create_local), root composes frame k - 1 while frame k travels",
+                                 "transport": "hipMemcpy2DAsync + events on one device (RCCL is the transport of --gpus N)"},
+                      "vs_baseline": None}))
+    comm.close()
+    for c in ctxs:
+        c.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--same-device", type=int, default=0,
+                    help="N > 1: the sharded (multi-GPU) driver with N ranks as N contexts of device 0 over a local communicator — the code path of --gpus N on one GPU "
+                         "(informational: no scaling can be read from it)")
     ap.add_argument("--mode", choices=["throughput", "capacity"], default="throughput",
                     help="throughput (default): the judged line — composited frames/s of configs[2] with inputs resident in HBM.  capacity: the reference's own "
                          "'rendering only' capacity benchmark shape (1 raw input uploaded per frame -> N outputs read back, largest N at the frame rate)")
@@ -424,6 +484,8 @@ def main():
     args = ap.parse_args()
     if args.mode == "capacity":
         return capacity_mode(args)
+    if args.same_device > 1:
+        return same_device_mode(args)
     if args.config is None:
         # N > 1 shards BASELINE's multi-GPU workload (configs[3]: 8x4K, one input per GPU at N = 8): configs[2]'s 1080p inputs leave a GPU
         # 7 us of work per tile it then sends over one xGMI link for 24 us — link-bound beyond one GPU

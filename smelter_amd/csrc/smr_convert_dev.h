@@ -94,11 +94,21 @@ __device__ __forceinline__ u32 yuv_byte(float r, float g, float b, int plane) {
 // ---- the same bytes through the fast path (smr_yuv_fast.h: three FMAs per value, proven equal to the sequence above wherever its guard
 //      flag is clear — tools/check_yuv_fast.cpp, the complete domain) with the sequence itself behind the flag: a divergent branch that
 //      2.4 values in 10 000 take.  The callers hold the bytes as floats already (v_cvt_f32_ubyteN: extract + convert in one instruction).
+// (the compiler otherwise speculates the side-effect-free reference sequence and selects: both paths on every value — seen in the first build's
+//  instruction counts; an empty volatile asm cannot be speculated, so the sequence stays behind s_cbranch_execz)
+#ifdef SMR_EMU
+#define YUV_SLOW_PATH_STAYS_A_BRANCH() do { } while (0)
+#else
+#define YUV_SLOW_PATH_STAYS_A_BRANCH() asm volatile("; reference sequence (guard flag set)" ::: "memory")
+#endif
 // Y' of a pixel: px = the RGBA8 bytes, fr / fg / fb = its colour bytes as floats
 __device__ __forceinline__ u32 yuv_luma_byte(u32 px, float fr, float fg, float fb) {
     bool flag;
     u32 y = yuvfast::convert<0>(fr, fg, fb, &flag);
-    if (flag) y = yuv_byte(unorm_of_byte(px & 0xffu), unorm_of_byte((px >> 8) & 0xffu), unorm_of_byte((px >> 16) & 0xffu), 0);
+    if (flag) {
+        YUV_SLOW_PATH_STAYS_A_BRANCH();
+        y = yuv_byte(unorm_of_byte(px & 0xffu), unorm_of_byte((px >> 8) & 0xffu), unorm_of_byte((px >> 16) & 0xffu), 0);
+    }
     return y;
 }
 // (Cb | Cr << 8) of a 2x2 block: pa, pb = the upper row's pixels, pc, pd = the lower row's; sr / sg / sb = the block's byte sums as floats
@@ -107,6 +117,7 @@ __device__ __forceinline__ u32 yuv_chroma_bytes(u32 pa, u32 pb, u32 pc, u32 pd, 
     bool f1, f2;
     u32 u = yuvfast::convert<1>(sr, sg, sb, &f1), v = yuvfast::convert<2>(sr, sg, sb, &f2);
     if (f1 || f2) {
+        YUV_SLOW_PATH_STAYS_A_BRANCH();
         const float mr = ((unorm_of_byte(pa & 0xffu) + unorm_of_byte(pb & 0xffu)) + (unorm_of_byte(pc & 0xffu) + unorm_of_byte(pd & 0xffu))) * 0.25f;
         const float mg = ((unorm_of_byte((pa >> 8) & 0xffu) + unorm_of_byte((pb >> 8) & 0xffu)) + (unorm_of_byte((pc >> 8) & 0xffu) + unorm_of_byte((pd >> 8) & 0xffu))) * 0.25f;
         const float mb = ((unorm_of_byte((pa >> 16) & 0xffu) + unorm_of_byte((pb >> 16) & 0xffu)) + (unorm_of_byte((pc >> 16) & 0xffu) + unorm_of_byte((pd >> 16) & 0xffu))) * 0.25f;

@@ -29,22 +29,22 @@ def test_device_code_hash_is_the_fatbin_sections_and_ignores_host_code(tmp_path)
 def test_profiles_are_quoted_only_for_the_library_they_were_collected_on(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     os.makedirs(tmp_path / "profiles")
-    data, ident = bench.quoted_profile("r05_traffic.json")
+    data, ident = bench.quoted_profile("r06_traffic.json")
     assert data is None and ident["stale"] and "does not exist" in ident["why"]
-    json.dump({"k": {"hbm_bytes_per_launch": 1}, "_identity": {"lib_kernels_sha256": "0" * 64}}, open(tmp_path / "profiles" / "r05_traffic.json", "w"))
-    data, ident = bench.quoted_profile("r05_traffic.json")
+    json.dump({"k": {"hbm_bytes_per_launch": 1}, "_identity": {"lib_kernels_sha256": "0" * 64}}, open(tmp_path / "profiles" / "r06_traffic.json", "w"))
+    data, ident = bench.quoted_profile("r06_traffic.json")
     assert data is None and ident["stale"] and "was collected on device code 000000000000" in ident["why"]
-    json.dump({"k": {"hbm_bytes_per_launch": 1}, "_identity": {"lib_kernels_sha256": B.kernels_sha256()}}, open(tmp_path / "profiles" / "r05_traffic.json", "w"))
-    data, ident = bench.quoted_profile("r05_traffic.json")
+    json.dump({"k": {"hbm_bytes_per_launch": 1}, "_identity": {"lib_kernels_sha256": B.kernels_sha256()}}, open(tmp_path / "profiles" / "r06_traffic.json", "w"))
+    data, ident = bench.quoted_profile("r06_traffic.json")
     assert data is not None and not ident["stale"]
 
 
 def test_committed_profiles_belong_to_the_library_that_is_built():
     """The counter files bench.py quotes in the judged line were collected on exactly this device code (the build is deterministic)."""
     have = B.kernels_sha256()
-    for name in ("r05_traffic.json", "r05_issue.json", "r05_traffic_configs3.json"):
+    for name in ("r06_traffic.json", "r06_issue.json", "r06_traffic_configs3.json"):
         ident = json.load(open(os.path.join(ROOT, "profiles", name)))["_identity"]
-        assert ident["lib_kernels_sha256"] == have, f"profiles/{name} is stale: re-run tools/round_end_r05.sh on the final build"
+        assert ident["lib_kernels_sha256"] == have, f"profiles/{name} is stale: re-run tools/round_end_r06.sh on the final build"
 
 
 def test_whole_frame_roofline_does_not_move_when_a_kernel_is_split(monkeypatch):
