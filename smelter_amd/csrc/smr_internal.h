@@ -99,6 +99,8 @@ struct LayoutSlot {
     size_t bytes = 0;
     hipEvent_t done = nullptr;
     bool busy = false;
+    bool unfenced = false;      // frames that REUSED this slot's device copy were queued after `done` was last recorded (smr_pack_done records no event for
+                                // them: a marker packet per frame costs ~5 us on the stream): recycling the slot then waits for the stream instead
     size_t resident_bytes = 0;  // leading bytes of host that the device copy holds (0 = none): smr_pack_commit's reuse
 };
 

@@ -71,6 +71,7 @@ struct PackedLayouts {
     void *extra_host = nullptr;  // caller-defined parameter block riding in the same slot
     void *extra_dev = nullptr;
     size_t copy_bytes = 0;
+    bool reused = false;  // smr_pack_commit found the previous frame's identical device copy: nothing was queued
 };
 
 // One layout of the POD list in the compact device form (rotation, quad and bounding box precomputed on the host in f32, as the vertex stage
