@@ -340,7 +340,10 @@ extern "C" __attribute__((visibility("default"))) int smr_debug_convert_stamps(u
 #endif
 
 template <bool NV>
-__global__ __launch_bounds__(BLOCK) void k_yuv420_to_rgba(const ConvBatch B) {
+#ifndef SMR_CONVERT_MIN_WAVES
+#define SMR_CONVERT_MIN_WAVES 1  // waves per SIMD the converter's register allocation must leave room for (A/B knob: 8 = at most 64 registers, so that more of its waves fit beside another lane's resampler)
+#endif
+__global__ __launch_bounds__(BLOCK, SMR_CONVERT_MIN_WAVES) void k_yuv420_to_rgba(const ConvBatch B) {
     __shared__ float s_ylut[256], s_nlut[256];
 #ifdef SMR_PRIO_CONVERT
     __builtin_amdgcn_s_setprio(SMR_PRIO_CONVERT);

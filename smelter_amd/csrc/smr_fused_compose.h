@@ -38,11 +38,13 @@ static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS cop
 // pack resident (profiles/r03_compose_ab.txt): four bands 23.2 us on configs[2] and 48.3 us on configs[4], eight bands 25.0 / 57.1 us.
 constexpr int B_SLICES = 4;          // ctx->compose_slices: 4 or 8 (a band holds whole 4x2 output blocks)
 #ifndef SMR_COMPOSE_MIN_WAVES
-#define SMR_COMPOSE_MIN_WAVES 2
+#define SMR_COMPOSE_MIN_WAVES 5
 #endif
-// waves per SIMD the register allocation must leave room for.  The kernel needs ~106 VGPRs: four workgroups per CU fit anyway (24 KB of
-// LDS each would allow six).  Asking for 5 / 6 costs spills (96 / 80 VGPRs, 48 / 80 B of scratch) and is slower on configs[2]
-// (23.5 -> 24.8 / 25.8 us) though faster on configs[4] (47.8 -> 44.0 / 43.1 us): profiles/r03_compose_occupancy.txt.
+// waves per SIMD the register allocation must leave room for.  Unconstrained the kernel takes ~106 VGPRs (four waves per SIMD).  Round 3 measured
+// 5 / 6 (96 / 80 VGPRs, some scratch in the compositing path) slower ALONE on configs[2] and faster on configs[4]
+// (profiles/r03_compose_occupancy.txt).  Round 6: with two frames in flight the kernel runs beside the other lane's resampler, whose two waves
+// per SIMD leave 160 registers — at 96 the frame gains 7 % (17.96 -> 19.24 k frames/s, alone unchanged: 17.3 us); 80 gains 3.6 % (spills);
+// the converter at 72 / 64 registers: neutral / slower (profiles/r06_sensitivity.txt).
 constexpr int B_MIN_WAVES = SMR_COMPOSE_MIN_WAVES;
 constexpr int B_BAND_ROWS = 4;       // rows of the workgroup's LDS pixel state: a band is at most this tall
 static_assert(B_TILE_H % B_BAND_ROWS == 0 && B_TILE_H / B_SLICES <= B_BAND_ROWS, "a band fits the LDS pixel state");
