@@ -698,6 +698,9 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
     }
     }
     // (uniform; one band of a listed tile, or the four bands of a tile — of each tile of the group — the list's bound left out)
+#ifdef SMR_COMPOSE_NO_FULL  // profiling builds only: the compositing path compiled out (what the copy paths alone need in registers and time)
+    if (full_entry || full_entry2) return;
+#endif
 #pragma unroll 1
     for (int q = 0; q < 2; q++) {
         const TileFull *e = q == 0 ? full_entry : full_entry2;
