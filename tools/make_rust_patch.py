@@ -104,7 +104,9 @@ def gen_sys_rs(header: str) -> str:
         rt, _ = rust_type(ret, is_param=False)
         tail = "" if rt == "c_void" else f" -> {rt}"
         lines.append(f"    pub fn {name}({', '.join(rparams)}){tail};")
-    return SYS_HEAD.replace("@@ENUMS@@", "\n".join(enums)) + "\n".join(lines) + "\n}\n"
+    abi = re.search(r"^#define SMR_ABI_VERSION (\d+)", header, re.M).group(1)
+    head = SYS_HEAD.replace("@@ENUMS@@", "\n".join(enums)).replace("@@ABI@@", abi)
+    return head + "\n".join(lines) + "\n}\n"
 
 
 SYS_HEAD = '''//! Raw binding of libsmr_hip (include/smr.h) — GENERATED by tools/make_rust_patch.py of the smelter_amd repository from that
@@ -142,6 +144,7 @@ pub struct smr_fontbook {
 pub const SMR_MAX_MASKS: usize = 20; // MAX_MASKS_COUNT (transformations/layout/params.rs:15)
 pub const SMR_NO_SOURCE: u32 = 0xffff_ffff;
 pub const SMR_COMM_ID_BYTES: usize = 128;
+pub const SMR_ABI_VERSION: u32 = @@ABI@@; // the header this file was generated from; HipCtx::new compares it with smr_abi_version()
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct smr_frame { pub format: u32, pub width: u32, pub height: u32, pub planes: [*mut smr_surface; 3] }
@@ -239,6 +242,10 @@ impl HipCtx {
             RenderingMode::CpuOptimized => SMR_MODE_CPU_OPTIMIZED,
             RenderingMode::GpuOptimized | RenderingMode::WebGl => SMR_MODE_GPU_OPTIMIZED,
         };
+        let abi = unsafe { smr_abi_version() };
+        if abi != SMR_ABI_VERSION {
+            return Err(WgpuError::Internal(format!("libsmr_hip has ABI version {abi}, this binding was generated for {SMR_ABI_VERSION}")));
+        }
         let mut raw = ptr::null_mut();
         let rc = unsafe { smr_ctx_create(hip_device, smr_mode, max_layouts as u32, ptr::null_mut(), &mut raw) };
         if rc != SMR_OK {
