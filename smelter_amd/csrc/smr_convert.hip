@@ -576,9 +576,13 @@ int smr_frames_to_rgba_batch(smr_ctx *ctx, const smr_frame *const *in, smr_surfa
             // request that caps a CU at exactly that number (an even spread: every SIMD the same number of waves) was measured and is no
             // faster in the kernel trace (6 per CU: 23.1 us capped, 22.0 us uncapped, 4 per CU: 23.3 / 23.7 — profiles/r05_convert_waves.txt)
             // while it keeps other launches' workgroups off the CU; the knob remains for laboratory builds (SMR_CONVERT_LDS_PAD)
-            const u32 per_cu = (u32)(ctx->convert_wg_per_cu < 1 ? 1 : ctx->convert_wg_per_cu > 6 ? 6 : ctx->convert_wg_per_cu);
             u32 total = 0;
             for (u32 j = 0; j < Q.nb; j++) total += (((u32)Q.B.j[j].dst.w + 255u) / 256u) * (((u32)Q.B.j[j].dst.h + 3u) / 4u);
+            // convert_wg_per_cu 0 (the default): five per CU for a batch of a few frames, six for a large one.  With two frames in flight the
+            // kernel runs beside the other lane's kernels; configs[2] (8 640 units: 1.4 per wave at six) gains 2 % at five, configs[3]
+            // (64 800 units) loses 1 % (profiles/r06_sensitivity.txt section 9)
+            const int want = ctx->convert_wg_per_cu > 0 ? ctx->convert_wg_per_cu : (total >= 32768u ? 6 : 5);
+            const u32 per_cu = (u32)(want > 6 ? 6 : want);
             u32 blocks = (u32)ctx->cu_count * per_cu;
             if (blocks > (total + 3u) / 4u) blocks = (total + 3u) / 4u;
             // the partition (smr_convert_420.h): bands of block rows dealt to the XCDs, equal shares per wave inside an XCD

@@ -38,13 +38,13 @@ static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS cop
 // pack resident (profiles/r03_compose_ab.txt): four bands 23.2 us on configs[2] and 48.3 us on configs[4], eight bands 25.0 / 57.1 us.
 constexpr int B_SLICES = 4;          // ctx->compose_slices: 4 or 8 (a band holds whole 4x2 output blocks)
 #ifndef SMR_COMPOSE_MIN_WAVES
-#define SMR_COMPOSE_MIN_WAVES 5
+#define SMR_COMPOSE_MIN_WAVES 6
 #endif
-// waves per SIMD the register allocation must leave room for.  Unconstrained the kernel takes ~106 VGPRs (four waves per SIMD).  Round 3 measured
-// 5 / 6 (96 / 80 VGPRs, some scratch in the compositing path) slower ALONE on configs[2] and faster on configs[4]
-// (profiles/r03_compose_occupancy.txt).  Round 6: with two frames in flight the kernel runs beside the other lane's resampler, whose two waves
-// per SIMD leave 160 registers — at 96 the frame gains 7 % (17.96 -> 19.24 k frames/s, alone unchanged: 17.3 us); 80 gains 3.6 % (spills);
-// the converter at 72 / 64 registers: neutral / slower (profiles/r06_sensitivity.txt).
+// waves per SIMD the register allocation must leave room for.  Round 3 measured the first compositor (~106 VGPRs unconstrained) at 5 / 6 waves
+// (96 / 80 VGPRs, scratch in the compositing path): slower ALONE on configs[2], faster on configs[4] (profiles/r03_compose_occupancy.txt).
+// Round 6: with two frames in flight the kernel runs beside the other lane's resampler, whose two waves per SIMD leave 160 registers — at 96
+// the frame gained 7 %.  The list compositor (compose_full below) fits 79 registers without scratch: six waves, and two of them beside the
+// resampler — configs[4] + 3 % over five waves (84 registers), configs[2] unchanged (profiles/r06_sensitivity.txt section 9).
 constexpr int B_MIN_WAVES = SMR_COMPOSE_MIN_WAVES;
 constexpr int B_BAND_ROWS = 4;       // rows of the workgroup's LDS pixel state: a band is at most this tall
 static_assert(B_TILE_H % B_BAND_ROWS == 0 && B_TILE_H / B_SLICES <= B_BAND_ROWS, "a band fits the LDS pixel state");
@@ -288,11 +288,14 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
 template <typename T>
 __device__ __forceinline__ T load_uniform(const T *p) {
     static_assert(sizeof(T) % 4 == 0, "dword records only");
-    T out;
-    const u32 *s = (const u32 *)p;
-    u32 *d = (u32 *)&out;
+    T out;  // (through memcpy both ways: the record's fields are floats and ints, not u32 objects)
 #pragma unroll
-    for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = __builtin_amdgcn_readfirstlane(s[i]);
+    for (int i = 0; i < (int)(sizeof(T) / 4); i++) {
+        u32 w;
+        __builtin_memcpy(&w, (const char *)p + 4 * i, 4);
+        w = __builtin_amdgcn_readfirstlane(w);
+        __builtin_memcpy((char *)&out + 4 * i, &w, 4);
+    }
     return out;
 }
 
@@ -407,19 +410,55 @@ __device__ __forceinline__ void store_yuv_block(const u32 (&acc)[8], int px0, in
     }
 }
 
-// Rows [band, band + rh) of tile `tile`, classified and composited by the whole workgroup (uniform call; may be called again).
+// One LDS atomic per wave hands the wave's flagged pixels their slots on the workgroup's list (uniform call).
+__device__ __forceinline__ u32 list_slot(u32 *count, bool want) {
+#ifdef SMR_EMU
+    return want ? atomicAdd(count, 1u) : 0u;  // (the lane emulator has no wave votes)
+#else
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return 0u;
+    const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));  // flagged lanes below this one
+    u32 base = 0u;
+    if (want && rank == 0u) base = atomicAdd(count, (u32)__popcll(m));
+    return (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m)) + rank;
+#endif
+}
+__device__ __forceinline__ bool wave_any(bool v) {
+#ifdef SMR_EMU
+    return true;
+#else
+    return __ballot(v) != 0ull;
+#endif
+}
+
+// Rows [band, band + rh) of tile `tile`, composited by the whole workgroup (uniform call; may be called again).
 // NV = 0: planar Y,U,V (4:2:0); NV = 1: NV12 (Y + interleaved UV); NV = 2: RGBA8 surface (in `yp`)
 // BIG: the layout list is longer than the LDS copy (B_MAX_LAYOUTS / B_MAX_MASKS) and is read where it lies in memory
 // `pre`: the tile's record from k_classify_tiles — touching layers, start layer and tile_needs' bits of the WHOLE tile, valid for every
 // band of it (a layer solid over the tile is solid over the band; a superset of the band's touching layers composites to the same
 // pixels) — so a band's workgroup does not classify again.
+//
+// Three steps, one pixel per thread and sweep (a wave covers 64 consecutive pixels of a row), layer records through scalar registers:
+//   A  every pixel's START: the topmost touched layer that is opaque, unrotated and solid at the pixel (else the tile's own start layer),
+//      and that layer's value there — an opaque colour's bytes, a 1:1 texel, a filtered sample of a texture at a fractional position:
+//      what compositing from the start layer upwards begins with (dst * (1 - 1) wipes what is below).  The layers are walked first and
+//      each pixel keeps where its value lies (address, weights); then ALL fetches go out together: one round trip whatever the number
+//      of layers (the earlier kernel composited layer after layer, sweep after sweep: a round trip for each).
+//   B  the pixels that some layer above their start touches (the layers' pixel boxes) go on a list in LDS — the edge of a video tile,
+//      a rounded corner, a label: a few dozen of a band's 512 pixels in a grid in motion.
+//   C  the listed pixels are composited upwards from their start value, a thread per listed pixel, by compose_px — the one copy of the
+//      general per-pixel code — and written back; the band is then converted and stored as 4 x 2 blocks.
 template <int NV, bool BIG>
 __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, int band, int rh, const SurfView &yp, const SurfView &up, const SurfView &vp, int W, int H,
                                              const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g, int n, int n_masks,
                                              int srgb_and_ablate, const float *__restrict__ tables, int tiles_x, float *s_tab) {
     const int tile = (int)pre->tile;
+    constexpr int BAND_PX = B_TILE_W * B_BAND_ROWS, SWEEPS = BAND_PX / 256;
+    static_assert(BAND_PX <= 2048, "a list entry keeps the pixel's index in 11 bits");
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS];
-    __shared__ u32 s_px[B_TILE_W * B_BAND_ROWS];  // the band's composited RGBA8
+    __shared__ u32 s_px[BAND_PX];    // the band's RGBA8: every pixel's start value, then the listed pixels composited
+    __shared__ u32 s_list[BAND_PX];  // pixels some layer above their start touches: index | (start layer + 1) << 11
+    __shared__ u32 s_count;
     // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
     // dependent scalar-memory round trip per field per layer per wave
     __shared__ __attribute__((aligned(16))) DevLayout s_lay[B_MAX_LAYOUTS];
@@ -449,6 +488,8 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
             if (tid + 256 * k < nm) wm[k] = gm[tid + 256 * k];
         }
         if (tid < SMR_TABLE_FLOATS / 4) wt = gt[tid];
+        u32 touch_w = 0u;
+        if (tid < MAX_LAYOUT_WORDS) touch_w = pre->touch[tid];
 #pragma unroll
         for (int k = 0; k < LW; k++)
             if (tid + 256 * k < nl) ((uint4 *)s_lay)[tid + 256 * k] = wl[k];
@@ -456,98 +497,157 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
         for (int k = 0; k < MW; k++)
             if (tid + 256 * k < nm) ((uint4 *)s_mask)[tid + 256 * k] = wm[k];
         if (tid < SMR_TABLE_FLOATS / 4) ((uint4 *)s_tab)[tid] = wt;
+        if (tid < MAX_LAYOUT_WORDS) s_touch[tid] = touch_w;
+        if (tid == 0) s_count = 0u;
     }
     const DevLayout *layouts = BIG ? layouts_g : s_lay;
     const DevMask *masks = BIG ? masks_g : s_mask;
     const int srgb = srgb_and_ablate & 1;
-    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 classify only, 8 base layer only
-    if (ablate & 1) return;
-    if (ty0 >= H) return;
-    if (tid < MAX_LAYOUT_WORDS) s_touch[tid] = pre->touch[tid];
+    const int ablate = srgb_and_ablate >> 8;  // profiling only (SMR_ABLATE bits 8..): 1 dispatch only, 2 list only, 4 no per-pixel start, 8 start values only, 16 no compositing
     const int start = pre->start;
     __syncthreads();
-    // (k_classify_tiles lists a tile here only when some layer needs blending arithmetic; copy, colour, clear and sampled tiles have
-    //  their own classes and never reach this function.  The general path is correct for any tile, so it is the only one.)
-    const bool general = true;
-    if (ablate & 2) return;
-    if (ablate & 16) return;   // profiling: copy tiles only
+    if (ablate & (1 | 2 | 16)) return;
+    if (ty0 >= H) return;
     const int words = (n + 31) >> 5;
     const bool no_block = px0 >= W || py0 >= H || 2 * (tid >> 5) >= rh;      // (W, H even: a block has four or two columns, always two rows)
     const int nsweeps = (B_TILE_W * rh) / 256;
+    const float *dec = s_tab, *thr = s_tab + 256;
+    const int sx = tx0 + (tid & (B_TILE_W - 1));  // this thread's pixels: column sx, rows ty0 + (tid >> 7) + 2 * sweep
 
-    if (general) {
-        const float *dec = s_tab, *thr = s_tab + 256;
-        // ---- one pixel per thread and sweep (a wave covers 64 consecutive pixels of one row); layers are the OUTER loop:
-        //      a layer's record is pulled into scalar registers once per wave and then applied to the wave's 8 sweeps.
-        //      Per-pixel state lives in LDS: s_px = running RGBA8, s_sp = per-pixel start layer.
-        constexpr int SWEEPS = (B_TILE_W * B_BAND_ROWS) / 256;
-        __shared__ short s_sp[B_TILE_W * B_BAND_ROWS];
-        __shared__ u32 s_raw[B_TILE_W * B_BAND_ROWS];  // prefetched texels of the aligned texture layer being applied
-#pragma unroll 1
-        for (int sweep = 0; sweep < nsweeps; sweep++) {
-            s_px[sweep * 256 + tid] = 0u;
-            s_sp[sweep * 256 + tid] = (short)start;
+    // ---- A. start layer and start value of every pixel
+    enum { K_NONE = 0, K_COLOUR = 1, K_TEXEL = 2, K_QUAD = 3 };
+    int sp[SWEEPS];          // the layer the pixel starts from (-1: none, a cleared pixel)
+    u32 kind[SWEEPS];        // where its start value lies
+    const u8 *sbase[SWEEPS];
+    u32 so[SWEEPS][4];       // K_COLOUR: [0] = the encoded bytes; K_TEXEL: [0] = byte offset; K_QUAD: the footprint's four byte offsets
+    float swx[SWEEPS], swy[SWEEPS];
+#pragma unroll
+    for (int s = 0; s < SWEEPS; s++) { sp[s] = -1; kind[s] = K_NONE; sbase[s] = nullptr; so[s][0] = so[s][1] = so[s][2] = so[s][3] = 0u; swx[s] = swy[s] = 0.0f; }
+    const auto claim = [&](const DevLayout &L, int li, int s, int py) {
+        sp[s] = li;
+        if (L.type != 0) {
+            kind[s] = K_COLOUR;
+            so[s][0] = L.solid_px;
+        } else if (L.flags & DL_ALIGNED) {
+            kind[s] = K_TEXEL;
+            sbase[s] = L.src.ptr;
+            so[s][0] = (u32)b_off(clampi(py - L.iy, 0, L.tex_h - 1), L.src.pitch, clampi(sx - L.ix, 0, L.tex_w - 1) * 4);
+        } else {
+            kind[s] = K_QUAD;
+            sbase[s] = L.src.ptr;
+            const SampledAxis X = sampled_axis_x(L, sx), Y = sampled_axis_y(L, py);
+            so[s][0] = Y.o0 + X.o0; so[s][1] = Y.o0 + X.o1; so[s][2] = Y.o1 + X.o0; so[s][3] = Y.o1 + X.o1;
+            swx[s] = X.f; swy[s] = Y.f;
         }
-        // (each thread only ever touches its own 8 pixels of s_px / s_sp: no barrier needed until the conversion phase)
-        // -- per-pixel start: the topmost touched layer above the tile's start whose solid region holds the pixel
-        for (int wi = (ablate & 4) ? -1 : words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {  // (4: profiling, no per-pixel start)
-            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
-            if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
-            while (bits) {
-                const int b = 31 - __builtin_clz(bits);
-                bits &= ~(1u << b);
-                const int li = (wi << 5) + b;
-                const DevLayout L = load_uniform(&layouts[li]);
-                if (!layout_base_opaque(L) || !(L.flags & DL_UNROTATED)) continue;
-#pragma unroll 1
-                for (int sweep = 0; sweep < nsweeps; sweep++) {
-                    const int idx = sweep * 256 + tid;
-                    const float fx = (float)(tx0 + (idx & (B_TILE_W - 1))) + 0.5f, fy = (float)(ty0 + (idx >> 7)) + 0.5f;
-                    if (s_sp[idx] == (short)start && layout_solid_box(L, masks, fx, fy, fx, fy)) s_sp[idx] = (short)li;
-                }
+    };
+    // (topmost first: a pixel is claimed once)
+    for (int wi = (ablate & 4) ? -1 : words - 1; wi >= (start < 0 ? 0 : (start >> 5)); wi--) {  // (4: profiling, the tile's start layer only)
+        u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
+        if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);  // strictly above start
+        while (bits) {
+            const int b = 31 - __builtin_clz(bits);
+            bits &= ~(1u << b);
+            const int li = (wi << 5) + b;
+            const DevLayout L = load_uniform(&layouts[li]);
+            if (!layout_base_opaque(L) || !(L.flags & DL_UNROTATED)) continue;
+#pragma unroll
+            for (int s = 0; s < SWEEPS; s++) {
+                const int py = ty0 + (tid >> 7) + 2 * s;
+                const float fx = (float)sx + 0.5f, fy = (float)py + 0.5f;
+                if (s < nsweeps && kind[s] == K_NONE && layout_solid_box(L, masks, fx, fy, fx, fy)) claim(L, li, s, py);
             }
         }
-        // -- composite upwards from the tile's start; a pixel joins at its own start layer
+    }
+    if (start >= 0) {  // (opaque, unrotated and solid over the whole tile: classify_layouts)
+        const DevLayout L = load_uniform(&layouts[start]);
+#pragma unroll
+        for (int s = 0; s < SWEEPS; s++)
+            if (s < nsweeps && kind[s] == K_NONE) claim(L, start, s, ty0 + (tid >> 7) + 2 * s);
+    }
+    u32 st[SWEEPS][4];
+#pragma unroll
+    for (int s = 0; s < SWEEPS; s++) {  // (every fetch of the band before the first use)
+        st[s][0] = st[s][1] = st[s][2] = st[s][3] = 0u;
+        if (kind[s] >= K_TEXEL) st[s][0] = g_ld_u32(sbase[s] + so[s][0]);
+        if (kind[s] == K_QUAD) { st[s][1] = g_ld_u32(sbase[s] + so[s][1]); st[s][2] = g_ld_u32(sbase[s] + so[s][2]); st[s][3] = g_ld_u32(sbase[s] + so[s][3]); }
+    }
+    u32 val[SWEEPS];
+#pragma unroll
+    for (int s = 0; s < SWEEPS; s++) {
+        // (compose_px's results for a layer that is opaque and solid at the pixel: an opaque colour stores its bytes; an opaque 1:1 texel
+        //  stores its own bytes, encode(decode(b)) == b; an opaque sample is filtered and encoded: composite_sampled_opaque)
+        val[s] = kind[s] == K_COLOUR ? so[s][0] : kind[s] == K_TEXEL ? st[s][0] : 0u;
+        if (kind[s] == K_QUAD) val[s] = filter_opaque_quad(st[s][0], st[s][1], st[s][2], st[s][3], swx[s], swy[s], srgb, dec, thr);
+    }
+
+    // ---- B. the pixels a layer above their start touches
+    bool listed[SWEEPS];
+#pragma unroll
+    for (int s = 0; s < SWEEPS; s++) listed[s] = false;
+    if (!(ablate & 8))
         for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
             u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
-            if (start >= 0 && wi == (start >> 5)) bits &= ~((1u << (start & 31)) - 1u);
+            if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);
             while (bits) {
                 const int li = (wi << 5) + __builtin_ctz(bits);
                 bits &= bits - 1;
-                const DevLayout L = load_uniform(&layouts[li]);
-                if (L.type == 0 && (L.flags & DL_ALIGNED) && L.src_kind != 0) {
-                    // aligned texture layer: all eight texel fetches of this thread are in flight together instead of one
-                    // exposed global-memory round trip per sweep (the addresses are clamped, so every lane may load)
-                    u32 pre[SWEEPS];
+                const DevLayout *Lp = &layouts[li];
+                const int bx0 = __builtin_amdgcn_readfirstlane(Lp->bx0), bx1 = __builtin_amdgcn_readfirstlane(Lp->bx1);
+                const int by0 = __builtin_amdgcn_readfirstlane(Lp->by0), by1 = __builtin_amdgcn_readfirstlane(Lp->by1);
 #pragma unroll
-                    for (int sweep = 0; sweep < SWEEPS; sweep++) {
-                        const int idx = sweep * 256 + tid;
-                        if (sweep < nsweeps) pre[sweep] = aligned_texel(L, tx0 + (idx & (B_TILE_W - 1)), ty0 + (idx >> 7));
-                    }
-#pragma unroll
-                    for (int sweep = 0; sweep < SWEEPS; sweep++)
-                        if (sweep < nsweeps) s_raw[sweep * 256 + tid] = pre[sweep];
-                }
-#pragma unroll 1
-                for (int sweep = 0; sweep < nsweeps; sweep++) {
-                    const int idx = sweep * 256 + tid;
-                    const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
-                    const int sp = s_sp[idx];
-                    if (px < W && py < H && li >= sp && !((ablate & 8) && li != sp))
-                        s_px[idx] = compose_px(s_px[idx], L, masks, px, py, li == sp, s_raw[idx], srgb, dec, thr);
+                for (int s = 0; s < SWEEPS; s++) {
+                    const int py = ty0 + (tid >> 7) + 2 * s;
+                    if (li > sp[s] && sx >= bx0 && sx < bx1 && py >= by0 && py < by1) listed[s] = true;
                 }
             }
         }
-        __syncthreads();
-        if (!no_block) {
-            const int lx0 = px0 - tx0, ly0 = py0 - ty0;
-            const uint4 t0 = *(const uint4 *)&s_px[ly0 * B_TILE_W + lx0], t1 = *(const uint4 *)&s_px[(ly0 + 1) * B_TILE_W + lx0];
-            acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
-            acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
-        }
+#pragma unroll
+    for (int s = 0; s < SWEEPS; s++) {
+        if (s >= nsweeps) break;  // (uniform)
+        const int idx = s * 256 + tid, py = ty0 + (tid >> 7) + 2 * s;
+        s_px[idx] = val[s];
+        const bool want = listed[s] && sx < W && py < H;
+        const u32 slot = list_slot(&s_count, want);
+        if (want) s_list[slot] = (u32)idx | ((u32)(sp[s] + 1) << 11);
     }
+    __syncthreads();
 
-    if (!no_block) store_yuv_block<NV>(acc, px0, py0, W, yp, up, vp);
+    // ---- C. the listed pixels, composited upwards from their start value
+    const u32 total = s_count;
+#pragma unroll 1
+    for (u32 k0 = 0; k0 < total; k0 += 256u) {
+        const bool act = k0 + (u32)tid < total;
+        const u32 e = act ? s_list[k0 + tid] : 0u;
+        const int idx = (int)(e & 2047u), from = (int)(e >> 11) - 1;
+        const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
+        u32 a = s_px[idx];
+        for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
+            u32 bits = __builtin_amdgcn_readfirstlane(s_touch[wi]);
+            if (start >= 0 && wi == (start >> 5)) bits &= ~((2u << (start & 31)) - 1u);
+            while (bits) {
+                const int li = (wi << 5) + __builtin_ctz(bits);
+                bits &= bits - 1;
+                const DevLayout *Lp = &layouts[li];
+                const int bx0 = __builtin_amdgcn_readfirstlane(Lp->bx0), bx1 = __builtin_amdgcn_readfirstlane(Lp->bx1);
+                const int by0 = __builtin_amdgcn_readfirstlane(Lp->by0), by1 = __builtin_amdgcn_readfirstlane(Lp->by1);
+                const bool need = act && li > from && px >= bx0 && px < bx1 && py >= by0 && py < by1;
+                if (!wave_any(need)) continue;  // (none of this wave's pixels: the layer's record stays where it is)
+                const DevLayout L = load_uniform(Lp);
+                u32 raw = 0u;
+                if (need && L.type == 0 && (L.flags & DL_ALIGNED) && L.src_kind != 0) raw = aligned_texel(L, px, py);
+                if (need) a = compose_px(a, L, masks, px, py, false, raw, srgb, dec, thr);
+            }
+        }
+        if (act) s_px[idx] = a;
+    }
+    __syncthreads();
+    if (!no_block) {
+        const int lx0 = px0 - tx0, ly0 = py0 - ty0;
+        const uint4 t0 = *(const uint4 *)&s_px[ly0 * B_TILE_W + lx0], t1 = *(const uint4 *)&s_px[(ly0 + 1) * B_TILE_W + lx0];
+        acc[0] = t0.x; acc[1] = t0.y; acc[2] = t0.z; acc[3] = t0.w;
+        acc[4] = t1.x; acc[5] = t1.y; acc[6] = t1.z; acc[7] = t1.w;
+        store_yuv_block<NV>(acc, px0, py0, W, yp, up, vp);
+    }
 }
 
 // Copy tiles per workgroup of the kernel's second part (their records, then all their texels, are fetched back to back).

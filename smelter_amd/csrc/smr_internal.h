@@ -187,7 +187,7 @@ struct smr_ctx {
     u32 ingest_impl = 0;         // smr_ingest_impl
     bool wave_node82 = true;     // SMR_WAVE_NODE82=0 (A/B): node textures at scales around 2 on the generic build of k_ingest_wave instead of the <8, 2> class
     bool rgb12_cls82 = false;    // SMR_RGB12_CLS82=1 (A/B): RGB12 node textures for that class too
-    int convert_wg_per_cu = 6;   // SMR_CONVERT_WG_PER_CU (laboratory builds): resident workgroups per CU of the persistent converter launch
+    int convert_wg_per_cu = 0;   // SMR_CONVERT_WG_PER_CU (laboratory builds): resident workgroups per CU of the persistent converter launch; 0 = by batch size (smr_convert.hip)
     u32 convert_lds_pad = 0;     // SMR_CONVERT_LDS_PAD (laboratory builds): extra dynamic LDS per workgroup of the block converter, i.e. a cap on its resident workgroups per CU
     u32 convert_impl = 0;        // smr_convert_impl (SMR_OPT_CONVERT_IMPL; SMR_CONVERT_GENERAL in the environment sets 1 at creation)
     bool mfma_attr_set = false;  // hipFuncSetAttribute is per device: kept per ctx, not per process

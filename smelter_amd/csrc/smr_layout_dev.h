@@ -412,6 +412,25 @@ __device__ __forceinline__ u32 composite_layout_solid(u32 acc, const DevLayout &
     return blend_store(acc, frag, srgb, dec, thr);
 }
 
+// The filter and store of a bilinear sample of an opaque RGBA8 texture onto a cleared pixel, given the footprint's four texels and the
+// 8-bit sub-texel weights of the second column / row: sample_rgba_bilinear's operations in their order on the three colour channels
+// (alpha is exactly 1: every texel's is, and 8-bit weights sum to 1 exactly), then the render-target store.
+__device__ __forceinline__ u32 filter_opaque_quad(u32 ta, u32 tb, u32 tc, u32 td, float fx, float fy, int srgb, const float *__restrict__ dec,
+                                                  const float *__restrict__ thr) {
+    const float gx = 1.0f - fx, gy = 1.0f - fy;
+    u32 out = 0xff000000u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const u32 ba = (ta >> (8 * ch)) & 0xffu, bb = (tb >> (8 * ch)) & 0xffu, bc = (tc >> (8 * ch)) & 0xffu, bd = (td >> (8 * ch)) & 0xffu;
+        float a, b, c, d;
+        if (srgb) { a = dec[ba]; b = dec[bb]; c = dec[bc]; d = dec[bd]; }
+        else { a = (float)ba / 255.0f; b = (float)bb / 255.0f; c = (float)bc / 255.0f; d = (float)bd / 255.0f; }
+        const float o = (a * gx + b * fx) * gy + (c * gx + d * fx) * fy;
+        out |= (srgb ? srgb_encode8(o, thr) : unorm8(o)) << (8 * ch);
+    }
+    return out;
+}
+
 // composite_layout_solid for the one case k_classify_tiles calls TC_SAMPLED: an opaque (src_kind 2) unrotated texture layer that is not
 // a 1:1 blit, onto a cleared pixel, in the layer's solid region.  Every texel's alpha is 1, the bilinear weights of a sample sum to 1
 // exactly (8-bit sub-texel fractions: 1 - f is exact), so the fragment's alpha is exactly 1, the blend keeps nothing of the
@@ -434,18 +453,7 @@ __device__ __forceinline__ u32 composite_sampled_opaque(const DevLayout &L, int 
     const u32 o0 = (u32)__umul24((u32)y0, s.pitch), o1 = (u32)__umul24((u32)y1, s.pitch);
     const u32 ta = g_ld_u32(s.ptr + (o0 + 4u * (u32)x0)), tb = g_ld_u32(s.ptr + (o0 + 4u * (u32)x1));  // (global loads: smr_internal.h)
     const u32 tc = g_ld_u32(s.ptr + (o1 + 4u * (u32)x0)), td = g_ld_u32(s.ptr + (o1 + 4u * (u32)x1));
-    const float gx = 1.0f - fx, gy = 1.0f - fy;
-    u32 out = 0xff000000u;
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        const u32 ba = (ta >> (8 * ch)) & 0xffu, bb = (tb >> (8 * ch)) & 0xffu, bc = (tc >> (8 * ch)) & 0xffu, bd = (td >> (8 * ch)) & 0xffu;
-        float a, b, c, d;
-        if (srgb) { a = dec[ba]; b = dec[bb]; c = dec[bc]; d = dec[bd]; }
-        else { a = (float)ba / 255.0f; b = (float)bb / 255.0f; c = (float)bc / 255.0f; d = (float)bd / 255.0f; }
-        const float o = (a * gx + b * fx) * gy + (c * gx + d * fx) * fy;
-        out |= (srgb ? srgb_encode8(o, thr) : unorm8(o)) << (8 * ch);
-    }
-    return out;
+    return filter_opaque_quad(ta, tb, tc, td, fx, fy, srgb, dec, thr);
 }
 
 // The same for a 4 x 2 block of pixels (columns px0 .. px0 + 3, rows py0, py0 + 1) of such a tile.  The layer is unrotated, so everything a
@@ -501,22 +509,8 @@ __device__ __forceinline__ void composite_sampled_opaque_block(const DevLayout &
             ta[q] = g_ld_u32(base + (Y[r].o0 + X[q].o0)); tb[q] = g_ld_u32(base + (Y[r].o0 + X[q].o1));
             tc[q] = g_ld_u32(base + (Y[r].o1 + X[q].o0)); td[q] = g_ld_u32(base + (Y[r].o1 + X[q].o1));
         }
-        const float fy = Y[r].f, gy = Y[r].g;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float fx = X[q].f, gx = X[q].g;
-            u32 o = 0xff000000u;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const u32 ba = (ta[q] >> (8 * ch)) & 0xffu, bb = (tb[q] >> (8 * ch)) & 0xffu, bc = (tc[q] >> (8 * ch)) & 0xffu, bd = (td[q] >> (8 * ch)) & 0xffu;
-                float a, b, c, d;
-                if (srgb) { a = dec[ba]; b = dec[bb]; c = dec[bc]; d = dec[bd]; }
-                else { a = (float)ba / 255.0f; b = (float)bb / 255.0f; c = (float)bc / 255.0f; d = (float)bd / 255.0f; }
-                const float v = (a * gx + b * fx) * gy + (c * gx + d * fx) * fy;
-                o |= (srgb ? srgb_encode8(v, thr) : unorm8(v)) << (8 * ch);
-            }
-            out[r * 4 + q] = o;
-        }
+        for (int q = 0; q < 4; q++) out[r * 4 + q] = filter_opaque_quad(ta[q], tb[q], tc[q], td[q], X[q].f, Y[r].f, srgb, dec, thr);
     }
 }
 

@@ -164,6 +164,26 @@ def test_tiles_in_transition_are_sampled_in_linear_light(emu, out, srgb):
     assert classes["sampled"] > 0 and classes["full"] > 0, classes
 
 
+@pytest.mark.parametrize("srgb", [True, False])
+def test_tiles_crossing_each_other_start_from_the_topmost_opaque_layer(emu, srgb):
+    """A grid whose tiles swap places: opaque tiles at fractional positions OVER one another and over a tile at rest, a translucent label and
+    a texture with an alpha channel on top.  In one band a pixel's start value is an opaque colour, a 1:1 texel, a filtered sample of one of
+    two moving tiles, or nothing (list compositor, step A); the edges and everything under the label go through the list (steps B, C)."""
+    W, H = 384, 70
+    sources = [_video(128, 40, 1), _video(120, 36, 2), _video(120, 36, 3), _video(64, 20, 4, alpha=True)]
+    kinds = [2, 2, 2, 1]
+    layouts = [orc.Layout(top=0.0, left=0.0, width=300.0, height=float(H), type=1, color=orc.color_to_shader((40, 20, 90, 255), srgb)),  # (x >= 300: cleared)
+               _tex(0, 16.0, 8.0, 128.0, 40.0),                      # at rest: 1:1 texels
+               _tex(1, 90.4, 3.3, 120.0, 36.0),                      # crossing it
+               _tex(2, 150.7, 20.6, 120.0, 36.0, border_radius=(6.0,) * 4),  # crossing both, rounded
+               orc.Layout(top=30.5, left=60.0, width=200.0, height=18.0, type=1, border_radius=(4.0,) * 4, color=orc.color_to_shader((0, 0, 0, 128), srgb)),
+               _tex(3, 250.25, 40.5, 64.0, 20.0)]
+    for out in ("planar", "rgba"):
+        got, classes = compose(emu, layouts, sources, kinds, W, H, out, srgb=srgb)
+        assert_same(got, oracle_output(layouts, sources, W, H, out, srgb), (out, srgb, classes))
+    assert classes["full"] > 0, classes
+
+
 def _zoo(W, H, rng, n, n_sources, srgb=True):
     layouts = []
     for _ in range(n):

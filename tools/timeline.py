@@ -11,6 +11,9 @@ def short(name):
         if k in name: return k
     return name[:40]
 
+ALL = os.environ.get("TL_ALL") == "1"          # every kernel of the trace, not only the three hot ones (configs[4]: shader, classify, text)
+SAMPLE = int(os.environ.get("TL_SAMPLE", "12"))  # launches printed with their relative times
+
 def main():
     p = sys.argv[1]
     skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
@@ -21,7 +24,7 @@ def main():
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), short(r["Kernel_Name"])))
         rows.sort()
         if not rows: continue
-        hot = [r for r in rows if r[3] in ("k_ingest_wave", "k_yuv420_to_rgba", "k_compose_output")]
+        hot = [r for r in rows if ALL or r[3] in ("k_ingest_wave", "k_yuv420_to_rgba", "k_compose_output")]
         if not hot: continue
         # the longest stretch without a gap above 1 ms = one timed loop; keep its last (1 - skip)
         runs, cur = [], [hot[0]]
@@ -66,7 +69,7 @@ def main():
             print(f"   overlap {a} x {b}: {v / nfr / 1e3:.2f} us per frame")
         # one frame's worth of launches, relative times
         print("   sample (us from the first):")
-        for s, e, q, k in run[:12]:
+        for s, e, q, k in run[:SAMPLE]:
             print(f"      q{q} {k:22s} {(s - run[0][0]) / 1e3:8.2f} -> {(e - run[0][0]) / 1e3:8.2f}")
 
 if __name__ == "__main__":
