@@ -179,7 +179,7 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_COMPOSE_SELECT")) ctx->compose_select = atoi(e) != 0;
     if (const char *e = getenv("SMR_COMPOSE_SLICES")) {
         const int v = atoi(e);
-        if (v == 4 || v == 8) ctx->compose_slices = v;
+        if (v == 2 || v == 4 || v == 8) ctx->compose_slices = v;
     }
 #endif
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||

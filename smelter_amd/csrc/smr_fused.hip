@@ -477,6 +477,8 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_class, (size_t)b_tiles * sizeof(TileClass)));
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_direct, b_tiles));
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_list, sizeof(TileList) + (size_t)b_tiles * sizeof(TileFull)));
+                SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, sizeof(u32) * B_LIST_COUNTERS, ctx->stream));
+                cm->counter = 0;
                 cm->n = b_tiles;
             }
             if (!cm->h_count) {
@@ -506,10 +508,13 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
     if (rc != SMR_OK) return rc;
     const MDirect *direct_dev = direct.cls ? (const MDirect *)((const u8 *)packed.extra_dev + order_bytes) : nullptr;
     if (classify_now) {
-        SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, 4, ctx->stream));
+        if (++cm->counter == B_LIST_COUNTERS) {  // (the ring of list counters: smr_fused_compose.h)
+            SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, sizeof(u32) * B_LIST_COUNTERS, ctx->stream));
+            cm->counter = 0;
+        }
         hipLaunchKernelGGL(k_classify_tiles, dim3((b_tiles + B_CLASSIFY_TILES - 1) / B_CLASSIFY_TILES), dim3(64 * B_CLASSIFY_TILES), 0, ctx->stream,
                            packed.layouts, packed.masks, packed.n, (int)out_w, (int)out_h, (int)b_tiles_x, (int)b_tiles, direct_mask, (TileClass *)cm->d_class, cm->d_direct, (TileList *)cm->d_list,
-                           ctx->compose_select ? 1 : 0);
+                           ctx->compose_select ? 1 : 0, cm->counter);
         SMR_HIP(ctx, hipGetLastError());
     }
     if (fuse_out) {
@@ -519,8 +524,10 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             cm->count_pending = false;
             cm->count_known = cm->count_serial == cm->class_serial;
         }
-        if (!cm->count_known && !cm->count_pending) {
-            SMR_HIP(ctx, hipMemcpyAsync(cm->h_count, cm->d_list, 4, hipMemcpyDeviceToHost, ctx->stream));
+        // (asked for by the first frame that REUSES the classes: a scene in motion classifies every frame and would pay a copy and a marker
+        //  packet per frame for lengths nobody reads)
+        if (!classify_now && !cm->count_known && !cm->count_pending) {
+            SMR_HIP(ctx, hipMemcpyAsync(cm->h_count, (const u32 *)cm->d_list + cm->counter, 4, hipMemcpyDeviceToHost, ctx->stream));
             SMR_HIP(ctx, hipEventRecord(cm->count_ev, ctx->stream));
             cm->count_pending = true;
             cm->count_serial = cm->class_serial;
@@ -615,12 +622,12 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             p2 = nv ? p1 : view_of(out->planes[2]);
         }
         typedef void (*ComposeKernel)(SurfView, SurfView, SurfView, int, int, const DevLayout *, const DevMask *, int, int, int, const float *, int, int,
-                                      const TileClass *, const TileList *, int, int);
+                                      const TileClass *, const TileList *, int, int, int);
         static const ComposeKernel kernels[3][2] = {{k_compose_output<0, false>, k_compose_output<0, true>},
                                                     {k_compose_output<1, false>, k_compose_output<1, true>},
                                                     {k_compose_output<2, false>, k_compose_output<2, true>}};
         hipLaunchKernelGGL(kernels[nv][big_list ? 1 : 0], grid, dim3(256), 0, ctx->stream, p0, p1, p2, (int)out_w, (int)out_h, packed.layouts, packed.masks,
-                           packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices);
+                           packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices, cm->counter);
         SMR_HIP(ctx, hipGetLastError());
         rc = smr_pack_done(ctx, &packed);
         if (rc != SMR_OK) return rc;

@@ -46,8 +46,11 @@ constexpr int B_SLICES = 4;          // ctx->compose_slices: 4 or 8 (a band hold
 // the frame gained 7 %.  The list compositor (compose_full below) fits 79 registers without scratch: six waves, and two of them beside the
 // resampler — configs[4] + 3 % over five waves (84 registers), configs[2] unchanged (profiles/r06_sensitivity.txt section 9).
 constexpr int B_MIN_WAVES = SMR_COMPOSE_MIN_WAVES;
-constexpr int B_BAND_ROWS = 4;       // rows of the workgroup's LDS pixel state: a band is at most this tall
-static_assert(B_TILE_H % B_BAND_ROWS == 0 && B_TILE_H / B_SLICES <= B_BAND_ROWS, "a band fits the LDS pixel state");
+#ifndef SMR_COMPOSE_BAND_ROWS
+#define SMR_COMPOSE_BAND_ROWS 4
+#endif
+constexpr int B_BAND_ROWS = SMR_COMPOSE_BAND_ROWS;       // rows of the workgroup's LDS pixel state: a band is at most this tall
+static_assert(B_TILE_H % B_BAND_ROWS == 0 && B_BAND_ROWS >= 2, "a band fits the LDS pixel state");
 
 // Host: tiles likely to need compositing -> their number.  A layer that can never be solid over a tile (translucent colour, texture
 // with an alpha channel, rotated quad) marks its whole pixel box; every other layer marks the corner squares of its rounded rect and
@@ -170,10 +173,12 @@ struct TileFull {
     u32 pad;
     u32 touch[MAX_LAYOUT_WORDS];
 };
+constexpr int B_LIST_COUNTERS = 64;
 struct TileList {
-    u32 count;      // zeroed before k_classify_tiles
-    u32 pad[3];
-    TileFull e[1];  // really one per tile
+    u32 count[B_LIST_COUNTERS];  // the list's length, one counter per classification (a ring: the host zeroes all of them once per
+                                 // B_LIST_COUNTERS classifications instead of one before every k_classify_tiles — a fill kernel on the stream
+                                 // of every frame of a scene in motion)
+    TileFull e[1];               // really one per tile
 };
 // Direct output: direct[tile] = the start layer when the tile is a copy tile of a texture layer in `direct_layers` (the tiles wave A
 // resamples in the same call, at even output positions) — wave A then writes that tile's Y'CbCr itself, the RGBA8 bytes of those
@@ -185,7 +190,7 @@ constexpr int B_CLASSIFY_TILES = 16;  // tiles per workgroup of k_classify_tiles
 __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const DevLayout *__restrict__ layouts, const DevMask *__restrict__ masks, int n,
                                                                           int W, int H, int tiles_x, int tiles, unsigned long long direct_layers,
                                                                           TileClass *__restrict__ tc, u8 *__restrict__ direct, TileList *__restrict__ full,
-                                                                          int allow_select) {
+                                                                          int allow_select, int counter) {
     __shared__ u32 s_touch_w[B_CLASSIFY_TILES][MAX_LAYOUT_WORDS], s_solid_w[B_CLASSIFY_TILES][MAX_LAYOUT_WORDS];
     __shared__ int s_start_w[B_CLASSIFY_TILES], s_general_w[B_CLASSIFY_TILES], s_slot_w[B_CLASSIFY_TILES];
     __shared__ TileClass s_class_w[B_CLASSIFY_TILES];
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
     if (threadIdx.x == 0) {
         int want = 0;
         for (int w = 0; w < B_CLASSIFY_TILES; w++) want += s_slot_w[w];
-        const u32 base = want ? atomicAdd(&full->count, (u32)want) : 0u;
+        const u32 base = want ? atomicAdd(&full->count[counter], (u32)want) : 0u;
         int at = 0;
         for (int w = 0; w < B_CLASSIFY_TILES; w++) {
             const int mine = s_slot_w[w] ? (int)base + at : -1;
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
                                                         const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
                                                         int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
                                                         int tiles_x, int tiles, const TileClass *__restrict__ tc, const TileList *__restrict__ full,
-                                                        int n_banded, int slices) {
+                                                        int n_banded, int slices, int counter) {
     const int tid = threadIdx.x;
 #if defined(SMR_PRIO_COMPOSE) && !defined(SMR_EMU)
     __builtin_amdgcn_s_setprio(SMR_PRIO_COMPOSE);
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
     int full_band = 0, full_end = B_TILE_H, full_rows = B_BAND_ROWS;
     if (rest < 0) {
         const u32 gi = blockIdx.x / (u32)slices;
-        if (gi >= full->count) return;
+        if (gi >= full->count[counter]) return;
         full_rows = B_TILE_H / slices;
         full_band = (int)(blockIdx.x % (u32)slices) * full_rows;
         full_end = full_band + full_rows;

@@ -102,6 +102,7 @@ struct LayoutSlot {
     bool unfenced = false;      // frames that REUSED this slot's device copy were queued after `done` was last recorded (smr_pack_done records no event for
                                 // them: a marker packet per frame costs ~5 us on the stream): recycling the slot then waits for the stream instead
     size_t resident_bytes = 0;  // leading bytes of host that the device copy holds (0 = none): smr_pack_commit's reuse
+    uint64_t last_reuse = 0;    // ctx->pack_clock when a frame last reused the device copy
 };
 
 struct StagePending {
@@ -121,6 +122,7 @@ struct TileClassMap {
     hipEvent_t count_ev = nullptr;
     bool count_pending = false, count_known = false;
     uint64_t class_serial = 0, count_serial = 0;  // classifications so far / the one the copy in flight belongs to
+    int counter = 0;               // TileList::count[counter] is this classification's (a ring, zeroed as a whole when it wraps)
     uint64_t last_use = 0;
 };
 
@@ -147,6 +149,7 @@ struct smr_ctx {
     // per-call layout parameters travel through a ring of pinned staging slots
     std::vector<LayoutSlot> layout_ring;
     size_t layout_ring_next = 0;
+    uint64_t pack_clock = 0;     // packs staged so far (LayoutSlot::last_reuse)
     int layout_last = -1;           // ring index of the pack committed last (its device copy is reused by an identical pack)
     bool no_pack_reuse = false;     // SMR_NO_PACK_REUSE (A/B, tests)
     unsigned long long pack_reused = 0;

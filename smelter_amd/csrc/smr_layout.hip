@@ -58,6 +58,14 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
 
     // ring of pinned staging slots; a slot is reusable once the kernel that read its device copy is done
     if (ctx->layout_ring.empty()) ctx->layout_ring.resize(8);
+    // (a slot whose device copy recent frames keep reusing — a node of the scene that does not move while another does — is passed over:
+    //  recycling it would wait for the stream)
+    ctx->pack_clock++;
+    for (size_t tries = 0; tries + 1 < ctx->layout_ring.size(); tries++) {
+        const LayoutSlot &c = ctx->layout_ring[ctx->layout_ring_next];
+        if (!(c.busy && c.unfenced && ctx->pack_clock - c.last_reuse < 64)) break;
+        ctx->layout_ring_next = (ctx->layout_ring_next + 1) % ctx->layout_ring.size();
+    }
     LayoutSlot &slot = ctx->layout_ring[ctx->layout_ring_next];
     ctx->layout_ring_next = (ctx->layout_ring_next + 1) % ctx->layout_ring.size();
     if (slot.busy) {
@@ -102,12 +110,20 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
 }
 
 // host -> device copy of the packed slot (after the caller filled the extra region)
-// A pack that equals, byte for byte, the one committed last (a scene that does not move between two frames: same layouts, same
-// source surfaces, same parameter block) reuses that pack's device copy: no copy is queued, the frame is its kernels only.  The
-// staging slot just filled goes back to the ring (it is the next one handed out), the reused slot stays busy until this frame is done.
+// A pack that equals, byte for byte, one whose device copy is still resident (a scene — or one node of it: every LayoutNode of a frame
+// packs its own list — that does not move between two frames: same layouts, same source surfaces, same parameter block) reuses that
+// device copy: no copy is queued, the frame is its kernels only.  The staging slot just filled goes back to the ring (it is the next one
+// handed out), the reused slot stays busy until this frame is done.
 int smr_pack_commit(smr_ctx *ctx, PackedLayouts *p) {
-    LayoutSlot *prev = ctx->layout_last >= 0 ? &ctx->layout_ring[(size_t)ctx->layout_last] : nullptr;
-    if (prev && prev != p->slot && !ctx->no_pack_reuse && prev->resident_bytes == p->copy_bytes && memcmp(prev->host, p->slot->host, p->copy_bytes) == 0) {
+    LayoutSlot *prev = nullptr;
+    if (!ctx->no_pack_reuse) {
+        const size_t nslots = ctx->layout_ring.size();
+        for (size_t k = 0; k < nslots && !prev; k++) {  // (the pack committed last first: a scene of one node at rest)
+            LayoutSlot *c = &ctx->layout_ring[((size_t)(ctx->layout_last < 0 ? 0 : ctx->layout_last) + nslots - k) % nslots];
+            if (c != p->slot && c->resident_bytes == p->copy_bytes && memcmp(c->host, p->slot->host, p->copy_bytes) == 0) prev = c;
+        }
+    }
+    if (prev) {
         const ptrdiff_t d = (const u8 *)prev->dev - (const u8 *)p->slot->dev;
         p->layouts = (const DevLayout *)((const u8 *)p->layouts + d);
         p->masks = (const DevMask *)((const u8 *)p->masks + d);
@@ -115,6 +131,7 @@ int smr_pack_commit(smr_ctx *ctx, PackedLayouts *p) {
         ctx->layout_ring_next = (size_t)(p->slot - ctx->layout_ring.data());
         p->slot = prev;
         p->reused = true;
+        prev->last_reuse = ctx->pack_clock;
         ctx->pack_reused++;
         return SMR_OK;
     }

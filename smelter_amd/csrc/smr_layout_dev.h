@@ -493,6 +493,14 @@ __device__ __forceinline__ SampledAxis sampled_axis_y(const DevLayout &L, int py
     a.o1 = (u32)__umul24((u32)clampi((int)fy0 + 1, 0, L.src.h - 1), L.src.pitch);
     return a;
 }
+// (wave-uniform when the kernel runs on the device; the lane emulator has no wave votes and lets every lane choose for itself)
+__device__ __forceinline__ bool sampled_block_all(bool v) {
+#ifdef SMR_EMU
+    return v;
+#else
+    return __ballot(!v) == 0ull;
+#endif
+}
 __device__ __forceinline__ void composite_sampled_opaque_block(const DevLayout &L, int px0, int py0, int srgb, const float *__restrict__ dec,
                                                                const float *__restrict__ thr, u32 (&out)[8]) {
     SampledAxis X[4], Y[2];
@@ -501,6 +509,48 @@ __device__ __forceinline__ void composite_sampled_opaque_block(const DevLayout &
 #pragma unroll
     for (int r = 0; r < 2; r++) Y[r] = sampled_axis_y(L, py0 + r);
     const u8 *base = L.src.ptr;
+    // A texture shown at its own size and a fractional position — every tile of a grid whose cells swap places — steps one texel per
+    // pixel: neighbouring pixels' footprints share a column, the block's two rows share a texel row.  The block then needs 5 x 3 texels,
+    // not 8 x 4: each is fetched and decoded once, and the horizontal half of the filter, (a * gx + b * fx), is evaluated once per texel
+    // row and pixel column — the same operations on the same values as below, the middle row's used by both pixel rows.
+    const bool unit = X[0].o1 == X[1].o0 && X[1].o1 == X[2].o0 && X[2].o1 == X[3].o0 && Y[0].o1 == Y[1].o0;
+    if (sampled_block_all(unit)) {
+        const u32 col[5] = {X[0].o0, X[1].o0, X[2].o0, X[3].o0, X[3].o1}, row[3] = {Y[0].o0, Y[0].o1, Y[1].o1};
+        u32 t[3][5];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 5; c++) t[r][c] = g_ld_u32(base + (row[r] + col[c]));
+        float h[3][4][3];  // [texel row][pixel column][channel]
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            float d[5][3];
+#pragma unroll
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const u32 b = (t[r][c] >> (8 * ch)) & 0xffu;
+                    d[c][ch] = srgb ? dec[b] : (float)b / 255.0f;
+                }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) h[r][q][ch] = d[q][ch] * X[q].g + d[q + 1][ch] * X[q].f;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32 o = 0xff000000u;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float v = h[r][q][ch] * Y[r].g + h[r + 1][q][ch] * Y[r].f;
+                    o |= (srgb ? srgb_encode8(v, thr) : unorm8(v)) << (8 * ch);
+                }
+                out[r * 4 + q] = o;
+            }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 2; r++) {  // (four pixels at a time: their texel fetches overlap)
         u32 ta[4], tb[4], tc[4], td[4];

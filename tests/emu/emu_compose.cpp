@@ -123,14 +123,14 @@ extern "C" int emu_compose(const smr_layout *layouts, int n, int n_sources, cons
     TileClass *tc = (TileClass *)tcb.ptr;
     TileList *full = (TileList *)listb.ptr;
     run_grid((unsigned)((tiles + B_CLASSIFY_TILES - 1) / B_CLASSIFY_TILES), 64 * B_CLASSIFY_TILES,
-             [&] { k_classify_tiles(hl, hm, n, W, H, tiles_x, tiles, 0ull, tc, directb.ptr, full, allow_select); });
+             [&] { k_classify_tiles(hl, hm, n, W, H, tiles_x, tiles, 0ull, tc, directb.ptr, full, allow_select, 0); });
     if (info) {
         for (int k = 0; k < 9; k++) info[k] = 0;
         for (int t = 0; t < tiles; t++)
             if (tc[t].kind <= TC_SELECT) info[tc[t].kind]++;
-        info[7] = (int)full->count;
+        info[7] = (int)full->count[0];
     }
-    u32 n_banded = banded < 0 ? full->count : (u32)banded;
+    u32 n_banded = banded < 0 ? full->count[0] : (u32)banded;
     if (n_banded > (u32)tiles) n_banded = (u32)tiles;
 
     Surface p0, p1, p2;
@@ -153,7 +153,7 @@ extern "C" int emu_compose(const smr_layout *layouts, int n, int n_sources, cons
     const float *tab = (const float *)tables.ptr;
     const int flags = srgb ? 1 : 0;
 #define EMU_COMPOSE(NVv, BIGv) \
-    run_grid(grid, 256, [&] { k_compose_output<NVv, BIGv>(p0.view, p1.view, p2.view, W, H, hl, hm, n, (int)mo, flags, tab, tiles_x, tiles, tc, full, (int)n_banded, slices); })
+    run_grid(grid, 256, [&] { k_compose_output<NVv, BIGv>(p0.view, p1.view, p2.view, W, H, hl, hm, n, (int)mo, flags, tab, tiles_x, tiles, tc, full, (int)n_banded, slices, 0); })
     if (nv == 0) { if (big) EMU_COMPOSE(0, true); else EMU_COMPOSE(0, false); }
     else if (nv == 1) { if (big) EMU_COMPOSE(1, true); else EMU_COMPOSE(1, false); }
     else { if (big) EMU_COMPOSE(2, true); else EMU_COMPOSE(2, false); }

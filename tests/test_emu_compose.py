@@ -184,6 +184,20 @@ def test_tiles_crossing_each_other_start_from_the_topmost_opaque_layer(emu, srgb
     assert classes["full"] > 0, classes
 
 
+@pytest.mark.parametrize("srgb", [True, False])
+@pytest.mark.parametrize("left,top", [(3.3, 2.7), (-40.5, -7.25), (100.0, 20.5)])
+def test_a_tile_at_its_own_size_and_a_fractional_position_shares_texels_between_neighbours(emu, left, top, srgb):
+    """Sampled tiles whose texel step is exactly one pixel (a tile of a grid whose cells swap places: its own size, a fractional position — here
+    also hanging over the frame's corner, where the clamped columns and rows repeat): the 5 x 3 neighbourhood path of the sampled block."""
+    W, H = 512, 96
+    sources = [_video(440, 90, 5)]
+    layouts = [orc.Layout(top=0.0, left=0.0, width=float(W), height=float(H), type=1, color=orc.color_to_shader((30, 30, 30, 255), srgb)),
+               _tex(0, left, top, 440.0, 90.0)]
+    got, classes = compose(emu, layouts, sources, [2], W, H, "planar", srgb=srgb)
+    assert_same(got, oracle_output(layouts, sources, W, H, "planar", srgb), (left, top, srgb, classes))
+    assert classes["sampled"] > 0, classes
+
+
 def _zoo(W, H, rng, n, n_sources, srgb=True):
     layouts = []
     for _ in range(n):
