@@ -472,8 +472,9 @@ def main():
                          "observer sampling GPU activity every few seconds to see it")
     ap.add_argument("--no-target", action="store_true", help="skip the child-process blocks: the north-star target (8x4K -> 4K on one GPU) and the sharded code path with one rank")
     ap.add_argument("--watchdog-seconds", type=float, default=60.0, help="N > 1 / --force-sharded: a step that makes no progress for this long ends the run with an error line and rc 3")
-    ap.add_argument("--inflight", type=int, default=2, help="frames in flight on one GPU (renderer contexts / HIP streams); 2 measured best with three kernels per "
-                                                           "frame (profiles/r04_inflight.txt: 15.8k / 14.6k / 14.1k frames/s at 2 / 3 / 4)")
+    ap.add_argument("--inflight", type=int, default=None, help="frames in flight on one GPU (renderer contexts / HIP streams).  Default 2: best with three kernels "
+                                                              "per frame (configs[2] 19.3k / 17.6k frames/s at 2 / 3); --config 4 defaults to 3 (a frame in motion is "
+                                                              "eleven launches, most of them small: 5.95k / 6.19k / 5.77k at 2 / 3 / 4 — profiles/r06_sensitivity.txt)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU code path (ingest per shard, gather, compose) with the ranks given")
     ap.add_argument("--transfers", action="store_true", help="also time host buffers in -> host buffers out (PCIe inclusive, informational)")
     ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4],
@@ -543,6 +544,8 @@ def main():
     plan = smr_dist.ShardPlan(n_inputs=N_IN, world=world)
     my_inputs = plan.inputs_of(rank)
     ring = make_inputs(ctx, hip, RING, my_inputs)
+    if args.inflight is None:
+        args.inflight = 3 if args.config == 4 else 2
     n_lanes = max(1, args.inflight) if single else 1
     # (single GPU: every renderer owns two alternating output frames; sharded path: the root's two)
     outs = [ctx.frame(hip.FRAME_PLANAR_YUV420, OUT_W, OUT_H) for _ in range(2)] if rank == 0 and not single else []

@@ -177,10 +177,6 @@ int smr_ctx_create(int hip_device, uint32_t mode, uint32_t max_layouts, void *hi
     if (const char *e = getenv("SMR_INGEST_MIN_ROWS")) ctx->ingest_min_rows = atoi(e);
     ctx->debug_ingest = getenv("SMR_DEBUG_INGEST") != nullptr;
     if (const char *e = getenv("SMR_COMPOSE_SELECT")) ctx->compose_select = atoi(e) != 0;
-    if (const char *e = getenv("SMR_COMPOSE_SLICES")) {
-        const int v = atoi(e);
-        if (v == 2 || v == 4 || v == 8) ctx->compose_slices = v;
-    }
 #endif
     if (hipMalloc((void **)&ctx->d_tables, sizeof(tables)) != hipSuccess ||
         hipMemcpy(ctx->d_tables, tables, sizeof(tables), hipMemcpyHostToDevice) != hipSuccess ||

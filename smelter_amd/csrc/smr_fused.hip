@@ -476,7 +476,7 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
                 cm->d_class = nullptr; cm->d_direct = nullptr; cm->d_list = nullptr; cm->n = 0;
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_class, (size_t)b_tiles * sizeof(TileClass)));
                 SMR_HIP(ctx, hipMalloc((void **)&cm->d_direct, b_tiles));
-                SMR_HIP(ctx, hipMalloc((void **)&cm->d_list, sizeof(TileList) + (size_t)b_tiles * sizeof(TileFull)));
+                SMR_HIP(ctx, hipMalloc((void **)&cm->d_list, sizeof(TileList) + (size_t)b_tiles * B_AREA_BANDS * sizeof(TileFull)));  // (an entry per band)
                 SMR_HIP(ctx, hipMemsetAsync(cm->d_list, 0, sizeof(u32) * B_LIST_COUNTERS, ctx->stream));
                 cm->counter = 0;
                 cm->n = b_tiles;
@@ -603,11 +603,12 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
         ctx->kernel_launches[SMR_KERNEL_COMPOSE_OUTPUT]++;
         // 1-D grid: bands of the tiles that need the (latency-bound) general path first — as many as the class list holds when its
         // length is known, as many as the host's own prediction says otherwise — then every tile in order
-        u32 n_banded = cm->count_known ? *cm->h_count : n_first;
-        if (n_banded > b_tiles) n_banded = b_tiles;
+        // (list entries are bands: at most B_AREA_BANDS per predicted tile)
+        u32 n_banded = cm->count_known ? *cm->h_count : n_first * (u32)B_AREA_BANDS;
+        if (n_banded > b_tiles * (u32)B_AREA_BANDS) n_banded = b_tiles * (u32)B_AREA_BANDS;
         if (ctx->debug_ingest)
-            fprintf(stderr, "k_compose_output: %u tiles, band list %u (%s; predicted %u, last read back %u)\n", b_tiles, n_banded, cm->count_known ? "known" : "predicted", n_first, *cm->h_count);
-        dim3 grid(ctx->compose_slices * n_banded + (b_tiles + B_COPY_TILES - 1) / B_COPY_TILES, 1, 1);
+            fprintf(stderr, "k_compose_output: %u tiles, %u bands on the list (%s; predicted tiles %u, last read back %u)\n", b_tiles, n_banded, cm->count_known ? "known" : "predicted", n_first, *cm->h_count);
+        dim3 grid(n_banded + (b_tiles + B_COPY_TILES - 1) / B_COPY_TILES, 1, 1);
         const TileList *full = (const TileList *)cm->d_list;
         const TileClass *tc = (const TileClass *)cm->d_class;
         const int flags = (ctx->srgb() ? 1 : 0) | ((ctx->ablate >> 8) << 8);
@@ -622,12 +623,12 @@ extern "C" int smr_render_layouts(smr_ctx *ctx, const smr_layout *layouts, uint3
             p2 = nv ? p1 : view_of(out->planes[2]);
         }
         typedef void (*ComposeKernel)(SurfView, SurfView, SurfView, int, int, const DevLayout *, const DevMask *, int, int, int, const float *, int, int,
-                                      const TileClass *, const TileList *, int, int, int);
+                                      const TileClass *, const TileList *, int, int);
         static const ComposeKernel kernels[3][2] = {{k_compose_output<0, false>, k_compose_output<0, true>},
                                                     {k_compose_output<1, false>, k_compose_output<1, true>},
                                                     {k_compose_output<2, false>, k_compose_output<2, true>}};
         hipLaunchKernelGGL(kernels[nv][big_list ? 1 : 0], grid, dim3(256), 0, ctx->stream, p0, p1, p2, (int)out_w, (int)out_h, packed.layouts, packed.masks,
-                           packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, ctx->compose_slices, cm->counter);
+                           packed.n, packed.n_masks, flags, ctx->d_tables, (int)b_tiles_x, (int)b_tiles, tc, full, (int)n_banded, cm->counter);
         SMR_HIP(ctx, hipGetLastError());
         rc = smr_pack_done(ctx, &packed);
         if (rc != SMR_OK) return rc;

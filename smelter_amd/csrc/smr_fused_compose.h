@@ -13,6 +13,8 @@
 //     keeps the kernel inside the instruction cache — eight unrolled copies did not.)
 #pragma once
 
+#include <type_traits>
+
 #include "smr_convert_dev.h"
 #include "smr_layout_dev.h"
 
@@ -32,11 +34,11 @@ static_assert(sizeof(DevLayout) % 16 == 0 && sizeof(DevMask) % 16 == 0, "LDS cop
 // take them band by band from the classifier's list (TileList).  The host sizes that part of the grid from the list's length once
 // it has come back from the device; for a list that is new this frame (a scene in transition) from this prediction — an upper
 // bound: a workgroup beyond the list's end returns at once, a listed tile beyond the prediction is composited by the workgroup that
-// owns it, four bands one after the other.
-// A tile that needs compositing is rendered by B_SLICES workgroups, each taking a band of B_TILE_H / B_SLICES rows of it, starting from
-// the classifier's per-tile record (touching layers, start layer) instead of classifying again.  Measured with the scene's parameter
-// pack resident (profiles/r03_compose_ab.txt): four bands 23.2 us on configs[2] and 48.3 us on configs[4], eight bands 25.0 / 57.1 us.
-constexpr int B_SLICES = 4;          // ctx->compose_slices: 4 or 8 (a band holds whole 4x2 output blocks)
+// owns it, band after band.
+// A tile that needs compositing is rendered band by band, a workgroup per band, each starting from the classifier's per-band record (touching
+// layers, start layer) instead of classifying again; how many bands a tile is cut into is the classifier's decision (B_AREA_BANDS / B_EDGE_BANDS
+// below).  Round 3 measured the first compositor with four bands for every tile at 23.2 us on configs[2] and 48.3 us on configs[4], with eight at
+// 25.0 / 57.1 us (profiles/r03_compose_ab.txt).
 #ifndef SMR_COMPOSE_MIN_WAVES
 #define SMR_COMPOSE_MIN_WAVES 6
 #endif
@@ -46,9 +48,6 @@ constexpr int B_SLICES = 4;          // ctx->compose_slices: 4 or 8 (a band hold
 // the frame gained 7 %.  The list compositor (compose_full below) fits 79 registers without scratch: six waves, and two of them beside the
 // resampler — configs[4] + 3 % over five waves (84 registers), configs[2] unchanged (profiles/r06_sensitivity.txt section 9).
 constexpr int B_MIN_WAVES = SMR_COMPOSE_MIN_WAVES;
-#ifndef SMR_COMPOSE_BAND_ROWS
-#define SMR_COMPOSE_BAND_ROWS 4
-#endif
 constexpr int B_BAND_ROWS = SMR_COMPOSE_BAND_ROWS;       // rows of the workgroup's LDS pixel state: a band is at most this tall
 static_assert(B_TILE_H % B_BAND_ROWS == 0 && B_BAND_ROWS >= 2, "a band fits the LDS pixel state");
 
@@ -139,6 +138,9 @@ __device__ __forceinline__ void tile_needs(const u32 *s_touch, int start, int *s
         const bool sample_layer = i == start && L.type == 0 && !(L.flags & DL_ALIGNED);  // opaque texture, solid over the tile, not a 1:1 blit
         if (sample_layer) atomicOr(s_general, 2);
         else if (!copy_layer) atomicOr(s_general, 1);
+        // 4: a layer that can blend over an area (translucent, an alpha channel, rotated, a shadow): the tile's list of pixels to composite may
+        // be most of the tile.  Without it the layers are opaque and unrotated and only their edges and corners blend.
+        if (!(layout_base_opaque(L) && (L.flags & DL_UNROTATED))) atomicOr(s_general, 4);
     }
 }
 
@@ -170,9 +172,16 @@ struct TileFull {
     u32 tile;
     int start;
     u32 general;
-    u32 pad;
+    u32 band;  // first row of the band within the tile | rows << 8
     u32 touch[MAX_LAYOUT_WORDS];
 };
+// Bands — list entries, workgroups — of a tile that needs compositing.  A workgroup's time is its round trips to memory (the layout list, the
+// start values, a trip per layer of the listed pixels) while its listed pixels fit a pass or two; a tile whose layers are all opaque and unrotated
+// blends along their edges and corners only — a few dozen listed pixels — and is two workgroups' (configs[4] in motion: 993 such tiles; root
+// compositor 52.5 -> 47.8 us).  A tile under a layer that blends over an area (a translucent label, text, a texture with an alpha channel) lists
+// most of its pixels: four shorter bands, four workgroups (configs[2]: alone 17.9 us; 25 us with two bands for every tile).
+constexpr int B_AREA_BANDS = 4, B_EDGE_BANDS = B_TILE_H / B_BAND_ROWS;
+static_assert(B_TILE_H / B_AREA_BANDS <= B_BAND_ROWS && B_EDGE_BANDS <= B_AREA_BANDS, "a band fits the workgroup's pixel state");
 constexpr int B_LIST_COUNTERS = 64;
 struct TileList {
     u32 count[B_LIST_COUNTERS];  // the list's length, one counter per classification (a ring: the host zeroes all of them once per
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
         TileClass c;
         c.base = nullptr; c.pitch_or_px = 0u; c.kind = TC_FULL;
         u32 d = B_CLASS_NONE;
-        if (s_general == 1 && allow_select) {  // some layer above the start: a tile of plain copies all the same?  (serial: a handful of layers)
+        if ((s_general & 3) == 1 && allow_select) {  // some layer above the start: a tile of plain copies all the same?  (serial: a handful of layers)
             const int x1 = min(tx0 + B_TILE_W, W), y1 = min(ty0 + B_TILE_H, H);
             u32 ids = 0xffffffffu;
             int cnt = 0;
@@ -238,10 +247,10 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
                 c.kind = TC_SELECT;
                 c.pitch_or_px = ids;
             }
-        } else if (s_general == 2 && start >= 0) {
+        } else if ((s_general & 3) == 2 && start >= 0) {
             c.kind = TC_SAMPLED;
             c.pitch_or_px = (u32)start;
-        } else if (s_general == 0) {
+        } else if ((s_general & 3) == 0) {
             if (start < 0) {
                 c.kind = TC_CLEAR;
             } else if (layouts[start].type != 0) {
@@ -258,7 +267,9 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
                 }
             }
         }
-        s_slot = (live && c.kind == TC_FULL) ? 1 : 0;  // (a request; the slot itself below)
+        // (a request; the slots themselves below)  A tile that needs compositing is B_AREA_BANDS bands' work when one of its layers blends over an
+        // area, B_EDGE_BANDS longer ones when all of them are opaque and unrotated: one list entry — one workgroup of the compositor — per band
+        s_slot = (live && c.kind == TC_FULL) ? ((s_general & 4) ? B_AREA_BANDS : B_EDGE_BANDS) : 0;
         s_class_w[wave] = c;
         s_direct_w[wave] = d;
     }
@@ -275,16 +286,20 @@ __global__ __launch_bounds__(64 * B_CLASSIFY_TILES) void k_classify_tiles(const 
         }
     }
     __syncthreads();
+    const int bands = (s_general & 4) ? B_AREA_BANDS : B_EDGE_BANDS;
     if (tid == 0 && live) {
         TileClass c = s_class_w[wave];
-        if (c.kind == TC_FULL) c.pitch_or_px = (u32)s_slot;
+        if (c.kind == TC_FULL) { c.pitch_or_px = (u32)s_slot; c.base = (const u8 *)(uintptr_t)bands; }  // (first entry, number of entries)
         tc[tile] = c;
         direct[tile] = (u8)s_direct_w[wave];
     }
-    if (s_slot >= 0) {  // (uniform per wave) the record the compositor's bands of this tile start from
-        TileFull &E = full->e[s_slot];
-        if (tid < MAX_LAYOUT_WORDS) E.touch[tid] = tid < ((n + 31) >> 5) ? s_touch[tid] : 0u;
-        if (tid == 0) { E.tile = (u32)tile; E.start = start; E.general = (u32)s_general; E.pad = 0u; }
+    if (s_slot >= 0) {  // (uniform per wave) the records the compositor's bands of this tile start from
+        const int rows = B_TILE_H / bands;
+        for (int j = 0; j < bands; j++) {
+            TileFull &E = full->e[s_slot + j];
+            if (tid < MAX_LAYOUT_WORDS) E.touch[tid] = tid < ((n + 31) >> 5) ? s_touch[tid] : 0u;
+            if (tid == 0) { E.tile = (u32)tile; E.start = start; E.general = (u32)s_general; E.band = (u32)(j * rows) | ((u32)rows << 8); }
+        }
     }
 }
 
@@ -458,11 +473,16 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
                                              const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g, int n, int n_masks,
                                              int srgb_and_ablate, const float *__restrict__ tables, int tiles_x, float *s_tab) {
     const int tile = (int)pre->tile;
-    constexpr int BAND_PX = B_TILE_W * B_BAND_ROWS, SWEEPS = BAND_PX / 256;
-    static_assert(BAND_PX <= 2048, "a list entry keeps the pixel's index in 11 bits");
+    constexpr int BAND_PX = B_TILE_W * B_BAND_ROWS;
+    constexpr int SWEEPS = 2;  // pixels per thread of steps A and B at a time (rows y and y + 2 of a four-row slab): the band is walked slab by slab
+    static_assert(BAND_PX % 512 == 0 && BAND_PX <= 2048, "whole slabs; a list entry keeps the pixel's index in IDX_BITS bits");
+    // a list entry: pixel index | (start layer + 1) << IDX_BITS — 16 bits while the list's layers fit the LDS copy, 32 for the build that reads the list in place
+    constexpr int IDX_BITS = BIG ? 11 : (BAND_PX <= 1024 ? 10 : 11);
+    constexpr bool WIDE = BIG || ((B_MAX_LAYOUTS + 1) > (1 << (16 - IDX_BITS)));
+    typedef typename std::conditional<WIDE, u32, u16>::type entry_t;
     __shared__ u32 s_touch[MAX_LAYOUT_WORDS];
-    __shared__ u32 s_px[BAND_PX];    // the band's RGBA8: every pixel's start value, then the listed pixels composited
-    __shared__ u32 s_list[BAND_PX];  // pixels some layer above their start touches: index | (start layer + 1) << 11
+    __shared__ u32 s_px[BAND_PX];         // the band's RGBA8: every pixel's start value, then the listed pixels composited
+    __shared__ entry_t s_list[BAND_PX];   // pixels some layer above their start touches
     __shared__ u32 s_count;
     // the whole layout list lives in LDS for the lifetime of the workgroup: one coalesced copy instead of a
     // dependent scalar-memory round trip per field per layer per wave
@@ -519,7 +539,9 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
     const float *dec = s_tab, *thr = s_tab + 256;
     const int sx = tx0 + (tid & (B_TILE_W - 1));  // this thread's pixels: column sx, rows ty0 + (tid >> 7) + 2 * sweep
 
-    // ---- A. start layer and start value of every pixel
+    // ---- A. start layer and start value of every pixel, B. the list — a slab of four rows at a time
+#pragma unroll 1
+    for (int slab = 0; slab < nsweeps; slab += SWEEPS) {
     enum { K_NONE = 0, K_COLOUR = 1, K_TEXEL = 2, K_QUAD = 3 };
     int sp[SWEEPS];          // the layer the pixel starts from (-1: none, a cleared pixel)
     u32 kind[SWEEPS];        // where its start value lies
@@ -557,9 +579,9 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
             if (!layout_base_opaque(L) || !(L.flags & DL_UNROTATED)) continue;
 #pragma unroll
             for (int s = 0; s < SWEEPS; s++) {
-                const int py = ty0 + (tid >> 7) + 2 * s;
+                const int py = ty0 + (tid >> 7) + 2 * (slab + s);
                 const float fx = (float)sx + 0.5f, fy = (float)py + 0.5f;
-                if (s < nsweeps && kind[s] == K_NONE && layout_solid_box(L, masks, fx, fy, fx, fy)) claim(L, li, s, py);
+                if (slab + s < nsweeps && kind[s] == K_NONE && layout_solid_box(L, masks, fx, fy, fx, fy)) claim(L, li, s, py);
             }
         }
     }
@@ -567,7 +589,7 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
         const DevLayout L = load_uniform(&layouts[start]);
 #pragma unroll
         for (int s = 0; s < SWEEPS; s++)
-            if (s < nsweeps && kind[s] == K_NONE) claim(L, start, s, ty0 + (tid >> 7) + 2 * s);
+            if (slab + s < nsweeps && kind[s] == K_NONE) claim(L, start, s, ty0 + (tid >> 7) + 2 * (slab + s));
     }
     u32 st[SWEEPS][4];
 #pragma unroll
@@ -601,19 +623,20 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
                 const int by0 = __builtin_amdgcn_readfirstlane(Lp->by0), by1 = __builtin_amdgcn_readfirstlane(Lp->by1);
 #pragma unroll
                 for (int s = 0; s < SWEEPS; s++) {
-                    const int py = ty0 + (tid >> 7) + 2 * s;
+                    const int py = ty0 + (tid >> 7) + 2 * (slab + s);
                     if (li > sp[s] && sx >= bx0 && sx < bx1 && py >= by0 && py < by1) listed[s] = true;
                 }
             }
         }
 #pragma unroll
     for (int s = 0; s < SWEEPS; s++) {
-        if (s >= nsweeps) break;  // (uniform)
-        const int idx = s * 256 + tid, py = ty0 + (tid >> 7) + 2 * s;
+        if (slab + s >= nsweeps) break;  // (uniform)
+        const int idx = (slab + s) * 256 + tid, py = ty0 + (tid >> 7) + 2 * (slab + s);
         s_px[idx] = val[s];
         const bool want = listed[s] && sx < W && py < H;
         const u32 slot = list_slot(&s_count, want);
-        if (want) s_list[slot] = (u32)idx | ((u32)(sp[s] + 1) << 11);
+        if (want) s_list[slot] = (entry_t)((u32)idx | ((u32)(sp[s] + 1) << IDX_BITS));
+    }
     }
     __syncthreads();
 
@@ -622,8 +645,8 @@ __device__ __forceinline__ void compose_full(const TileFull *__restrict__ pre, i
 #pragma unroll 1
     for (u32 k0 = 0; k0 < total; k0 += 256u) {
         const bool act = k0 + (u32)tid < total;
-        const u32 e = act ? s_list[k0 + tid] : 0u;
-        const int idx = (int)(e & 2047u), from = (int)(e >> 11) - 1;
+        const u32 e = act ? (u32)s_list[k0 + tid] : 0u;
+        const int idx = (int)(e & ((1u << IDX_BITS) - 1u)), from = (int)(e >> IDX_BITS) - 1;
         const int px = tx0 + (idx & (B_TILE_W - 1)), py = ty0 + (idx >> 7);
         u32 a = s_px[idx];
         for (int wi = start < 0 ? 0 : (start >> 5); wi < words; wi++) {
@@ -670,27 +693,23 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
                                                         const DevLayout *__restrict__ layouts_g, const DevMask *__restrict__ masks_g,
                                                         int n, int n_masks, int srgb_and_ablate, const float *__restrict__ tables,
                                                         int tiles_x, int tiles, const TileClass *__restrict__ tc, const TileList *__restrict__ full,
-                                                        int n_banded, int slices, int counter) {
+                                                        int n_banded, int counter) {
     const int tid = threadIdx.x;
 #if defined(SMR_PRIO_COMPOSE) && !defined(SMR_EMU)
     __builtin_amdgcn_s_setprio(SMR_PRIO_COMPOSE);
 #endif
     __shared__ __attribute__((aligned(16))) float s_tab[SMR_TABLE_FLOATS];  // decode / encode tables (whoever needs them loads them)
-    // The first `slices * n_banded` workgroups take the tiles that need compositing (TileList; the host sized the grid from the
-    // list's length when it knows it, from its own prediction otherwise), band by band — they are latency-bound and would be the
-    // tail of the kernel.  Every other workgroup takes B_COPY_TILES consecutive tiles of the row-major order.
+    // The first `n_banded` workgroups take the bands of the tiles that need compositing, an entry of the TileList each (the host sized the
+    // grid from the list's length when it knows it, from its own prediction otherwise) — they are latency-bound and would be the tail of
+    // the kernel.  Every other workgroup takes B_COPY_TILES consecutive tiles of the row-major order.
     // (the compositing path is most of the kernel's code: it is instantiated once, at the end, and both ways into it — a band of a
     //  listed tile; a tile the list had no room for — only choose its arguments)
-    const int rest = (int)blockIdx.x - slices * n_banded;
+    const int rest = (int)blockIdx.x - n_banded;
     const TileFull *full_entry = nullptr, *full_entry2 = nullptr;
-    int full_band = 0, full_end = B_TILE_H, full_rows = B_BAND_ROWS;
+    int full_entries = 1, full_entries2 = 1;
     if (rest < 0) {
-        const u32 gi = blockIdx.x / (u32)slices;
-        if (gi >= full->count[counter]) return;
-        full_rows = B_TILE_H / slices;
-        full_band = (int)(blockIdx.x % (u32)slices) * full_rows;
-        full_end = full_band + full_rows;
-        full_entry = &full->e[gi];
+        if (blockIdx.x >= full->count[counter]) return;
+        full_entry = &full->e[blockIdx.x];
     } else {
     // ---- copy tiles, straight from their class records (k_classify_tiles): no layout list, no classification, no barrier
     const int t0 = rest * B_COPY_TILES;
@@ -794,15 +813,19 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
         }
         if (px0 < W && py0 < H) store_yuv_block<NV>(a, px0, py0, W, yp, up, vp);
     }
-    // a tile that needs compositing and found no room on the band list (the host's bound was short): here, band after band
-    if (c[0].kind == TC_FULL && (int)c[0].pitch_or_px >= n_banded) full_entry = &full->e[c[0].pitch_or_px];
-    if (B_COPY_TILES > 1 && c[B_COPY_TILES - 1].kind == TC_FULL && (int)c[B_COPY_TILES - 1].pitch_or_px >= n_banded) {
+    // a tile that needs compositing and whose bands found no room (or not all of them) among the first workgroups (the host's bound was
+    // short): here, band after band
+    if (c[0].kind == TC_FULL && (int)c[0].pitch_or_px + (int)(uintptr_t)c[0].base > n_banded) {
+        full_entry = &full->e[c[0].pitch_or_px];
+        full_entries = (int)(uintptr_t)c[0].base;
+    }
+    if (B_COPY_TILES > 1 && c[B_COPY_TILES - 1].kind == TC_FULL && (int)c[B_COPY_TILES - 1].pitch_or_px + (int)(uintptr_t)c[B_COPY_TILES - 1].base > n_banded) {
         const TileFull *e = &full->e[c[B_COPY_TILES - 1].pitch_or_px];
-        if (full_entry) full_entry2 = e;
-        else full_entry = e;
+        if (full_entry) { full_entry2 = e; full_entries2 = (int)(uintptr_t)c[B_COPY_TILES - 1].base; }
+        else { full_entry = e; full_entries = (int)(uintptr_t)c[B_COPY_TILES - 1].base; }
     }
     }
-    // (uniform; one band of a listed tile, or the four bands of a tile — of each tile of the group — the list's bound left out)
+    // (uniform; one band of a listed tile, or the bands of a tile — of each tile of the group — that the list's bound left out)
 #ifdef SMR_COMPOSE_NO_FULL  // profiling builds only: the compositing path compiled out (what the copy paths alone need in registers and time)
     if (full_entry || full_entry2) return;
 #endif
@@ -810,9 +833,13 @@ __global__ __launch_bounds__(256, B_MIN_WAVES) void k_compose_output(SurfView yp
     for (int q = 0; q < 2; q++) {
         const TileFull *e = q == 0 ? full_entry : full_entry2;
         if (!e) break;
+        const int entries = q == 0 ? full_entries : full_entries2;
 #pragma unroll 1
-        for (int band = full_band; band < full_end; band += full_rows)
-            compose_full<NV, BIG>(e, band, full_rows, yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+        for (int j = 0; j < entries; j++) {
+            if (rest >= 0 && (int)(e - full->e) + j < n_banded) continue;  // (that band has a workgroup of its own)
+            const u32 bw = __builtin_amdgcn_readfirstlane(e[j].band);
+            compose_full<NV, BIG>(&e[j], (int)(bw & 0xffu), (int)(bw >> 8), yp, up, vp, W, H, layouts_g, masks_g, n, n_masks, srgb_and_ablate, tables, tiles_x, s_tab);
+        }
     }
 }
 

@@ -24,6 +24,11 @@ constexpr bool SMR_LAB_BUILD = true;
 constexpr bool SMR_LAB_BUILD = false;
 #endif
 
+// Rows of the longest band of a tile that needs compositing (k_compose_output, smr_fused_compose.h: the workgroup's LDS pixel state).
+#ifndef SMR_COMPOSE_BAND_ROWS
+#define SMR_COMPOSE_BAND_ROWS 8
+#endif
+
 
 typedef uint8_t u8;
 typedef uint16_t u16;
@@ -205,7 +210,6 @@ struct smr_ctx {
     int ablate = 0;           // SMR_ABLATE (laboratory builds: profiling experiments only)
     bool ablate_read = false;
     bool compose_select = true;  // SMR_COMPOSE_SELECT=0 (tests, profiling): no TC_SELECT tiles — seams between opaque 1:1 layers take the compositing path
-    int compose_slices = 4;      // SMR_COMPOSE_SLICES (profiling): workgroups per tile of the compositor's band list (4 or 8)
     std::vector<u32> compose_bitmap;  // compose_predict's scratch
     int ingest_min_rows = 0;     // SMR_INGEST_MIN_ROWS (profiling): least tile rows per wave of k_ingest_wave (0: the default, 1)
     bool plane_source = false;   // SMR_OPT_PLANE_SOURCE (off by default: measured slower): 4:2:0 frames inside the matrix-core kernel's class windows are converted in the kernel itself (exactly: smr_convert_420.h's blocks through LDS) — no node texture in memory

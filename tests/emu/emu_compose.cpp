@@ -79,11 +79,11 @@ void read_back(const Surface &s, u8 *tight, int bpp) {
 // textures, tight rows (src_px[i] == NULL: no texture), src_kind[i] 1 = RGBA8, 2 = RGBA8 known to be opaque (a resampled video tile).
 // Output W x H (even): nv 0 -> out0 / out1 / out2 = Y, U, V planes (tight), nv 1 -> out0 = Y, out1 = interleaved UV, nv 2 -> out0 = RGBA8.
 // banded: how many tiles the host's grid gives the band list — -1: the classifier's own count (a list that was read back), >= 0: that
-// many (0: a prediction that missed everything: every composited tile is done by the workgroup that owns it).  slices: 4 or 8.
+// many (0: a prediction that missed everything: every composited tile is done by the workgroup that owns it).  slices: unused (the classifier decides a tile's bands).
 // info[0..6] = tiles per class (TC_CLEAR .. TC_SELECT), info[7] = tiles on the compositing list, info[8] = workgroups of the compositor.
 extern "C" int emu_compose(const smr_layout *layouts, int n, int n_sources, const u8 *const *src_px, const int *src_w, const int *src_h, const int *src_kind,
                            int W, int H, int nv, int srgb, int banded, int slices, int allow_select, u8 *out0, u8 *out1, u8 *out2, int *info) {
-    if (W < 2 || H < 2 || (W & 1) || (H & 1) || n < 0 || n > MAX_LAYOUT_WORDS * 32 || (slices != 4 && slices != 8) || nv < 0 || nv > 2) return -1;
+    if (W < 2 || H < 2 || (W & 1) || (H & 1) || n < 0 || n > MAX_LAYOUT_WORDS * 32 || (slices != 2 && slices != 4 && slices != 8) || nv < 0 || nv > 2) return -1;
     static float tables_src[SMR_TABLE_FLOATS];
     static u32 lut16[SMR_LUT16_WORDS];
     static bool have_tables = false;
@@ -119,7 +119,7 @@ extern "C" int emu_compose(const smr_layout *layouts, int n, int n_sources, cons
     GuardBuf tcb, directb, listb;
     tcb.alloc((size_t)tiles * sizeof(TileClass), 0, 16);
     directb.alloc(((size_t)tiles + 15) & ~(size_t)15, 0xff, 16);
-    listb.alloc(sizeof(TileList) + (size_t)tiles * sizeof(TileFull), 0, 16);
+    listb.alloc(sizeof(TileList) + (size_t)tiles * B_AREA_BANDS * sizeof(TileFull), 0, 16);
     TileClass *tc = (TileClass *)tcb.ptr;
     TileList *full = (TileList *)listb.ptr;
     run_grid((unsigned)((tiles + B_CLASSIFY_TILES - 1) / B_CLASSIFY_TILES), 64 * B_CLASSIFY_TILES,
@@ -129,9 +129,12 @@ extern "C" int emu_compose(const smr_layout *layouts, int n, int n_sources, cons
         for (int t = 0; t < tiles; t++)
             if (tc[t].kind <= TC_SELECT) info[tc[t].kind]++;
         info[7] = (int)full->count[0];
+#ifdef SMR_EMU_HEAVY_DEBUG
+        { int hv = 0; for (u32 k = 0; k < full->count[0]; k++) hv += (full->e[k].general & 4u) ? 1 : 0; fprintf(stderr, "listed %u heavy %d\n", full->count[0], hv); }
+#endif
     }
     u32 n_banded = banded < 0 ? full->count[0] : (u32)banded;
-    if (n_banded > (u32)tiles) n_banded = (u32)tiles;
+    if (n_banded > (u32)tiles * B_AREA_BANDS) n_banded = (u32)tiles * B_AREA_BANDS;
 
     Surface p0, p1, p2;
     if (nv == 2) {
@@ -148,12 +151,12 @@ extern "C" int emu_compose(const smr_layout *layouts, int n, int n_sources, cons
         }
     }
     const bool big = n > B_MAX_LAYOUTS || (int)mo > B_MAX_MASKS;
-    const unsigned grid = (unsigned)slices * n_banded + (unsigned)((tiles + B_COPY_TILES - 1) / B_COPY_TILES);
+    const unsigned grid = n_banded + (unsigned)((tiles + B_COPY_TILES - 1) / B_COPY_TILES);
     if (info) info[8] = (int)grid;
     const float *tab = (const float *)tables.ptr;
     const int flags = srgb ? 1 : 0;
 #define EMU_COMPOSE(NVv, BIGv) \
-    run_grid(grid, 256, [&] { k_compose_output<NVv, BIGv>(p0.view, p1.view, p2.view, W, H, hl, hm, n, (int)mo, flags, tab, tiles_x, tiles, tc, full, (int)n_banded, slices, 0); })
+    run_grid(grid, 256, [&] { k_compose_output<NVv, BIGv>(p0.view, p1.view, p2.view, W, H, hl, hm, n, (int)mo, flags, tab, tiles_x, tiles, tc, full, (int)n_banded, 0); })
     if (nv == 0) { if (big) EMU_COMPOSE(0, true); else EMU_COMPOSE(0, false); }
     else if (nv == 1) { if (big) EMU_COMPOSE(1, true); else EMU_COMPOSE(1, false); }
     else { if (big) EMU_COMPOSE(2, true); else EMU_COMPOSE(2, false); }

@@ -49,13 +49,15 @@ def _build_one(name, source, deps=()):
     asan = bool(os.environ.get("SMR_EMU_ASAN"))
     out_dir = os.path.join(EMU, "_build")
     os.makedirs(out_dir, exist_ok=True)
-    lib = os.path.join(out_dir, f"lib{name}{'_asan' if asan else ''}.so")
+    extra = os.environ.get("SMR_EMU_DEFINES", "").split()  # e.g. -DSMR_COMPOSE_BAND_ROWS=8: the same tests against another build of the kernels
+    tag = "".join(c if c.isalnum() else "_" for c in "".join(extra))
+    lib = os.path.join(out_dir, f"lib{name}{'_asan' if asan else ''}{tag}.so")
     srcs = [os.path.join(EMU, source), os.path.join(EMU, "emu_device.h"), os.path.join(EMU, "emu_guard.h"), os.path.join(EMU, "shim/hip/hip_runtime.h"),
             os.path.join(CSRC, "smr_internal.h")] + [os.path.join(CSRC, d) for d in deps]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
         flags = ["-std=c++17", "-fPIC", "-shared", "-DSMR_EMU=1", "-ffp-contract=off", "-Wno-unused-function"]
         flags += ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-shared-libasan", "-DSMR_EMU_ASAN=1"] if asan else ["-O2"]
-        cmd = [CLANG] + flags + ["-I", os.path.join(EMU, "shim"), "-I", EMU, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0], "-lpthread"]
+        cmd = [CLANG] + flags + extra + ["-I", os.path.join(EMU, "shim"), "-I", EMU, "-I", CSRC, "-I", os.path.join(ROOT, "include"), "-o", lib, srcs[0], "-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
     return lib

@@ -122,7 +122,8 @@ def test_a_grid_of_tiles_with_labels_is_the_oracle_byte_for_byte(emu, W, H, cols
     layouts, sources, kinds = _grid_scene(W, H, cols, rows, gap)
     got, classes = compose(emu, layouts, sources, kinds, W, H, out)
     assert_same(got, oracle_output(layouts, sources, W, H, out), (W, H, cols, rows, gap, out, classes))
-    assert classes["full"] > 0 and classes["full"] == classes["listed"]
+    # (the list holds a tile's BANDS: four under a layer that blends over an area — the labels —, two along opaque layers' edges)
+    assert classes["full"] > 0 and 2 * classes["full"] <= classes["listed"] <= 4 * classes["full"]
     if (W, gap) == (384, 0):
         assert classes["texture"] > 0 and classes["colour"] > 0   # whole tiles inside a video tile / inside the empty cell
 
