@@ -219,6 +219,40 @@ def test_animated_grid_with_blur_layer_matches_the_oracle_mid_transition(ctx, hi
         f.destroy()
 
 
+def test_a_long_transition_reclassifies_every_frame_and_stays_byte_equal_to_a_fresh_renderer(ctx, hip, renderer):
+    """150 frames of a grid in motion (quarter-size configs[4]): every frame has a new root layout list — a new parameter pack, a new
+    classification, a new band list — while the blur layer's node repeats its own.  Frames 70 and 149 — after the ring of list counters
+    (64) wrapped twice and the ring of parameter packs came round past the slot the static node keeps reusing — must equal, byte for
+    byte, what a fresh renderer that jumps straight to the same presentation time renders."""
+    from smelter_amd import synth
+    from smelter_amd.renderer import Renderer
+    iw, ih, W, H, n, lw, lh = 480, 270, 960, 540, 16, 240, 136
+    _, frames = _frames(ctx, hip, n, iw, ih)
+    frames = {f"input_{i}": frames[f"in{i}"] for i in range(n)}
+    fresh = Renderer(ctx)
+    for r in (renderer, fresh):
+        for k in frames:
+            r.register_input(k)
+        r.register_shader("soften")
+        r.update_scene("out", W, H, synth.animated_grid_scene(n, 0, lw, lh))
+        r.render(0.0, frames, {k: 0.0 for k in frames})
+        r.update_scene("out", W, H, synth.animated_grid_scene(n, 5, lw, lh))
+    ts = [0.003 * (k + 1) for k in range(150)]           # 3 ms apart: all inside the 500 ms transition
+    kept = {}
+    for k, t in enumerate(ts):
+        out = renderer.render(t, frames, {q: t for q in frames})["out"]
+        if k in (0, 70, 149):
+            kept[k] = out.download()
+    assert not (kept[70][0] == kept[149][0]).all()       # really moving
+    for k in (0, 70, 149):
+        want = fresh.render(ts[k], frames, {q: ts[k] for q in frames})["out"].download()
+        for g, w_ in zip(kept[k], want):
+            assert (g == w_).all(), k
+    fresh.close()
+    for f in frames.values():
+        f.destroy()
+
+
 def test_configs0_two_720p_packed_rgba_inputs_static_view_cpu_optimized_is_bit_exact(hip):
     """BASELINE configs[0] — the integration-tests plumbing scene (pixel_input_format_tests.rs:30-150 at 720p): two 1280x720 inputs handed
     over as FrameData::Bgra / FrameData::Argb bytes, a static View, RenderingMode::CpuOptimized, RGBA output.  Integer work end to end
