@@ -46,6 +46,22 @@ for G in FETCH_SIZE WRITE_SIZE; do
 done
 python tools/traffic_json.py gpurun_out/prof_r06_ps > $O/traffic_plane_source.json
 find gpurun_out/prof_r06_ps -name "*kernel_trace.csv" -delete; find gpurun_out/prof_r06_ps -name "*counter_collection.csv" -delete
+# configs[4] frozen half-way through a transition (tools/r06/c4probe.py): what the kernels of a frame in motion take, from the kernel trace
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_r06_c4m -o t -- python $R/tools/r06/c4probe.py 200 0.5 > $O/prof_c4m.log 2>&1)
+python - > $O/configs4_motion_kernels.txt <<PY
+import csv, glob, collections
+f = glob.glob("gpurun_out/prof_r06_c4m/**/*kernel_trace.csv", recursive=True)[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    d[(r["Kernel_Name"][:64], int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print("configs[4] frozen half-way through a transition, one frame in flight, the same presentation time 200 times (tools/r06/c4probe.py): kernel, workgroups, launches, median / min us")
+for k, v in sorted(d.items(), key=lambda x: -sum(x[1])):
+    if len(v) < 50: continue
+    v2 = sorted(v)
+    print("  %-66s %6d  n %4d  %7.2f  %7.2f" % (k[0], k[1], len(v), v2[len(v2) // 2] / 1e3, v2[0] / 1e3))
+PY
+find gpurun_out/prof_r06_c4m -name "*kernel_trace.csv" -delete
+timeout 300 python bench.py --config 4 --inflight 2 --no-cpu-baseline --no-target --long-seconds 2 > $O/bench_c4_inflight2.json 2>/dev/null
 timeout 900 python bench.py --mode capacity > $O/bench_capacity.json 2> $O/bench_capacity.err
 timeout 200 python tools/host_rate.py > $O/host_rate.txt 2>&1
 rocm-smi --showclocks --showpower > $O/rocm_smi_idle.txt 2>&1
