@@ -25,7 +25,38 @@ struct Source {
     const smr_surface *surface = nullptr;
     const smr_frame *frame = nullptr;
     uint32_t w = 0, h = 0;
+    bool opaque = false;  // every texel's alpha is 255 (the renderer writes its node surfaces itself, so it may know): the compositor then copies
+                          // or samples the layer where it would otherwise blend it (SMR_SOURCE_OPAQUE_SURFACE) — the same bytes, fewer of them touched
 };
+
+// every YUV-family FrameData variant converts to alpha == 1 (wgpu/format/*_to_rgba.wgsl return vec4(.., 1.0)); BGRA / ARGB / RGBA carry their own
+bool frame_opaque(const smr_frame *f) { return f && f->format <= SMR_FRAME_NV12; }
+
+// Does a LayoutNode's output have alpha 255 everywhere?  Yes when one of its layers is opaque — a colour with alpha 1, a texture whose source
+// is opaque: bilinear weights are 8-bit fractions and sum to 1 exactly, so an opaque texture samples alpha exactly 1 —, has no rotation, rounded
+// corner, border or mask, lies on half-integer coordinates (the coverage arithmetic is then exact) and covers every pixel centre by at least half
+// a pixel: its fragment's alpha is exactly 1 there, and whatever is blended above leaves src.a + 1 * (1 - src.a), which stores 255.
+// Conservative: `false` only costs the compositor its shortcut.
+bool layouts_leave_an_opaque_surface(const std::vector<smr_layout> &layouts, const std::vector<Source> &kids, uint32_t w, uint32_t h) {
+    auto half_int = [](float v) { return v * 2.0f == std::floor(v * 2.0f) && std::fabs(v) < 32768.0f; };
+    for (const smr_layout &L : layouts) {
+        if (L.rotation_degrees != 0.0f || L.border_width != 0.0f || L.masks_len != 0) continue;
+        if (L.border_radius[0] != 0.0f || L.border_radius[1] != 0.0f || L.border_radius[2] != 0.0f || L.border_radius[3] != 0.0f) continue;
+        if (L.type == 1) {
+            if (L.color[3] != 1.0f) continue;
+        } else if (L.type == 0) {
+            if (L.source_index >= kids.size()) continue;
+            const Source &k = kids[L.source_index];
+            const bool src_opaque = (k.kind == SMR_SOURCE_FRAME && frame_opaque(k.frame)) || (k.kind == SMR_SOURCE_SURFACE && k.opaque);
+            if (!src_opaque) continue;
+        } else {
+            continue;
+        }
+        if (!(half_int(L.left) && half_int(L.top) && half_int(L.width) && half_int(L.height))) continue;
+        if (L.left <= 0.0f && L.top <= 0.0f && L.left + L.width >= (float)w && L.top + L.height >= (float)h) return true;
+    }
+    return false;
+}
 
 // What one frame in flight owns of an output: its two alternating output frames and the per-node intermediate surfaces.
 // (One lane = the reference's renderer; with more lanes consecutive frames are enqueued on different contexts / HIP streams
@@ -211,6 +242,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
         if (rc < 0) return rc;
         // shader nodes sample RGBA node textures: raw input frames are converted first (InputTexture::convert_to_node_texture)
         std::vector<const smr_surface *> srcs;
+        std::vector<bool> src_opaque;
         for (size_t k = 0; k < kids.size(); k++) {
             if (kids[k].kind == SMR_SOURCE_FRAME) {
                 smr_surface *&t = o.l->node_surface[g.children[k]];
@@ -219,10 +251,13 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
                 rc = gpu(r, smr_frame_to_rgba(r->ctx, kids[k].frame, t), "input node texture");
                 if (rc < 0) return rc;
                 srcs.push_back(t);
+                src_opaque.push_back(frame_opaque(kids[k].frame));
             } else if (kids[k].kind == SMR_SOURCE_SURFACE) {
                 srcs.push_back(kids[k].surface);
+                src_opaque.push_back(kids[k].opaque);
             }
         }
+        bool out_opaque = false;
         // the @group(1) uniform: ShaderParam::to_bytes (shader/node.rs:95-112), the values in order, little endian, no padding
         std::vector<uint8_t> params;
         flatten_shader_param(c.shader_param, params);
@@ -239,6 +274,11 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
                 rc = gpu(r, smr_rescale_bilinear(r->ctx, src0, t), "shader source");
                 if (rc < 0) return rc;
                 srcs[0] = t;
+            } else {
+                // The blur of an opaque texture is opaque: both passes accumulate alpha as sum += 1 * w in the very order they accumulate the
+                // weights' own sum, so alpha = sum / sum == 1 exactly and the store writes 255 (k_gauss_axis, smr_misc.hip).  (Not claimed
+                // through the rescale above: its weights are not 8-bit fractions.)
+                out_opaque = src_opaque[0];
             }
             if (params.size() < sizeof(smr_gaussian_blur_params)) params.assign(sizeof(smr_gaussian_blur_params), 0);
         }
@@ -246,7 +286,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
                                        (float)((double)fs.pts_ns / 1e9)),
                  "shader node");
         if (rc < 0) return rc;
-        out.kind = SMR_SOURCE_SURFACE; out.surface = o.l->node_surface[idx]; out.w = w; out.h = h;
+        out.kind = SMR_SOURCE_SURFACE; out.surface = o.l->node_surface[idx]; out.w = w; out.h = h; out.opaque = out_opaque;
         return 0;
     }
     // layout node (nested): LayoutNode::render into an RGBA8 node surface
@@ -254,19 +294,21 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
     std::vector<smr_source> srcs(kids.size());
     for (size_t k = 0; k < kids.size(); k++) {
         if (kids[k].kind != SMR_SOURCE_NONE) res[k] = Size{(float)kids[k].w, (float)kids[k].h};
-        srcs[k].kind = kids[k].kind; srcs[k].surface = kids[k].surface; srcs[k].frame = kids[k].frame;
+        srcs[k].kind = (kids[k].kind == SMR_SOURCE_SURFACE && kids[k].opaque) ? (uint32_t)SMR_SOURCE_OPAQUE_SURFACE : kids[k].kind;
+        srcs[k].surface = kids[k].surface; srcs[k].frame = kids[k].frame;
     }
     uint32_t w = 0, h = 0;
     std::string err;
     if (!o.scene.node_layouts(idx, fs.pts_ns, res, smr_ctx_mode(r->ctx) == SMR_MODE_GPU_OPTIMIZED, r->layouts, w, h, err)) return fail(r, -1, err);
     if (w == 0 || h == 0) return 0;
+    const bool node_opaque = layouts_leave_an_opaque_surface(r->layouts, kids, w, h);
     int rc = ensure_surface(r, o.l->node_surface[idx], w, h);
     if (rc < 0) return rc;
     rc = gpu(r, smr_render_layouts(r->ctx, r->layouts.data(), (uint32_t)r->layouts.size(), srcs.data(), (uint32_t)srcs.size(), w, h, nullptr,
                                    o.l->node_surface[idx]),
              "layout node");
     if (rc < 0) return rc;
-    out.kind = SMR_SOURCE_SURFACE; out.surface = o.l->node_surface[idx]; out.w = w; out.h = h;
+    out.kind = SMR_SOURCE_SURFACE; out.surface = o.l->node_surface[idx]; out.w = w; out.h = h; out.opaque = node_opaque;
     return 0;
 }
 
@@ -286,7 +328,8 @@ int render_output(smr_renderer *r, Output &o, const FrameSetView &fs, const smr_
         std::vector<smr_source> srcs(kids.size());
         for (size_t k = 0; k < kids.size(); k++) {
             if (kids[k].kind != SMR_SOURCE_NONE) res[k] = Size{(float)kids[k].w, (float)kids[k].h};
-            srcs[k].kind = kids[k].kind; srcs[k].surface = kids[k].surface; srcs[k].frame = kids[k].frame;
+            srcs[k].kind = (kids[k].kind == SMR_SOURCE_SURFACE && kids[k].opaque) ? (uint32_t)SMR_SOURCE_OPAQUE_SURFACE : kids[k].kind;
+            srcs[k].surface = kids[k].surface; srcs[k].frame = kids[k].frame;
         }
         uint32_t w = 0, h = 0;
         std::string err;

@@ -484,6 +484,17 @@ def test_gaussian_blur(ctx, hip, sigma):
     check(got, orc.gaussian_blur(src, sigma), TOL, 0.99, f"gaussian blur {sigma}")
 
 
+@pytest.mark.parametrize("sigma", [0.0, 0.7, 3.0, 10.0, 64.0])
+def test_gaussian_blur_of_an_opaque_texture_is_opaque(ctx, hip, sigma):
+    """What the renderer relies on when it hands a blurred opaque node to the compositor as an opaque layer (renderer.cpp: the layer is then
+    copied or sampled, not blended): both passes accumulate alpha in the order they accumulate the weights' sum, so it is exactly 1."""
+    src = np.random.default_rng(16).integers(0, 256, (67, 131, 4), dtype=np.uint8)
+    src[..., 3] = 255
+    got = ctx.gaussian_blur(ctx.surface_from(src), sigma).download()
+    assert (got[..., 3] == 255).all()
+    assert (np.asarray(orc.gaussian_blur(src, sigma))[..., 3] == 255).all()
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_errors_are_reported_not_swallowed(ctx, hip):
     with pytest.raises(hip.SmrError, match="Validation"):

@@ -152,3 +152,15 @@ def test_known_mid_transition_layouts(key):
                 assert r[0] == x[0] and all(abs(a - b) <= 1e-3 for a, b in zip(r[1:], x[1:])), (who, key, pts_ms, rec, exp)
     _run(BY_NAME[key], check)
     assert seen == set(KNOWN[key])
+
+
+def test_the_oracle_blurs_an_opaque_texture_to_an_opaque_one():
+    """The renderer hands a blurred opaque node to the compositor as an opaque layer (csrc/host/renderer.cpp); the device's proof is
+    tests/test_gpu_parity.py::test_gaussian_blur_of_an_opaque_texture_is_opaque — the oracle's passes agree."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    src = np.random.default_rng(16).integers(0, 256, (37, 61, 4), dtype=np.uint8)
+    src[..., 3] = 255
+    for sigma in (0.0, 0.7, 3.0, 10.0):
+        assert (np.asarray(orc.gaussian_blur(src, sigma))[..., 3] == 255).all(), sigma
