@@ -413,7 +413,6 @@ __device__ __forceinline__ void wave_piece(const WJob &J, const MDirect *__restr
     // leaves (resampler.rs: downsample.wgsl into an Rgba16Float texture): the f16 texels ARE the operand's hi halves, lo = 0.
     constexpr bool FX = (FL & 262144) != 0;  // the source is a 4:2:0 frame, converted exactly in the wave (header)
     static_assert(!FX || (NKS_T != 0 && SMR_WAVE_PIPE && !(FL & (8192 | 16384 | 32768 | 65536 | 131072 | 2048))), "plane-source builds: class builds of the pipelined loop only");
-    constexpr int ORG = FX ? 0 : -1;  // first row of chunk 0 (w_chunk_of_row)
     constexpr bool RG = (FL & 8192) != 0, RH = RG && (FL & 16384) != 0;
     // 131072 (with 8192): the node texture as 12-byte groups of four pixels (smr_convert_420.h rgb12): lane (m, q) loads the group of texels
     // 4 q .. 4 q + 3 — a dword per channel
