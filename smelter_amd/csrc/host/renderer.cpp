@@ -18,6 +18,7 @@ namespace {
 struct ImageRes {
     smr_surface *surface = nullptr;  // premultiplied RGBA8 node texture at the image's own resolution
     uint32_t w = 0, h = 0;
+    bool opaque = false;             // every pixel's alpha is 255 (seen at registration; premultiplication keeps the alpha byte)
 };
 
 struct Source {
@@ -205,7 +206,7 @@ int render_node(smr_renderer *r, Output &o, int idx, const FrameSetView &fs, Sou
         if (it == r->images.end()) return 0;
         const uint32_t w = as_u32(c.leaf_size.width), h = as_u32(c.leaf_size.height);
         if (w == it->second.w && h == it->second.h) {
-            out.kind = SMR_SOURCE_SURFACE; out.surface = it->second.surface; out.w = w; out.h = h;
+            out.kind = SMR_SOURCE_SURFACE; out.surface = it->second.surface; out.w = w; out.h = h; out.opaque = it->second.opaque;
             return 0;
         }
         if (w == 0 || h == 0) return 0;
@@ -433,6 +434,8 @@ SMR_API int smr_renderer_register_image(smr_renderer *r, const char *image_id, c
     }
     ImageRes res;
     res.surface = pm; res.w = width; res.h = height;
+    res.opaque = true;
+    for (size_t i = 0, n = (size_t)width * height; i < n && res.opaque; i++) res.opaque = rgba[4 * i + 3] == 255;
     r->images[image_id] = res;
     for (auto &kv : r->outputs) kv.second.scene.register_image(image_id, (float)width, (float)height);
     return 0;

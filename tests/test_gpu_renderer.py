@@ -141,6 +141,36 @@ def test_shader_node_with_nested_layout_and_image(ctx, hip, renderer):
     assert got[0].std() > 5  # not a blank frame
 
 
+@pytest.mark.parametrize("opaque", [True, False])
+def test_an_opaque_image_is_composited_as_an_opaque_layer_to_the_same_bytes(ctx, hip, renderer, opaque):
+    """The renderer knows an image whose every alpha byte is 255 to be opaque and names it SMR_SOURCE_OPAQUE_SURFACE (copy / select tiles where it
+    lies 1:1, start values where something blends over it); the same list by hand with the image as a plain surface blends it everywhere: the
+    same bytes.  With one translucent pixel in the image both go the blending way."""
+    W, H = 640, 360
+    rng = np.random.default_rng(11)
+    pic = rng.integers(0, 256, (128, 256, 4), dtype=np.uint8)
+    pic[..., 3] = 255
+    if not opaque:
+        pic[40, 100, 3] = 90
+    renderer.register_image("pic", pic)
+    scene = {"type": "view", "background_color": "#203040FF", "children": [
+        {"type": "view", "top": 40, "left": 64, "width": 256, "height": 128, "children": [{"type": "image", "image_id": "pic"}]},
+        {"type": "view", "top": 100, "left": 200, "width": 300, "height": 120, "background_color": "#FFFFFF60", "border_radius": 12},
+    ]}
+    renderer.update_scene("out", W, H, scene)
+    got = renderer.render(0.0, {})["out"].download()
+    from smelter_amd.scene import Scene
+    sc = Scene()
+    sc.register_image("pic", 256, 128)
+    sc.update(scene, W, H)
+    image = ctx.add_premultiplied_alpha(ctx.surface_from(pic))
+    out = ctx.frame(hip.FRAME_PLANAR_YUV420, W, H)
+    ctx.render_layouts(sc.layouts(0, 0, [(256, 128)]), [image], W, H, out=out)
+    for a, b in zip(got, out.download()):
+        assert (a == b).all()
+    assert got[0].std() > 5
+
+
 def test_transition_animates_between_updates(ctx, hip, renderer):
     iw, ih, W, H = 320, 180, 640, 360
     _, frames = _frames(ctx, hip, 1, iw, ih)
