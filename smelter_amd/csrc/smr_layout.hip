@@ -66,6 +66,14 @@ int smr_pack_layouts(smr_ctx *ctx, const smr_layout *layouts, u32 n, const SurfV
         if (!(c.busy && c.unfenced && ctx->pack_clock - c.last_reuse < 64)) break;
         ctx->layout_ring_next = (ctx->layout_ring_next + 1) % ctx->layout_ring.size();
     }
+    {   // every slot is some node's resident pack (a scene of many nested layout nodes at rest under one that moves): the ring grows rather
+        // than recycle one of them every frame (slots are addressed by index between calls: ctx->layout_last)
+        const LayoutSlot &c = ctx->layout_ring[ctx->layout_ring_next];
+        if (c.busy && c.unfenced && ctx->pack_clock - c.last_reuse < 64 && ctx->layout_ring.size() < 64) {
+            ctx->layout_ring.emplace_back();
+            ctx->layout_ring_next = ctx->layout_ring.size() - 1;
+        }
+    }
     LayoutSlot &slot = ctx->layout_ring[ctx->layout_ring_next];
     ctx->layout_ring_next = (ctx->layout_ring_next + 1) % ctx->layout_ring.size();
     if (slot.busy) {

@@ -283,6 +283,43 @@ def test_a_long_transition_reclassifies_every_frame_and_stays_byte_equal_to_a_fr
         f.destroy()
 
 
+def test_many_nested_nodes_at_rest_under_a_root_in_motion(ctx, hip, renderer):
+    """Ten shader nodes, each over its own nested layout node that never changes, under a root whose rescaler is in a transition: every frame
+    stages eleven parameter packs of which ten repeat — more resident packs than the ring's eight slots (it grows instead of recycling one of
+    them and waiting for the stream every frame).  The last of 40 frames equals a fresh renderer's."""
+    from smelter_amd.renderer import Renderer
+    iw, ih, W, H = 320, 180, 640, 360
+    _, frames = _frames(ctx, hip, 1, iw, ih)
+
+    def scene(width, tr=None):
+        kids = [{"type": "view", "top": 8 + 34 * (k // 5), "left": 8 + 70 * (k % 5), "width": 64, "height": 30,
+                 "children": [{"type": "shader", "shader_id": "soften", "resolution": {"width": 64, "height": 30}, "shader_param": {"type": "f32", "value": 1.0 + 0.2 * k},
+                               "children": [{"type": "view", "width": 64, "height": 30, "background_color": "#%02X4080FF" % (20 * k),
+                                             "children": [{"type": "rescaler", "child": {"type": "input_stream", "input_id": "in0"}}]}]}]}
+                for k in range(10)]
+        pip = {"type": "rescaler", "id": "pip", "width": width, "height": width * 9 / 16, "top": 100, "left": 40, "child": {"type": "input_stream", "input_id": "in0"}}
+        if tr:
+            pip["transition"] = tr
+        return {"type": "view", "background_color": "#101010FF", "children": kids + [pip]}
+
+    fresh = Renderer(ctx)
+    for r in (renderer, fresh):
+        r.register_input("in0")
+        r.register_shader("soften")
+        r.update_scene("out", W, H, scene(200.0))
+        r.render(0.0, frames, {"in0": 0.0})
+        r.update_scene("out", W, H, scene(420.0, {"duration_ms": 1000}))
+    ts = [0.02 * (k + 1) for k in range(40)]
+    for t in ts:
+        got = renderer.render(t, frames, {"in0": t})["out"].download()
+    fresh.render(ts[0], frames, {"in0": ts[0]})
+    want = fresh.render(ts[-1], frames, {"in0": ts[-1]})["out"].download()
+    fresh.close()
+    for g, w_ in zip(got, want):
+        assert (g == w_).all()
+    assert got[0].std() > 5
+
+
 def test_configs0_two_720p_packed_rgba_inputs_static_view_cpu_optimized_is_bit_exact(hip):
     """BASELINE configs[0] — the integration-tests plumbing scene (pixel_input_format_tests.rs:30-150 at 720p): two 1280x720 inputs handed
     over as FrameData::Bgra / FrameData::Argb bytes, a static View, RenderingMode::CpuOptimized, RGBA output.  Integer work end to end
